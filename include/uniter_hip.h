@@ -1,0 +1,295 @@
+/*
+ * uniter_hip.h — C ABI of libuniter_hip.so, the MI355X (gfx950 / CDNA4) implementation of the
+ * UNITER encoder training hot path.
+ *
+ * The reference (ChenRocks/UNITER) has no FFI for this path: its seam is the Python nn.Module /
+ * Optimizer surface.  Each entry point below therefore cites the reference Python
+ * code (file:line, relative to the reference checkout) whose arithmetic it replaces.  The Python
+ * side of the boundary (uniter_amd/model, uniter_amd/optim, uniter_amd/utils) keeps the reference
+ * class names / signatures and binds these symbols with ctypes (uniter_amd/_lib.py).
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, >0 = hipError_t, <0 = argument error (see uniter_hip_last_error());
+ *   - never throw, never allocate or free caller memory, never synchronise the device;
+ *   - every tensor argument is a raw DEVICE pointer owned by the caller (a torch tensor), contiguous,
+ *     16-byte aligned, kept alive by the caller until `stream` has passed the call;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *   - activations / weights / gradients are bf16 (uint16 storage), statistics and optimizer state fp32;
+ *   - nn.Linear weights keep the reference layout [out, in] row-major (model/layer.py:64-66);
+ *   - dropout randomness is a counter-based Philox4x32-10 stream keyed by (seed, offset) supplied by
+ *     the caller; p == 0 disables it (utils/misc.py:57-63 set_dropout).
+ */
+#ifndef UNITER_HIP_H
+#define UNITER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNITER_HIP_ABI_VERSION 1
+
+/* ------------------------------------------------------------------------------------------------
+ * Library
+ * ---------------------------------------------------------------------------------------------- */
+int uniter_hip_abi_version(void);
+/* Thread-local text of the last non-zero status returned on this thread ("" if none). */
+const char* uniter_hip_last_error(void);
+/* Writes device facts of the current HIP device: [0]=CU count, [1]=wavefront size, [2]=LDS bytes/CU,
+ * [3]=gfx arch number (950).  Returns 0 / hipError_t. */
+int uniter_hip_device_info(int32_t out[4]);
+/* Test / tuning hook: force the GEMM tile (0=128x128, 1=128x64, 2=64x128, 3=64x64; -1 = heuristic)
+ * and the wgrad split-K factor (-1 = heuristic). */
+int uniter_gemm_debug_force(int cfg, int splits);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM family — bf16 operands, fp32 MFMA accumulation, fused epilogues.
+ * Replaces the cuBLAS calls behind nn.Linear in model/layer.py:76-78,112,140,153 (forward) and the
+ * autograd-generated dgrad / wgrad GEMMs of the same layers.
+ *   M = rows (tokens, B*L), K = in_features, N = out_features for the forward layer.
+ *   Requirements: N % 64 == 0, K % 64 == 0 for fwd/dgrad shapes; wgrad needs N % 64 == 0 and K % 64 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* y[M,N] = x[M,K] * w[N,K]^T + bias[N]        (bias may be NULL)                 layer.py:76-78 */
+int uniter_gemm_bias_fwd(const void* x, const void* w, const void* bias, void* y,
+                         int64_t M, int64_t N, int64_t K, void* stream);
+
+/* u = x*w^T + bias ; g = u*0.5*(1+erf(u/sqrt2))   writes both u (pre-activation, kept for backward)
+ * and g.                                                                    layer.py:31-37,139-142 */
+int uniter_gemm_bias_gelu_fwd(const void* x, const void* w, const void* bias, void* u, void* g,
+                              int64_t M, int64_t N, int64_t K, void* stream);
+
+/* z = dropout_p(x*w^T + bias) + resid     (the input of the following LayerNorm)
+ *                                                                      layer.py:111-115,152-156 */
+int uniter_gemm_bias_dropout_residual_fwd(const void* x, const void* w, const void* bias,
+                                          const void* resid, void* z,
+                                          int64_t M, int64_t N, int64_t K,
+                                          float p_drop, uint64_t seed, uint64_t offset, void* stream);
+
+/* dx[M,K] = dy[M,N] * w[N,K]  (+ resid[M,K] if resid != NULL)          autograd of layer.py:76-78 */
+int uniter_gemm_dgrad(const void* dy, const void* w, const void* resid, void* dx,
+                      int64_t M, int64_t N, int64_t K, void* stream);
+
+/* dpre[M,K] = (dy[M,N] * w[N,K]) .* gelu'(u[M,K])                      autograd of layer.py:139-142 */
+int uniter_gemm_dgrad_gelu(const void* dy, const void* w, const void* u, void* dpre,
+                           int64_t M, int64_t N, int64_t K, void* stream);
+
+/* dw[N,K] (+)= dy[M,N]^T * x[M,K] ; db[N] (+)= column sums of dy (db may be NULL).
+ * accumulate != 0 adds to the existing contents (gradient accumulation, pretrain.py:298-312).
+ * workspace: fp32 scratch of at least uniter_gemm_wgrad_workspace_bytes(M,N,K) bytes. */
+size_t uniter_gemm_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int uniter_gemm_wgrad(const void* dy, const void* x, void* dw, void* db,
+                      int64_t M, int64_t N, int64_t K, int accumulate,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused self-attention (scale + additive key mask + softmax + dropout + P·V), head_dim fixed at 64,
+ * L <= 256.  qkv is the fused projection output [B*L, 3H] = [Q | K | V], head h owns columns
+ * h*64..h*64+63 of each third.  mask_bias[B,L] fp32 is the reference's extended_attention_mask
+ * (1-m)*-10000 (model/model.py:342-345) without the two singleton dims.   model/layer.py:75-101
+ * ---------------------------------------------------------------------------------------------- */
+/* ctx[B*L,H] ; lse[B,heads,L] fp32 = log-sum-exp of the masked scaled scores (kept for backward). */
+int uniter_attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse,
+                         int64_t B, int64_t L, int64_t heads,
+                         float p_drop, uint64_t seed, uint64_t offset, void* stream);
+/* dqkv[B*L,3H] from dctx[B*L,H]; needs the forward's qkv, ctx, lse and the same (seed, offset). */
+int uniter_attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, const float* lse,
+                         const void* dctx, void* dqkv,
+                         int64_t B, int64_t L, int64_t heads,
+                         float p_drop, uint64_t seed, uint64_t offset, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm (apex FusedLayerNorm semantics: biased variance, eps inside the sqrt, fp32 statistics).
+ * Call sites: model/layer.py:108,149 ; model/model.py:229,252,253,258.
+ * ---------------------------------------------------------------------------------------------- */
+/* y = (z-mean)*rstd*gamma + beta ; mean/rstd [rows] fp32 are written for backward (may be NULL).
+ * If p_drop > 0 the dropout of the embedding blocks (model/model.py:230,259) is applied to y. */
+int uniter_layernorm_fwd(const void* z, const void* gamma, const void* beta, void* y,
+                         float* mean, float* rstd, int64_t rows, int64_t H, float eps,
+                         float p_drop, uint64_t seed, uint64_t offset, void* stream);
+
+/* Backward of  z = dropout_p(d) + r ; y = LN(z):
+ *   dz  [rows,H]  = dL/dz                       (gradient of the residual branch r)
+ *   dd  [rows,H]  = dz .* keep/(1-p)            (gradient of the dense output d; NULL or p==0 -> not written,
+ *                                                the caller then uses dz for both)
+ *   dgamma, dbeta [H] (+)= ...                  (bf16, accumulate flag)
+ *   dbias [H] (+)= column sums of dd            (bias gradient of the dense layer feeding the LN; may be NULL)
+ * dy_extra (may be NULL) is added to dy first (lets a caller fold a second incoming gradient in).
+ * drop_on_output != 0: the dropout was applied to the LN OUTPUT (embedding blocks, model/model.py:230,259):
+ *   dy is multiplied by the keep mask on load, dd is not produced.
+ * workspace: fp32 scratch >= uniter_layernorm_bwd_workspace_bytes(rows,H). */
+size_t uniter_layernorm_bwd_workspace_bytes(int64_t rows, int64_t H);
+int uniter_layernorm_bwd(const void* dy, const void* dy_extra, const void* z, const float* mean,
+                         const float* rstd, const void* gamma,
+                         void* dz, void* dd, void* dgamma, void* dbeta, void* dbias,
+                         int64_t rows, int64_t H, int accumulate,
+                         float p_drop, uint64_t seed, uint64_t offset, int drop_on_output,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[N] (+)= column sums of a[rows,N] (bias gradients of QKV / FFN1).  autograd of layer.py:76-78,140 */
+size_t uniter_colsum_workspace_bytes(int64_t rows, int64_t N);
+int uniter_colsum(const void* a, void* out, int64_t rows, int64_t N, int accumulate,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Embeddings                                                         model/model.py:217-272,321-334
+ * ---------------------------------------------------------------------------------------------- */
+/* fp32 scratch size (bytes) sufficient for every uniter_embed_*_bwd call on a [rows, N] gradient. */
+size_t uniter_embed_ws_bytes(int64_t rows, int64_t N);
+
+/* z[b,t,:] = word[ids[b,t]] + pos[position_ids[t]] + type[type_ids[b,t] or 0]   (pre-LayerNorm sum, bf16)
+ * ids/type_ids int64 [B,Lt]; position_ids int64 [Lt] (broadcast over the batch, data/mlm.py:115-116);
+ * type_ids may be NULL (= zeros, model/model.py:233-234).  The LayerNorm + dropout that follow are
+ * uniter_layernorm_fwd. */
+int uniter_embed_txt_fwd(const int64_t* ids, const int64_t* position_ids, const int64_t* type_ids,
+                         const void* word, const void* pos, const void* type, void* z,
+                         int64_t B, int64_t Lt, int64_t H, int64_t vocab, int64_t max_pos,
+                         int64_t n_types, void* stream);
+/* Scatter dz[B*Lt,H] into the three tables' gradients (always accumulating; deterministic: one owner
+ * per distinct table row, fp32 summation). */
+int uniter_embed_txt_bwd(const int64_t* ids, const int64_t* position_ids, const int64_t* type_ids,
+                         const void* dz, void* dword, void* dpos, void* dtype,
+                         int64_t B, int64_t Lt, int64_t H, int64_t vocab, int64_t max_pos,
+                         int64_t n_types, void* stream);
+
+/* f_out[rows,D] (bf16) = img_feat[rows,D] (fp32 or bf16, see feat_is_fp32) + (img_masks[row] ? mask_row[D] : 0)
+ *                                                                        model/model.py:262-265 */
+int uniter_embed_img_prep(const void* img_feat, int feat_is_fp32, const uint8_t* img_masks,
+                          const void* mask_row, void* f_out, int64_t rows, int64_t D, void* stream);
+
+/* pos_lin[rows,H] = pos_feat[rows,7] * wpos[H,7]^T + bpos   (K=7 is too thin for MFMA)  model.py:268 */
+int uniter_embed_pos_linear_fwd(const void* pos_feat, int feat_is_fp32, const void* wpos,
+                                const void* bpos, void* out, int64_t rows, int64_t H, void* stream);
+/* dwpos[H,7] (+)= d^T * pos_feat ; dbpos[H] (+)= colsum(d) */
+int uniter_embed_pos_linear_bwd(const void* pos_feat, int feat_is_fp32, const void* d,
+                                void* dwpos, void* dbpos, int64_t rows, int64_t H,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
+/* z[r,:] = a[r,:] + b[r,:] + type[type_ids[r] (or 1 if NULL)]   (input of the last image LayerNorm)
+ *                                                                model/model.py:269 ; :313-316 */
+int uniter_embed_img_combine_fwd(const void* a, const void* b, const int64_t* type_ids, const void* type,
+                                 void* z, int64_t rows, int64_t H, int64_t n_types, void* stream);
+/* dtype_table[n_types,H] += per-type column sums of dz[rows,H] (type_ids NULL -> all rows are type 1). */
+int uniter_embed_type_bwd(const void* dz, const int64_t* type_ids, void* dtype_table,
+                          int64_t rows, int64_t H, int64_t n_types, int default_type,
+                          void* workspace, size_t workspace_bytes, void* stream);
+/* dmask_row[D] += sum over rows with img_masks[row] != 0 of df[row,:]   (mask_embedding.weight[1]) */
+int uniter_embed_mask_bwd(const void* df, const uint8_t* img_masks, void* dmask_row,
+                          int64_t rows, int64_t D, void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[b,j,:] = cat(txt[b], img[b])[gather_index[b,j], :]                  model/model.py:330-333 */
+int uniter_embed_gather_fwd(const void* txt, const void* img, const int64_t* gather_index, void* out,
+                            int64_t B, int64_t Lt, int64_t Li, int64_t Lout, int64_t H, void* stream);
+/* dtxt / dimg = scatter-add of dout through gather_index (deterministic, overwrite semantics). */
+int uniter_embed_gather_bwd(const void* dout, const int64_t* gather_index, void* dtxt, void* dimg,
+                            int64_t B, int64_t Lt, int64_t Li, int64_t Lout, int64_t H, void* stream);
+
+/* mask_bias[B,L] fp32 = (1 - attn_masks[B,L]) * -10000                    model/model.py:342-345 */
+int uniter_mask_bias(const int64_t* attn_masks, float* mask_bias, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole-encoder entry points (one C call launches every kernel of layers [layer_begin, layer_end)).
+ * Replaces UniterEncoder.forward (model/model.py:282-292) -> BertLayer.forward (model/layer.py:166-170)
+ * and its autograd backward.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct UniterLayerParams {
+    /* parameters, bf16.  wqkv = [query.weight; key.weight; value.weight] stacked to [3H,H]
+     * (three separate nn.Linear in the reference, model/layer.py:64-66; the Python side keeps
+     * them as three named Parameters that are views of one buffer). */
+    const void *wqkv, *bqkv;          /* [3H,H], [3H]                attention.self.{query,key,value} */
+    const void *wo, *bo;              /* [H,H],  [H]                 attention.output.dense           */
+    const void *ln1_g, *ln1_b;        /* [H]                         attention.output.LayerNorm       */
+    const void *w1, *b1;              /* [I,H],  [I]                 intermediate.dense               */
+    const void *w2, *b2;              /* [H,I],  [H]                 output.dense                     */
+    const void *ln2_g, *ln2_b;        /* [H]                         output.LayerNorm                 */
+    /* gradients, bf16, same shapes; accumulated into (+=).  Unused by forward. */
+    void *g_wqkv, *g_bqkv, *g_wo, *g_bo, *g_ln1_g, *g_ln1_b, *g_w1, *g_b1, *g_w2, *g_b2, *g_ln2_g, *g_ln2_b;
+} UniterLayerParams;
+
+typedef struct UniterEncoderShape {
+    int64_t B, L, H, heads, I;
+    float p_hidden;      /* hidden_dropout_prob           (config/uniter-base.json:5) */
+    float p_attn;        /* attention_probs_dropout_prob  (config/uniter-base.json:2) */
+    float ln_eps;        /* 1e-12 (model/layer.py:108)    */
+    int32_t training;    /* 0: inference (no dropout, activations not kept) */
+} UniterEncoderShape;
+
+/* Bytes of saved activations per layer / of shared scratch, for the caller to allocate. */
+size_t uniter_encoder_layer_act_bytes(const UniterEncoderShape* s);
+size_t uniter_encoder_scratch_bytes(const UniterEncoderShape* s);
+/* Byte offset (inside one layer's activation block) of the layer OUTPUT y [B*L,H] bf16. */
+size_t uniter_encoder_layer_out_offset(const UniterEncoderShape* s);
+
+/* Forward of layers [layer_begin, layer_end).  x_in [B*L,H] is the input of layer_begin.
+ * acts: n_layers * uniter_encoder_layer_act_bytes() bytes (block l belongs to layer l);
+ * the output of layer l is at acts + l*act_bytes + out_offset.  scratch: uniter_encoder_scratch_bytes().
+ * Dropout stream for layer l uses offset + l*8 + site. */
+int uniter_encoder_forward(const UniterEncoderShape* s, const UniterLayerParams* layers,
+                           int32_t layer_begin, int32_t layer_end,
+                           const void* x_in, const float* mask_bias,
+                           void* acts, void* scratch, uint64_t seed, uint64_t offset, void* stream);
+
+/* Backward of layers [layer_begin, layer_end), run from layer_end-1 down to layer_begin.
+ * dy [B*L,H]: gradient w.r.t. the output of layer layer_end-1 (read only).
+ * dx [B*L,H]: receives the gradient w.r.t. x_in of layer_begin.
+ * Parameter gradients are ACCUMULATED into layers[l].g_*.  Needs the forward's acts and (seed, offset). */
+int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams* layers,
+                            int32_t layer_begin, int32_t layer_end,
+                            const void* x_in, const float* mask_bias, const void* dy, void* dx,
+                            void* acts, void* scratch, uint64_t seed, uint64_t offset, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused multi-tensor AdamW + global gradient norm / clipping.                 optim/adamw.py:40-103
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct UniterAdamTensor {
+    void*    param;      /* bf16 or fp32 (see param_is_bf16), updated in place                         */
+    const void* grad;    /* same dtype as param                                                       */
+    float*   master;     /* fp32 master copy (required when param is bf16, else NULL)                  */
+    float*   exp_avg;    /* fp32                                                                      */
+    float*   exp_avg_sq; /* fp32                                                                      */
+    int64_t  numel;
+    int32_t  group;      /* index into the per-group hyper-parameter arrays                           */
+    int32_t  param_is_bf16;
+} UniterAdamTensor;
+
+typedef struct UniterAdamGroup {
+    float lr, beta1, beta2, eps, weight_decay;
+    int32_t correct_bias;
+    int32_t step;        /* value of state['step'] AFTER this update (>= 1)                           */
+} UniterAdamGroup;
+
+/* Opaque plan: the tensor table lives on the device; build once, reuse every step. */
+int uniter_adamw_plan_create(const UniterAdamTensor* tensors, int64_t n_tensors, void** plan_out);
+int uniter_adamw_plan_destroy(void* plan);
+
+/* norm_out[0] = sqrt(sum g^2) * grad_scale ; norm_out[1] = clip coefficient
+ *   coef = grad_scale * min(1, max_norm / (norm + 1e-6))     (max_norm <= 0: coef = grad_scale)
+ * = torch.nn.utils.clip_grad_norm_ as called at pretrain.py:329-331, with the 1/world averaging of
+ * the allreduce (utils/distributed.py:35) foldable into grad_scale.  No host synchronisation. */
+int uniter_adamw_grad_norm(void* plan, float grad_scale, float max_norm, float* norm_out, void* stream);
+
+/* One AdamW update of every tensor of the plan.  clip_coef (device pointer, may be NULL = 1.0)
+ * multiplies every gradient element on the fly (fused clipping). */
+int uniter_adamw_step(void* plan, const UniterAdamGroup* groups, int32_t n_groups,
+                      const float* clip_coef, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * RCCL communicator (one process per GPU).                              utils/distributed.py:16-209
+ * The Python launcher exchanges the 128-byte unique id (rank 0 creates it, broadcasts it through the
+ * torch.distributed store) and each rank calls uniter_comm_init.
+ * ---------------------------------------------------------------------------------------------- */
+int uniter_comm_unique_id(uint8_t id_out[128]);
+int uniter_comm_init(const uint8_t id[128], int32_t rank, int32_t world, void** comm_out);
+int uniter_comm_destroy(void* comm);
+/* In-place sum-allreduce of a bf16 (dtype=0) or fp32 (dtype=1) buffer, then multiply by `scale`
+ * (1/world for Horovod's average, utils/distributed.py:35-36) as part of the consumer (see adamw). */
+int uniter_comm_allreduce(void* comm, void* buf, int64_t count, int32_t dtype, void* stream);
+int uniter_comm_broadcast(void* comm, void* buf, int64_t bytes, int32_t root, void* stream);
+int uniter_comm_allgather(void* comm, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNITER_HIP_H */

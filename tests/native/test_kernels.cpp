@@ -1,0 +1,720 @@
+// test_kernels.cpp — native (no Python) GPU check + micro-benchmark of libuniter_hip.so.
+//
+// Build:  python tests/native/build.py        Run (on a gfx950 box):  tests/native/build/test_kernels [--bench]
+// Every check compares the HIP kernel with a plain fp32 host loop on bf16-rounded inputs (the host
+// reference lives in THIS file, it is test code).  Exit code = number of failed checks.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/uniter_hip.h"
+
+#define HIPCHK(x)                                                                        \
+    do {                                                                                 \
+        hipError_t e_ = (x);                                                             \
+        if (e_ != hipSuccess) {                                                          \
+            fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(99);                                                                    \
+        }                                                                                \
+    } while (0)
+#define UHCHK(x)                                                                         \
+    do {                                                                                 \
+        int r_ = (x);                                                                    \
+        if (r_ != 0) {                                                                   \
+            fprintf(stderr, "uniter error %d (%s) at %s:%d\n", r_, uniter_hip_last_error(), __FILE__, __LINE__); \
+            exit(98);                                                                    \
+        }                                                                                \
+    } while (0)
+
+static int g_fail = 0;
+
+// ---------------------------------------------------------------------------------------------
+// host helpers
+// ---------------------------------------------------------------------------------------------
+static inline uint16_t f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf2f(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline float rbf(float f) { return bf2f(f2bf(f)); }
+
+static uint64_t g_rng = 0x9E3779B97F4A7C15ull;
+static inline uint32_t rnd32() {
+    g_rng ^= g_rng << 13; g_rng ^= g_rng >> 7; g_rng ^= g_rng << 17;
+    return (uint32_t)(g_rng >> 32);
+}
+static inline float rndu() { return (rnd32() >> 8) * (1.0f / 16777216.0f) * 2.f - 1.f; }   // [-1,1)
+
+struct HostBf {   // host mirror of a bf16 device tensor (values kept as the rounded floats)
+    std::vector<float> v;
+    std::vector<uint16_t> raw;
+    void fill(size_t n, float scale) {
+        v.resize(n); raw.resize(n);
+        for (size_t i = 0; i < n; ++i) { raw[i] = f2bf(rndu() * scale); v[i] = bf2f(raw[i]); }
+    }
+};
+
+template <typename T>
+static T* dalloc(size_t n) {
+    T* p = nullptr;
+    HIPCHK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
+    return p;
+}
+static uint16_t* upload(const HostBf& h) {
+    uint16_t* d = dalloc<uint16_t>(h.raw.size());
+    HIPCHK(hipMemcpy(d, h.raw.data(), h.raw.size() * 2, hipMemcpyHostToDevice));
+    return d;
+}
+static std::vector<float> download_bf(const uint16_t* d, size_t n) {
+    std::vector<uint16_t> r(n);
+    HIPCHK(hipMemcpy(r.data(), d, n * 2, hipMemcpyDeviceToHost));
+    std::vector<float> f(n);
+    for (size_t i = 0; i < n; ++i) f[i] = bf2f(r[i]);
+    return f;
+}
+static std::vector<float> download_f(const float* d, size_t n) {
+    std::vector<float> f(n);
+    HIPCHK(hipMemcpy(f.data(), d, n * 4, hipMemcpyDeviceToHost));
+    return f;
+}
+
+// compare with mixed tolerance |a-b| <= atol + rtol*|b|
+static bool check(const char* name, const std::vector<float>& got, const std::vector<float>& ref, float atol, float rtol) {
+    double maxerr = 0, maxref = 0;
+    size_t bad = 0, worst = 0;
+    for (size_t i = 0; i < ref.size(); ++i) {
+        const double e = fabs((double)got[i] - (double)ref[i]);
+        if (!(e <= atol + rtol * fabs(ref[i]))) { if (bad == 0 || e > maxerr) worst = i; ++bad; }
+        if (e > maxerr || e != e) maxerr = e;
+        maxref = std::max(maxref, (double)fabs(ref[i]));
+    }
+    const bool ok = bad == 0;
+    printf("[%s] %-52s n=%zu max|err|=%.3e max|ref|=%.3e bad=%zu", ok ? " OK " : "FAIL", name, ref.size(), maxerr, maxref, bad);
+    if (!ok) printf("  (worst idx %zu got %.6f ref %.6f)", worst, got[worst], ref[worst]);
+    printf("\n");
+    if (!ok) ++g_fail;
+    return ok;
+}
+
+// host Philox4x32-10, identical to common.cuh
+static void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+static float drop_mult(float p, uint64_t seed, uint64_t offset, uint64_t elem) {
+    if (p <= 0.f) return 1.f;
+    double t = (double)p * 4294967296.0;
+    const uint32_t thresh = (uint32_t)std::min(t, 4294967295.0);
+    uint32_t r[4];
+    const uint64_t idx4 = elem >> 2;
+    philox((uint32_t)idx4, (uint32_t)(idx4 >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    return r[elem & 3] >= thresh ? 1.0f / (1.0f - p) : 0.f;
+}
+static float gelu_h(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+static float gelu_grad_h(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+
+struct Timer {
+    hipEvent_t a, b;
+    Timer() { HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); }
+    template <typename F>
+    double run(F f, int warm = 3, int iters = 20) {
+        for (int i = 0; i < warm; ++i) f();
+        HIPCHK(hipEventRecord(a, 0));
+        for (int i = 0; i < iters; ++i) f();
+        HIPCHK(hipEventRecord(b, 0));
+        HIPCHK(hipEventSynchronize(b));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, a, b));
+        return ms * 1000.0 / iters;   // microseconds
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// probe kernels: MFMA fragment layout and ds_read_b64_tr_b16 semantics
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__global__ void probe_mfma(const uint16_t* A, const uint16_t* B, float* D) {
+    // A [16][32] row-major, B [32][16] row-major; hypothesis: lane l holds A[l&15][8*(l>>4)+j], B[8*(l>>4)+j][l&15];
+    // D[4*(l>>4)+r][l&15]
+    const int l = threadIdx.x, g = l >> 4, i = l & 15;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = (short)A[i * 32 + 8 * g + j]; b[j] = (short)B[(8 * g + j) * 16 + i]; }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) D[(4 * g + r) * 16 + i] = acc[r];
+}
+__global__ void probe_tr(const uint16_t* src, uint16_t* out) {
+    // LDS block [4][16] row-major; lane i of each 16-lane group gives the address of row (i>>2), cols 4*(i&3)..;
+    // hypothesis: lane i receives column i (rows 0..3).  Four groups read four different blocks.
+    __shared__ __attribute__((aligned(16))) uint16_t lds[4 * 64];
+    const int l = threadIdx.x;
+    for (int k = l; k < 256; k += 64) lds[k] = src[k];
+    __syncthreads();
+    const int g = l >> 4, i = l & 15;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const uint16_t* p = lds + g * 64 + (i >> 2) * 16 + (i & 3) * 4;
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+    for (int j = 0; j < 4; ++j) out[l * 4 + j] = (uint16_t)v[j];
+}
+
+static void run_probes() {
+    printf("== probes ==\n");
+    {
+        HostBf A, B;
+        A.fill(16 * 32, 1.f); B.fill(32 * 16, 1.f);
+        uint16_t* dA = upload(A); uint16_t* dB = upload(B);
+        float* dD = dalloc<float>(256);
+        hipLaunchKernelGGL(probe_mfma, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+        HIPCHK(hipDeviceSynchronize());
+        std::vector<float> got = download_f(dD, 256), ref(256);
+        for (int m = 0; m < 16; ++m)
+            for (int n = 0; n < 16; ++n) {
+                float s = 0;
+                for (int k = 0; k < 32; ++k) s += A.v[m * 32 + k] * B.v[k * 16 + n];
+                ref[m * 16 + n] = s;
+            }
+        check("mfma_f32_16x16x32_bf16 fragment layout", got, ref, 1e-4f, 1e-4f);
+    }
+    {
+        std::vector<uint16_t> src(256);
+        for (int k = 0; k < 256; ++k) src[k] = (uint16_t)k;
+        uint16_t* dS = dalloc<uint16_t>(256);
+        uint16_t* dO = dalloc<uint16_t>(256);
+        HIPCHK(hipMemcpy(dS, src.data(), 512, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(probe_tr, dim3(1), dim3(64), 0, 0, dS, dO);
+        HIPCHK(hipDeviceSynchronize());
+        std::vector<uint16_t> o(256);
+        HIPCHK(hipMemcpy(o.data(), dO, 512, hipMemcpyDeviceToHost));
+        std::vector<float> got(256), ref(256);
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 4; ++j) {
+                got[l * 4 + j] = o[l * 4 + j];
+                ref[l * 4 + j] = (float)((l >> 4) * 64 + j * 16 + (l & 15));
+            }
+        if (!check("ds_read_b64_tr_b16 semantics", got, ref, 0.f, 0.f)) {
+            printf("   raw dump (lane: 4 values):\n");
+            for (int l = 0; l < 64; ++l) printf("   %2d: %3d %3d %3d %3d\n", l, o[l * 4], o[l * 4 + 1], o[l * 4 + 2], o[l * 4 + 3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEMM family
+// ---------------------------------------------------------------------------------------------
+static void host_gemm_nt(const std::vector<float>& X, const std::vector<float>& W, std::vector<float>& Y, int M, int N, int K) {
+    Y.assign((size_t)M * N, 0.f);
+    for (int m = 0; m < M; ++m)
+        for (int n = 0; n < N; ++n) {
+            float s = 0;
+            const float* x = &X[(size_t)m * K];
+            const float* w = &W[(size_t)n * K];
+            for (int k = 0; k < K; ++k) s += x[k] * w[k];
+            Y[(size_t)m * N + n] = s;
+        }
+}
+
+static void test_gemm(int M, int N, int K, int cfg, int splits) {
+    char tag[128];
+    HostBf X, W, Bv, R, DY;
+    X.fill((size_t)M * K, 1.f); W.fill((size_t)N * K, 0.5f); Bv.fill(N, 1.f); R.fill((size_t)M * N, 1.f); DY.fill((size_t)M * N, 1.f);
+    uint16_t *dX = upload(X), *dW = upload(W), *dB = upload(Bv), *dR = upload(R), *dDY = upload(DY);
+    uint16_t* dY = dalloc<uint16_t>((size_t)M * N);
+    uint16_t* dY2 = dalloc<uint16_t>((size_t)M * N);
+    uniter_gemm_debug_force(cfg, splits);
+
+    std::vector<float> acc;
+    host_gemm_nt(X.v, W.v, acc, M, N, K);
+    // --- fwd bias ---
+    UHCHK(uniter_gemm_bias_fwd(dX, dW, dB, dY, M, N, K, 0));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<float> ref((size_t)M * N);
+    for (int m = 0; m < M; ++m) for (int n = 0; n < N; ++n) ref[(size_t)m * N + n] = acc[(size_t)m * N + n] + Bv.v[n];
+    snprintf(tag, sizeof tag, "gemm_bias_fwd M%d N%d K%d cfg%d", M, N, K, cfg);
+    check(tag, download_bf(dY, (size_t)M * N), ref, 0.02f * sqrtf((float)K) * 0.05f + 0.02f, 0.01f);
+    // --- fwd bias + gelu ---
+    UHCHK(uniter_gemm_bias_gelu_fwd(dX, dW, dB, dY, dY2, M, N, K, 0));
+    HIPCHK(hipDeviceSynchronize());
+    {
+        std::vector<float> gu = download_bf(dY, (size_t)M * N), gg = download_bf(dY2, (size_t)M * N), rg((size_t)M * N);
+        for (size_t i = 0; i < rg.size(); ++i) rg[i] = gelu_h(gu[i]);   // g must be gelu of the stored (rounded) u
+        snprintf(tag, sizeof tag, "gemm_bias_gelu_fwd(u) M%d N%d K%d cfg%d", M, N, K, cfg);
+        check(tag, gu, ref, 0.05f, 0.01f);
+        snprintf(tag, sizeof tag, "gemm_bias_gelu_fwd(g=gelu(u)) cfg%d", cfg);
+        check(tag, gg, rg, 0.01f, 0.01f);
+    }
+    // --- fwd bias + dropout + residual ---
+    for (float p : {0.0f, 0.25f}) {
+        const uint64_t seed = 1234, off = 77;
+        UHCHK(uniter_gemm_bias_dropout_residual_fwd(dX, dW, dB, dR, dY, M, N, K, p, seed, off, 0));
+        HIPCHK(hipDeviceSynchronize());
+        std::vector<float> rz((size_t)M * N);
+        for (int m = 0; m < M; ++m)
+            for (int n = 0; n < N; ++n) {
+                const size_t i = (size_t)m * N + n;
+                rz[i] = ref[i] * drop_mult(p, seed, off, i) + R.v[i];
+            }
+        snprintf(tag, sizeof tag, "gemm_bias_dropout_residual_fwd p=%.2f cfg%d", p, cfg);
+        check(tag, download_bf(dY, (size_t)M * N), rz, 0.06f, 0.01f);
+    }
+    // --- dgrad: dx[M,K] = dy[M,N] * w[N,K] (+resid) ---  (needs K % 64 == 0)
+    if (K % 64 == 0) {
+        uint16_t* dDX = dalloc<uint16_t>((size_t)M * K);
+        HostBf RX, U;
+        RX.fill((size_t)M * K, 1.f); U.fill((size_t)M * K, 2.f);
+        uint16_t *dRX = upload(RX), *dU = upload(U);
+        std::vector<float> dxr((size_t)M * K, 0.f);
+        for (int m = 0; m < M; ++m)
+            for (int n = 0; n < N; ++n) {
+                const float d = DY.v[(size_t)m * N + n];
+                const float* w = &W.v[(size_t)n * K];
+                float* o = &dxr[(size_t)m * K];
+                for (int k = 0; k < K; ++k) o[k] += d * w[k];
+            }
+        UHCHK(uniter_gemm_dgrad(dDY, dW, nullptr, dDX, M, N, K, 0));
+        HIPCHK(hipDeviceSynchronize());
+        snprintf(tag, sizeof tag, "gemm_dgrad M%d N%d K%d cfg%d", M, N, K, cfg);
+        check(tag, download_bf(dDX, (size_t)M * K), dxr, 0.02f * sqrtf((float)N) * 0.05f + 0.03f, 0.01f);
+        UHCHK(uniter_gemm_dgrad(dDY, dW, dRX, dDX, M, N, K, 0));
+        HIPCHK(hipDeviceSynchronize());
+        std::vector<float> r2(dxr);
+        for (size_t i = 0; i < r2.size(); ++i) r2[i] += RX.v[i];
+        snprintf(tag, sizeof tag, "gemm_dgrad+resid cfg%d", cfg);
+        check(tag, download_bf(dDX, (size_t)M * K), r2, 0.05f, 0.01f);
+        UHCHK(uniter_gemm_dgrad_gelu(dDY, dW, dU, dDX, M, N, K, 0));
+        HIPCHK(hipDeviceSynchronize());
+        for (size_t i = 0; i < r2.size(); ++i) r2[i] = dxr[i] * gelu_grad_h(U.v[i]);
+        snprintf(tag, sizeof tag, "gemm_dgrad_gelu cfg%d", cfg);
+        check(tag, download_bf(dDX, (size_t)M * K), r2, 0.05f, 0.01f);
+        HIPCHK(hipFree(dDX)); HIPCHK(hipFree(dRX)); HIPCHK(hipFree(dU));
+    }
+    // --- wgrad: dw[N,K] (+)= dy^T x ; db = colsum(dy) ---
+    if (K % 64 == 0) {
+        const size_t wsb = uniter_gemm_wgrad_workspace_bytes(M, N, K);
+        void* ws = dalloc<char>(wsb);
+        HostBf Old, OldB;
+        Old.fill((size_t)N * K, 1.f); OldB.fill(N, 1.f);
+        uint16_t *dDW = upload(Old), *dDB = upload(OldB);
+        std::vector<float> dwr((size_t)N * K, 0.f), dbr(N, 0.f);
+        for (int m = 0; m < M; ++m)
+            for (int n = 0; n < N; ++n) {
+                const float d = DY.v[(size_t)m * N + n];
+                dbr[n] += d;
+                const float* x = &X.v[(size_t)m * K];
+                float* o = &dwr[(size_t)n * K];
+                for (int k = 0; k < K; ++k) o[k] += d * x[k];
+            }
+        UHCHK(uniter_gemm_wgrad(dDY, dX, dDW, dDB, M, N, K, 0, ws, wsb, 0));
+        HIPCHK(hipDeviceSynchronize());
+        snprintf(tag, sizeof tag, "gemm_wgrad M%d N%d K%d cfg%d splits%d", M, N, K, cfg, splits);
+        const float tol = 0.02f * sqrtf((float)M) + 0.05f;
+        check(tag, download_bf(dDW, (size_t)N * K), dwr, tol, 0.01f);
+        check("  wgrad bias (colsum)", download_bf(dDB, N), dbr, tol, 0.01f);
+        // accumulate on top of the result just written
+        std::vector<float> cur = download_bf(dDW, (size_t)N * K), curb = download_bf(dDB, N);
+        UHCHK(uniter_gemm_wgrad(dDY, dX, dDW, dDB, M, N, K, 1, ws, wsb, 0));
+        HIPCHK(hipDeviceSynchronize());
+        for (size_t i = 0; i < cur.size(); ++i) cur[i] += dwr[i];
+        for (int n = 0; n < N; ++n) curb[n] += dbr[n];
+        check("  wgrad accumulate", download_bf(dDW, (size_t)N * K), cur, 2 * tol, 0.02f);
+        check("  wgrad bias accumulate", download_bf(dDB, N), curb, 2 * tol, 0.02f);
+        HIPCHK(hipFree(ws)); HIPCHK(hipFree(dDW)); HIPCHK(hipFree(dDB));
+    }
+    uniter_gemm_debug_force(-1, -1);
+    HIPCHK(hipFree(dX)); HIPCHK(hipFree(dW)); HIPCHK(hipFree(dB)); HIPCHK(hipFree(dR)); HIPCHK(hipFree(dDY));
+    HIPCHK(hipFree(dY)); HIPCHK(hipFree(dY2));
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention
+// ---------------------------------------------------------------------------------------------
+static void test_attention(int B, int L, int heads, float p) {
+    const int H = heads * 64;
+    const size_t T = (size_t)B * L;
+    char tag[128];
+    HostBf QKV, DO;
+    QKV.fill(T * 3 * H, 1.5f); DO.fill(T * H, 1.f);
+    std::vector<float> mask(B * L);
+    for (int b = 0; b < B; ++b) {
+        const int valid = L - (b * 7) % (L / 2);
+        for (int k = 0; k < L; ++k) mask[b * L + k] = k < valid ? 0.f : -10000.f;
+    }
+    uint16_t *dQKV = upload(QKV), *dDO = upload(DO);
+    float* dMask = dalloc<float>(B * L);
+    HIPCHK(hipMemcpy(dMask, mask.data(), mask.size() * 4, hipMemcpyHostToDevice));
+    uint16_t* dCtx = dalloc<uint16_t>(T * H);
+    uint16_t* dDQKV = dalloc<uint16_t>(T * 3 * H);
+    float* dLse = dalloc<float>((size_t)B * heads * L);
+    HIPCHK(hipMemset(dDQKV, 0xff, T * 3 * H * 2));
+    const uint64_t seed = 99, off = 5;
+    UHCHK(uniter_attention_fwd(dQKV, dMask, dCtx, dLse, B, L, heads, p, seed, off, 0));
+    UHCHK(uniter_attention_bwd(dQKV, dMask, dCtx, dLse, dDO, dDQKV, B, L, heads, p, seed, off, 0));
+    HIPCHK(hipDeviceSynchronize());
+
+    std::vector<float> ctx_ref(T * H, 0.f), lse_ref((size_t)B * heads * L), dqkv_ref(T * 3 * H, 0.f);
+    std::vector<float> P((size_t)L * L), Pd((size_t)L * L), dPd((size_t)L * L);
+    for (int b = 0; b < B; ++b)
+        for (int h = 0; h < heads; ++h) {
+            const int bh = b * heads + h;
+            auto q = [&](int i, int d) { return QKV.v[((size_t)b * L + i) * 3 * H + h * 64 + d]; };
+            auto k = [&](int i, int d) { return QKV.v[((size_t)b * L + i) * 3 * H + H + h * 64 + d]; };
+            auto v = [&](int i, int d) { return QKV.v[((size_t)b * L + i) * 3 * H + 2 * H + h * 64 + d]; };
+            for (int i = 0; i < L; ++i) {
+                float mx = -INFINITY;
+                for (int j = 0; j < L; ++j) {
+                    float s = 0;
+                    for (int d = 0; d < 64; ++d) s += q(i, d) * k(j, d);
+                    s = s * 0.125f + mask[b * L + j];
+                    P[(size_t)i * L + j] = s;
+                    mx = fmaxf(mx, s);
+                }
+                float sum = 0;
+                for (int j = 0; j < L; ++j) { P[(size_t)i * L + j] = expf(P[(size_t)i * L + j] - mx); sum += P[(size_t)i * L + j]; }
+                lse_ref[(size_t)bh * L + i] = mx + logf(sum);
+                for (int j = 0; j < L; ++j) {
+                    P[(size_t)i * L + j] /= sum;
+                    const uint64_t elem = ((uint64_t)bh * L + i) * 256 + j;
+                    Pd[(size_t)i * L + j] = P[(size_t)i * L + j] * drop_mult(p, seed, off, elem);
+                }
+                for (int d = 0; d < 64; ++d) {
+                    float o = 0;
+                    for (int j = 0; j < L; ++j) o += rbf(Pd[(size_t)i * L + j]) * v(j, d);
+                    ctx_ref[((size_t)b * L + i) * H + h * 64 + d] = o;
+                }
+            }
+            // backward
+            for (int i = 0; i < L; ++i) {
+                float Di = 0;
+                for (int d = 0; d < 64; ++d) Di += DO.v[((size_t)b * L + i) * H + h * 64 + d] * rbf(ctx_ref[((size_t)b * L + i) * H + h * 64 + d]);
+                for (int j = 0; j < L; ++j) {
+                    float dp = 0;
+                    for (int d = 0; d < 64; ++d) dp += DO.v[((size_t)b * L + i) * H + h * 64 + d] * v(j, d);
+                    const uint64_t elem = ((uint64_t)bh * L + i) * 256 + j;
+                    const float mult = drop_mult(p, seed, off, elem);
+                    dPd[(size_t)i * L + j] = P[(size_t)i * L + j] * (dp * mult - Di) * 0.125f;   // dS * scale
+                }
+            }
+            for (int i = 0; i < L; ++i)
+                for (int d = 0; d < 64; ++d) {
+                    float dq = 0;
+                    for (int j = 0; j < L; ++j) dq += dPd[(size_t)i * L + j] * k(j, d);
+                    dqkv_ref[((size_t)b * L + i) * 3 * H + h * 64 + d] = dq;
+                }
+            for (int j = 0; j < L; ++j)
+                for (int d = 0; d < 64; ++d) {
+                    float dk = 0, dv = 0;
+                    for (int i = 0; i < L; ++i) {
+                        dk += dPd[(size_t)i * L + j] * q(i, d);
+                        dv += Pd[(size_t)i * L + j] * DO.v[((size_t)b * L + i) * H + h * 64 + d];
+                    }
+                    dqkv_ref[((size_t)b * L + j) * 3 * H + H + h * 64 + d] = dk;
+                    dqkv_ref[((size_t)b * L + j) * 3 * H + 2 * H + h * 64 + d] = dv;
+                }
+        }
+    snprintf(tag, sizeof tag, "attention_fwd ctx B%d L%d heads%d p=%.2f", B, L, heads, p);
+    check(tag, download_bf(dCtx, T * H), ctx_ref, 0.03f, 0.02f);
+    snprintf(tag, sizeof tag, "attention_fwd lse B%d L%d", B, L);
+    check(tag, download_f(dLse, (size_t)B * heads * L), lse_ref, 1e-3f, 1e-4f);
+    snprintf(tag, sizeof tag, "attention_bwd dqkv B%d L%d heads%d p=%.2f", B, L, heads, p);
+    check(tag, download_bf(dDQKV, T * 3 * H), dqkv_ref, 0.06f, 0.03f);
+    HIPCHK(hipFree(dQKV)); HIPCHK(hipFree(dDO)); HIPCHK(hipFree(dMask)); HIPCHK(hipFree(dCtx)); HIPCHK(hipFree(dDQKV)); HIPCHK(hipFree(dLse));
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm / colsum
+// ---------------------------------------------------------------------------------------------
+static void test_layernorm(int rows, int H, float p, int post) {
+    char tag[128];
+    HostBf Z, G, Bt, DY;
+    Z.fill((size_t)rows * H, 2.f); G.fill(H, 1.f); Bt.fill(H, 1.f); DY.fill((size_t)rows * H, 1.f);
+    for (auto& g : G.v) g += 1.0f;
+    for (size_t i = 0; i < G.v.size(); ++i) { G.raw[i] = f2bf(G.v[i]); G.v[i] = bf2f(G.raw[i]); }
+    uint16_t *dZ = upload(Z), *dG = upload(G), *dB = upload(Bt), *dDY = upload(DY);
+    uint16_t* dY = dalloc<uint16_t>((size_t)rows * H);
+    uint16_t* dDZ = dalloc<uint16_t>((size_t)rows * H);
+    uint16_t* dDD = dalloc<uint16_t>((size_t)rows * H);
+    uint16_t *dDG = dalloc<uint16_t>(H), *dDB = dalloc<uint16_t>(H), *dDBias = dalloc<uint16_t>(H);
+    float *dMean = dalloc<float>(rows), *dRstd = dalloc<float>(rows);
+    const float eps = 1e-12f;
+    const uint64_t seed = 7, off = 3;
+    UHCHK(uniter_layernorm_fwd(dZ, dG, dB, dY, dMean, dRstd, rows, H, eps, post ? p : 0.f, seed, off, 0));
+    const size_t wsb = uniter_layernorm_bwd_workspace_bytes(rows, H);
+    void* ws = dalloc<char>(wsb);
+    UHCHK(uniter_layernorm_bwd(dDY, nullptr, dZ, dMean, dRstd, dG, dDZ, dDD, dDG, dDB, dDBias, rows, H, 0, p, seed, off, post, ws, wsb, 0));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<float> yr((size_t)rows * H), dzr((size_t)rows * H), ddr((size_t)rows * H), dgr(H, 0.f), dbr(H, 0.f), dbias(H, 0.f);
+    for (int r = 0; r < rows; ++r) {
+        double mean = 0, var = 0;
+        for (int c = 0; c < H; ++c) mean += Z.v[(size_t)r * H + c];
+        mean /= H;
+        for (int c = 0; c < H; ++c) { const double d = Z.v[(size_t)r * H + c] - mean; var += d * d; }
+        var /= H;
+        const float rstd = (float)(1.0 / sqrt(var + eps));
+        double c1 = 0, c2 = 0;
+        std::vector<float> xh(H), gy(H), dyv(H);
+        for (int c = 0; c < H; ++c) {
+            const size_t i = (size_t)r * H + c;
+            xh[c] = (float)((Z.v[i] - mean) * rstd);
+            float y = xh[c] * G.v[c] + Bt.v[c];
+            if (post && p > 0) y = rbf(y) * drop_mult(p, seed, off, i);
+            yr[i] = y;
+            dyv[c] = DY.v[i] * (post ? drop_mult(p, seed, off, i) : 1.f);
+            gy[c] = dyv[c] * G.v[c];
+            c1 += gy[c]; c2 += gy[c] * xh[c];
+            dgr[c] += dyv[c] * xh[c]; dbr[c] += dyv[c];
+        }
+        c1 /= H; c2 /= H;
+        for (int c = 0; c < H; ++c) {
+            const size_t i = (size_t)r * H + c;
+            dzr[i] = rstd * (gy[c] - (float)c1 - xh[c] * (float)c2);
+            ddr[i] = rbf(dzr[i]) * (post ? 1.f : drop_mult(p, seed, off, i));
+            dbias[c] += ddr[i];
+        }
+    }
+    snprintf(tag, sizeof tag, "layernorm_fwd rows%d H%d p=%.2f post=%d", rows, H, p, post);
+    check(tag, download_bf(dY, (size_t)rows * H), yr, 0.03f, 0.01f);
+    snprintf(tag, sizeof tag, "layernorm_bwd dz rows%d H%d", rows, H);
+    check(tag, download_bf(dDZ, (size_t)rows * H), dzr, 0.03f, 0.02f);
+    if (p > 0 && !post) check("  layernorm_bwd dd (dropout-masked)", download_bf(dDD, (size_t)rows * H), ddr, 0.03f, 0.02f);
+    const float tol = 0.02f * sqrtf((float)rows) + 0.05f;
+    check("  layernorm_bwd dgamma", download_bf(dDG, H), dgr, tol, 0.01f);
+    check("  layernorm_bwd dbeta", download_bf(dDB, H), dbr, tol, 0.01f);
+    if (!post) check("  layernorm_bwd dbias", download_bf(dDBias, H), dbias, tol, 0.01f);
+    HIPCHK(hipFree(dZ)); HIPCHK(hipFree(dG)); HIPCHK(hipFree(dB)); HIPCHK(hipFree(dDY)); HIPCHK(hipFree(dY)); HIPCHK(hipFree(dDZ));
+    HIPCHK(hipFree(dDD)); HIPCHK(hipFree(dDG)); HIPCHK(hipFree(dDB)); HIPCHK(hipFree(dDBias)); HIPCHK(hipFree(dMean)); HIPCHK(hipFree(dRstd)); HIPCHK(hipFree(ws));
+}
+
+// ---------------------------------------------------------------------------------------------
+// AdamW
+// ---------------------------------------------------------------------------------------------
+static void test_adamw() {
+    const int NT = 3;
+    const int64_t numel[NT] = {4096 * 3 + 5, 768, 100003};
+    std::vector<UniterAdamTensor> tab(NT);
+    std::vector<std::vector<float>> hp(NT), hg(NT), hm(NT), hv(NT);
+    std::vector<HostBf> hgbf(NT);
+    for (int t = 0; t < NT; ++t) {
+        const size_t n = (size_t)numel[t];
+        hp[t].resize(n); hm[t].assign(n, 0.f); hv[t].assign(n, 0.f);
+        for (auto& x : hp[t]) x = rndu();
+        const bool bf = (t != 1);
+        float* master = dalloc<float>(n);
+        HIPCHK(hipMemcpy(master, hp[t].data(), n * 4, hipMemcpyHostToDevice));
+        float *m = dalloc<float>(n), *v = dalloc<float>(n);
+        HIPCHK(hipMemset(m, 0, n * 4)); HIPCHK(hipMemset(v, 0, n * 4));
+        tab[t].numel = numel[t]; tab[t].group = t == 2 ? 1 : 0; tab[t].param_is_bf16 = bf;
+        tab[t].exp_avg = m; tab[t].exp_avg_sq = v;
+        if (bf) {
+            hgbf[t].fill(n, 0.1f);
+            hg[t] = hgbf[t].v;
+            tab[t].grad = upload(hgbf[t]);
+            tab[t].param = dalloc<uint16_t>(n);
+            tab[t].master = master;
+        } else {
+            hg[t].resize(n);
+            for (auto& x : hg[t]) x = rndu() * 0.1f;
+            float* g = dalloc<float>(n);
+            HIPCHK(hipMemcpy(g, hg[t].data(), n * 4, hipMemcpyHostToDevice));
+            tab[t].grad = g; tab[t].param = master; tab[t].master = nullptr;
+        }
+    }
+    void* plan = nullptr;
+    UHCHK(uniter_adamw_plan_create(tab.data(), NT, &plan));
+    float* dnorm = dalloc<float>(2);
+    UniterAdamGroup groups[2] = {{3e-3f, 0.9f, 0.98f, 1e-6f, 0.01f, 1, 1}, {1e-3f, 0.9f, 0.98f, 1e-6f, 0.0f, 1, 1}};
+    const float max_norm = 2.0f, gscale = 0.5f;
+    double sq = 0;
+    for (int t = 0; t < NT; ++t) for (float g : hg[t]) sq += (double)g * g;
+    const float norm = (float)sqrt(sq) * gscale;
+    float coef = gscale;
+    if (max_norm / (norm + 1e-6f) < 1.f) coef = gscale * max_norm / (norm + 1e-6f);
+    for (int step = 1; step <= 2; ++step) {
+        groups[0].step = groups[1].step = step;
+        UHCHK(uniter_adamw_grad_norm(plan, gscale, max_norm, dnorm, 0));
+        UHCHK(uniter_adamw_step(plan, groups, 2, dnorm + 1, 0));
+        for (int t = 0; t < NT; ++t) {
+            const UniterAdamGroup& g = groups[tab[t].group];
+            const double ss = g.lr * sqrt(1.0 - pow((double)g.beta2, step)) / (1.0 - pow((double)g.beta1, step));
+            for (size_t i = 0; i < hp[t].size(); ++i) {
+                const float ge = hg[t][i] * coef;
+                hm[t][i] = g.beta1 * hm[t][i] + (1.f - g.beta1) * ge;
+                hv[t][i] = g.beta2 * hv[t][i] + (1.f - g.beta2) * ge * ge;
+                hp[t][i] = hp[t][i] - (float)ss * (hm[t][i] / (sqrtf(hv[t][i]) + g.eps));
+                if (g.weight_decay > 0) hp[t][i] = hp[t][i] - g.lr * g.weight_decay * hp[t][i];
+            }
+        }
+    }
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<float> nr = download_f(dnorm, 2);
+    check("adamw grad_norm / clip coef", nr, std::vector<float>{norm, coef}, 1e-4f, 1e-4f);
+    for (int t = 0; t < NT; ++t) {
+        char tag[64];
+        const size_t n = (size_t)numel[t];
+        snprintf(tag, sizeof tag, "adamw tensor %d fp32 state (p)", t);
+        check(tag, download_f(tab[t].param_is_bf16 ? tab[t].master : (float*)tab[t].param, n), hp[t], 1e-6f, 1e-5f);
+        snprintf(tag, sizeof tag, "adamw tensor %d exp_avg_sq", t);
+        check(tag, download_f(tab[t].exp_avg_sq, n), hv[t], 1e-9f, 1e-5f);
+        if (tab[t].param_is_bf16) {
+            std::vector<float> r(n);
+            for (size_t i = 0; i < n; ++i) r[i] = rbf(hp[t][i]);
+            snprintf(tag, sizeof tag, "adamw tensor %d bf16 copy", t);
+            check(tag, download_bf((uint16_t*)tab[t].param, n), r, 1e-2f, 1e-2f);
+        }
+    }
+    UHCHK(uniter_adamw_plan_destroy(plan));
+}
+
+// ---------------------------------------------------------------------------------------------
+// benchmark: kernels at the UNITER-base 60+36 / batch-32 shapes, and the whole 12-layer encoder
+// ---------------------------------------------------------------------------------------------
+static void bench(int B, int L, int H, int heads, int I, int layers) {
+    printf("== bench B%d L%d H%d I%d layers%d ==\n", B, L, H, I, layers);
+    const int64_t T = (int64_t)B * L;
+    Timer tm;
+    HostBf X, W, Bv;
+    X.fill((size_t)T * I, 1.f); W.fill((size_t)I * H * 3, 0.05f); Bv.fill(I, 0.1f);
+    uint16_t *dX = upload(X), *dW = upload(W), *dB = upload(Bv);
+    uint16_t* dY = dalloc<uint16_t>((size_t)T * I);
+    uint16_t* dY2 = dalloc<uint16_t>((size_t)T * I);
+    uint16_t* dG = dalloc<uint16_t>((size_t)I * H * 3);
+    const size_t wsb = (size_t)8 * I * H * 4 * 3;
+    void* ws = dalloc<char>(wsb);
+    struct Shape { const char* name; int64_t M, N, K; } shapes[] = {
+        {"qkv   ", T, 3 * (int64_t)H, H}, {"out   ", T, H, H}, {"ffn1  ", T, I, H}, {"ffn2  ", T, H, I}};
+    for (auto& s : shapes) {
+        const double fl = 2.0 * s.M * s.N * s.K;
+        for (int cfg = -1; cfg < 4; ++cfg) {
+            uniter_gemm_debug_force(cfg, -1);
+            double t1 = tm.run([&] { UHCHK(uniter_gemm_bias_fwd(dX, dW, dB, dY, s.M, s.N, s.K, 0)); });
+            double t2 = tm.run([&] { UHCHK(uniter_gemm_dgrad(dY, dW, nullptr, dY2, s.M, s.N, s.K, 0)); });
+            printf("  %s cfg%2d  fwd %8.1f us %7.1f TF | dgrad %8.1f us %7.1f TF", s.name, cfg, t1, fl / t1 * 1e-6, t2, fl / t2 * 1e-6);
+            for (int sp : {1, 2, 4, 8}) {
+                uniter_gemm_debug_force(cfg, cfg < 0 ? -1 : sp);
+                double t3 = tm.run([&] { UHCHK(uniter_gemm_wgrad(dY, dX, dG, nullptr, s.M, s.N, s.K, 1, ws, wsb, 0)); });
+                printf(" | wgrad s%d %7.1f us %6.1f TF", cfg < 0 ? -1 : sp, t3, fl / t3 * 1e-6);
+                if (cfg < 0) break;
+            }
+            printf("\n");
+        }
+    }
+    uniter_gemm_debug_force(-1, -1);
+    {
+        double t1 = tm.run([&] { UHCHK(uniter_gemm_bias_gelu_fwd(dX, dW, dB, dY, dY2, T, I, H, 0)); });
+        double t2 = tm.run([&] { UHCHK(uniter_gemm_bias_dropout_residual_fwd(dX, dW, dB, dY2, dY, T, H, I, 0.1f, 1, 2, 0)); });
+        double t3 = tm.run([&] { UHCHK(uniter_gemm_dgrad_gelu(dY, dW, dX, dY2, T, H, I, 0)); });
+        printf("  ffn1+gelu %.1f us | ffn2+drop+res %.1f us | dgrad_gelu %.1f us\n", t1, t2, t3);
+    }
+    {
+        float* dMask = dalloc<float>((size_t)B * L);
+        HIPCHK(hipMemset(dMask, 0, (size_t)B * L * 4));
+        float* dLse = dalloc<float>((size_t)B * heads * L);
+        for (float p : {0.f, 0.1f}) {
+            double t1 = tm.run([&] { UHCHK(uniter_attention_fwd(dX, dMask, dY, dLse, B, L, heads, p, 1, 2, 0)); });
+            double t2 = tm.run([&] { UHCHK(uniter_attention_bwd(dX, dMask, dY, dLse, dY2, dW, B, L, heads, p, 1, 2, 0)); });
+            const double fl = 4.0 * T * L * H;
+            printf("  attention p=%.1f fwd %.1f us (%.1f TF) | bwd %.1f us (%.1f TF)\n", p, t1, fl / t1 * 1e-6, t2, 2.5 * fl / t2 * 1e-6);
+        }
+        float *dMean = dalloc<float>(T), *dRstd = dalloc<float>(T);
+        double t1 = tm.run([&] { UHCHK(uniter_layernorm_fwd(dX, dB, dB, dY, dMean, dRstd, T, H, 1e-12f, 0.f, 0, 0, 0)); });
+        const size_t lws = uniter_layernorm_bwd_workspace_bytes(T, H);
+        double t2 = tm.run([&] { UHCHK(uniter_layernorm_bwd(dX, nullptr, dY, dMean, dRstd, dB, dY2, dY2 + T * H, dG, dG + H, dG + 2 * H, T, H, 1, 0.1f, 1, 2, 0, ws, lws, 0)); });
+        double t3 = tm.run([&] { UHCHK(uniter_colsum(dX, dG, T, I, 1, ws, wsb, 0)); });
+        printf("  layernorm fwd %.1f us (%.0f GB/s) | bwd %.1f us (%.0f GB/s) | colsum[T,I] %.1f us (%.0f GB/s)\n", t1,
+               2.0 * T * H * 2 / t1 * 1e-3, t2, 4.0 * T * H * 2 / t2 * 1e-3, t3, (double)T * I * 2 / t3 * 1e-3);
+    }
+    // whole encoder
+    {
+        UniterEncoderShape sh{B, L, H, heads, I, 0.1f, 0.1f, 1e-12f, 1};
+        const size_t act = uniter_encoder_layer_act_bytes(&sh), scr = uniter_encoder_scratch_bytes(&sh);
+        char* acts = dalloc<char>(act * layers);
+        char* scratch = dalloc<char>(scr);
+        const size_t per = (size_t)3 * H * H + 3 * H + (size_t)H * H + H + 2 * H + (size_t)I * H + I + (size_t)H * I + H + 2 * H;
+        HostBf P;
+        P.fill(per, 0.03f);
+        std::vector<UniterLayerParams> lp(layers);
+        for (int l = 0; l < layers; ++l) {
+            uint16_t* p = upload(P);
+            uint16_t* g = dalloc<uint16_t>(per);
+            HIPCHK(hipMemset(g, 0, per * 2));
+            size_t o = 0;
+            auto nxt = [&](size_t n) { size_t r = o; o += n; return r; };
+            size_t o_wqkv = nxt((size_t)3 * H * H), o_bqkv = nxt(3 * H), o_wo = nxt((size_t)H * H), o_bo = nxt(H), o_g1 = nxt(H), o_b1n = nxt(H);
+            size_t o_w1 = nxt((size_t)I * H), o_b1 = nxt(I), o_w2 = nxt((size_t)H * I), o_b2 = nxt(H), o_g2 = nxt(H), o_b2n = nxt(H);
+            lp[l] = UniterLayerParams{p + o_wqkv, p + o_bqkv, p + o_wo, p + o_bo, p + o_g1, p + o_b1n, p + o_w1, p + o_b1, p + o_w2, p + o_b2, p + o_g2, p + o_b2n,
+                                      g + o_wqkv, g + o_bqkv, g + o_wo, g + o_bo, g + o_g1, g + o_b1n, g + o_w1, g + o_b1, g + o_w2, g + o_b2, g + o_g2, g + o_b2n};
+        }
+        float* dMask = dalloc<float>((size_t)B * L);
+        HIPCHK(hipMemset(dMask, 0, (size_t)B * L * 4));
+        uint16_t* dDx = dalloc<uint16_t>((size_t)T * H);
+        double tf = tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 10);
+        double tb = tm.run([&] { UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0)); }, 2, 10);
+        const double flf = (double)layers * (24.0 * T * H * H + 4.0 * T * L * H);
+        printf("  ENCODER fwd %.1f us (%.1f TF) | bwd %.1f us (%.1f TF) | fwd+bwd %.1f us = %.1f TF = %.1f%% of 2.5 PF ; %.0f ex/s\n", tf,
+               flf / tf * 1e-6, tb, 2 * flf / tb * 1e-6, tf + tb, 3 * flf / (tf + tb) * 1e-6, 3 * flf / (tf + tb) * 1e-6 / 2500 * 100,
+               B / ((tf + tb) * 1e-6));
+    }
+}
+
+int main(int argc, char** argv) {
+    bool do_bench = false, quick = false;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--bench")) do_bench = true;
+        if (!strcmp(argv[i], "--quick")) quick = true;
+    }
+    int32_t info[4];
+    UHCHK(uniter_hip_device_info(info));
+    printf("device: %d CUs, wave %d, LDS/CU %d, gfx%d, abi %d\n", info[0], info[1], info[2], info[3], uniter_hip_abi_version());
+    run_probes();
+    printf("== gemm ==\n");
+    for (int cfg = 0; cfg < 4; ++cfg) test_gemm(200, 256, 128, cfg, cfg == 0 ? 1 : 2);
+    test_gemm(77, 128, 192, 3, 3);
+    test_gemm(384, 384, 320, -1, -1);
+    if (!quick) test_gemm(1000, 768, 768, -1, -1);
+    printf("== attention ==\n");
+    test_attention(2, 96, 2, 0.f);
+    test_attention(3, 40, 1, 0.f);
+    test_attention(2, 96, 2, 0.2f);
+    test_attention(2, 178, 2, 0.1f);
+    test_attention(1, 250, 1, 0.f);
+    test_attention(2, 17, 1, 0.1f);
+    printf("== layernorm ==\n");
+    test_layernorm(37, 128, 0.f, 0);
+    test_layernorm(300, 768, 0.2f, 0);
+    test_layernorm(300, 768, 0.2f, 1);
+    test_layernorm(129, 1024, 0.f, 0);
+    test_layernorm(64, 2048, 0.1f, 0);
+    printf("== adamw ==\n");
+    test_adamw();
+    if (do_bench) {
+        bench(32, 96, 768, 12, 3072, 12);
+    }
+    printf("== %d check(s) failed ==\n", g_fail);
+    return g_fail;
+}

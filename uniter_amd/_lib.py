@@ -1,0 +1,160 @@
+"""ctypes binding of libuniter_hip.so (the C ABI declared in include/uniter_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call returns a non-zero
+status, an exception is raised.  The library is built in-tree by ``uniter_amd/csrc/build.py``
+(``__graft_entry__.build()``) into ``uniter_amd/csrc/build/libuniter_hip.so``.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint8,
+                    c_uint64, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "build", "libuniter_hip.so")
+
+
+class UniterHipError(RuntimeError):
+    pass
+
+
+class UniterLayerParams(Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2", "ln2_g", "ln2_b",
+        "g_wqkv", "g_bqkv", "g_wo", "g_bo", "g_ln1_g", "g_ln1_b", "g_w1", "g_b1", "g_w2", "g_b2",
+        "g_ln2_g", "g_ln2_b")]
+
+
+class UniterEncoderShape(Structure):
+    _fields_ = [("B", c_int64), ("L", c_int64), ("H", c_int64), ("heads", c_int64), ("I", c_int64),
+                ("p_hidden", c_float), ("p_attn", c_float), ("ln_eps", c_float), ("training", c_int32)]
+
+
+class UniterAdamTensor(Structure):
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("master", c_void_p), ("exp_avg", c_void_p),
+                ("exp_avg_sq", c_void_p), ("numel", c_int64), ("group", c_int32), ("param_is_bf16", c_int32)]
+
+
+class UniterAdamGroup(Structure):
+    _fields_ = [("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
+                ("weight_decay", c_float), ("correct_bias", c_int32), ("step", c_int32)]
+
+
+_P = c_void_p
+_I = c_int64
+# name -> (restype, argtypes).  Must list EVERY symbol of include/uniter_hip.h (checked by tests).
+SIGNATURES = {
+    "uniter_hip_abi_version": (c_int, []),
+    "uniter_hip_last_error": (c_char_p, []),
+    "uniter_hip_device_info": (c_int, [POINTER(c_int32)]),
+    "uniter_gemm_debug_force": (c_int, [c_int, c_int]),
+    "uniter_gemm_bias_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "uniter_gemm_bias_gelu_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "uniter_gemm_bias_dropout_residual_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
+    "uniter_gemm_dgrad": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "uniter_gemm_dgrad_gelu": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "uniter_gemm_wgrad_workspace_bytes": (c_size_t, [_I, _I, _I]),
+    "uniter_gemm_wgrad": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_int, _P, c_size_t, _P]),
+    "uniter_attention_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
+    "uniter_attention_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
+    "uniter_layernorm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, c_float, c_float, c_uint64, c_uint64, _P]),
+    "uniter_layernorm_bwd_workspace_bytes": (c_size_t, [_I, _I]),
+    "uniter_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, c_int,
+                                     c_float, c_uint64, c_uint64, c_int, _P, c_size_t, _P]),
+    "uniter_colsum_workspace_bytes": (c_size_t, [_I, _I]),
+    "uniter_colsum": (c_int, [_P, _P, _I, _I, c_int, _P, c_size_t, _P]),
+    "uniter_embed_ws_bytes": (c_size_t, [_I, _I]),
+    "uniter_embed_txt_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "uniter_embed_txt_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "uniter_embed_img_prep": (c_int, [_P, c_int, _P, _P, _P, _I, _I, _P]),
+    "uniter_embed_pos_linear_fwd": (c_int, [_P, c_int, _P, _P, _P, _I, _I, _P]),
+    "uniter_embed_pos_linear_bwd": (c_int, [_P, c_int, _P, _P, _P, _I, _I, _P, c_size_t, _P]),
+    "uniter_embed_img_combine_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "uniter_embed_type_bwd": (c_int, [_P, _P, _P, _I, _I, _I, c_int, _P, c_size_t, _P]),
+    "uniter_embed_mask_bwd": (c_int, [_P, _P, _P, _I, _I, _P, c_size_t, _P]),
+    "uniter_embed_gather_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "uniter_embed_gather_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "uniter_mask_bias": (c_int, [_P, _P, _I, _P]),
+    "uniter_encoder_layer_act_bytes": (c_size_t, [POINTER(UniterEncoderShape)]),
+    "uniter_encoder_scratch_bytes": (c_size_t, [POINTER(UniterEncoderShape)]),
+    "uniter_encoder_layer_out_offset": (c_size_t, [POINTER(UniterEncoderShape)]),
+    "uniter_encoder_forward": (c_int, [POINTER(UniterEncoderShape), POINTER(UniterLayerParams), c_int32, c_int32,
+                                       _P, _P, _P, _P, c_uint64, c_uint64, _P]),
+    "uniter_encoder_backward": (c_int, [POINTER(UniterEncoderShape), POINTER(UniterLayerParams), c_int32, c_int32,
+                                        _P, _P, _P, _P, _P, _P, c_uint64, c_uint64, _P]),
+    "uniter_adamw_plan_create": (c_int, [POINTER(UniterAdamTensor), _I, POINTER(c_void_p)]),
+    "uniter_adamw_plan_destroy": (c_int, [_P]),
+    "uniter_adamw_grad_norm": (c_int, [_P, c_float, c_float, _P, _P]),
+    "uniter_adamw_step": (c_int, [_P, POINTER(UniterAdamGroup), c_int32, _P, _P]),
+    "uniter_comm_unique_id": (c_int, [POINTER(c_uint8)]),
+    "uniter_comm_init": (c_int, [POINTER(c_uint8), c_int32, c_int32, POINTER(c_void_p)]),
+    "uniter_comm_destroy": (c_int, [_P]),
+    "uniter_comm_allreduce": (c_int, [_P, _P, _I, c_int32, _P]),
+    "uniter_comm_broadcast": (c_int, [_P, _P, _I, c_int32, _P]),
+    "uniter_comm_allgather": (c_int, [_P, _P, _P, _I, _P]),
+}
+
+# functions that return a size / pointer rather than a status code
+_NO_STATUS = {"uniter_hip_abi_version", "uniter_hip_last_error", "uniter_gemm_wgrad_workspace_bytes",
+              "uniter_layernorm_bwd_workspace_bytes", "uniter_colsum_workspace_bytes", "uniter_embed_ws_bytes",
+              "uniter_encoder_layer_act_bytes", "uniter_encoder_scratch_bytes", "uniter_encoder_layer_out_offset"}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises UniterHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UniterHipError(
+            "libuniter_hip.so not found at %s — build it with `python uniter_amd/csrc/build.py` "
+            "(there is no CPU / PyTorch fallback for the encoder hot path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class _Checked:
+    """Attribute access returns a wrapper that raises on a non-zero status."""
+
+    def __getattr__(self, name):
+        lib = load()
+        fn = getattr(lib, name)
+        if name in _NO_STATUS:
+            wrapper = fn
+        else:
+            def wrapper(*args, _fn=fn, _name=name):
+                rc = _fn(*args)
+                if rc != 0:
+                    msg = lib.uniter_hip_last_error()
+                    raise UniterHipError("%s failed with status %d: %s" % (
+                        _name, rc, msg.decode("utf-8", "replace") if msg else ""))
+                return 0
+        setattr(self, name, wrapper)
+        return wrapper
+
+
+C = _Checked()
+
+
+def ptr(t):
+    """Device pointer of a (contiguous) torch tensor, or None."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def device_info():
+    out = (c_int32 * 4)()
+    C.uniter_hip_device_info(out)
+    return {"cus": out[0], "wave": out[1], "lds_per_cu": out[2], "gfx": out[3]}

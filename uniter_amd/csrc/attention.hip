@@ -1,0 +1,420 @@
+// attention.hip — fused BERT self-attention forward / backward for gfx950 (head_dim 64, L <= 256).
+//
+// Reference arithmetic: model/layer.py:75-101 (BertSelfAttention.forward)
+//   S = Q K^T / sqrt(dh) + mask ; P = dropout(softmax(S)) ; ctx = P V, heads merged back to [B,L,H].
+//
+// One workgroup per (batch, head).  K and V of that head live in LDS for the whole block; each wave
+// owns 16-query tiles.  Scores are computed TRANSPOSED (S^T = K Q^T) so that the softmax axis (keys)
+// runs over a lane's registers plus the 4 lane groups, and the accumulator registers of two adjacent
+// key tiles are directly the MFMA operand of the P·V product (no LDS round trip for P).  V^T / K^T /
+// Q^T / dO^T operands come from ds_read_b64_tr_b16.  The backward pass recomputes P from the saved
+// log-sum-exp and makes two sweeps: query-tile owners produce dQ, key-tile owners produce dK and dV
+// (scores recomputed in the other orientation instead of transposing through LDS).
+//
+// LDS tile layout (all tiles): [rows][64] bf16, 8-byte chunk ch of row r stored at ch ^ (((r>>1)&3)<<2):
+// conflict-free for both ds_read_b128 row fragments and the transposed 8-byte reads used here.
+#include "common.cuh"
+#include "kernels.h"
+
+namespace {
+
+constexpr int DH = 64;
+constexpr int LMAX = 256;
+
+__device__ __forceinline__ int at_off8(int r, int ch8) { return r * 64 + ((ch8 ^ (((r >> 1) & 3) << 2)) << 2); }
+
+__device__ __forceinline__ bf16x8 at_frag(const bf16_t* tile, int row, int ks, int g) {
+    return *reinterpret_cast<const bf16x8*>(tile + at_off8(row, 2 * (ks * 4 + g)));
+}
+__device__ __forceinline__ s16x4 at_read_tr(const bf16_t* p) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+}
+// transposed fragment: 8 "row" values (rows 32u+4g+{0..3} and 32u+16+4g+{0..3}) of column dt*16+i
+__device__ __forceinline__ bf16x8 at_frag_tr(const bf16_t* tile, int u, int dt, int g, int i) {
+    const int j = i >> 2, q = i & 3;
+    const int r0 = 32 * u + 4 * g + j;
+    const int ch = dt * 4 + q;
+    const s16x4 lo = at_read_tr(tile + at_off8(r0, ch));
+    const s16x4 hi = at_read_tr(tile + at_off8(r0 + 16, ch));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 pack_frag(const float (&a)[4], const float (&b)[4]) {
+    u32x4 w;
+    w[0] = pack_bf16x2(a[0], a[1]); w[1] = pack_bf16x2(a[2], a[3]);
+    w[2] = pack_bf16x2(b[0], b[1]); w[3] = pack_bf16x2(b[2], b[3]);
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+// copy rows [0,Lp) x 64 columns starting at src (row stride ld) into an LDS tile, zero beyond L
+__device__ __forceinline__ void load_tile(bf16_t* tile, const bf16_t* src, int64_t ld, int L, int Lp) {
+    for (int idx = threadIdx.x; idx < Lp * 8; idx += blockDim.x) {
+        const int row = idx >> 3, c = idx & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < L) v = *reinterpret_cast<const u32x4*>(src + (int64_t)row * ld + c * 8);
+        *reinterpret_cast<u32x4*>(tile + at_off8(row, 2 * c)) = v;
+    }
+}
+
+struct AttnArgs {
+    const bf16_t* qkv;
+    const float* mask_bias;
+    bf16_t* ctx;        // fwd: out ; bwd: forward output (for D = rowsum(dO*O))
+    float* lse;
+    const bf16_t* dctx;
+    bf16_t* dqkv;
+    int B, L, heads, Lp;
+    DropoutCfg drop;
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int MAXKT>
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* Vs = Ks + p.Lp * 64;
+    float* mb = reinterpret_cast<float*>(Vs + p.Lp * 64);
+
+    const int bh = blockIdx.x;
+    const int b = bh / p.heads, h = bh % p.heads;
+    const int H = p.heads * DH;
+    const int L = p.L, Lp = p.Lp;
+    const int64_t ld = 3 * (int64_t)H;
+    const bf16_t* base = p.qkv + (int64_t)b * L * ld + h * DH;
+
+    load_tile(Ks, base + H, ld, L, Lp);
+    load_tile(Vs, base + 2 * H, ld, L, Lp);
+    for (int k = threadIdx.x; k < Lp; k += blockDim.x)
+        mb[k] = (k < L) ? p.mask_bias[(int64_t)b * L + k] : -INFINITY;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int nkt = Lp >> 4;           // key tiles (even)
+    const int nqt = (L + 15) >> 4;
+
+    for (int qt = wid; qt < nqt; qt += nw) {
+        const int q = qt * 16 + i;
+        bf16x8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (q < L) v = *reinterpret_cast<const u32x4*>(base + (int64_t)q * ld + ks * 32 + g * 8);
+            qf[ks] = __builtin_bit_cast(bf16x8, v);
+        }
+        // S^T tiles: lane holds keys kt*16+4g+{0..3} of query i
+        f32x4 s[MAXKT];
+#pragma unroll
+        for (int kt = 0; kt < MAXKT; ++kt) {
+            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kt < nkt) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Ks, kt * 16 + i, ks, g), qf[ks], s[kt], 0, 0, 0);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < MAXKT; ++kt) {
+            if (kt < nkt) {
+                const f32x4 mv = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[kt][r] = s[kt][r] * 0.125f + mv[r];
+                    mx = fmaxf(mx, s[kt][r]);
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < MAXKT; ++kt) {
+            if (kt < nkt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __expf(s[kt][r] - mx);
+                    s[kt][r] = e;
+                    sum += e;
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 16, WAVE);
+        sum += __shfl_xor(sum, 32, WAVE);
+        const float inv = 1.0f / sum;
+        if (g == 0 && q < L && p.lse != nullptr) p.lse[(int64_t)bh * L + q] = mx + __logf(sum);
+
+        const bool drop = p.drop.p > 0.f;
+        const uint64_t drow = ((uint64_t)bh * (uint64_t)L + (uint64_t)q) * (LMAX / 4);
+#pragma unroll
+        for (int kt = 0; kt < MAXKT; ++kt) {
+            if (kt < nkt) {
+                float mult[4] = {1.f, 1.f, 1.f, 1.f};
+                if (drop) dropout_mult4(p.drop, drow + (uint64_t)(kt * 4 + g), mult);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[kt][r] = s[kt][r] * inv * mult[r];
+            }
+        }
+        // O^T[d][query] = sum_keys V^T[d][key] * P^T[key][query]
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < MAXKT / 2; ++u) {
+            if (2 * u < nkt) {
+                const float a4[4] = {s[2 * u][0], s[2 * u][1], s[2 * u][2], s[2 * u][3]};
+                const float b4[4] = {s[2 * u + 1][0], s[2 * u + 1][1], s[2 * u + 1][2], s[2 * u + 1][3]};
+                const bf16x8 pf = pack_frag(a4, b4);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Vs, u, dt, g, i), pf, o[dt], 0, 0, 0);
+            }
+        }
+        if (q < L) {
+            bf16_t* dst = p.ctx + ((int64_t)b * L + q) * H + h * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const float v[4] = {o[dt][0], o[dt][1], o[dt][2], o[dt][3]};
+                *reinterpret_cast<u32x2*>(dst + dt * 16) = pack4(v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int Lp = p.Lp, L = p.L;
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* Ks = Qs + Lp * 64;
+    bf16_t* Vs = Ks + Lp * 64;
+    bf16_t* Os = Vs + Lp * 64;            // dO
+    float* mb = reinterpret_cast<float*>(Os + Lp * 64);
+    float* lse_s = mb + Lp;
+    float* D_s = lse_s + Lp;
+
+    const int bh = blockIdx.x;
+    const int b = bh / p.heads, h = bh % p.heads;
+    const int H = p.heads * DH;
+    const int64_t ld = 3 * (int64_t)H;
+    const bf16_t* base = p.qkv + (int64_t)b * L * ld + h * DH;
+    const bf16_t* dO = p.dctx + (int64_t)b * L * H + h * DH;
+    const bf16_t* O = p.ctx + (int64_t)b * L * H + h * DH;
+
+    load_tile(Qs, base, ld, L, Lp);
+    load_tile(Ks, base + H, ld, L, Lp);
+    load_tile(Vs, base + 2 * H, ld, L, Lp);
+    load_tile(Os, dO, H, L, Lp);
+    for (int k = threadIdx.x; k < Lp; k += blockDim.x) {
+        mb[k] = (k < L) ? p.mask_bias[(int64_t)b * L + k] : -INFINITY;
+        lse_s[k] = (k < L) ? p.lse[(int64_t)bh * L + k] : INFINITY;
+    }
+    // D[q] = sum_d dO[q][d] * O[q][d]
+    for (int idx = threadIdx.x; idx < Lp * 8; idx += blockDim.x) {
+        const int row = idx >> 3, c = idx & 7;
+        float part = 0.f;
+        if (row < L) {
+            float a[8], o[8];
+            unpack8(*reinterpret_cast<const u32x4*>(dO + (int64_t)row * H + c * 8), a);
+            unpack8(*reinterpret_cast<const u32x4*>(O + (int64_t)row * H + c * 8), o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part += a[e] * o[e];
+        }
+        part += __shfl_xor(part, 1, WAVE);
+        part += __shfl_xor(part, 2, WAVE);
+        part += __shfl_xor(part, 4, WAVE);
+        if (c == 0) D_s[row] = part;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int npair = Lp >> 5;             // pairs of 16-row tiles
+    const int nt = (L + 15) >> 4;          // tiles that contain real rows
+    const bool drop = p.drop.p > 0.f;
+
+    // ---- sweep 1: query-tile owners -> dQ ----
+    for (int qt = wid; qt < nt; qt += nw) {
+        const int q = qt * 16 + i;
+        const bf16x8 qf0 = at_frag(Qs, q, 0, g), qf1 = at_frag(Qs, q, 1, g);
+        const bf16x8 of0 = at_frag(Os, q, 0, g), of1 = at_frag(Os, q, 1, g);
+        const float lse_q = lse_s[q], D_q = D_s[q];
+        const uint64_t drow = ((uint64_t)bh * (uint64_t)L + (uint64_t)q) * (LMAX / 4);
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < npair; ++u) {
+            float ds[2][4];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int kt = 2 * u + hf;
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Ks, kt * 16 + i, 0, g), qf0, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Ks, kt * 16 + i, 1, g), qf1, s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Vs, kt * 16 + i, 0, g), of0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Vs, kt * 16 + i, 1, g), of1, dp, 0, 0, 0);
+                const f32x4 mv = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
+                float mult[4] = {1.f, 1.f, 1.f, 1.f};
+                if (drop) dropout_mult4(p.drop, drow + (uint64_t)(kt * 4 + g), mult);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = __expf(s[r] * 0.125f + mv[r] - lse_q);
+                    ds[hf][r] = pr * (dp[r] * mult[r] - D_q) * 0.125f;
+                }
+            }
+            const bf16x8 dsf = pack_frag(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Ks, u, dt, g, i), dsf, dq[dt], 0, 0, 0);
+        }
+        if (q < L) {
+            bf16_t* dst = p.dqkv + ((int64_t)b * L + q) * ld + h * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const float v[4] = {dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]};
+                *reinterpret_cast<u32x2*>(dst + dt * 16) = pack4(v);
+            }
+        }
+    }
+
+    // ---- sweep 2: key-tile owners -> dK, dV ----
+    for (int kt = wid; kt < nt; kt += nw) {
+        const int key = kt * 16 + i;
+        const bf16x8 kf0 = at_frag(Ks, key, 0, g), kf1 = at_frag(Ks, key, 1, g);
+        const bf16x8 vf0 = at_frag(Vs, key, 0, g), vf1 = at_frag(Vs, key, 1, g);
+        const float mb_k = mb[key];
+        f32x4 dk[4], dv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int u = 0; u < npair; ++u) {
+            float ds[2][4], pd[2][4];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int qt = 2 * u + hf;
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                // S[query 4g+r][key i]
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Qs, qt * 16 + i, 0, g), kf0, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Qs, qt * 16 + i, 1, g), kf1, s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Os, qt * 16 + i, 0, g), vf0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Os, qt * 16 + i, 1, g), vf1, dp, 0, 0, 0);
+                const int qb = qt * 16 + 4 * g;
+                const f32x4 lv = *reinterpret_cast<const f32x4*>(lse_s + qb);
+                const f32x4 Dv = *reinterpret_cast<const f32x4*>(D_s + qb);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float mult = 1.f;
+                    if (drop)
+                        mult = dropout_mult1(p.drop,
+                                             ((uint64_t)bh * (uint64_t)L + (uint64_t)(qb + r)) * (LMAX / 4) + (uint64_t)(key >> 2),
+                                             key & 3);
+                    const float pr = __expf(s[r] * 0.125f + mb_k - lv[r]);
+                    pd[hf][r] = pr * mult;
+                    ds[hf][r] = pr * (dp[r] * mult - Dv[r]) * 0.125f;
+                }
+            }
+            const bf16x8 pdf = pack_frag(pd[0], pd[1]);
+            const bf16x8 dsf = pack_frag(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Os, u, dt, g, i), pdf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Qs, u, dt, g, i), dsf, dk[dt], 0, 0, 0);
+            }
+        }
+        if (key < L) {
+            bf16_t* dst = p.dqkv + ((int64_t)b * L + key) * ld + h * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const float kv[4] = {dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]};
+                const float vv[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
+                *reinterpret_cast<u32x2*>(dst + H + dt * 16) = pack4(kv);
+                *reinterpret_cast<u32x2*>(dst + 2 * H + dt * 16) = pack4(vv);
+            }
+        }
+    }
+}
+
+int pick_waves(int nt) {
+    const int rounds = (nt + 7) / 8;
+    for (int w = 1; w <= 8; ++w)
+        if ((nt + w - 1) / w == rounds) return w < 2 ? 2 : w;
+    return 8;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) { uh_set_error("attention: hipFuncSetAttribute(%zu) -> %s", bytes, hipGetErrorString(e)); return (int)e; }
+    }
+    return 0;
+}
+
+}  // namespace
+
+namespace uh {
+
+static int check(int64_t B, int64_t L, int64_t heads) {
+    if (B <= 0 || L <= 0 || heads <= 0) { uh_set_error("attention: non-positive dimension"); return -1; }
+    if (L > LMAX) { uh_set_error("attention: L=%lld exceeds the supported maximum %d", (long long)L, LMAX); return -1; }
+    if (B * heads > INT32_MAX) { uh_set_error("attention: grid too large"); return -1; }
+    return 0;
+}
+
+int attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse,
+                  int64_t B, int64_t L, int64_t heads, const DropoutCfg& drop, hipStream_t st) {
+    if (check(B, L, heads)) return -1;
+    AttnArgs a{};
+    a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = lse;
+    a.dctx = nullptr; a.dqkv = nullptr;
+    a.B = (int)B; a.L = (int)L; a.heads = (int)heads; a.Lp = (int)((L + 31) / 32 * 32);
+    a.drop = drop;
+    const int nkt = a.Lp / 16;
+    const int nw = pick_waves((int)((L + 15) / 16));
+    const size_t lds = (size_t)a.Lp * 64 * 2 * 2 + (size_t)a.Lp * 4;
+    dim3 grid((unsigned)(B * heads)), block(nw * 64);
+    int rc;
+    if (nkt <= 6) {
+        if ((rc = set_lds(attn_fwd_kernel<6>, lds))) return rc;
+        hipLaunchKernelGGL(attn_fwd_kernel<6>, grid, block, lds, st, a);
+    } else if (nkt <= 8) {
+        if ((rc = set_lds(attn_fwd_kernel<8>, lds))) return rc;
+        hipLaunchKernelGGL(attn_fwd_kernel<8>, grid, block, lds, st, a);
+    } else if (nkt <= 12) {
+        if ((rc = set_lds(attn_fwd_kernel<12>, lds))) return rc;
+        hipLaunchKernelGGL(attn_fwd_kernel<12>, grid, block, lds, st, a);
+    } else {
+        if ((rc = set_lds(attn_fwd_kernel<16>, lds))) return rc;
+        hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, block, lds, st, a);
+    }
+    UH_LAUNCH_CHECK();
+    return 0;
+}
+
+int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, const float* lse,
+                  const void* dctx, void* dqkv, int64_t B, int64_t L, int64_t heads,
+                  const DropoutCfg& drop, hipStream_t st) {
+    if (check(B, L, heads)) return -1;
+    AttnArgs a{};
+    a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)const_cast<void*>(ctx);
+    a.lse = const_cast<float*>(lse); a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv;
+    a.B = (int)B; a.L = (int)L; a.heads = (int)heads; a.Lp = (int)((L + 31) / 32 * 32);
+    a.drop = drop;
+    const int nw = pick_waves((int)((L + 15) / 16));
+    const size_t lds = (size_t)a.Lp * 64 * 2 * 4 + (size_t)a.Lp * 4 * 3;
+    int rc;
+    if ((rc = set_lds(attn_bwd_kernel, lds))) return rc;
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * heads)), dim3(nw * 64), lds, st, a);
+    UH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace uh

@@ -1,0 +1,155 @@
+// capi.hip — extern "C" entry points of libuniter_hip.so for the single-kernel operations
+// (GEMM family, attention, LayerNorm, column sums) plus status plumbing.  See include/uniter_hip.h.
+#include "common.cuh"
+#include "kernels.h"
+#include "../../include/uniter_hip.h"
+
+#include <cstdarg>
+#include <cstdio>
+
+namespace {
+thread_local char g_err[512] = {0};
+}
+
+void uh_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+extern "C" {
+
+int uniter_hip_abi_version(void) { return UNITER_HIP_ABI_VERSION; }
+const char* uniter_hip_last_error(void) { return g_err; }
+
+int uniter_hip_device_info(int32_t out[4]) {
+    UH_CHECK_ARG(out != nullptr, "null pointer");
+    int dev = 0;
+    UH_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    UH_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    out[0] = prop.multiProcessorCount;
+    out[1] = prop.warpSize;
+    out[2] = (int32_t)prop.maxSharedMemoryPerMultiProcessor;
+    int arch = 0;
+    const char* n = prop.gcnArchName;   // "gfx950:sramecc+:xnack-"
+    if (n[0] == 'g' && n[1] == 'f' && n[2] == 'x') {
+        for (const char* c = n + 3; *c && *c != ':'; ++c) {
+            int d = (*c >= '0' && *c <= '9') ? (*c - '0') : ((*c >= 'a' && *c <= 'f') ? (*c - 'a' + 10) : -1);
+            if (d < 0) break;
+            arch = arch * (d > 9 ? 16 : 10) + d;
+        }
+    }
+    out[3] = arch;
+    uh::gemm_set_num_cus(prop.multiProcessorCount);
+    return 0;
+}
+
+// test / tuning hook: force a GEMM tile config (0..3, -1 = heuristic) and split count (-1 = heuristic)
+int uniter_gemm_debug_force(int cfg, int splits) {
+    uh::gemm_debug_force(cfg, splits);
+    return 0;
+}
+
+int uniter_gemm_bias_fwd(const void* x, const void* w, const void* bias, void* y,
+                         int64_t M, int64_t N, int64_t K, void* stream) {
+    UH_CHECK_ARG(x && w && y, "null pointer");
+    return uh::gemm_fwd(uh::GEMM_EPI_BIAS, x, w, bias, nullptr, y, nullptr, M, N, K, make_dropout(0.f, 0, 0), (hipStream_t)stream);
+}
+
+int uniter_gemm_bias_gelu_fwd(const void* x, const void* w, const void* bias, void* u, void* g,
+                              int64_t M, int64_t N, int64_t K, void* stream) {
+    UH_CHECK_ARG(x && w && u && g, "null pointer");
+    return uh::gemm_fwd(uh::GEMM_EPI_BIAS_GELU, x, w, bias, nullptr, u, g, M, N, K, make_dropout(0.f, 0, 0), (hipStream_t)stream);
+}
+
+int uniter_gemm_bias_dropout_residual_fwd(const void* x, const void* w, const void* bias,
+                                          const void* resid, void* z, int64_t M, int64_t N, int64_t K,
+                                          float p_drop, uint64_t seed, uint64_t offset, void* stream) {
+    UH_CHECK_ARG(x && w && z, "null pointer");
+    UH_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "dropout probability must be in [0,1)");
+    return uh::gemm_fwd(uh::GEMM_EPI_BIAS_DROP_RES, x, w, bias, resid, z, nullptr, M, N, K, make_dropout(p_drop, seed, offset),
+                        (hipStream_t)stream);
+}
+
+int uniter_gemm_dgrad(const void* dy, const void* w, const void* resid, void* dx,
+                      int64_t M, int64_t N, int64_t K, void* stream) {
+    UH_CHECK_ARG(dy && w && dx, "null pointer");
+    return uh::gemm_dgrad(uh::GEMM_EPI_RES, dy, w, resid, dx, M, N, K, (hipStream_t)stream);
+}
+
+int uniter_gemm_dgrad_gelu(const void* dy, const void* w, const void* u, void* dpre,
+                           int64_t M, int64_t N, int64_t K, void* stream) {
+    UH_CHECK_ARG(dy && w && u && dpre, "null pointer");
+    return uh::gemm_dgrad(uh::GEMM_EPI_GELU_BWD, dy, w, u, dpre, M, N, K, (hipStream_t)stream);
+}
+
+size_t uniter_gemm_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    size_t a = uh::gemm_wgrad_workspace_bytes(M, N, K);
+    size_t b = uh::colsum_workspace_bytes(M, N);
+    return a > b ? a : b;
+}
+
+int uniter_gemm_wgrad(const void* dy, const void* x, void* dw, void* db,
+                      int64_t M, int64_t N, int64_t K, int accumulate,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    UH_CHECK_ARG(dy && x && dw, "null pointer");
+    RC(uh::gemm_wgrad(dy, x, dw, M, N, K, accumulate, workspace, workspace_bytes, (hipStream_t)stream));
+    if (db != nullptr) {
+        UH_CHECK_ARG(workspace != nullptr, "bias gradient needs a workspace");
+        RC(uh::colsum(dy, db, M, N, accumulate, workspace, workspace_bytes, (hipStream_t)stream));
+    }
+    return 0;
+}
+
+int uniter_attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse,
+                         int64_t B, int64_t L, int64_t heads,
+                         float p_drop, uint64_t seed, uint64_t offset, void* stream) {
+    UH_CHECK_ARG(qkv && mask_bias && ctx, "null pointer");
+    UH_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "dropout probability must be in [0,1)");
+    return uh::attention_fwd(qkv, mask_bias, ctx, lse, B, L, heads, make_dropout(p_drop, seed, offset), (hipStream_t)stream);
+}
+
+int uniter_attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, const float* lse,
+                         const void* dctx, void* dqkv, int64_t B, int64_t L, int64_t heads,
+                         float p_drop, uint64_t seed, uint64_t offset, void* stream) {
+    UH_CHECK_ARG(qkv && mask_bias && ctx && lse && dctx && dqkv, "null pointer");
+    UH_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "dropout probability must be in [0,1)");
+    return uh::attention_bwd(qkv, mask_bias, ctx, lse, dctx, dqkv, B, L, heads, make_dropout(p_drop, seed, offset),
+                             (hipStream_t)stream);
+}
+
+int uniter_layernorm_fwd(const void* z, const void* gamma, const void* beta, void* y,
+                         float* mean, float* rstd, int64_t rows, int64_t H, float eps,
+                         float p_drop, uint64_t seed, uint64_t offset, void* stream) {
+    UH_CHECK_ARG(z && gamma && beta && y, "null pointer");
+    UH_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "dropout probability must be in [0,1)");
+    return uh::layernorm_fwd(z, gamma, beta, y, mean, rstd, rows, H, eps, make_dropout(p_drop, seed, offset), (hipStream_t)stream);
+}
+
+size_t uniter_layernorm_bwd_workspace_bytes(int64_t rows, int64_t H) { return uh::layernorm_bwd_workspace_bytes(rows, H); }
+
+int uniter_layernorm_bwd(const void* dy, const void* dy_extra, const void* z, const float* mean,
+                         const float* rstd, const void* gamma,
+                         void* dz, void* dd, void* dgamma, void* dbeta, void* dbias,
+                         int64_t rows, int64_t H, int accumulate,
+                         float p_drop, uint64_t seed, uint64_t offset, int drop_on_output,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    UH_CHECK_ARG(dy && z && mean && rstd && gamma && dz && workspace, "null pointer");
+    UH_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "dropout probability must be in [0,1)");
+    return uh::layernorm_bwd(dy, dy_extra, z, mean, rstd, gamma, dz, dd, dgamma, dbeta, dbias, rows, H, accumulate,
+                             make_dropout(p_drop, seed, offset), drop_on_output, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+size_t uniter_colsum_workspace_bytes(int64_t rows, int64_t N) { return uh::colsum_workspace_bytes(rows, N); }
+
+int uniter_colsum(const void* a, void* out, int64_t rows, int64_t N, int accumulate,
+                  void* workspace, size_t workspace_bytes, void* stream) {
+    UH_CHECK_ARG(a && out && workspace, "null pointer");
+    return uh::colsum(a, out, rows, N, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,160 @@
+// common.cuh — shared device helpers for the gfx950 (CDNA4, wave64) kernels of libuniter_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WAVE 64
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+// ---------------------------------------------------------------------------------------------
+// bf16 <-> fp32 (round-to-nearest-even; the compiler lowers the casts to v_cvt_pk_bf16_f32 on gfx950)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ float bits2f_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ float bits2f_lo(uint32_t w) { return __uint_as_float(w << 16); }
+
+// pack two floats into one dword of 2 x bf16 (lo = a, hi = b)
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    bf16x2 t;
+    t[0] = (bf16_t)a;
+    t[1] = (bf16_t)b;
+    return __builtin_bit_cast(uint32_t, t);
+}
+
+// 8-byte vector of 4 bf16 <-> 4 floats
+__device__ __forceinline__ void unpack4(const u32x2 w, float (&f)[4]) {
+    f[0] = bits2f_lo(w[0]); f[1] = bits2f_hi(w[0]);
+    f[2] = bits2f_lo(w[1]); f[3] = bits2f_hi(w[1]);
+}
+__device__ __forceinline__ u32x2 pack4(const float (&f)[4]) {
+    u32x2 w;
+    w[0] = pack_bf16x2(f[0], f[1]);
+    w[1] = pack_bf16x2(f[2], f[3]);
+    return w;
+}
+__device__ __forceinline__ void unpack8(const u32x4 w, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = bits2f_lo(w[i]); f[2 * i + 1] = bits2f_hi(w[i]); }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+    u32x4 w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+    return w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave64 reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 counter-based RNG.  One call gives 4 x 32 random bits for counter (c0..c3) under
+// key (k0,k1).  Dropout sites use: key = seed, counter = (element_index/4 lo, hi, site offset lo, hi).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n1 = lo1;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        const uint32_t n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    u32x4 out;
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+    return out;
+}
+
+struct DropoutCfg {
+    float    p;          // drop probability (0 => disabled)
+    float    scale;      // 1/(1-p)
+    uint32_t thresh;     // keep iff rnd >= thresh ; thresh = p * 2^32
+    uint32_t seed_lo, seed_hi;
+    uint32_t off_lo, off_hi;
+};
+
+static inline DropoutCfg make_dropout(float p, uint64_t seed, uint64_t offset) {
+    DropoutCfg d;
+    d.p = p;
+    d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    double t = (double)p * 4294967296.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    if (t < 0) t = 0;
+    d.thresh = (uint32_t)t;
+    d.seed_lo = (uint32_t)seed; d.seed_hi = (uint32_t)(seed >> 32);
+    d.off_lo = (uint32_t)offset; d.off_hi = (uint32_t)(offset >> 32);
+    return d;
+}
+
+// Keep-multipliers (0 or 1/(1-p)) for the 4 consecutive elements of group `idx4` (= element index / 4).
+__device__ __forceinline__ void dropout_mult4(const DropoutCfg& d, uint64_t idx4, float (&m)[4]) {
+    const u32x4 r = philox4x32_10((uint32_t)idx4, (uint32_t)(idx4 >> 32), d.off_lo, d.off_hi,
+                                  d.seed_lo, d.seed_hi);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = (r[i] >= d.thresh) ? d.scale : 0.f;
+}
+// Single element `e` (0..3) of group idx4.
+__device__ __forceinline__ float dropout_mult1(const DropoutCfg& d, uint64_t idx4, int e) {
+    const u32x4 r = philox4x32_10((uint32_t)idx4, (uint32_t)(idx4 >> 32), d.off_lo, d.off_hi,
+                                  d.seed_lo, d.seed_hi);
+    const uint32_t v = e == 0 ? r[0] : (e == 1 ? r[1] : (e == 2 ? r[2] : r[3]));
+    return (v >= d.thresh) ? d.scale : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact erf GELU (model/layer.py:31-37) and its derivative
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf(float x) {
+    return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side status plumbing for the C ABI
+// ---------------------------------------------------------------------------------------------
+void uh_set_error(const char* fmt, ...);
+#define UH_CHECK_ARG(cond, msg)                                                         \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            uh_set_error("%s: argument error: %s (%s)", __func__, msg, #cond);          \
+            return -1;                                                                  \
+        }                                                                               \
+    } while (0)
+#define UH_CHECK_HIP(expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            uh_set_error("%s: %s -> %s", __func__, #expr, hipGetErrorString(_e));       \
+            return (int)_e;                                                             \
+        }                                                                               \
+    } while (0)
+#define UH_LAUNCH_CHECK() UH_CHECK_HIP(hipGetLastError())

@@ -1,0 +1,204 @@
+// encoder.hip — layer-stack runtime: one C call enqueues every kernel of a range of BertLayers.
+//
+// Reference control flow: UniterEncoder.forward (model/model.py:282-292) ->
+// BertLayer.forward (model/layer.py:166-170) = BertAttention (:124-127: BertSelfAttention :75-101 +
+// BertSelfOutput :111-115) -> BertIntermediate (:139-142) -> BertOutput (:152-156); backward is the
+// autograd transpose of the same graph.  Per layer: 4 GEMMs + attention + 2 LayerNorms forward;
+// 8 GEMMs + attention + 2 LayerNorm-backward + 2 column sums backward.  Everything is asynchronous on
+// the caller's stream; activations needed by backward live in the caller-provided `acts` arena.
+#include "common.cuh"
+#include "kernels.h"
+#include "../../include/uniter_hip.h"
+
+namespace {
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct ActLayout {
+    size_t qkv, lse, ctx, z1, mean1, rstd1, a, u, g, z2, mean2, rstd2, y, total;
+};
+ActLayout act_layout(const UniterEncoderShape& s) {
+    const size_t T = (size_t)s.B * s.L, H = s.H, I = s.I;
+    ActLayout l{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += align256(bytes); return r; };
+    l.qkv = take(T * 3 * H * 2);
+    l.lse = take((size_t)s.B * s.heads * s.L * 4);
+    l.ctx = take(T * H * 2);
+    l.z1 = take(T * H * 2);
+    l.mean1 = take(T * 4);
+    l.rstd1 = take(T * 4);
+    l.a = take(T * H * 2);
+    l.u = take(T * I * 2);
+    l.g = take(T * I * 2);
+    l.z2 = take(T * H * 2);
+    l.mean2 = take(T * 4);
+    l.rstd2 = take(T * 4);
+    l.y = take(T * H * 2);
+    l.total = o;
+    return l;
+}
+
+struct ScratchLayout {
+    size_t bufA, bufB, dd, dctx, dqkv, dpre, red, red_bytes, wg, wg_bytes, total;
+};
+ScratchLayout scratch_layout(const UniterEncoderShape& s) {
+    const size_t T = (size_t)s.B * s.L, H = s.H, I = s.I;
+    ScratchLayout l{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += align256(bytes); return r; };
+    l.bufA = take(T * H * 2);
+    l.bufB = take(T * H * 2);
+    l.dd = take(T * H * 2);
+    l.dctx = take(T * H * 2);
+    l.dqkv = take(T * 3 * H * 2);
+    l.dpre = take(T * I * 2);
+    size_t red = uh::layernorm_bwd_workspace_bytes((int64_t)T, (int64_t)H);
+    size_t c1 = uh::colsum_workspace_bytes((int64_t)T, (int64_t)(3 * H));
+    size_t c2 = uh::colsum_workspace_bytes((int64_t)T, (int64_t)I);
+    if (c1 > red) red = c1;
+    if (c2 > red) red = c2;
+    l.red_bytes = red;
+    l.red = take(red);
+    // split-K partials: up to 8 slices of the largest weight gradient
+    size_t big = 3 * H * H;
+    if (I * H > big) big = I * H;
+    l.wg_bytes = big * 8 * sizeof(float);
+    l.wg = take(l.wg_bytes);
+    l.total = o;
+    return l;
+}
+
+int check_shape(const UniterEncoderShape* s) {
+    if (s == nullptr) { uh_set_error("encoder: null shape"); return -1; }
+    if (s->B <= 0 || s->L <= 0 || s->H <= 0 || s->heads <= 0 || s->I <= 0) { uh_set_error("encoder: non-positive dimension"); return -1; }
+    if (s->H != s->heads * 64) { uh_set_error("encoder: hidden_size must be heads*64 (H=%lld heads=%lld)", (long long)s->H, (long long)s->heads); return -1; }
+    if (s->H % 64 != 0 || s->I % 64 != 0) { uh_set_error("encoder: H and I must be multiples of 64"); return -1; }
+    if (s->L > 256) { uh_set_error("encoder: L=%lld > 256 unsupported", (long long)s->L); return -1; }
+    return 0;
+}
+
+}  // namespace
+
+#define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+extern "C" {
+
+size_t uniter_encoder_layer_act_bytes(const UniterEncoderShape* s) {
+    if (check_shape(s)) return 0;
+    return act_layout(*s).total;
+}
+size_t uniter_encoder_scratch_bytes(const UniterEncoderShape* s) {
+    if (check_shape(s)) return 0;
+    return scratch_layout(*s).total;
+}
+size_t uniter_encoder_layer_out_offset(const UniterEncoderShape* s) {
+    if (check_shape(s)) return 0;
+    return act_layout(*s).y;
+}
+
+int uniter_encoder_forward(const UniterEncoderShape* s, const UniterLayerParams* layers,
+                           int32_t layer_begin, int32_t layer_end,
+                           const void* x_in, const float* mask_bias,
+                           void* acts, void* scratch, uint64_t seed, uint64_t offset, void* stream) {
+    RC(check_shape(s));
+    UH_CHECK_ARG(layers != nullptr && x_in != nullptr && mask_bias != nullptr && acts != nullptr, "null pointer");
+    UH_CHECK_ARG(layer_begin >= 0 && layer_end >= layer_begin, "bad layer range");
+    (void)scratch;
+    hipStream_t st = (hipStream_t)stream;
+    const ActLayout al = act_layout(*s);
+    const int64_t T = s->B * s->L, H = s->H, I = s->I;
+    const bool tr = s->training != 0;
+    const DropoutCfg nodrop = make_dropout(0.f, 0, 0);
+    const char* x = (const char*)x_in;
+    for (int l = layer_begin; l < layer_end; ++l) {
+        const UniterLayerParams& P = layers[l];
+        char* A = (char*)acts + (size_t)l * al.total;
+        const uint64_t off = offset + (uint64_t)l * 8;
+        const DropoutCfg d_attn = tr ? make_dropout(s->p_attn, seed, off + 0) : nodrop;
+        const DropoutCfg d_h1 = tr ? make_dropout(s->p_hidden, seed, off + 1) : nodrop;
+        const DropoutCfg d_h2 = tr ? make_dropout(s->p_hidden, seed, off + 2) : nodrop;
+        // model/layer.py:76-78  (three Linear(H,H) fused into one [3H,H] GEMM)
+        RC(uh::gemm_fwd(uh::GEMM_EPI_BIAS, x, P.wqkv, P.bqkv, nullptr, A + al.qkv, nullptr, T, 3 * H, H, nodrop, st));
+        // model/layer.py:80-100
+        RC(uh::attention_fwd(A + al.qkv, mask_bias, A + al.ctx, (float*)(A + al.lse), s->B, s->L, s->heads, d_attn, st));
+        // model/layer.py:112-114  dense + dropout + residual
+        RC(uh::gemm_fwd(uh::GEMM_EPI_BIAS_DROP_RES, A + al.ctx, P.wo, P.bo, x, A + al.z1, nullptr, T, H, H, d_h1, st));
+        RC(uh::layernorm_fwd(A + al.z1, P.ln1_g, P.ln1_b, A + al.a, (float*)(A + al.mean1), (float*)(A + al.rstd1),
+                             T, H, s->ln_eps, nodrop, st));
+        // model/layer.py:140-141  dense + erf-GELU
+        RC(uh::gemm_fwd(uh::GEMM_EPI_BIAS_GELU, A + al.a, P.w1, P.b1, nullptr, A + al.u, A + al.g, T, I, H, nodrop, st));
+        // model/layer.py:153-155
+        RC(uh::gemm_fwd(uh::GEMM_EPI_BIAS_DROP_RES, A + al.g, P.w2, P.b2, A + al.a, A + al.z2, nullptr, T, H, I, d_h2, st));
+        RC(uh::layernorm_fwd(A + al.z2, P.ln2_g, P.ln2_b, A + al.y, (float*)(A + al.mean2), (float*)(A + al.rstd2),
+                             T, H, s->ln_eps, nodrop, st));
+        x = A + al.y;
+    }
+    return 0;
+}
+
+int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams* layers,
+                            int32_t layer_begin, int32_t layer_end,
+                            const void* x_in, const float* mask_bias, const void* dy, void* dx,
+                            void* acts, void* scratch, uint64_t seed, uint64_t offset, void* stream) {
+    RC(check_shape(s));
+    UH_CHECK_ARG(layers != nullptr && x_in != nullptr && mask_bias != nullptr && acts != nullptr && scratch != nullptr, "null pointer");
+    UH_CHECK_ARG(dy != nullptr && dx != nullptr, "null gradient pointer");
+    UH_CHECK_ARG(layer_begin >= 0 && layer_end > layer_begin, "bad layer range");
+    UH_CHECK_ARG(s->training != 0, "backward needs a training-mode forward");
+    hipStream_t st = (hipStream_t)stream;
+    const ActLayout al = act_layout(*s);
+    const ScratchLayout sl = scratch_layout(*s);
+    const int64_t T = s->B * s->L, H = s->H, I = s->I;
+    char* S = (char*)scratch;
+    char* bufA = S + sl.bufA;
+    char* bufB = S + sl.bufB;
+    char* ddb = S + sl.dd;
+    char* dctx = S + sl.dctx;
+    char* dqkv = S + sl.dqkv;
+    char* dpre = S + sl.dpre;
+    void* red = S + sl.red;
+    void* wg = S + sl.wg;
+    const bool hdrop = s->p_hidden > 0.f;
+    const char* dyl = (const char*)dy;
+    for (int l = layer_end - 1; l >= layer_begin; --l) {
+        const UniterLayerParams& P = layers[l];
+        char* A = (char*)acts + (size_t)l * al.total;
+        // input of this layer: the caller's x_in for the first layer of the range, else layer l-1's output
+        const char* xin = (l == layer_begin) ? (const char*)x_in : ((char*)acts + (size_t)(l - 1) * al.total + al.y);
+        const uint64_t off = offset + (uint64_t)l * 8;
+        const DropoutCfg d_attn = make_dropout(s->p_attn, seed, off + 0);
+        const DropoutCfg d_h1 = make_dropout(s->p_hidden, seed, off + 1);
+        const DropoutCfg d_h2 = make_dropout(s->p_hidden, seed, off + 2);
+
+        // ---- BertOutput backward (model/layer.py:152-156) ----
+        RC(uh::layernorm_bwd(dyl, nullptr, A + al.z2, (const float*)(A + al.mean2), (const float*)(A + al.rstd2), P.ln2_g,
+                             bufA, hdrop ? ddb : nullptr, P.g_ln2_g, P.g_ln2_b, P.g_b2, T, H, 1, d_h2, 0,
+                             red, sl.red_bytes, st));
+        const char* dd2 = hdrop ? ddb : bufA;
+        RC(uh::gemm_dgrad(uh::GEMM_EPI_GELU_BWD, dd2, P.w2, A + al.u, dpre, T, H, I, st));
+        RC(uh::gemm_wgrad(dd2, A + al.g, P.g_w2, T, H, I, 1, wg, sl.wg_bytes, st));
+        // ---- BertIntermediate backward (model/layer.py:139-142) ----
+        RC(uh::colsum(dpre, P.g_b1, T, I, 1, red, sl.red_bytes, st));
+        RC(uh::gemm_wgrad(dpre, A + al.a, P.g_w1, T, I, H, 1, wg, sl.wg_bytes, st));
+        RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dpre, P.w1, bufA, bufB, T, I, H, st));          // da = dpre*W1 + dz2
+        // ---- BertSelfOutput backward (model/layer.py:111-115) ----
+        RC(uh::layernorm_bwd(bufB, nullptr, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1), P.ln1_g,
+                             bufA, hdrop ? ddb : nullptr, P.g_ln1_g, P.g_ln1_b, P.g_bo, T, H, 1, d_h1, 0,
+                             red, sl.red_bytes, st));
+        const char* dd1 = hdrop ? ddb : bufA;
+        RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dd1, P.wo, nullptr, dctx, T, H, H, st));
+        RC(uh::gemm_wgrad(dd1, A + al.ctx, P.g_wo, T, H, H, 1, wg, sl.wg_bytes, st));
+        // ---- BertSelfAttention backward (model/layer.py:75-101) ----
+        RC(uh::attention_bwd(A + al.qkv, mask_bias, A + al.ctx, (const float*)(A + al.lse), dctx, dqkv,
+                             s->B, s->L, s->heads, d_attn, st));
+        RC(uh::colsum(dqkv, P.g_bqkv, T, 3 * H, 1, red, sl.red_bytes, st));
+        RC(uh::gemm_wgrad(dqkv, xin, P.g_wqkv, T, 3 * H, H, 1, wg, sl.wg_bytes, st));
+        char* dxl = (l == layer_begin) ? (char*)dx : bufB;
+        RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dqkv, P.wqkv, bufA, dxl, T, 3 * H, H, st));     // dx = dqkv*Wqkv + dz1
+        dyl = dxl;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+// kernels.h — internal C++ interface between the .hip translation units of libuniter_hip.so.
+// The public C ABI (include/uniter_hip.h) is implemented in capi.hip on top of these.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+struct DropoutCfg;
+
+namespace uh {
+
+// ---- gemm.hip ----
+enum { GEMM_EPI_BIAS = 0, GEMM_EPI_BIAS_GELU = 1, GEMM_EPI_BIAS_DROP_RES = 2, GEMM_EPI_RES = 3, GEMM_EPI_GELU_BWD = 4 };
+int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void* resid, void* y, void* y2,
+             int64_t M, int64_t N, int64_t K, const DropoutCfg& drop, hipStream_t st);
+int gemm_dgrad(int epi, const void* dy, const void* w, const void* aux, void* dx,
+               int64_t M, int64_t N, int64_t K, hipStream_t st);
+size_t gemm_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int gemm_wgrad(const void* dy, const void* x, void* dw, int64_t M, int64_t N, int64_t K, int accumulate,
+               void* workspace, size_t ws_bytes, hipStream_t st);
+void gemm_debug_force(int cfg, int splits);
+void gemm_set_num_cus(int n);
+
+// ---- attention.hip ----
+int attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse,
+                  int64_t B, int64_t L, int64_t heads, const DropoutCfg& drop, hipStream_t st);
+int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, const float* lse,
+                  const void* dctx, void* dqkv, int64_t B, int64_t L, int64_t heads,
+                  const DropoutCfg& drop, hipStream_t st);
+
+// ---- layernorm.hip ----
+int layernorm_fwd(const void* z, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                  int64_t rows, int64_t H, float eps, const DropoutCfg& drop, hipStream_t st);
+size_t layernorm_bwd_workspace_bytes(int64_t rows, int64_t H);
+int layernorm_bwd(const void* dy, const void* dy_extra, const void* z, const float* mean, const float* rstd,
+                  const void* gamma, void* dz, void* dd, void* dgamma, void* dbeta, void* dbias,
+                  int64_t rows, int64_t H, int accumulate, const DropoutCfg& drop, int post_drop,
+                  void* workspace, size_t ws_bytes, hipStream_t st);
+size_t colsum_workspace_bytes(int64_t rows, int64_t N);
+int colsum(const void* a, void* out, int64_t rows, int64_t N, int accumulate,
+           void* workspace, size_t ws_bytes, hipStream_t st);
+
+}  // namespace uh

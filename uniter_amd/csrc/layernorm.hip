@@ -1,0 +1,327 @@
+// layernorm.hip — LayerNorm forward / backward and column-sum reductions (HBM-bound row kernels).
+//
+// Reference: apex FusedLayerNorm(H, eps=1e-12) as used at model/layer.py:108,149 and
+// model/model.py:229,252,253,258 — biased variance, eps inside the sqrt, affine, fp32 statistics.
+// One wave64 owns a row; every lane keeps its slice of the row in registers (8-byte bf16x4 loads,
+// row fully coalesced), statistics by wave-level reductions, no LDS on the forward path.
+#include "common.cuh"
+#include "kernels.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;   // 4 waves, one row each
+
+template <int NC>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ z, const bf16_t* __restrict__ gamma,
+                                                     const bf16_t* __restrict__ beta, bf16_t* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     int rows, int H, float eps, const DropoutCfg drop) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row = blockIdx.x * ROWS_PER_BLOCK + wid;
+    if (row >= rows) return;
+    const int nch = H >> 2;
+    const bf16_t* zr = z + (int64_t)row * H;
+    float x[NC][4];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+            unpack4(*reinterpret_cast<const u32x2*>(zr + ch * 4), x[c]);
+            s += (x[c][0] + x[c][1]) + (x[c][2] + x[c][3]);
+        } else {
+            x[c][0] = x[c][1] = x[c][2] = x[c][3] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = x[c][e] - mean; v += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(v) / (float)H + eps);
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+    bf16_t* yr = y + (int64_t)row * H;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+            float gv[4], bv[4], o[4];
+            unpack4(*reinterpret_cast<const u32x2*>(gamma + ch * 4), gv);
+            unpack4(*reinterpret_cast<const u32x2*>(beta + ch * 4), bv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (x[c][e] - mean) * rstd * gv[e] + bv[e];
+            if (drop.p > 0.f) {
+                // the dropped value is the bf16-rounded LN output (what a separate dropout kernel would see)
+                float mult[4], oq[4];
+                unpack4(pack4(o), oq);
+                dropout_mult4(drop, ((uint64_t)row * (uint64_t)H + (uint64_t)ch * 4) >> 2, mult);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = oq[e] * mult[e];
+            }
+            *reinterpret_cast<u32x2*>(yr + ch * 4) = pack4(o);
+        }
+    }
+}
+
+// Backward.  partial layout: [gridDim.x][3][H] fp32 = per-block column sums of (dgamma, dbeta, dbias).
+template <int NC>
+struct LnBwd {
+    static __device__ void run(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dy_extra,
+                               const bf16_t* __restrict__ z, const float* __restrict__ mean_in,
+                               const float* __restrict__ rstd_in, const bf16_t* __restrict__ gamma,
+                               bf16_t* __restrict__ dz, bf16_t* __restrict__ dd, float* __restrict__ partial,
+                               int rows, int H, int want_dbias, int post_drop, const DropoutCfg& drop, float* red) {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        const int nch = H >> 2;
+        float gv[NC][4];
+        float ag[NC][4], ab[NC][4], ad[NC][4];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) unpack4(*reinterpret_cast<const u32x2*>(gamma + ch * 4), gv[c]);
+            else gv[c][0] = gv[c][1] = gv[c][2] = gv[c][3] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; ad[c][e] = 0.f; }
+        }
+        const bool use_drop = drop.p > 0.f && !post_drop;   // dropout sat on the dense branch feeding z
+        const bool use_post = drop.p > 0.f && post_drop;    // dropout sat on the LN output (embedding blocks)
+        for (int row = blockIdx.x * ROWS_PER_BLOCK + wid; row < rows; row += gridDim.x * ROWS_PER_BLOCK) {
+            const float mean = mean_in[row], rstd = rstd_in[row];
+            const int64_t ro = (int64_t)row * H;
+            float xh[NC][4], gy[NC][4];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int ch = lane + 64 * c;
+                if (ch < nch) {
+                    float zv[4], dv[4];
+                    unpack4(*reinterpret_cast<const u32x2*>(z + ro + ch * 4), zv);
+                    unpack4(*reinterpret_cast<const u32x2*>(dy + ro + ch * 4), dv);
+                    if (dy_extra != nullptr) {
+                        float ev[4];
+                        unpack4(*reinterpret_cast<const u32x2*>(dy_extra + ro + ch * 4), ev);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dv[e] += ev[e];
+                    }
+                    if (use_post) {
+                        float mult[4];
+                        dropout_mult4(drop, ((uint64_t)row * (uint64_t)H + (uint64_t)ch * 4) >> 2, mult);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dv[e] *= mult[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        xh[c][e] = (zv[e] - mean) * rstd;
+                        gy[c][e] = dv[e] * gv[c][e];
+                        s1 += gy[c][e];
+                        s2 += gy[c][e] * xh[c][e];
+                        ag[c][e] += dv[e] * xh[c][e];
+                        ab[c][e] += dv[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { xh[c][e] = 0.f; gy[c][e] = 0.f; }
+                }
+            }
+            const float c1 = wave_sum(s1) / (float)H;
+            const float c2 = wave_sum(s2) / (float)H;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int ch = lane + 64 * c;
+                if (ch < nch) {
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = rstd * (gy[c][e] - c1 - xh[c][e] * c2);
+                    const u32x2 packed = pack4(o);
+                    *reinterpret_cast<u32x2*>(dz + ro + ch * 4) = packed;
+                    if (use_drop) {
+                        float oq[4], mult[4];
+                        unpack4(packed, oq);
+                        dropout_mult4(drop, ((uint64_t)row * (uint64_t)H + (uint64_t)ch * 4) >> 2, mult);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { oq[e] *= mult[e]; ad[c][e] += oq[e]; }
+                        if (dd != nullptr) *reinterpret_cast<u32x2*>(dd + ro + ch * 4) = pack4(oq);
+                    } else if (want_dbias) {
+                        float oq[4];
+                        unpack4(packed, oq);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ad[c][e] += oq[e];
+                    }
+                }
+            }
+        }
+        // block reduction over the 4 waves, one quantity at a time: red[4][NC*256]
+        constexpr int W = NC * 256;
+        float* pout = partial + (int64_t)blockIdx.x * 3 * H;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int col = (lane + 64 * c) * 4 + e;
+                    red[wid * W + col] = (k == 0) ? ag[c][e] : ((k == 1) ? ab[c][e] : ad[c][e]);
+                }
+            }
+            __syncthreads();
+            for (int col = threadIdx.x; col < H; col += 256) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < ROWS_PER_BLOCK; ++w) s += red[w * W + col];
+                pout[k * H + col] = s;
+            }
+            __syncthreads();
+        }
+    }
+};
+
+template <int NC>
+__global__ __launch_bounds__(256) void ln_bwd_kernel2(const bf16_t* dy, const bf16_t* dy_extra, const bf16_t* z,
+                                                      const float* mean_in, const float* rstd_in, const bf16_t* gamma,
+                                                      bf16_t* dz, bf16_t* dd, float* partial, int rows, int H,
+                                                      int want_dbias, int post_drop, const DropoutCfg drop) {
+    __shared__ float red[ROWS_PER_BLOCK * NC * 256];
+    LnBwd<NC>::run(dy, dy_extra, z, mean_in, rstd_in, gamma, dz, dd, partial, rows, H, want_dbias, post_drop, drop, red);
+}
+
+// out_k[col] (+)= sum_b partial[b][k][col]   for k < nk (nk <= 3), partial [nb][nk][H]
+__global__ __launch_bounds__(256) void finalize_cols_kernel(const float* __restrict__ partial, int nb, int nk, int H,
+                                                            bf16_t* o0, bf16_t* o1, bf16_t* o2, int accumulate) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nk * H) return;
+    const int k = idx / H, col = idx % H;
+    bf16_t* out = k == 0 ? o0 : (k == 1 ? o1 : o2);
+    if (out == nullptr) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += partial[((int64_t)b * nk + k) * H + col];
+    if (accumulate) s += bf2f(out[col]);
+    out[col] = f2bf(s);
+}
+
+// per-block column sums of a[rows][N]: grid (strips of 512 cols, row blocks); partial [gridDim.y][N]
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ a, float* __restrict__ partial,
+                                                     int rows, int N) {
+    __shared__ float red[ROWS_PER_BLOCK][512];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int col = blockIdx.x * 512 + lane * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (col < N) {
+        for (int row = blockIdx.y * ROWS_PER_BLOCK + wid; row < rows; row += gridDim.y * ROWS_PER_BLOCK) {
+            float v[8];
+            unpack8(*reinterpret_cast<const u32x4*>(a + (int64_t)row * N + col), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wid][lane * 8 + e] = acc[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        const int gc = blockIdx.x * 512 + c;
+        if (gc < N) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < ROWS_PER_BLOCK; ++w) s += red[w][c];
+            partial[(int64_t)blockIdx.y * N + gc] = s;
+        }
+    }
+}
+
+int ln_bwd_blocks(int64_t rows) {
+    int64_t nb = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    if (nb > 256) nb = 256;
+    return (int)nb;
+}
+int colsum_blocks(int64_t rows, int64_t N) {
+    const int64_t strips = (N + 511) / 512;
+    int64_t nb = 1024 / strips;
+    if (nb < 1) nb = 1;
+    const int64_t maxb = (rows + ROWS_PER_BLOCK * 4 - 1) / (ROWS_PER_BLOCK * 4);   // >= 4 rows per wave
+    if (nb > maxb) nb = maxb;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+}  // namespace
+
+namespace uh {
+
+int layernorm_fwd(const void* z, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                  int64_t rows, int64_t H, float eps, const DropoutCfg& drop, hipStream_t st) {
+    if (rows <= 0 || H <= 0 || H % 4 != 0 || H > 4096) { uh_set_error("layernorm_fwd: need H %% 4 == 0 and H <= 4096 (H=%lld)", (long long)H); return -1; }
+    const int nc = (int)((H / 4 + 63) / 64);
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+#define LN_FWD(NCV)                                                                                         \
+    hipLaunchKernelGGL(ln_fwd_kernel<NCV>, grid, block, 0, st, (const bf16_t*)z, (const bf16_t*)gamma,      \
+                       (const bf16_t*)beta, (bf16_t*)y, mean, rstd, (int)rows, (int)H, eps, drop)
+    if (nc <= 1) LN_FWD(1);
+    else if (nc == 2) LN_FWD(2);
+    else if (nc == 3) LN_FWD(3);
+    else if (nc == 4) LN_FWD(4);
+    else if (nc <= 8) LN_FWD(8);
+    else LN_FWD(16);
+#undef LN_FWD
+    UH_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t layernorm_bwd_workspace_bytes(int64_t rows, int64_t H) {
+    return (size_t)ln_bwd_blocks(rows) * 3 * (size_t)H * sizeof(float);
+}
+
+int layernorm_bwd(const void* dy, const void* dy_extra, const void* z, const float* mean, const float* rstd,
+                  const void* gamma, void* dz, void* dd, void* dgamma, void* dbeta, void* dbias,
+                  int64_t rows, int64_t H, int accumulate, const DropoutCfg& drop, int post_drop,
+                  void* workspace, size_t ws_bytes, hipStream_t st) {
+    if (rows <= 0 || H <= 0 || H % 4 != 0 || H > 2048) { uh_set_error("layernorm_bwd: need H %% 4 == 0 and H <= 2048 (H=%lld)", (long long)H); return -1; }
+    if (ws_bytes < layernorm_bwd_workspace_bytes(rows, H)) { uh_set_error("layernorm_bwd: workspace too small"); return -1; }
+    const int nc = (int)((H / 4 + 63) / 64);
+    const int nb = ln_bwd_blocks(rows);
+    float* partial = (float*)workspace;
+    const int want_dbias = dbias != nullptr;
+#define LN_BWD(NCV)                                                                                              \
+    hipLaunchKernelGGL(ln_bwd_kernel2<NCV>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)dy_extra, \
+                       (const bf16_t*)z, mean, rstd, (const bf16_t*)gamma, (bf16_t*)dz, (bf16_t*)dd, partial,     \
+                       (int)rows, (int)H, want_dbias, post_drop, drop)
+    if (nc <= 1) LN_BWD(1);
+    else if (nc == 2) LN_BWD(2);
+    else if (nc == 3) LN_BWD(3);
+    else if (nc == 4) LN_BWD(4);
+    else LN_BWD(8);
+#undef LN_BWD
+    UH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(finalize_cols_kernel, dim3((unsigned)((3 * H + 255) / 256)), dim3(256), 0, st,
+                       (const float*)partial, nb, 3, (int)H, (bf16_t*)dgamma, (bf16_t*)dbeta, (bf16_t*)dbias, accumulate);
+    UH_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t colsum_workspace_bytes(int64_t rows, int64_t N) {
+    return (size_t)colsum_blocks(rows, N) * (size_t)N * sizeof(float);
+}
+
+int colsum(const void* a, void* out, int64_t rows, int64_t N, int accumulate,
+           void* workspace, size_t ws_bytes, hipStream_t st) {
+    if (rows <= 0 || N <= 0 || N % 8 != 0) { uh_set_error("colsum: need N %% 8 == 0"); return -1; }
+    if (ws_bytes < colsum_workspace_bytes(rows, N)) { uh_set_error("colsum: workspace too small"); return -1; }
+    const int nb = colsum_blocks(rows, N);
+    dim3 grid((unsigned)((N + 511) / 512), nb);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, (const bf16_t*)a, (float*)workspace, (int)rows, (int)N);
+    UH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(finalize_cols_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st,
+                       (const float*)workspace, nb, 1, (int)N, (bf16_t*)out, (bf16_t*)nullptr, (bf16_t*)nullptr, accumulate);
+    UH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace uh
