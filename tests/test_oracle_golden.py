@@ -1,0 +1,115 @@
+"""Pins the CPU oracle (oracle/uniter_oracle.py) against vectors produced by the REAL reference
+(tests/golden/make_golden.py -> tests/golden/uniter_tiny.npz).  fp32, no GPU needed."""
+import math
+
+import pytest
+import torch
+
+from oracle import uniter_oracle as O
+from tests.common import rel_l2
+
+
+def _close(g, g_ref, tol=2e-4):
+    """Relative L2 match, or both numerically zero (e.g. the key-bias gradient, which softmax makes vanish)."""
+    return rel_l2(g, g_ref) < tol or float((g - g_ref).abs().max()) < 1e-7
+
+TASK_FN = {
+    'mlm': O.mlm_loss, 'mrfr': O.mrfr_loss, 'itm': O.itm_loss,
+    'mrckl': lambda sd, cfg, b: O.mrc_loss(sd, cfg, b, kl=True),
+    'mrc': lambda sd, cfg, b: O.mrc_loss(sd, cfg, b, kl=False),
+}
+
+
+def _leafs(sd):
+    out = {}
+    for k, v in sd.items():
+        out[k] = v.clone().requires_grad_(True)
+    out['cls.predictions.decoder.weight'] = out['uniter.embeddings.word_embeddings.weight']
+    return out
+
+
+@pytest.mark.parametrize("task", ['mlm', 'mrfr', 'mrckl', 'mrc', 'itm'])
+def test_pretrain_tasks_match_reference(golden, task):
+    sd = _leafs(golden.weights('pre'))
+    batch = golden.batch(task)
+    ref = golden.out(task)
+    loss, seq = TASK_FN[task](sd, golden.cfg, batch)
+    assert loss.shape == ref['loss'].shape
+    torch.testing.assert_close(loss.detach(), ref['loss'], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(seq.detach(), ref['seq'], rtol=1e-4, atol=2e-5)
+    loss.mean().backward()
+    for name, g_ref in golden.grads(task).items():
+        g = sd[name].grad
+        assert g is not None, name
+        assert _close(g, g_ref), (name, rel_l2(g, g_ref))
+
+
+def test_mlm_all_gradients(golden):
+    sd = _leafs(golden.weights('pre'))
+    loss, _ = O.mlm_loss(sd, golden.cfg, golden.batch('mlm'))
+    loss.mean().backward()
+    grads = golden.grads('mlm')
+    assert len(grads) > 50
+    for name, g_ref in grads.items():
+        g = sd[name].grad
+        if g is None:
+            assert float(g_ref.abs().max()) == 0.0, name
+            continue
+        if float(g_ref.abs().max()) == 0:
+            assert float(g.abs().max()) < 1e-8, name
+        else:
+            assert _close(g, g_ref), (name, rel_l2(g, g_ref))
+
+
+def test_vqa_matches_reference(golden):
+    sd = _leafs({**golden.weights('pre'), **golden.weights('vqa')})
+    loss, _ = O.vqa_loss(sd, golden.cfg, golden.batch('vqa'))
+    torch.testing.assert_close(loss.detach(), golden.out('vqa')['loss'], rtol=1e-4, atol=1e-5)
+    (loss.mean() * loss.shape[1]).backward()          # train_vqa.py:188
+    for name, g_ref in golden.grads('vqa').items():
+        assert _close(sd[name].grad, g_ref), name
+
+
+def test_nlvr2_paired_attn_matches_reference(golden):
+    w = golden.weights('pre')
+    w.update(golden.weights('nlvr2'))                 # includes the grown 3-row token-type table
+    sd = _leafs(w)
+    loss, _ = O.nlvr2_paired_attn_loss(sd, golden.cfg, golden.batch('nlvr2'))
+    torch.testing.assert_close(loss.detach(), golden.out('nlvr2')['loss'], rtol=1e-4, atol=1e-5)
+    loss.mean().backward()
+    for name, g_ref in golden.grads('nlvr2').items():
+        assert _close(sd[name].grad, g_ref), name
+
+
+def test_adamw_two_clipped_steps(golden):
+    """optim/adamw.py + optim/misc.py grouping + clip_grad_norm_(0.5): weights after two steps on the MLM gradients."""
+    sd = golden.weights('pre')
+    grads = golden.grads('mlm')
+    norm_ref, p_ref, v_ref = golden.adamw()
+    total, coef = O.clip_coef(list(grads.values()), 0.5)
+    assert math.isclose(total, norm_ref, rel_tol=1e-5)
+    assert coef < 1.0
+    for name, want in p_ref.items():
+        p, g = sd[name], grads[name] * coef
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        wd = 0.0 if O.no_decay(name) else 0.01
+        for step in (1, 2):
+            p, m, v = O.adamw_step(p, g, m, v, step, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=wd)
+        torch.testing.assert_close(p, want, rtol=1e-5, atol=1e-7)
+        if name in v_ref:
+            torch.testing.assert_close(v, v_ref[name], rtol=1e-5, atol=1e-12)
+
+
+def test_schedule_and_helpers():
+    assert O.warmup_linear(0, 10, 100) == 0
+    assert O.warmup_linear(5, 10, 100) == 0.5
+    assert O.warmup_linear(10, 10, 100) == 1.0
+    assert O.warmup_linear(100, 10, 100) == 0
+    assert O.get_lr_sched(100, 3e-5, 10, 100) == 1e-8
+    assert O.no_decay('uniter.encoder.layer.0.output.LayerNorm.weight')
+    assert not O.no_decay('uniter.img_embeddings.img_layer_norm.weight')      # decayed: the reference quirk
+    assert not O.no_decay('vqa_output.2.weight')
+    a, b = torch.ones(3), torch.full((3,), 3.0)
+    torch.testing.assert_close(O.allreduce_average([a, b], 2.0), torch.ones(3))
+    gi = O.get_gather_index([2, 3], [2, 1], 2, 3, 5)
+    assert gi.tolist() == [[0, 1, 3, 4, 4], [0, 1, 2, 3, 4]]

@@ -1,0 +1,125 @@
+"""UNITER for NLVR2: paired, triplet and paired-attention heads.  Reference: model/nlvr2.py:17-204.
+
+All three share the encoder call and the token-type table growth (2 -> 3 rows, `init_type_embedding`,
+model/nlvr2.py:26-34), factored into a base class here; public class names, constructor signatures and
+sub-module names (state_dict keys) are the reference's.
+"""
+from collections import defaultdict
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from .attention import MultiheadAttention
+from .model import UniterModel, UniterPreTrainedModel
+
+
+class _Nlvr2Base(UniterPreTrainedModel):
+    def __init__(self, config, img_dim):
+        super().__init__(config)
+        self.uniter = UniterModel(config, img_dim)
+
+    def init_type_embedding(self):
+        """Grow token_type_embeddings to 3 rows: rows 0/1 copied, row 2 starts as a copy of row 1."""
+        hidden = self.uniter.config.hidden_size
+        old = self.uniter.embeddings.token_type_embeddings.weight.data
+        new_emb = nn.Embedding(3, hidden)
+        new_emb.apply(self.init_weights)
+        new_emb = new_emb.to(device=old.device, dtype=old.dtype)
+        new_emb.weight.data[0, :].copy_(old[0, :])
+        new_emb.weight.data[1, :].copy_(old[1, :])
+        new_emb.weight.data[2, :].copy_(old[1, :])
+        self.uniter.embeddings.token_type_embeddings = new_emb
+
+    def _encode(self, batch):
+        batch = defaultdict(lambda: None, batch)
+        seq = self.uniter(batch['input_ids'], batch['position_ids'], batch['img_feat'], batch['img_pos_feat'],
+                          batch['attn_masks'], batch['gather_index'], output_all_encoded_layers=False,
+                          img_type_ids=batch['img_type_ids'])
+        return batch, seq
+
+    @staticmethod
+    def _finish(answer_scores, batch, compute_loss):
+        if not compute_loss:
+            return answer_scores
+        return F.cross_entropy(answer_scores.float(), batch['targets'], reduction='none')
+
+
+class UniterForNlvr2Paired(_Nlvr2Base):
+    """Concatenate the [CLS] states of the two (text, image_i) rows of a pair -> Linear(2H, 2)."""
+
+    def __init__(self, config, img_dim):
+        super().__init__(config, img_dim)
+        self.nlvr2_output = nn.Linear(config.hidden_size * 2, 2)
+        self.apply(self.init_weights)
+
+    def forward(self, batch, compute_loss=True):
+        batch, seq = self._encode(batch)
+        pooled = self.uniter.pooler(seq)
+        n_pair = pooled.size(0) // 2
+        scores = self.nlvr2_output(pooled.contiguous().view(n_pair, -1))
+        return self._finish(scores, batch, compute_loss)
+
+
+class UniterForNlvr2Triplet(_Nlvr2Base):
+    """One row per (text, image_left, image_right) triplet -> Linear(H, 2)."""
+
+    def __init__(self, config, img_dim):
+        super().__init__(config, img_dim)
+        self.nlvr2_output = nn.Linear(config.hidden_size, 2)
+        self.apply(self.init_weights)
+
+    def forward(self, batch, compute_loss=True):
+        batch, seq = self._encode(batch)
+        scores = self.nlvr2_output(self.uniter.pooler(seq))
+        return self._finish(scores, batch, compute_loss)
+
+
+class AttentionPool(nn.Module):
+    """Softmax-weighted average over the sequence; scores from Linear(H,1)+ReLU; padded slots get -1e4."""
+
+    def __init__(self, hidden_size, drop=0.0):
+        super().__init__()
+        self.fc = nn.Sequential(nn.Linear(hidden_size, 1), nn.ReLU())
+        self.dropout = nn.Dropout(drop)
+
+    def forward(self, input_, mask=None):
+        """input_ [B, T, D], mask [B, T] (True = padding)."""
+        score = self.fc(input_).squeeze(-1)
+        if mask is not None:
+            score = score + mask.to(dtype=input_.dtype) * -1e4
+        norm_score = self.dropout(F.softmax(score, dim=1))
+        return norm_score.unsqueeze(1).matmul(input_).squeeze(1)
+
+
+class UniterForNlvr2PairedAttn(_Nlvr2Base):
+    """Paired format + bidirectional cross attention between the two images' sequences
+    (config/train-nlvr2-base-1gpu.json "model": "paired-attn")."""
+
+    def __init__(self, config, img_dim):
+        super().__init__(config, img_dim)
+        self.attn1 = MultiheadAttention(config.hidden_size, config.num_attention_heads,
+                                        config.attention_probs_dropout_prob)
+        self.attn2 = MultiheadAttention(config.hidden_size, config.num_attention_heads,
+                                        config.attention_probs_dropout_prob)
+        self.fc = nn.Sequential(nn.Linear(2 * config.hidden_size, config.hidden_size), nn.ReLU(),
+                                nn.Dropout(config.hidden_dropout_prob))
+        self.attn_pool = AttentionPool(config.hidden_size, config.attention_probs_dropout_prob)
+        self.nlvr2_output = nn.Linear(2 * config.hidden_size, 2)
+        self.apply(self.init_weights)
+
+    def forward(self, batch, compute_loss=True):
+        batch, seq = self._encode(batch)
+        bs, tl, d = seq.size()
+        # rows 2i / 2i+1 are the left / right image of pair i
+        left, right = seq.contiguous().view(bs // 2, tl * 2, d).chunk(2, dim=1)
+        pad = batch['attn_masks'] == 0
+        left_pad, right_pad = pad.contiguous().view(bs // 2, tl * 2).chunk(2, dim=1)
+        left = left.transpose(0, 1)        # (L, N, E) for the attention module
+        right = right.transpose(0, 1)
+        l2r, _ = self.attn1(left, right, right, key_padding_mask=right_pad)
+        r2l, _ = self.attn2(right, left, left, key_padding_mask=left_pad)
+        left = self.fc(torch.cat([l2r, left], dim=-1)).transpose(0, 1)
+        right = self.fc(torch.cat([r2l, right], dim=-1)).transpose(0, 1)
+        pooled = torch.cat([self.attn_pool(left, left_pad), self.attn_pool(right, right_pad)], dim=-1)
+        return self._finish(self.nlvr2_output(pooled), batch, compute_loss)

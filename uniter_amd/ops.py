@@ -1,0 +1,478 @@
+"""torch.autograd glue between the drop-in nn.Modules (uniter_amd/model) and the C ABI (include/uniter_hip.h).
+
+Every function here launches HIP kernels of libuniter_hip.so on the current torch stream through ctypes;
+PyTorch only provides device memory, streams and the autograd graph at block granularity.  There is no
+eager / CPU fallback: non-CUDA or non-bf16 inputs raise.
+
+Parameter gradients are written by the kernels straight into ``param.grad`` (accumulating, like autograd's
+own AccumulateGrad would, pretrain.py:298-312 sums micro-step gradients) instead of being returned to
+autograd: the wgrad GEMMs fuse the accumulation, which saves one read+write of every gradient per step.
+"""
+import ctypes
+import threading
+
+import torch
+
+from . import _lib
+from ._lib import C, UniterEncoderShape, UniterLayerParams, ptr
+
+_BF16 = torch.bfloat16
+
+
+# ----------------------------------------------------------------------------------------------------
+# dropout random stream: (seed, offset) pairs for the Philox generator inside the kernels
+# ----------------------------------------------------------------------------------------------------
+class _Rng(threading.local):
+    def __init__(self):
+        self.seed = None
+        self.offset = 0
+
+
+_rng = _Rng()
+
+
+def manual_seed(seed):
+    """Reset the dropout stream (utils.misc.set_random_seed calls this)."""
+    _rng.seed = int(seed) & 0x7FFFFFFFFFFFFFFF
+    _rng.offset = 0
+
+
+def _next_offsets(n):
+    if _rng.seed is None:
+        _rng.seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+    off = _rng.offset
+    _rng.offset += int(n)
+    return _rng.seed, off
+
+
+# ----------------------------------------------------------------------------------------------------
+# helpers
+# ----------------------------------------------------------------------------------------------------
+def _check_dev(t, name, dtype=_BF16):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.UniterHipError(
+            "%s must be a CUDA(HIP) tensor: the UNITER encoder path only exists as gfx950 kernels "
+            "(no CPU / PyTorch fallback)" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.UniterHipError("%s must be %s, got %s (cast the model with .bfloat16())" % (name, dtype, t.dtype))
+    return t
+
+
+def ensure_grad(p):
+    """param.grad as a zero-initialised contiguous tensor the kernels can accumulate into."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    elif not p.grad.is_contiguous() or p.grad.dtype != p.dtype:
+        raise _lib.UniterHipError("param.grad must be contiguous and of the parameter's dtype")
+    return p.grad
+
+
+_scratch_cache = {}
+
+
+def _scratch(key, nbytes, device):
+    buf = _scratch_cache.get(key)
+    if buf is None or buf.numel() < nbytes or buf.device != device:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _scratch_cache[key] = buf
+    return buf
+
+
+def _dummy_grad_like(t, pool):
+    """Scratch gradient buffer for a frozen parameter (result is discarded)."""
+    g = pool.get(t.numel())
+    if g is None:
+        g = torch.empty(t.numel(), dtype=t.dtype, device=t.device)
+        pool[t.numel()] = g
+    return g
+
+
+# ----------------------------------------------------------------------------------------------------
+# encoder stack
+# ----------------------------------------------------------------------------------------------------
+class LayerView(object):
+    """The 12 (+12 gradient) device pointers of one BertLayer, in UniterLayerParams order."""
+
+    NAMES = ("wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2", "ln2_g", "ln2_b")
+
+    def __init__(self, layer):
+        self.layer = layer
+
+    def params(self):
+        """12 parameter tensors; wqkv / bqkv are the fused [3H,H] / [3H] storages."""
+        lay = self.layer
+        att = lay.attention.self
+        wqkv, bqkv = att.fused_qkv()
+        return [wqkv, bqkv,
+                lay.attention.output.dense.weight, lay.attention.output.dense.bias,
+                lay.attention.output.LayerNorm.weight, lay.attention.output.LayerNorm.bias,
+                lay.intermediate.dense.weight, lay.intermediate.dense.bias,
+                lay.output.dense.weight, lay.output.dense.bias,
+                lay.output.LayerNorm.weight, lay.output.LayerNorm.bias]
+
+    def grads(self, pool):
+        lay = self.layer
+        att = lay.attention.self
+        gw, gb = att.fused_qkv_grad()
+        out = [gw, gb]
+        for p in (lay.attention.output.dense.weight, lay.attention.output.dense.bias,
+                  lay.attention.output.LayerNorm.weight, lay.attention.output.LayerNorm.bias,
+                  lay.intermediate.dense.weight, lay.intermediate.dense.bias,
+                  lay.output.dense.weight, lay.output.dense.bias,
+                  lay.output.LayerNorm.weight, lay.output.LayerNorm.bias):
+            out.append(ensure_grad(p) if p.requires_grad else _dummy_grad_like(p, pool))
+        return out
+
+
+def _layer_table(layers, with_grads):
+    n = len(layers)
+    table = (UniterLayerParams * n)()
+    keep = []
+    pool = {}
+    for i, lay in enumerate(layers):
+        view = LayerView(lay)
+        ps = view.params()
+        for t in ps:
+            _check_dev(t, "encoder parameter")
+            if not t.is_contiguous():
+                raise _lib.UniterHipError("encoder parameters must be contiguous")
+        keep.append(ps)
+        for name, t in zip(LayerView.NAMES, ps):
+            setattr(table[i], name, t.data_ptr())
+        if with_grads:
+            gs = view.grads(pool)
+            keep.append(gs)
+            for name, t in zip(LayerView.NAMES, gs):
+                setattr(table[i], "g_" + name, t.data_ptr())
+    return table, keep
+
+
+def _shape(cfg_like, B, L, training):
+    s = UniterEncoderShape()
+    s.B, s.L, s.H, s.heads, s.I = B, L, cfg_like["H"], cfg_like["heads"], cfg_like["I"]
+    s.p_hidden = float(cfg_like["p_hidden"]) if training else 0.0
+    s.p_attn = float(cfg_like["p_attn"]) if training else 0.0
+    s.ln_eps = float(cfg_like["ln_eps"])
+    s.training = 1 if training else 0
+    return s
+
+
+class _EncoderFn(torch.autograd.Function):
+    """All BertLayers of a UniterEncoder in one autograd node (model/model.py:282-292)."""
+
+    @staticmethod
+    def forward(ctx, x, mask_bias, layers, cfg_like, training, need_all, hook, *params):
+        B, L, H = x.shape
+        s = _shape(cfg_like, B, L, training)
+        n = len(layers)
+        act_bytes = C.uniter_encoder_layer_act_bytes(ctypes.byref(s))
+        if act_bytes == 0:
+            raise _lib.UniterHipError("bad encoder shape: " + _lib.load().uniter_hip_last_error().decode())
+        out_off = C.uniter_encoder_layer_out_offset(ctypes.byref(s))
+        acts = torch.empty(n * act_bytes, dtype=torch.uint8, device=x.device)
+        table, keep = _layer_table(layers, with_grads=False)
+        seed, off = _next_offsets(n * 8) if training else (0, 0)
+        xc = x.contiguous()
+        C.uniter_encoder_forward(ctypes.byref(s), table, 0, n, ptr(xc), ptr(mask_bias), ptr(acts), None,
+                                 seed, off, _lib.stream_ptr())
+
+        def layer_out(l):
+            o = l * act_bytes + out_off
+            return acts[o:o + B * L * H * 2].view(_BF16).view(B, L, H)
+
+        ctx.layers, ctx.cfg_like, ctx.s = layers, cfg_like, s
+        ctx.acts, ctx.act_bytes = acts, act_bytes
+        ctx.seed, ctx.off = seed, off
+        ctx.need_all, ctx.hook = need_all, hook
+        ctx.save_for_backward(xc, mask_bias)
+        del keep
+        if need_all:
+            return tuple(layer_out(l) for l in range(n))
+        return layer_out(n - 1)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        xc, mask_bias = ctx.saved_tensors
+        layers, s = ctx.layers, ctx.s
+        n = len(layers)
+        if not s.training:
+            raise _lib.UniterHipError("backward through an encoder forward that ran in eval mode / under no_grad")
+        B, L, H = xc.shape
+        scr_bytes = C.uniter_encoder_scratch_bytes(ctypes.byref(s))
+        scratch = _scratch(("enc", xc.device.index), scr_bytes, xc.device)
+        table, keep = _layer_table(layers, with_grads=True)
+        # split the stack where an intermediate layer output received a gradient of its own
+        if ctx.need_all:
+            extra = [g for g in grads]
+        else:
+            extra = [None] * (n - 1) + [grads[0]]
+        if extra[n - 1] is None:
+            extra[n - 1] = torch.zeros(B, L, H, dtype=_BF16, device=xc.device)
+        dy = extra[n - 1].contiguous()
+        end = n
+        st = _lib.stream_ptr()
+        act_bytes = ctx.act_bytes
+        out_off = C.uniter_encoder_layer_out_offset(ctypes.byref(s))
+        dx = torch.empty(B, L, H, dtype=_BF16, device=xc.device)
+        cuts = set(l for l in range(n - 1) if extra[l] is not None)
+        hook = ctx.hook
+        while end > 0:
+            if hook is not None:
+                begin = end - 1        # per-layer calls so the hook fires as soon as a layer's gradients are enqueued
+            else:
+                inner = [c for c in cuts if c + 1 < end]
+                begin = (max(inner) + 1) if inner else 0
+            if begin == 0:
+                x_in = ptr(xc)
+            else:
+                x_in = ctx.acts.data_ptr() + (begin - 1) * act_bytes + out_off
+            C.uniter_encoder_backward(ctypes.byref(s), table, begin, end, x_in, ptr(mask_bias), ptr(dy), ptr(dx),
+                                      ptr(ctx.acts), ptr(scratch), ctx.seed, ctx.off, st)
+            if hook is not None:
+                for l in range(end - 1, begin - 1, -1):
+                    hook(l)
+            end = begin
+            if end > 0:
+                # dx is the gradient w.r.t. the output of layer end-1
+                if (end - 1) in cuts:
+                    dx = dx + extra[end - 1]
+                dy, dx = dx, torch.empty_like(dx)
+        del keep
+        return (dx if ctx.needs_input_grad[0] else None, None, None, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 7)
+
+
+def encoder_forward(layers, x, mask_bias, cfg_like, training, need_all=False, hook=None):
+    """Run a list of BertLayer modules on x [B,L,H] bf16.  mask_bias: [B,L] fp32 additive key mask."""
+    _check_dev(x, "hidden_states")
+    _check_dev(mask_bias, "attention_mask", torch.float32)
+    if x.dim() != 3:
+        raise _lib.UniterHipError("hidden_states must be [B, L, H]")
+    B, L, H = x.shape
+    if mask_bias.numel() != B * L:
+        raise _lib.UniterHipError("attention_mask must have B*L elements (got %d for B=%d L=%d)" % (mask_bias.numel(), B, L))
+    mask_bias = mask_bias.reshape(B, L).contiguous()
+    params = []
+    for lay in layers:
+        params.extend(p for p in lay.parameters() if p.requires_grad)
+    track = torch.is_grad_enabled() and training
+    if not track:
+        with torch.no_grad():
+            return _EncoderFn.apply(x, mask_bias, list(layers), cfg_like, False, need_all, None)
+    return _EncoderFn.apply(x, mask_bias, list(layers), cfg_like, True, need_all, hook, *params)
+
+
+# ----------------------------------------------------------------------------------------------------
+# additive attention mask (model/model.py:342-345)
+# ----------------------------------------------------------------------------------------------------
+def mask_bias(attention_mask):
+    m = attention_mask
+    if not m.is_cuda:
+        raise _lib.UniterHipError("attention_mask must be a CUDA tensor")
+    m = m.to(torch.int64).contiguous()
+    out = torch.empty(m.shape, dtype=torch.float32, device=m.device)
+    C.uniter_mask_bias(ptr(m), ptr(out), m.numel(), _lib.stream_ptr())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# LayerNorm (+ dropout on the output) as used by the embedding blocks
+# ----------------------------------------------------------------------------------------------------
+def _ln_fwd(z, weight, bias, eps, p, seed, off):
+    rows, H = z.shape
+    y = torch.empty_like(z)
+    mean = torch.empty(rows, dtype=torch.float32, device=z.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=z.device)
+    C.uniter_layernorm_fwd(ptr(z), ptr(weight), ptr(bias), ptr(y), ptr(mean), ptr(rstd), rows, H, eps, p, seed, off,
+                           _lib.stream_ptr())
+    return y, mean, rstd
+
+
+def _ln_bwd(dy, z, mean, rstd, weight, bias_param, p, seed, off, post, dbias=None):
+    rows, H = z.shape
+    dz = torch.empty_like(z)
+    wsb = C.uniter_layernorm_bwd_workspace_bytes(rows, H)
+    ws = _scratch(("ln", z.device.index), wsb, z.device)
+    pool = {}
+    gw = ensure_grad(weight) if weight.requires_grad else _dummy_grad_like(weight, pool)
+    gb = ensure_grad(bias_param) if bias_param.requires_grad else _dummy_grad_like(bias_param, pool)
+    C.uniter_layernorm_bwd(ptr(dy), None, ptr(z), ptr(mean), ptr(rstd), ptr(weight), ptr(dz), None, ptr(gw), ptr(gb),
+                           ptr(dbias), rows, H, 1, p, seed, off, 1 if post else 0, ptr(ws), wsb, _lib.stream_ptr())
+    return dz
+
+
+class _TxtEmbedFn(torch.autograd.Function):
+    """UniterTextEmbeddings.forward (model/model.py:232-245)."""
+
+    @staticmethod
+    def forward(ctx, input_ids, position_ids, token_type_ids, mod, p, word, pos, typ, ln_w, ln_b):
+        for t, n in ((word, "word_embeddings"), (pos, "position_embeddings"), (typ, "token_type_embeddings"),
+                     (ln_w, "LayerNorm.weight"), (ln_b, "LayerNorm.bias")):
+            _check_dev(t, n)
+        B, Lt = input_ids.shape
+        H = word.shape[1]
+        ids = input_ids.to(torch.int64).contiguous()
+        pids = position_ids.to(torch.int64).reshape(-1).contiguous()
+        if pids.numel() != Lt:
+            raise _lib.UniterHipError("position_ids must have Lt=%d entries (shape [1, Lt], data/mlm.py:115-116)" % Lt)
+        tids = None if token_type_ids is None else token_type_ids.to(torch.int64).contiguous()
+        z = torch.empty(B * Lt, H, dtype=_BF16, device=word.device)
+        st = _lib.stream_ptr()
+        C.uniter_embed_txt_fwd(ptr(ids), ptr(pids), ptr(tids), ptr(word), ptr(pos), ptr(typ), ptr(z), B, Lt, H,
+                               word.shape[0], pos.shape[0], typ.shape[0], st)
+        seed, off = _next_offsets(1) if p > 0 else (0, 0)
+        y, mean, rstd = _ln_fwd(z, ln_w, ln_b, 1e-12, p, seed, off)
+        ctx.mod, ctx.p, ctx.seed, ctx.off = mod, p, seed, off
+        ctx.ids, ctx.pids, ctx.tids = ids, pids, tids
+        ctx.save_for_backward(z, mean, rstd)
+        return y.view(B, Lt, H)
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, mean, rstd = ctx.saved_tensors
+        mod = ctx.mod
+        B, Lt = ctx.ids.shape
+        H = z.shape[1]
+        dy = dy.contiguous().view(B * Lt, H)
+        dz = _ln_bwd(dy, z, mean, rstd, mod.LayerNorm.weight, mod.LayerNorm.bias, ctx.p, ctx.seed, ctx.off, post=True)
+        st = _lib.stream_ptr()
+        word, pos, typ = mod.word_embeddings.weight, mod.position_embeddings.weight, mod.token_type_embeddings.weight
+        gword = ensure_grad(word) if word.requires_grad else None
+        gpos = ensure_grad(pos) if pos.requires_grad else None
+        C.uniter_embed_txt_bwd(ptr(ctx.ids), ptr(ctx.pids), ptr(ctx.tids), ptr(dz), ptr(gword), ptr(gpos), None, B, Lt, H,
+                               word.shape[0], pos.shape[0], typ.shape[0], st)
+        if typ.requires_grad:
+            gtyp = ensure_grad(typ)
+            wsb = C.uniter_embed_ws_bytes(B * Lt, H)
+            ws = _scratch(("emb", z.device.index), wsb, z.device)
+            C.uniter_embed_type_bwd(ptr(dz), ptr(ctx.tids), ptr(gtyp), B * Lt, H, typ.shape[0], 0, ptr(ws), wsb, st)
+        return (None,) * 10
+
+
+def txt_embeddings(mod, input_ids, position_ids, token_type_ids):
+    p = float(mod.dropout.p) if (mod.training and torch.is_grad_enabled()) else 0.0
+    args = (input_ids, position_ids, token_type_ids, mod, p, mod.word_embeddings.weight, mod.position_embeddings.weight,
+            mod.token_type_embeddings.weight, mod.LayerNorm.weight, mod.LayerNorm.bias)
+    return _TxtEmbedFn.apply(*args)
+
+
+class _ImgEmbedFn(torch.autograd.Function):
+    """UniterImageEmbeddings.forward (model/model.py:261-272)."""
+
+    @staticmethod
+    def forward(ctx, img_feat, img_pos_feat, type_ids, img_masks, mod, type_table, p, *params):
+        dev = type_table.device
+        B, Li, D = img_feat.shape
+        rows = B * Li
+        H = type_table.shape[1]
+        st = _lib.stream_ptr()
+        feat = img_feat.contiguous()
+        if feat.dtype not in (torch.float32, _BF16):
+            feat = feat.float()
+        posf = img_pos_feat.contiguous()
+        if posf.dtype not in (torch.float32, _BF16):
+            posf = posf.float()
+        masks = None
+        mask_row = None
+        if img_masks is not None:
+            # model/model.py:262-265: row 0 of mask_embedding is forced to zero, masked regions add row 1
+            mod.mask_embedding.weight.data[0, :].fill_(0)
+            masks = img_masks.to(torch.uint8).contiguous().view(-1)
+            mask_row = mod.mask_embedding.weight.data[1]
+        tids = None if type_ids is None else type_ids.to(torch.int64).contiguous().view(-1)
+        f = torch.empty(rows, D, dtype=_BF16, device=dev)
+        C.uniter_embed_img_prep(ptr(feat), 1 if feat.dtype == torch.float32 else 0, ptr(masks), ptr(mask_row), ptr(f),
+                                rows, D, st)
+        lin = torch.empty(rows, H, dtype=_BF16, device=dev)
+        C.uniter_gemm_bias_fwd(ptr(f), ptr(mod.img_linear.weight), ptr(mod.img_linear.bias), ptr(lin), rows, H, D, st)
+        t_im, mean_i, rstd_i = _ln_fwd(lin, mod.img_layer_norm.weight, mod.img_layer_norm.bias, 1e-12, 0.0, 0, 0)
+        pl = torch.empty(rows, H, dtype=_BF16, device=dev)
+        C.uniter_embed_pos_linear_fwd(ptr(posf), 1 if posf.dtype == torch.float32 else 0, ptr(mod.pos_linear.weight),
+                                      ptr(mod.pos_linear.bias), ptr(pl), rows, H, st)
+        t_pos, mean_p, rstd_p = _ln_fwd(pl, mod.pos_layer_norm.weight, mod.pos_layer_norm.bias, 1e-12, 0.0, 0, 0)
+        z = torch.empty(rows, H, dtype=_BF16, device=dev)
+        C.uniter_embed_img_combine_fwd(ptr(t_im), ptr(t_pos), ptr(tids), ptr(type_table), ptr(z), rows, H,
+                                       type_table.shape[0], st)
+        seed, off = _next_offsets(1) if p > 0 else (0, 0)
+        y, mean_z, rstd_z = _ln_fwd(z, mod.LayerNorm.weight, mod.LayerNorm.bias, 1e-12, p, seed, off)
+        ctx.mod, ctx.type_table, ctx.p, ctx.seed, ctx.off = mod, type_table, p, seed, off
+        ctx.tids, ctx.masks, ctx.posf, ctx.shape = tids, masks, posf, (B, Li, D, H)
+        ctx.save_for_backward(f, lin, mean_i, rstd_i, pl, mean_p, rstd_p, z, mean_z, rstd_z)
+        return y.view(B, Li, H)
+
+    @staticmethod
+    def backward(ctx, dy):
+        f, lin, mean_i, rstd_i, pl, mean_p, rstd_p, z, mean_z, rstd_z = ctx.saved_tensors
+        mod, type_table = ctx.mod, ctx.type_table
+        B, Li, D, H = ctx.shape
+        rows = B * Li
+        st = _lib.stream_ptr()
+        dev = z.device
+        dy = dy.contiguous().view(rows, H)
+        dz = _ln_bwd(dy, z, mean_z, rstd_z, mod.LayerNorm.weight, mod.LayerNorm.bias, ctx.p, ctx.seed, ctx.off, post=True)
+        wsb = max(C.uniter_embed_ws_bytes(rows, max(H, D)), C.uniter_gemm_wgrad_workspace_bytes(rows, H, D))
+        ws = _scratch(("emb", dev.index), wsb, dev)
+        if type_table.requires_grad:
+            C.uniter_embed_type_bwd(ptr(dz), ptr(ctx.tids), ptr(ensure_grad(type_table)), rows, H, type_table.shape[0], 1,
+                                    ptr(ws), wsb, st)
+        # position branch
+        dpl = _ln_bwd(dz, pl, mean_p, rstd_p, mod.pos_layer_norm.weight, mod.pos_layer_norm.bias, 0.0, 0, 0, post=False)
+        gwp = ensure_grad(mod.pos_linear.weight) if mod.pos_linear.weight.requires_grad else None
+        gbp = ensure_grad(mod.pos_linear.bias) if mod.pos_linear.bias.requires_grad else None
+        C.uniter_embed_pos_linear_bwd(ptr(ctx.posf), 1 if ctx.posf.dtype == torch.float32 else 0, ptr(dpl), ptr(gwp),
+                                      ptr(gbp), rows, H, ptr(ws), wsb, st)
+        # feature branch
+        gbi = ensure_grad(mod.img_linear.bias) if mod.img_linear.bias.requires_grad else None
+        dlin = _ln_bwd(dz, lin, mean_i, rstd_i, mod.img_layer_norm.weight, mod.img_layer_norm.bias, 0.0, 0, 0, post=False,
+                       dbias=gbi)
+        w = mod.img_linear.weight
+        if w.requires_grad:
+            C.uniter_gemm_wgrad(ptr(dlin), ptr(f), ptr(ensure_grad(w)), None, rows, H, D, 1, ptr(ws), wsb, st)
+        if ctx.masks is not None and mod.mask_embedding.weight.requires_grad:
+            df = torch.empty(rows, D, dtype=_BF16, device=dev)
+            C.uniter_gemm_dgrad(ptr(dlin), ptr(w), None, ptr(df), rows, H, D, st)
+            gme = ensure_grad(mod.mask_embedding.weight)
+            C.uniter_embed_mask_bwd(ptr(df), ptr(ctx.masks), ptr(gme[1]), rows, D, ptr(ws), wsb, st)
+        return (None,) * (7 + 11)
+
+
+def img_embeddings(mod, img_feat, img_pos_feat, type_table, type_ids, img_masks):
+    for t, n in ((mod.img_linear.weight, "img_linear.weight"), (type_table, "token_type_embeddings.weight")):
+        _check_dev(t, n)
+    _check_dev(img_feat, "img_feat", None)
+    _check_dev(img_pos_feat, "img_pos_feat", None)
+    p = float(mod.dropout.p) if (mod.training and torch.is_grad_enabled()) else 0.0
+    params = (mod.img_linear.weight, mod.img_linear.bias, mod.img_layer_norm.weight, mod.img_layer_norm.bias,
+              mod.pos_layer_norm.weight, mod.pos_layer_norm.bias, mod.pos_linear.weight, mod.pos_linear.bias,
+              mod.mask_embedding.weight, mod.LayerNorm.weight, mod.LayerNorm.bias)
+    return _ImgEmbedFn.apply(img_feat, img_pos_feat, type_ids, img_masks, mod, type_table, p, *params)
+
+
+class _GatherFn(torch.autograd.Function):
+    """torch.gather(cat([txt, img], 1), 1, gather_index) (model/model.py:330-333)."""
+
+    @staticmethod
+    def forward(ctx, txt, img, gather_index):
+        B, Lt, H = txt.shape
+        Li = img.shape[1]
+        gi = gather_index.to(torch.int64).contiguous()
+        Lout = gi.shape[1]
+        out = torch.empty(B, Lout, H, dtype=_BF16, device=txt.device)
+        C.uniter_embed_gather_fwd(ptr(txt.contiguous()), ptr(img.contiguous()), ptr(gi), ptr(out), B, Lt, Li, Lout, H,
+                                  _lib.stream_ptr())
+        ctx.gi, ctx.dims = gi, (B, Lt, Li, Lout, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, Lt, Li, Lout, H = ctx.dims
+        dtxt = torch.empty(B, Lt, H, dtype=_BF16, device=dout.device)
+        dimg = torch.empty(B, Li, H, dtype=_BF16, device=dout.device)
+        C.uniter_embed_gather_bwd(ptr(dout.contiguous()), ptr(ctx.gi), ptr(dtxt), ptr(dimg), B, Lt, Li, Lout, H,
+                                  _lib.stream_ptr())
+        return dtxt, dimg, None
+
+
+def gather_embeddings(txt, img, gather_index):
+    _check_dev(txt, "txt_emb")
+    _check_dev(img, "img_emb")
+    return _GatherFn.apply(txt, img, gather_index)

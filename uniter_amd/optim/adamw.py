@@ -1,0 +1,214 @@
+"""AdamW with decoupled weight decay, as one fused HIP kernel over every parameter.
+
+Reference: optim/adamw.py:11-103 (HF AdamW: a Python loop of ~6 elementwise ops per tensor).  Same
+constructor, `param_groups` keys (`lr, betas, eps, weight_decay, correct_bias`, mutated from outside every
+step, pretrain.py:317-318) and `state[p]` keys (`step, exp_avg, exp_avg_sq`); the update rule is the
+reference's, including weight decay applied AFTER the Adam update with the un-corrected lr
+(optim/adamw.py:88-101).
+
+MI355X specifics:
+  * all tensors are updated by ONE kernel launch (`uniter_adamw_step`); the tensor table lives on the
+    device and is rebuilt only when the set of (param, grad) storages changes;
+  * bf16 parameters (the apex-O2 replacement: bf16 model, fp32 master weights) keep an fp32 master copy
+    in `state[p]['master']`; fp32 parameters are updated directly;
+  * gradient clipping is fused: `clip_grad_norm_(optimizer, max_norm)` computes the global norm on the
+    device (no host sync) and leaves a device-side coefficient that the next `step()` applies while it
+    reads the gradients — identical to scaling the gradients in place first.
+"""
+import ctypes
+
+import torch
+from torch.optim import Optimizer
+
+from .. import _lib
+from .._lib import C, UniterAdamGroup, UniterAdamTensor, ptr
+
+
+class AdamW(Optimizer):
+    """Adam with the weight-decay fix.
+
+    Parameters:
+        lr (float): learning rate. Default 1e-3.
+        betas (tuple of 2 floats): Adam's beta parameters (b1, b2). Default: (0.9, 0.999)
+        eps (float): Adam's epsilon (added OUTSIDE the square root). Default: 1e-6
+        weight_decay (float): decoupled weight decay. Default: 0.0
+        correct_bias (bool): apply the bias correction (False reproduces the BERT TF repository). Default True.
+    """
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+        if lr < 0.0:
+            raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
+        if not 0.0 <= betas[0] < 1.0:
+            raise ValueError("Invalid beta parameter: {} - should be in [0.0, 1.0[".format(betas[0]))
+        if not 0.0 <= betas[1] < 1.0:
+            raise ValueError("Invalid beta parameter: {} - should be in [0.0, 1.0[".format(betas[1]))
+        if not 0.0 <= eps:
+            raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(eps))
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias)
+        super(AdamW, self).__init__(params, defaults)
+        self._plan = None
+        self._plan_key = None
+        self._plan_groups = None      # internal group id -> (param_group index, [params])
+        self._keep = None
+        self._clip = None             # device tensor [norm, coef] left by clip_grad_norm_
+        self._norm_buf = None
+
+    # ---- plan management ------------------------------------------------------------------------------
+    def _active(self):
+        """[(group_index, param)] for parameters that currently have a gradient (optim/adamw.py:52-53)."""
+        out = []
+        for gi, group in enumerate(self.param_groups):
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse:
+                    raise RuntimeError('Adam does not support sparse gradients, please consider SparseAdam instead')
+                out.append((gi, p))
+        return out
+
+    def _init_state(self, active):
+        fresh = [p for _, p in active if len(self.state[p]) == 0]
+        if not fresh:
+            return
+        dev = fresh[0].device
+        align = 64      # elements: keeps every tensor's fp32 streams 256-byte aligned
+        total = sum((p.numel() + align - 1) // align * align for p in fresh)
+        n_master = sum((p.numel() + align - 1) // align * align for p in fresh if p.dtype == torch.bfloat16)
+        moments = torch.zeros(2, total, dtype=torch.float32, device=dev)
+        master = torch.empty(max(n_master, 1), dtype=torch.float32, device=dev)
+        o = om = 0
+        for p in fresh:
+            n = p.numel()
+            st = self.state[p]
+            st['step'] = 0
+            st['exp_avg'] = moments[0, o:o + n].view_as(p)
+            st['exp_avg_sq'] = moments[1, o:o + n].view_as(p)
+            o += (n + align - 1) // align * align
+            if p.dtype == torch.bfloat16:
+                m = master[om:om + n].view_as(p)
+                m.copy_(p.data)
+                st['master'] = m
+                om += (n + align - 1) // align * align
+
+    def _build_plan(self, active):
+        for _, p in active:
+            if not p.is_cuda:
+                raise _lib.UniterHipError("uniter_amd AdamW updates CUDA(HIP) parameters only (fused gfx950 kernel)")
+            if p.dtype not in (torch.bfloat16, torch.float32):
+                raise _lib.UniterHipError("AdamW supports bf16 (with fp32 master) and fp32 parameters, got %s" % p.dtype)
+            if not p.data.is_contiguous() or not p.grad.is_contiguous() or p.grad.dtype != p.dtype:
+                raise _lib.UniterHipError("AdamW needs contiguous parameters / gradients of matching dtype")
+        self._init_state(active)
+        # internal groups = (param group, step cohort): parameters of one cohort advance their step together
+        cohorts = {}
+        for gi, p in active:
+            cohorts.setdefault((gi, self.state[p]['step']), []).append(p)
+        if len(cohorts) > 16:
+            raise _lib.UniterHipError("more than 16 (param group x step) cohorts are not supported by the fused AdamW")
+        table = (UniterAdamTensor * len(active))()
+        groups = []
+        i = 0
+        for ig, ((gi, _), plist) in enumerate(sorted(cohorts.items(), key=lambda kv: kv[0])):
+            groups.append((gi, plist))
+            for p in plist:
+                st = self.state[p]
+                t = table[i]
+                t.param, t.grad = p.data.data_ptr(), p.grad.data_ptr()
+                t.master = st['master'].data_ptr() if p.dtype == torch.bfloat16 else None
+                t.exp_avg, t.exp_avg_sq = st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()
+                t.numel, t.group, t.param_is_bf16 = p.numel(), ig, 1 if p.dtype == torch.bfloat16 else 0
+                i += 1
+        self._destroy_plan()
+        handle = ctypes.c_void_p()
+        C.uniter_adamw_plan_create(table, len(active), ctypes.byref(handle))
+        self._plan, self._plan_groups = handle, groups
+
+    def _destroy_plan(self):
+        if self._plan is not None:
+            try:
+                C.uniter_adamw_plan_destroy(self._plan)
+            finally:
+                self._plan = None
+
+    def __del__(self):
+        try:
+            self._destroy_plan()
+        except Exception:
+            pass
+
+    def _ensure_plan(self):
+        active = self._active()
+        if not active:
+            return False
+        key = tuple((gi, p.data.data_ptr(), p.grad.data_ptr(), p.numel()) for gi, p in active)
+        if self._plan is None or key != self._plan_key:
+            self._build_plan(active)
+            self._plan_key = key
+        return True
+
+    # ---- public API -----------------------------------------------------------------------------------
+    def grad_norm(self, max_norm=0.0, grad_scale=1.0):
+        """Global L2 norm of all gradients times `grad_scale`, as a 0-dim device tensor (no sync), and arm the fused
+        clipping coefficient `grad_scale * min(1, max_norm / (norm + 1e-6))` for the next step()."""
+        if not self._ensure_plan():
+            return torch.zeros((), device='cuda')
+        dev = self._plan_groups[0][1][0].device
+        if self._norm_buf is None or self._norm_buf.device != dev:
+            self._norm_buf = torch.zeros(2, dtype=torch.float32, device=dev)
+        C.uniter_adamw_grad_norm(self._plan, float(grad_scale), float(max_norm), ptr(self._norm_buf), _lib.stream_ptr())
+        self._clip = self._norm_buf
+        return self._norm_buf[0]
+
+    def step(self, closure=None):
+        """One optimisation step over every parameter that has a gradient."""
+        loss = None
+        if closure is not None:
+            loss = closure()
+        if not self._ensure_plan():
+            return loss           # nothing has a gradient: no-op, like the reference's dummy first step (pretrain.py:261-263)
+        hyper = (UniterAdamGroup * len(self._plan_groups))()
+        for ig, (gi, plist) in enumerate(self._plan_groups):
+            group = self.param_groups[gi]
+            for p in plist:
+                self.state[p]['step'] += 1
+            h = hyper[ig]
+            h.lr, h.beta1, h.beta2 = float(group['lr']), float(group['betas'][0]), float(group['betas'][1])
+            h.eps, h.weight_decay = float(group['eps']), float(group['weight_decay'])
+            h.correct_bias = 1 if group['correct_bias'] else 0
+            h.step = int(self.state[plist[0]]['step'])
+        clip = self._clip
+        self._clip = None
+        C.uniter_adamw_step(self._plan, hyper, len(self._plan_groups), ptr(clip[1:]) if clip is not None else None,
+                            _lib.stream_ptr())
+        return loss
+
+    def zero_grad(self, set_to_none=False):
+        """Zero the gradients IN PLACE by default: the kernels accumulate into `.grad` storages that may be views of
+        one flat arena (utils.arena), which must survive the step."""
+        if set_to_none:
+            return super(AdamW, self).zero_grad(set_to_none=True)
+        seen = set()
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.grad is not None:
+                    base = p.grad._base if p.grad._base is not None else p.grad
+                    key = (base.data_ptr(), base.numel())
+                    if getattr(base, '_uniter_flat_grad', False):
+                        if key not in seen:
+                            seen.add(key)
+                            base.zero_()
+                    else:
+                        p.grad.zero_()
+
+
+def clip_grad_norm_(parameters_or_optimizer, max_norm, grad_scale=1.0):
+    """Counterpart of `torch.nn.utils.clip_grad_norm_(amp.master_params(optimizer), max_norm)` (pretrain.py:329-331).
+
+    Pass the uniter_amd AdamW instance: the norm is computed by one HIP reduction over all gradients and the
+    clipping is deferred into the next `optimizer.step()` (fused).  Returns the (un-clipped) total norm as a
+    0-dim device tensor — call `.item()` only when you need the number on the host.  `grad_scale` folds a global
+    factor (e.g. 1/world_size of the averaged allreduce) into both the norm and the update."""
+    if isinstance(parameters_or_optimizer, AdamW):
+        return parameters_or_optimizer.grad_norm(max_norm, grad_scale)
+    raise TypeError("clip_grad_norm_ expects the uniter_amd.optim.AdamW instance whose step() will consume the "
+                    "fused clipping coefficient")

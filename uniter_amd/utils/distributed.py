@@ -1,0 +1,291 @@
+"""Data-parallel helpers on RCCL (torch.distributed backend "nccl" IS RCCL on ROCm) — one process per GPU.
+
+Reference: utils/distributed.py:16-209, which wraps Horovod 0.16 (`hvd.allreduce_` = average over ranks,
+`hvd.broadcast_`, `hvd.allgather`).  The function names, argument meaning and in-place behaviour are kept:
+
+    all_reduce_and_rescale_tensors(tensors, rescale_denom)      average over ranks, then / rescale_denom
+    all_reduce_and_rescale_tensors_chunked(tensors, rescale_denom, buffer_size)
+    broadcast_tensors(tensors, root_rank, buffer_size)
+    all_gather_list(data) -> list (rank order)                  any picklable object
+    any_broadcast(data, root_rank)
+
+MI355X design notes (xGMI is point-to-point, 7 links x ~153 GB/s per GPU):
+  * when the tensors are views of one flat arena (utils/arena.py) the collective runs IN PLACE on the
+    covering range — no flatten / unflatten copies (the reference does 2 x 228 copy kernels per step);
+  * `GradientReducer` splits the gradient arena into per-layer buckets and starts each bucket's allreduce
+    on a side HIP stream as soon as backward has produced it (hook from UniterEncoder), overlapping
+    communication with the remaining backward compute; the 1/world averaging is folded into the fused
+    gradient-norm / AdamW kernels instead of a separate pass over the gradients.
+The CPU tests run the same code over gloo with world_size 2.
+"""
+import math
+import os
+
+import torch
+import torch.distributed as dist
+
+# ------------------------------------------------------------------------------------------------------
+# process-group plumbing (hvd.init / rank / size / local_rank)
+# ------------------------------------------------------------------------------------------------------
+
+
+def init(backend=None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run).
+    Single-process runs need no initialisation."""
+    if dist.is_available() and dist.is_initialized():
+        return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank())
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend=backend)
+
+
+def _on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else int(os.environ.get("RANK", "0"))
+
+
+def size():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def local_rank():
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+# ------------------------------------------------------------------------------------------------------
+# flat-range detection
+# ------------------------------------------------------------------------------------------------------
+def _covering_flat(tensors):
+    """If every tensor is a contiguous window of ONE storage (views of a flat arena, also after `.data`),
+    return a 1-D tensor over that storage spanning all of them (gaps are the arena's zero padding); else None.
+    Only used when the windows are dense enough that reducing the whole span is cheaper than copying."""
+    first = tensors[0]
+    try:
+        st = first.untyped_storage()
+    except Exception:
+        return None
+    sptr = st.data_ptr()
+    lo, hi, used = None, None, 0
+    for t in tensors:
+        if t.dtype != first.dtype or t.device != first.device or not t.is_contiguous():
+            return None
+        if t.untyped_storage().data_ptr() != sptr:
+            return None
+        start = t.storage_offset()
+        end = start + t.numel()
+        used += t.numel()
+        lo = start if lo is None else min(lo, start)
+        hi = end if hi is None else max(hi, end)
+    if len(tensors) < 2 or (hi - lo) > used * 1.05 + 4096:
+        return None        # a single tensor, or too sparse a cover: take the generic path
+    return torch.empty(0, dtype=first.dtype, device=first.device).set_(st, lo, (hi - lo,))
+
+
+def _flatten(tensors):
+    flat = tensors[0].new_zeros(sum(t.numel() for t in tensors))
+    o = 0
+    for t in tensors:
+        flat[o:o + t.numel()].copy_(t.reshape(-1))
+        o += t.numel()
+    return flat
+
+
+def _unflatten(flat, tensors):
+    o = 0
+    for t in tensors:
+        t.copy_(flat[o:o + t.numel()].view_as(t))
+        o += t.numel()
+
+
+# ------------------------------------------------------------------------------------------------------
+# reference API
+# ------------------------------------------------------------------------------------------------------
+def all_reduce_and_rescale_tensors(tensors, rescale_denom):
+    """In-place: every tensor becomes mean-over-ranks(tensor) / rescale_denom, all tensors in ONE collective."""
+    tensors = list(tensors)
+    if not tensors:
+        return
+    world = size()
+    scale = 1.0 / (float(world) * float(rescale_denom))
+    flat = _covering_flat(tensors)
+    if flat is not None:
+        if _on():
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if scale != 1.0:
+            flat.mul_(scale)
+        return
+    buf = _flatten(tensors)
+    if _on():
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    if scale != 1.0:
+        buf.mul_(scale)
+    _unflatten(buf, tensors)
+
+
+def _chunks(tensors, buffer_size):
+    """Greedy packing of tensors into groups of at most buffer_size bytes; oversized tensors travel alone."""
+    group, filled = [], 0
+    for t in tensors:
+        nbytes = t.numel() * t.element_size()
+        if nbytes > buffer_size:
+            yield [t], True
+            continue
+        if filled + nbytes > buffer_size and group:
+            yield group, False
+            group, filled = [], 0
+        group.append(t)
+        filled += nbytes
+    if group:
+        yield group, False
+
+
+def all_reduce_and_rescale_tensors_chunked(tensors, rescale_denom, buffer_size=10485760):
+    """Same result as all_reduce_and_rescale_tensors, in collectives of at most buffer_size bytes."""
+    world = size()
+    scale = 1.0 / (float(world) * float(rescale_denom))
+    for group, alone in _chunks(list(tensors), buffer_size):
+        if alone:
+            t = group[0]
+            if _on():
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            if scale != 1.0:
+                t.mul_(scale)
+        else:
+            all_reduce_and_rescale_tensors(group, rescale_denom)
+
+
+def broadcast_tensors(tensors, root_rank, buffer_size=10485760):
+    """In-place broadcast of every tensor from root_rank (parameters at start-up, pretrain.py:225)."""
+    tensors = list(tensors)
+    if not tensors or not _on():
+        return
+    flat = _covering_flat(tensors)
+    if flat is not None:
+        dist.broadcast(flat, src=root_rank)
+        return
+    for group, alone in _chunks(tensors, buffer_size):
+        if alone:
+            dist.broadcast(group[0], src=root_rank)
+        else:
+            buf = _flatten(group)
+            dist.broadcast(buf, src=root_rank)
+            _unflatten(buf, group)
+
+
+def all_gather_list(data):
+    """Gathers arbitrary picklable data from all ranks into a list ordered by rank."""
+    if not _on():
+        return [data]
+    out = [None] * size()
+    dist.all_gather_object(out, data)
+    return out
+
+
+def any_broadcast(data, root_rank):
+    """Broadcast arbitrary picklable data from root_rank to all ranks."""
+    if not _on():
+        return data
+    box = [data if rank() == root_rank else None]
+    dist.broadcast_object_list(box, src=root_rank)
+    return box[0]
+
+
+# ------------------------------------------------------------------------------------------------------
+# overlapped, bucketed gradient allreduce
+# ------------------------------------------------------------------------------------------------------
+class GradientReducer(object):
+    """Bucketed in-place sum-allreduce of a gradient arena, overlapped with backward.
+
+    Usage (one optimizer step, accumulation boundary only — earlier micro-steps just accumulate):
+
+        reducer = GradientReducer(arena, model.uniter.encoder)        # once
+        reducer.begin()                     # before loss.backward() of the LAST micro-step
+        loss.backward()                     # encoder hook fires per layer -> bucket allreduce on a side stream
+        scale = reducer.finish()            # joins the side stream; returns 1/world
+        clip_grad_norm_(optimizer, max_norm, grad_scale=scale); optimizer.step()
+
+    Buckets are contiguous arena ranges: one per `layers_per_bucket` encoder layers (reverse order, as backward
+    produces them) plus one for everything outside the encoder (embeddings, pooler, heads), reduced at finish()
+    (heads finish first in backward, embeddings last: both are small next to the encoder).
+    """
+
+    def __init__(self, arena, encoder=None, layers_per_bucket=2):
+        self.arena = arena
+        self.encoder = encoder
+        self.buckets = []          # (lo, hi) element ranges
+        self.layer_bucket = {}
+        self.rest = []
+        self._armed = False
+        self._stream = None
+        self._pending = []
+        covered = []
+        if encoder is not None:
+            layers = list(encoder.layer)
+            n = len(layers)
+            for hi_l in range(n, 0, -layers_per_bucket):
+                lo_l = max(0, hi_l - layers_per_bucket)
+                params = [p for l in range(lo_l, hi_l) for p in layers[l].parameters()]
+                span = arena.span(params)
+                self.layer_bucket[lo_l] = len(self.buckets)     # ready once layer lo_l's backward is enqueued
+                self.buckets.append(span)
+                covered.append(span)
+            encoder.grad_ready_hook = self._on_layer
+        covered.sort()
+        pos = 0
+        for lo, hi in covered:
+            if lo > pos:
+                self.rest.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < arena.numel:
+            self.rest.append((pos, arena.numel))
+
+    def begin(self):
+        self._armed = True
+        self._pending = []
+        if _on() and self.arena.grad.is_cuda and self._stream is None:
+            self._stream = torch.cuda.Stream()
+
+    def _reduce_range(self, lo, hi):
+        if not _on() or hi <= lo:
+            return
+        g = self.arena.grad[lo:hi]
+        if g.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._stream.wait_event(ev)
+            with torch.cuda.stream(self._stream):
+                self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+
+    def _on_layer(self, layer_index):
+        if not self._armed:
+            return
+        b = self.layer_bucket.get(layer_index)
+        if b is not None:
+            self._reduce_range(*self.buckets[b])
+
+    def finish(self):
+        """Reduce what is left (non-encoder parameters), wait for every bucket, return the averaging factor."""
+        if self._armed:
+            if self.encoder is None:
+                self._reduce_range(0, self.arena.numel)
+            else:
+                for lo, hi in self.rest:
+                    self._reduce_range(lo, hi)
+        for w in self._pending:
+            w.wait()
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
+        self._pending = []
+        self._armed = False
+        return 1.0 / float(size())
