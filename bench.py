@@ -1,0 +1,339 @@
+#!/usr/bin/env python3
+"""Headline benchmark: UNITER-base training throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full optimizer step of the reference's NLVR2 fine-tuning loop (train_nlvr2.py:153-195) on a
+synthetic batch already resident in HBM: UniterForNlvr2PairedAttn forward (32 sequences of 60 text + 36 region
+tokens per GPU = 16 pairs), loss.mean(), backward, gradient allreduce (N > 1, RCCL, overlapped with backward),
+LR schedule, global-norm clipping (2.0), fused AdamW, zero_grad.  Model = config/uniter-base.json shapes,
+hyper-parameters = config/train-nlvr2-base-1gpu.json (lr 3e-5, betas (0.9, 0.98), wd 0.01, dropout 0.1,
+accumulation 1), bf16 parameters/activations with fp32 master weights and fp32 Adam state (the apex-O2 analogue).
+Prints ONE JSON line (rank 0).  `value` counts encoder sequences ("examples") per second over all GPUs.
+
+Extra objects on the line:
+  roofline      the dominant HIP kernel (largest share of the step by launches x duration) timed live with HIP
+                events on the stream the kernels run on; algorithmic FLOP / average launch duration vs the dense
+                bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).  `step` adds the whole-step figure
+                (encoder fwd+bwd algorithmic FLOP / step time).
+  cpu_baseline  the CPU oracle (oracle/uniter_oracle.py, a port of the reference path) timed on this box's host
+                cores on the same workload — a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+BASE_CFG = dict(vocab_size=28996, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+                max_position_embeddings=512, type_vocab_size=2, initializer_range=0.02)
+TRAIN = dict(batch=32, max_txt_len=60, num_bb=36, learning_rate=3e-5, betas=(0.9, 0.98), weight_decay=0.01,
+             grad_norm=2.0, warmup_steps=800, num_train_steps=8000, dropout=0.1, optim='adamw')
+MFMA_PEAK_TFLOPS = 2500.0
+
+
+def encoder_flops(B, L, H, I, n_layers):
+    """Algorithmic FLOP of one encoder forward: n_layers * (24*T*H^2 + 4*T*L*H); I = 4H."""
+    T = B * L
+    return n_layers * (2.0 * T * H * (3 * H + H + 2 * I) + 4.0 * T * L * H)
+
+
+def write_cfg(path):
+    with open(path, "w") as f:
+        json.dump(BASE_CFG, f)
+
+
+def build_model(device, cfg_path, seed):
+    from uniter_amd.model.nlvr2 import UniterForNlvr2PairedAttn
+    from uniter_amd.utils.misc import set_dropout, set_random_seed
+    set_random_seed(seed)
+    model = UniterForNlvr2PairedAttn.from_pretrained(cfg_path, {}, img_dim=2048)      # no checkpoint: random init
+    model.init_type_embedding()                                                       # use_img_type (train_nlvr2.py:117)
+    model.to(device).bfloat16()
+    set_dropout(model, TRAIN['dropout'])
+    model.train()
+    return model
+
+
+def time_kernels(device):
+    """Live HIP-event timing of the GEMM kernels of one encoder layer at the benchmark shape."""
+    from uniter_amd._lib import C, ptr, stream_ptr
+    B, L, H, I = TRAIN['batch'], TRAIN['max_txt_len'] + TRAIN['num_bb'], BASE_CFG['hidden_size'], BASE_CFG['intermediate_size']
+    T = B * L
+    bf = torch.bfloat16
+    g = torch.Generator(device='cpu').manual_seed(0)
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g) * scale).to(device=device, dtype=bf)
+
+    x_h, x_i = rnd(T, H), rnd(T, I)
+    w_qkv, w_o, w_1, w_2 = rnd(3 * H, H, scale=0.02), rnd(H, H, scale=0.02), rnd(I, H, scale=0.02), rnd(H, I, scale=0.02)
+    bias = rnd(I, scale=0.1)
+    y_3h, y_h, y_i, y_i2 = rnd(T, 3 * H), rnd(T, H), rnd(T, I), rnd(T, I)
+    gw = torch.zeros(I * H, dtype=bf, device=device)
+    wsb = C.uniter_gemm_wgrad_workspace_bytes(T, I, H)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=device)
+    st = stream_ptr()
+    n_layers = BASE_CFG['num_hidden_layers']
+    # (name, launches per step, FLOP per launch, thunk)
+    kernels = [
+        ("gemm fwd qkv   [T,3H]x[H]", n_layers, 2.0 * T * 3 * H * H, lambda: C.uniter_gemm_bias_fwd(ptr(x_h), ptr(w_qkv), ptr(bias), ptr(y_3h), T, 3 * H, H, st)),
+        ("gemm fwd out   [T,H]x[H]+drop+res", n_layers, 2.0 * T * H * H, lambda: C.uniter_gemm_bias_dropout_residual_fwd(ptr(x_h), ptr(w_o), ptr(bias), ptr(x_h), ptr(y_h), T, H, H, 0.1, 1, 2, st)),
+        ("gemm fwd ffn1  [T,I]x[H]+gelu", n_layers, 2.0 * T * I * H, lambda: C.uniter_gemm_bias_gelu_fwd(ptr(x_h), ptr(w_1), ptr(bias), ptr(y_i), ptr(y_i2), T, I, H, st)),
+        ("gemm fwd ffn2  [T,H]x[I]+drop+res", n_layers, 2.0 * T * H * I, lambda: C.uniter_gemm_bias_dropout_residual_fwd(ptr(x_i), ptr(w_2), ptr(bias), ptr(x_h), ptr(y_h), T, H, I, 0.1, 1, 2, st)),
+        ("gemm dgrad ffn2 +gelu'", n_layers, 2.0 * T * H * I, lambda: C.uniter_gemm_dgrad_gelu(ptr(x_h), ptr(w_2), ptr(x_i), ptr(y_i), T, H, I, st)),
+        ("gemm dgrad ffn1 +res", n_layers, 2.0 * T * I * H, lambda: C.uniter_gemm_dgrad(ptr(x_i), ptr(w_1), ptr(x_h), ptr(y_h), T, I, H, st)),
+        ("gemm dgrad out", n_layers, 2.0 * T * H * H, lambda: C.uniter_gemm_dgrad(ptr(x_h), ptr(w_o), None, ptr(y_h), T, H, H, st)),
+        ("gemm dgrad qkv +res", n_layers, 2.0 * T * 3 * H * H, lambda: C.uniter_gemm_dgrad(ptr(y_3h), ptr(w_qkv), ptr(x_h), ptr(y_h), T, 3 * H, H, st)),
+        ("gemm wgrad ffn2", n_layers, 2.0 * T * H * I, lambda: C.uniter_gemm_wgrad(ptr(x_h), ptr(x_i), ptr(gw), None, T, H, I, 1, ptr(ws), wsb, st)),
+        ("gemm wgrad ffn1", n_layers, 2.0 * T * I * H, lambda: C.uniter_gemm_wgrad(ptr(x_i), ptr(x_h), ptr(gw), None, T, I, H, 1, ptr(ws), wsb, st)),
+        ("gemm wgrad out", n_layers, 2.0 * T * H * H, lambda: C.uniter_gemm_wgrad(ptr(y_h), ptr(x_h), ptr(gw), None, T, H, H, 1, ptr(ws), wsb, st)),
+        ("gemm wgrad qkv", n_layers, 2.0 * T * 3 * H * H, lambda: C.uniter_gemm_wgrad(ptr(y_3h), ptr(x_h), ptr(gw), None, T, 3 * H, H, 1, ptr(ws), wsb, st)),
+    ]
+    out = []
+    for name, per_step, flop, fn in kernels:
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        iters = 20
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        e1.synchronize()
+        us = e0.elapsed_time(e1) * 1000.0 / iters
+        out.append({"kernel": name, "launches_per_step": per_step, "us": round(us, 2), "tflops": round(flop / us * 1e-6, 1)})
+    return out
+
+
+def usable_cores():
+    """Host cores this process may actually use: affinity mask and cgroup CPU quota, not the raw host count."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
+def cpu_baseline(seed=77, budget_s=20.0):
+    """The oracle (CPU port of the reference path) on the same workload: fwd + bwd + clip + AdamW, fp32.
+    Runs in this process; main() calls it through a subprocess with a hard timeout."""
+    from oracle import uniter_oracle as O
+    from uniter_amd.model.nlvr2 import UniterForNlvr2PairedAttn
+    from uniter_amd.utils.synthetic import make_batch
+    cores = min(usable_cores(), 64)
+    torch.set_num_threads(cores)
+    cfg_path = os.path.join("/tmp", "uniter_base_cpu_%d.json" % os.getpid())
+    write_cfg(cfg_path)
+    torch.manual_seed(seed)
+    ref_model = UniterForNlvr2PairedAttn.from_pretrained(cfg_path, {}, img_dim=2048)   # only a weight container
+    ref_model.init_type_embedding()
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in ref_model.state_dict().items()}
+    del ref_model
+    os.remove(cfg_path)
+    B = TRAIN['batch']
+    batch = make_batch('nlvr2', B, TRAIN['max_txt_len'], TRAIN['num_bb'], seed=seed)
+    state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in sd.items()}
+
+    def step(i):
+        for v in sd.values():
+            v.grad = None
+        loss, _ = O.nlvr2_paired_attn_loss(sd, BASE_CFG, batch)
+        loss.mean().backward()
+        grads = [v.grad for v in sd.values() if v.grad is not None]
+        _, coef = O.clip_coef(grads, TRAIN['grad_norm'])
+        lr = O.get_lr_sched(i + 1, TRAIN['learning_rate'], TRAIN['warmup_steps'], TRAIN['num_train_steps'])
+        with torch.no_grad():
+            for k, v in sd.items():
+                if v.grad is None:
+                    continue
+                m, s = state[k]
+                if coef != 1.0:
+                    v.grad.mul_(coef)                    # clip_grad_norm_ scales in place (pretrain.py:329-331)
+                O.adamw_step_(v.data, v.grad, m, s, i + 1, lr, TRAIN['betas'], 1e-6,
+                              0.0 if O.no_decay(k) else TRAIN['weight_decay'])
+
+    t0 = time.time()
+    step(0)                                   # warm-up
+    warm = time.time() - t0
+    times = []
+    i = 1
+    while i <= 3 and (sum(times) + warm) < budget_s:
+        t0 = time.time()
+        step(i)
+        times.append(time.time() - t0)
+        i += 1
+    best = min(times) if times else warm
+    return {"value": round(B / best, 2), "unit": "examples/s", "cores": cores, "kind": "port",
+            "sample": "oracle/uniter_oracle.py (fp32 torch-CPU port of the reference NLVR2 paired-attn step: fwd+bwd+clip+AdamW) "
+                      "on the same UNITER-base workload, B=%d x (60+36), 1 warm-up + %d timed step(s), best %.2f s/step, "
+                      "%d torch threads" % (B, len(times), best, cores)}
+
+
+def cpu_baseline_subprocess(timeout_s=150):
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True, text=True,
+                           timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "examples/s", "cores": usable_cores(), "kind": "port",
+                "sample": "cpu baseline subprocess failed: " + (r.stderr.strip().splitlines() or ["?"])[-1][:200]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "examples/s", "cores": usable_cores(), "kind": "port",
+                "sample": "cpu baseline did not finish within %d s" % timeout_s}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline()), flush=True)
+        return
+
+    from uniter_amd.optim import build_optimizer, clip_grad_norm_, get_lr_sched
+    from uniter_amd.utils import distributed as D
+    from uniter_amd.utils.arena import flatten_model
+    from uniter_amd.utils.misc import Struct
+    from uniter_amd.utils.synthetic import make_batch, to_device
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                             "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the encoder path has no CPU fallback")
+    local = D.local_rank()
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    D.init("nccl")
+    rank = D.rank()
+
+    cfg_path = os.path.join("/tmp", "uniter_base_bench_%d.json" % os.getpid())
+    write_cfg(cfg_path)
+    opts = Struct(TRAIN)
+    model = build_model(device, cfg_path, seed=77)                      # same seed -> same init on every rank
+    arena = flatten_model(model)
+    D.broadcast_tensors([p.data for p in model.parameters()], 0)        # train_nlvr2.py:118
+    optimizer = build_optimizer(model, opts)
+    reducer = D.GradientReducer(arena, model.uniter.encoder) if world > 1 else None
+    # each rank trains on its own shard (data/data.py:222): different synthetic batch per rank, resident in HBM
+    batch = to_device(make_batch('nlvr2', TRAIN['batch'], TRAIN['max_txt_len'], TRAIN['num_bb'], seed=1000 + rank), device)
+    batch['img_feat'] = batch['img_feat'].to(torch.bfloat16)            # fp16 features under amp O2 in the reference
+    batch['img_pos_feat'] = batch['img_pos_feat'].to(torch.bfloat16)
+
+    optimizer.zero_grad()
+    optimizer.step()                                                     # train_nlvr2.py:150-151 dummy step (no-op)
+    global_step = 0
+
+    def train_step():
+        nonlocal global_step
+        if reducer is not None:
+            reducer.begin()
+        loss = model(batch, compute_loss=True)
+        loss = loss.mean()
+        loss.backward()
+        scale = reducer.finish() if reducer is not None else 1.0
+        global_step += 1
+        lr_this_step = get_lr_sched(global_step, opts)
+        for group in optimizer.param_groups:
+            group['lr'] = lr_this_step
+        clip_grad_norm_(optimizer, opts.grad_norm, grad_scale=scale)
+        optimizer.step()
+        optimizer.zero_grad()
+        return loss
+
+    for _ in range(args.warmup):
+        train_step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+    assert final_loss == final_loss, "loss is NaN"
+
+    if rank == 0:
+        B, L = TRAIN['batch'], TRAIN['max_txt_len'] + TRAIN['num_bb']
+        ms = elapsed / args.steps * 1e3
+        value = B * world * args.steps / elapsed
+        flop_step = 3.0 * encoder_flops(B, L, BASE_CFG['hidden_size'], BASE_CFG['intermediate_size'], BASE_CFG['num_hidden_layers'])
+        step_tf = flop_step / (ms * 1e-3) * 1e-12
+        roofline = None
+        kernels = None
+        if not args.no_kernel_timing:
+            kernels = time_kernels(device)
+            dom = max(kernels, key=lambda k: k["us"] * k["launches_per_step"])
+            roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "avg_launch_us": dom["us"], "launches_per_step": dom["launches_per_step"],
+                        "step": {"algorithmic_tflop_per_step": round(flop_step * 1e-12, 4), "achieved": round(step_tf, 1),
+                                 "frac": round(step_tf / MFMA_PEAK_TFLOPS, 4),
+                                 "note": "encoder fwd+bwd algorithmic FLOP (heads, embeddings, optimizer excluded) / whole step time"}}
+        result = {
+            "metric": "train examples/sec UNITER-base seq=60txt+36img bs32/GPU", "value": round(value, 1), "unit": "examples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "UNITER-base NLVR2 paired-attn finetune step (config/train-nlvr2-base-1gpu.json shapes): "
+                                   "fwd+bwd+clip+fused AdamW, dropout 0.1, random-init weights",
+                       "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world,
+                       "examples": "encoder sequences (32/GPU = 16 NLVR2 pairs)"},
+            "final_loss": round(final_loss, 4),
+            "roofline": roofline,
+        }
+        if kernels is not None:
+            result["kernels"] = kernels
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline_subprocess()
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    try:
+        os.remove(cfg_path)
+    except OSError:
+        pass
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -107,7 +107,7 @@ def uniter_model(sd, cfg, input_ids, position_ids, img_feat, img_pos_feat, atten
         txt = text_embeddings(sd, prefix + 'embeddings.', input_ids, position_ids, txt_type_ids)
     if img_feat is not None:
         if img_type_ids is None:
-            img_type_ids = torch.ones(img_feat.shape[:2], dtype=torch.long)          # :313-314
+            img_type_ids = torch.ones(img_feat.shape[:2], dtype=torch.long, device=img_feat.device)   # :313-314
         type_emb = sd[prefix + 'embeddings.token_type_embeddings.weight'][img_type_ids]
         img = image_embeddings(sd, prefix + 'img_embeddings.', img_feat.to(dtype), img_pos_feat.to(dtype), type_emb,
                                img_masks)
@@ -257,6 +257,21 @@ def adamw_step(p, g, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-6
     if weight_decay > 0.0:                                                           # :100-101 (after the update, raw lr)
         p = p - lr * weight_decay * p
     return p, exp_avg, exp_avg_sq
+
+
+def adamw_step_(p, g, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+    """In-place form of adamw_step with exactly the reference's op sequence (optim/adamw.py:77-101); used where the
+    oracle is TIMED as the CPU baseline so that it does not pay for extra allocations the reference does not make."""
+    b1, b2 = betas
+    exp_avg.mul_(b1).add_(g, alpha=1.0 - b1)
+    exp_avg_sq.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+    denom = exp_avg_sq.sqrt().add_(eps)
+    step_size = lr
+    if correct_bias:
+        step_size = step_size * math.sqrt(1.0 - b2 ** step) / (1.0 - b1 ** step)
+    p.addcdiv_(exp_avg, denom, value=-step_size)
+    if weight_decay > 0.0:
+        p.add_(p, alpha=-lr * weight_decay)
 
 
 def no_decay(name):

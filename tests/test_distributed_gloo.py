@@ -1,0 +1,125 @@
+"""Data-parallel helpers over gloo with world_size 2 on CPU (the N>1 path of utils/distributed.py).
+
+Semantics checked against the oracle's statement of Horovod 0.16 behaviour (utils/distributed.py:16-43,100-209):
+average over ranks then divide, in-place; broadcast from root; object gather in rank order."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, fn_name, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from uniter_amd.utils import distributed as D
+    D.init(backend="gloo")
+    try:
+        globals()[fn_name](rank, world, D)
+        open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(fn_name, tmp_path, world=2):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, fn_name, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert (tmp_path / ("ok%d" % r)).exists()
+
+
+def _case_allreduce(rank, world, D):
+    from oracle import uniter_oracle as O
+    assert D.rank() == rank and D.size() == world
+    gens = [torch.Generator().manual_seed(100 + r) for r in range(world)]
+    shapes = [(7, 5), (3,), (64, 9), (1,)]
+    per_rank = [[torch.randn(s, generator=g) for s in shapes] for g in gens]
+    # separate storages -> flatten path
+    mine = [t.clone() for t in per_rank[rank]]
+    D.all_reduce_and_rescale_tensors(mine, 2.0)
+    for i, t in enumerate(mine):
+        torch.testing.assert_close(t, O.allreduce_average([per_rank[r][i] for r in range(world)], 2.0))
+    # views of one flat arena (also through .data) -> in-place path, padding stays zero
+    flat = torch.zeros(1024)
+    views, o = [], 0
+    for t in per_rank[rank]:
+        n = t.numel()
+        v = flat[o:o + n].view(t.shape)
+        v.copy_(t)
+        views.append(v.data)
+        o += (n + 127) // 128 * 128
+    assert D._covering_flat(views) is not None
+    D.all_reduce_and_rescale_tensors(views, 1.0)
+    for i, v in enumerate(views):
+        torch.testing.assert_close(v, O.allreduce_average([per_rank[r][i] for r in range(world)]))
+    # chunked variant, tiny buffer so that one tensor travels alone
+    mine = [t.clone() for t in per_rank[rank]]
+    D.all_reduce_and_rescale_tensors_chunked(mine, 1.0, buffer_size=256)
+    for i, t in enumerate(mine):
+        torch.testing.assert_close(t, O.allreduce_average([per_rank[r][i] for r in range(world)]))
+
+
+def _case_broadcast_and_objects(rank, world, D):
+    t = [torch.full((5,), float(rank)), torch.full((300,), float(rank) + 0.5), torch.full((2, 2), float(rank) - 1)]
+    D.broadcast_tensors(t, 1, buffer_size=64)
+    assert float(t[0][0]) == 1.0 and float(t[1][7]) == 1.5 and float(t[2][1, 1]) == 0.0
+    got = D.all_gather_list({"rank": rank, "n": [rank] * (rank + 1)})
+    assert [g["rank"] for g in got] == list(range(world)) and got[1]["n"] == [1, 1]
+    assert D.any_broadcast("task_%d" % rank, 0) == "task_0"
+    assert D.any_broadcast(("mlm", rank), 1) == ("mlm", 1)
+
+
+def _case_gradient_reducer(rank, world, D):
+    """Bucketed overlap path on CPU tensors: per-layer hooks + finish() == one big averaged allreduce."""
+    from tests.common import IMG_DIM, LABEL_DIM, TINY_CONFIG
+    from uniter_amd.model.pretrain import UniterForPretraining
+    from uniter_amd.utils.arena import flatten_model
+    torch.manual_seed(0)
+    model = UniterForPretraining.from_pretrained(TINY_CONFIG, {}, img_dim=IMG_DIM, img_label_dim=LABEL_DIM)
+    arena = flatten_model(model)
+    reducer = D.GradientReducer(arena, model.uniter.encoder, layers_per_bucket=1)
+    covered = sorted(reducer.buckets + reducer.rest)
+    assert covered[0][0] == 0 and covered[-1][1] == arena.numel
+    for (a, b), (c, d) in zip(covered, covered[1:]):
+        assert b == c                                         # buckets tile the arena exactly once
+    g = torch.Generator().manual_seed(50 + rank)
+    arena.grad.copy_(torch.randn(arena.numel, generator=g))
+    mine = arena.grad.clone()
+    reducer.begin()
+    n_layers = len(model.uniter.encoder.layer)
+    for l in reversed(range(n_layers)):                       # what _EncoderFn.backward does through the hook
+        model.uniter.encoder.grad_ready_hook(l)
+    scale = reducer.finish()
+    assert scale == 1.0 / world
+    both = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    torch.testing.assert_close(arena.grad * scale, sum(both) / world)
+    # an un-armed reducer (earlier micro-steps of an accumulation window) must not communicate
+    before = arena.grad.clone()
+    model.uniter.encoder.grad_ready_hook(0)
+    assert torch.equal(arena.grad, before)
+
+
+@pytest.mark.parametrize("case", ["_case_allreduce", "_case_broadcast_and_objects", "_case_gradient_reducer"])
+def test_world_size_2(case, tmp_path):
+    _spawn(case, tmp_path)
+
+
+def test_single_process_is_a_noop():
+    from uniter_amd.utils import distributed as D
+    t = [torch.ones(3), torch.ones(4) * 2]
+    D.all_reduce_and_rescale_tensors(t, 2.0)
+    assert float(t[0][0]) == 0.5 and float(t[1][0]) == 1.0
+    D.broadcast_tensors(t, 0)
+    assert D.all_gather_list(5) == [5] and D.any_broadcast("x", 0) == "x"
+    assert D.rank() == 0 and D.size() == 1

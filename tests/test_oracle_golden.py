@@ -113,3 +113,15 @@ def test_schedule_and_helpers():
     torch.testing.assert_close(O.allreduce_average([a, b], 2.0), torch.ones(3))
     gi = O.get_gather_index([2, 3], [2, 1], 2, 3, 5)
     assert gi.tolist() == [[0, 1, 3, 4, 4], [0, 1, 2, 3, 4]]
+
+
+def test_inplace_adamw_equals_functional():
+    g = torch.Generator().manual_seed(0)
+    p, grad = torch.randn(50, generator=g), torch.randn(50, generator=g)
+    m, v = torch.zeros(50), torch.zeros(50)
+    p1, m1, v1 = p.clone(), m.clone(), v.clone()
+    for step in (1, 2, 3):
+        p, m, v = O.adamw_step(p, grad, m, v, step, 1e-2, (0.9, 0.98), 1e-6, 0.01)
+        O.adamw_step_(p1, grad, m1, v1, step, 1e-2, (0.9, 0.98), 1e-6, 0.01)
+    torch.testing.assert_close(p, p1, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(v, v1, rtol=1e-6, atol=1e-12)

@@ -9,7 +9,8 @@
 
 namespace {
 
-constexpr int ROWS_PER_BLOCK = 4;   // 4 waves, one row each
+constexpr int ROWS_PER_BLOCK = 4;   // forward: 4 waves, one row each
+constexpr int BWD_WAVES = 16;       // backward / column sums: 16 waves per block (fewer partial rows to finalize)
 
 template <int NC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ z, const bf16_t* __restrict__ gamma,
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 }
 
 // Backward.  partial layout: [gridDim.x][3][H] fp32 = per-block column sums of (dgamma, dbeta, dbias).
-template <int NC>
+template <int NC, int NW>
 struct LnBwd {
     static __device__ void run(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dy_extra,
                                const bf16_t* __restrict__ z, const float* __restrict__ mean_in,
@@ -93,7 +94,7 @@ struct LnBwd {
         }
         const bool use_drop = drop.p > 0.f && !post_drop;   // dropout sat on the dense branch feeding z
         const bool use_post = drop.p > 0.f && post_drop;    // dropout sat on the LN output (embedding blocks)
-        for (int row = blockIdx.x * ROWS_PER_BLOCK + wid; row < rows; row += gridDim.x * ROWS_PER_BLOCK) {
+        for (int row = blockIdx.x * NW + wid; row < rows; row += gridDim.x * NW) {
             const float mean = mean_in[row], rstd = rstd_in[row];
             const int64_t ro = (int64_t)row * H;
             float xh[NC][4], gy[NC][4];
@@ -158,65 +159,76 @@ struct LnBwd {
                 }
             }
         }
-        // block reduction over the 4 waves, one quantity at a time: red[4][NC*256]
-        constexpr int W = NC * 256;
+        // block reduction over the NW waves, one (quantity, 256-column chunk) at a time: red[NW][256]
         float* pout = partial + (int64_t)blockIdx.x * 3 * H;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int col = (lane + 64 * c) * 4 + e;
-                    red[wid * W + col] = (k == 0) ? ag[c][e] : ((k == 1) ? ab[c][e] : ad[c][e]);
-                }
-            }
-            __syncthreads();
-            for (int col = threadIdx.x; col < H; col += 256) {
-                float s = 0.f;
+                for (int e = 0; e < 4; ++e)
+                    red[wid * 256 + lane * 4 + e] = (k == 0) ? ag[c][e] : ((k == 1) ? ab[c][e] : ad[c][e]);
+                __syncthreads();
+                if (threadIdx.x < 256) {
+                    const int col = c * 256 + threadIdx.x;
+                    float s = 0.f;
 #pragma unroll
-                for (int w = 0; w < ROWS_PER_BLOCK; ++w) s += red[w * W + col];
-                pout[k * H + col] = s;
+                    for (int w = 0; w < NW; ++w) s += red[w * 256 + threadIdx.x];
+                    if (col < H) pout[k * H + col] = s;
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
 };
 
-template <int NC>
-__global__ __launch_bounds__(256) void ln_bwd_kernel2(const bf16_t* dy, const bf16_t* dy_extra, const bf16_t* z,
+template <int NC, int NW>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_kernel2(const bf16_t* dy, const bf16_t* dy_extra, const bf16_t* z,
                                                       const float* mean_in, const float* rstd_in, const bf16_t* gamma,
                                                       bf16_t* dz, bf16_t* dd, float* partial, int rows, int H,
                                                       int want_dbias, int post_drop, const DropoutCfg drop) {
-    __shared__ float red[ROWS_PER_BLOCK * NC * 256];
-    LnBwd<NC>::run(dy, dy_extra, z, mean_in, rstd_in, gamma, dz, dd, partial, rows, H, want_dbias, post_drop, drop, red);
+    __shared__ float red[NW * 256];
+    LnBwd<NC, NW>::run(dy, dy_extra, z, mean_in, rstd_in, gamma, dz, dd, partial, rows, H, want_dbias, post_drop, drop, red);
 }
 
-// out_k[col] (+)= sum_b partial[b][k][col]   for k < nk (nk <= 3), partial [nb][nk][H]
-__global__ __launch_bounds__(256) void finalize_cols_kernel(const float* __restrict__ partial, int nb, int nk, int H,
-                                                            bf16_t* o0, bf16_t* o1, bf16_t* o2, int accumulate) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nk * H) return;
-    const int k = idx / H, col = idx % H;
-    bf16_t* out = k == 0 ? o0 : (k == 1 ? o1 : o2);
-    if (out == nullptr) return;
+// out_k[col] (+)= sum_b partial[b][k][col]   for k < nk (nk <= 3), partial [nb][nk][H].
+// One block = 64 columns x 16 groups of partial rows (coalesced 256-byte reads), LDS tree over the groups.
+__global__ __launch_bounds__(1024) void finalize_cols_kernel(const float* __restrict__ partial, int nb, int nk, int H,
+                                                             bf16_t* o0, bf16_t* o1, bf16_t* o2, int accumulate) {
+    __shared__ float red[16][64];
+    const int cx = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + cx;
+    const int total = nk * H;
     float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += partial[((int64_t)b * nk + k) * H + col];
-    if (accumulate) s += bf2f(out[col]);
-    out[col] = f2bf(s);
+    if (idx < total) {
+        for (int b = grp; b < nb; b += 16) s += partial[(int64_t)b * total + idx];
+    }
+    red[grp][cx] = s;
+    __syncthreads();
+    if (grp == 0 && idx < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][cx];
+        const int k = idx / H, col = idx % H;
+        bf16_t* out = k == 0 ? o0 : (k == 1 ? o1 : o2);
+        if (out != nullptr) {
+            if (accumulate) t += bf2f(out[col]);
+            out[col] = f2bf(t);
+        }
+    }
 }
 
 // per-block column sums of a[rows][N]: grid (strips of 512 cols, row blocks); partial [gridDim.y][N]
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ a, float* __restrict__ partial,
-                                                     int rows, int N) {
-    __shared__ float red[ROWS_PER_BLOCK][512];
+__global__ __launch_bounds__(1024) void colsum_kernel(const bf16_t* __restrict__ a, float* __restrict__ partial,
+                                                      int rows, int N) {
+    __shared__ float red[BWD_WAVES][512];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int col = blockIdx.x * 512 + lane * 8;
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
     if (col < N) {
-        for (int row = blockIdx.y * ROWS_PER_BLOCK + wid; row < rows; row += gridDim.y * ROWS_PER_BLOCK) {
+        for (int row = blockIdx.y * BWD_WAVES + wid; row < rows; row += gridDim.y * BWD_WAVES) {
             float v[8];
             unpack8(*reinterpret_cast<const u32x4*>(a + (int64_t)row * N + col), v);
 #pragma unroll
@@ -226,27 +238,29 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[wid][lane * 8 + e] = acc[e];
     __syncthreads();
-    for (int c = threadIdx.x; c < 512; c += 256) {
-        const int gc = blockIdx.x * 512 + c;
+    if (threadIdx.x < 512) {
+        const int gc = blockIdx.x * 512 + threadIdx.x;
         if (gc < N) {
             float s = 0.f;
 #pragma unroll
-            for (int w = 0; w < ROWS_PER_BLOCK; ++w) s += red[w][c];
+            for (int w = 0; w < BWD_WAVES; ++w) s += red[w][threadIdx.x];
             partial[(int64_t)blockIdx.y * N + gc] = s;
         }
     }
 }
 
-int ln_bwd_blocks(int64_t rows) {
-    int64_t nb = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    if (nb > 256) nb = 256;
+int ln_bwd_waves(int nc) { return nc <= 3 ? 16 : (nc == 4 ? 8 : 4); }   // register budget: 128 / 256 / 512 per lane
+int ln_bwd_blocks(int64_t rows, int nw) {
+    int64_t nb = (rows + nw - 1) / nw;     // one row per wave until the chip is ~3x covered
+    const int64_t cap = 4096 / nw;
+    if (nb > cap) nb = cap;
     return (int)nb;
 }
 int colsum_blocks(int64_t rows, int64_t N) {
     const int64_t strips = (N + 511) / 512;
-    int64_t nb = 1024 / strips;
+    int64_t nb = 256 / strips;                           // ~256 blocks x 16 waves in flight
     if (nb < 1) nb = 1;
-    const int64_t maxb = (rows + ROWS_PER_BLOCK * 4 - 1) / (ROWS_PER_BLOCK * 4);   // >= 4 rows per wave
+    const int64_t maxb = (rows + BWD_WAVES * 2 - 1) / (BWD_WAVES * 2);   // >= 2 rows per wave
     if (nb > maxb) nb = maxb;
     if (nb < 1) nb = 1;
     return (int)nb;
@@ -276,7 +290,8 @@ int layernorm_fwd(const void* z, const void* gamma, const void* beta, void* y, f
 }
 
 size_t layernorm_bwd_workspace_bytes(int64_t rows, int64_t H) {
-    return (size_t)ln_bwd_blocks(rows) * 3 * (size_t)H * sizeof(float);
+    const int nc = (int)((H / 4 + 63) / 64);
+    return (size_t)ln_bwd_blocks(rows, ln_bwd_waves(nc)) * 3 * (size_t)H * sizeof(float);
 }
 
 int layernorm_bwd(const void* dy, const void* dy_extra, const void* z, const float* mean, const float* rstd,
@@ -286,21 +301,22 @@ int layernorm_bwd(const void* dy, const void* dy_extra, const void* z, const flo
     if (rows <= 0 || H <= 0 || H % 4 != 0 || H > 2048) { uh_set_error("layernorm_bwd: need H %% 4 == 0 and H <= 2048 (H=%lld)", (long long)H); return -1; }
     if (ws_bytes < layernorm_bwd_workspace_bytes(rows, H)) { uh_set_error("layernorm_bwd: workspace too small"); return -1; }
     const int nc = (int)((H / 4 + 63) / 64);
-    const int nb = ln_bwd_blocks(rows);
+    const int nw = ln_bwd_waves(nc);
+    const int nb = ln_bwd_blocks(rows, nw);
     float* partial = (float*)workspace;
     const int want_dbias = dbias != nullptr;
-#define LN_BWD(NCV)                                                                                              \
-    hipLaunchKernelGGL(ln_bwd_kernel2<NCV>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)dy_extra, \
+#define LN_BWD(NCV, NWV)                                                                                              \
+    hipLaunchKernelGGL((ln_bwd_kernel2<NCV, NWV>), dim3(nb), dim3(64 * NWV), 0, st, (const bf16_t*)dy, (const bf16_t*)dy_extra, \
                        (const bf16_t*)z, mean, rstd, (const bf16_t*)gamma, (bf16_t*)dz, (bf16_t*)dd, partial,     \
                        (int)rows, (int)H, want_dbias, post_drop, drop)
-    if (nc <= 1) LN_BWD(1);
-    else if (nc == 2) LN_BWD(2);
-    else if (nc == 3) LN_BWD(3);
-    else if (nc == 4) LN_BWD(4);
-    else LN_BWD(8);
+    if (nc <= 1) LN_BWD(1, 16);
+    else if (nc == 2) LN_BWD(2, 16);
+    else if (nc == 3) LN_BWD(3, 16);
+    else if (nc == 4) LN_BWD(4, 8);
+    else LN_BWD(8, 4);
 #undef LN_BWD
     UH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(finalize_cols_kernel, dim3((unsigned)((3 * H + 255) / 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(finalize_cols_kernel, dim3((unsigned)((3 * H + 63) / 64)), dim3(1024), 0, st,
                        (const float*)partial, nb, 3, (int)H, (bf16_t*)dgamma, (bf16_t*)dbeta, (bf16_t*)dbias, accumulate);
     UH_LAUNCH_CHECK();
     return 0;
@@ -316,9 +332,9 @@ int colsum(const void* a, void* out, int64_t rows, int64_t N, int accumulate,
     if (ws_bytes < colsum_workspace_bytes(rows, N)) { uh_set_error("colsum: workspace too small"); return -1; }
     const int nb = colsum_blocks(rows, N);
     dim3 grid((unsigned)((N + 511) / 512), nb);
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, (const bf16_t*)a, (float*)workspace, (int)rows, (int)N);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(64 * BWD_WAVES), 0, st, (const bf16_t*)a, (float*)workspace, (int)rows, (int)N);
     UH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(finalize_cols_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(finalize_cols_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, st,
                        (const float*)workspace, nb, 1, (int)N, (bf16_t*)out, (bf16_t*)nullptr, (bf16_t*)nullptr, accumulate);
     UH_LAUNCH_CHECK();
     return 0;

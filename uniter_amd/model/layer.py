@@ -87,8 +87,12 @@ class BertSelfAttention(nn.Module):
 
     @staticmethod
     def _adjacent(tensors):
+        """Back to back inside ONE storage (views of an arena / of a fused buffer) — being neighbours in the
+        allocator's address space by accident does not count: as_strided cannot span storages."""
         step = tensors[0].numel() * tensors[0].element_size()
-        return all(t.is_contiguous() and t.data_ptr() == tensors[0].data_ptr() + i * step for i, t in enumerate(tensors))
+        base = tensors[0].untyped_storage().data_ptr()
+        return all(t.is_contiguous() and t.untyped_storage().data_ptr() == base
+                   and t.data_ptr() == tensors[0].data_ptr() + i * step for i, t in enumerate(tensors))
 
     def fused_qkv(self):
         """([3H,H] weight, [3H] bias) whose thirds ARE query/key/value .weight/.bias (re-fused lazily after
