@@ -240,6 +240,10 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
                             const void* x_in, const float* mask_bias, const void* dy, void* dx,
                             void* acts, void* scratch, uint64_t seed, uint64_t offset, void* stream);
 
+/* Test / tuning hook: backward runs the weight-gradient GEMMs and bias column sums on an internal side stream
+ * (ordered against `stream` purely by events) unless disabled with 0. */
+int uniter_encoder_debug_side_stream(int enable);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused multi-tensor AdamW + global gradient norm / clipping.                 optim/adamw.py:40-103
  * ---------------------------------------------------------------------------------------------- */

@@ -675,6 +675,10 @@ static void bench(int B, int L, int H, int heads, int I, int layers) {
         uint16_t* dDx = dalloc<uint16_t>((size_t)T * H);
         double tf = tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 10);
         double tb = tm.run([&] { UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0)); }, 2, 10);
+        uniter_encoder_debug_side_stream(0);
+        double tb0 = tm.run([&] { UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0)); }, 2, 10);
+        uniter_encoder_debug_side_stream(1);
+        printf("  (backward with the wgrad side stream disabled: %.1f us)\n", tb0);
         const double flf = (double)layers * (24.0 * T * H * H + 4.0 * T * L * H);
         printf("  ENCODER fwd %.1f us (%.1f TF) | bwd %.1f us (%.1f TF) | fwd+bwd %.1f us = %.1f TF = %.1f%% of 2.5 PF ; %.0f ex/s\n", tf,
                flf / tf * 1e-6, tb, 2 * flf / tb * 1e-6, tf + tb, 3 * flf / (tf + tb) * 1e-6, 3 * flf / (tf + tb) * 1e-6 / 2500 * 100,
@@ -682,11 +686,44 @@ static void bench(int B, int L, int H, int heads, int I, int layers) {
     }
 }
 
+// --one <fwd|gelu|dgrad|wgrad> M N K cfg splits iters : launch one GEMM flavour repeatedly (for rocprofv3 --pmc runs)
+static int run_one(int argc, char** argv, int at) {
+    if (at + 7 > argc) { fprintf(stderr, "usage: --one kind M N K cfg splits iters\n"); return 2; }
+    const std::string kind = argv[at];
+    const int64_t M = atoll(argv[at + 1]), N = atoll(argv[at + 2]), K = atoll(argv[at + 3]);
+    const int cfg = atoi(argv[at + 4]), splits = atoi(argv[at + 5]), iters = atoi(argv[at + 6]);
+    HostBf X, W, Bv;
+    const size_t big = (size_t)std::max(M, std::max(N, K));
+    X.fill((size_t)M * big, 1.f); W.fill((size_t)N * big, 0.05f); Bv.fill(big, 0.1f);
+    uint16_t *dX = upload(X), *dW = upload(W), *dB = upload(Bv);
+    uint16_t* dY = dalloc<uint16_t>((size_t)M * big);
+    uint16_t* dY2 = dalloc<uint16_t>((size_t)M * big);
+    const size_t wsb = uniter_gemm_wgrad_workspace_bytes(M, N, K);
+    void* ws = dalloc<char>(wsb);
+    uniter_gemm_debug_force(cfg, splits);
+    Timer tm;
+    auto fn = [&] {
+        if (kind == "fwd") UHCHK(uniter_gemm_bias_fwd(dX, dW, dB, dY, M, N, K, 0));
+        else if (kind == "gelu") UHCHK(uniter_gemm_bias_gelu_fwd(dX, dW, dB, dY, dY2, M, N, K, 0));
+        else if (kind == "dgrad") UHCHK(uniter_gemm_dgrad(dX, dW, nullptr, dY, M, N, K, 0));
+        else UHCHK(uniter_gemm_wgrad(dX, dY, dW, nullptr, M, N, K, 1, ws, wsb, 0));
+    };
+    const double us = tm.run(fn, 3, iters);
+    printf("%s M%lld N%lld K%lld cfg%d splits%d: %.2f us  %.1f TF\n", kind.c_str(), (long long)M, (long long)N, (long long)K, cfg,
+           splits, us, 2.0 * M * N * K / us * 1e-6);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     bool do_bench = false, quick = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--bench")) do_bench = true;
         if (!strcmp(argv[i], "--quick")) quick = true;
+        if (!strcmp(argv[i], "--one")) {
+            int32_t inf[4];
+            UHCHK(uniter_hip_device_info(inf));
+            return run_one(argc, argv, i + 1);
+        }
     }
     int32_t info[4];
     UHCHK(uniter_hip_device_info(info));

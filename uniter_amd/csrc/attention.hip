@@ -200,6 +200,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
     float* mb = reinterpret_cast<float*>(Os + Lp * 64);
     float* lse_s = mb + Lp;
     float* D_s = lse_s + Lp;
+    uint8_t* keep_s = reinterpret_cast<uint8_t*>(D_s + Lp);     // dropout keep nibbles [q][Lp/4], written by sweep 1
+    const int kstride = Lp >> 2;
 
     const int bh = blockIdx.x;
     const int b = bh / p.heads, h = bh % p.heads;
@@ -263,7 +265,13 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Vs, kt * 16 + i, 1, g), of1, dp, 0, 0, 0);
                 const f32x4 mv = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
                 float mult[4] = {1.f, 1.f, 1.f, 1.f};
-                if (drop) dropout_mult4(p.drop, drow + (uint64_t)(kt * 4 + g), mult);
+                if (drop) {
+                    // one Philox call per 4 keys; the keep bits are parked in LDS for the key-owner sweep
+                    const uint32_t keep = dropout_keep4(p.drop, drow + (uint64_t)(kt * 4 + g));
+                    keep_s[q * kstride + kt * 4 + g] = (uint8_t)keep;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mult[r] = ((keep >> r) & 1u) ? p.drop.scale : 0.f;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float pr = __expf(s[r] * 0.125f + mv[r] - lse_q);
@@ -285,6 +293,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
         }
     }
 
+    if (drop) __syncthreads();         // keep_s complete before the key-owner sweep reads it
     // ---- sweep 2: key-tile owners -> dK, dV ----
     for (int kt = wid; kt < nt; kt += nw) {
         const int key = kt * 16 + i;
@@ -311,10 +320,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float mult = 1.f;
-                    if (drop)
-                        mult = dropout_mult1(p.drop,
-                                             ((uint64_t)bh * (uint64_t)L + (uint64_t)(qb + r)) * (LMAX / 4) + (uint64_t)(key >> 2),
-                                             key & 3);
+                    if (drop) mult = ((keep_s[(qb + r) * kstride + (key >> 2)] >> (key & 3)) & 1u) ? p.drop.scale : 0.f;
                     const float pr = __expf(s[r] * 0.125f + mb_k - lv[r]);
                     pd[hf][r] = pr * mult;
                     ds[hf][r] = pr * (dp[r] * mult - Dv[r]) * 0.125f;
@@ -409,7 +415,7 @@ int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, cons
     a.B = (int)B; a.L = (int)L; a.heads = (int)heads; a.Lp = (int)((L + 31) / 32 * 32);
     a.drop = drop;
     const int nw = pick_waves((int)((L + 15) / 16));
-    const size_t lds = (size_t)a.Lp * 64 * 2 * 4 + (size_t)a.Lp * 4 * 3;
+    const size_t lds = (size_t)a.Lp * 64 * 2 * 4 + (size_t)a.Lp * 4 * 3 + (size_t)a.Lp * (a.Lp / 4);
     int rc;
     if ((rc = set_lds(attn_bwd_kernel, lds))) return rc;
     hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * heads)), dim3(nw * 64), lds, st, a);

@@ -118,6 +118,13 @@ __device__ __forceinline__ void dropout_mult4(const DropoutCfg& d, uint64_t idx4
 #pragma unroll
     for (int i = 0; i < 4; ++i) m[i] = (r[i] >= d.thresh) ? d.scale : 0.f;
 }
+// Keep bits (bit e set = element e of the group survives) for the 4 consecutive elements of group `idx4`.
+__device__ __forceinline__ uint32_t dropout_keep4(const DropoutCfg& d, uint64_t idx4) {
+    const u32x4 r = philox4x32_10((uint32_t)idx4, (uint32_t)(idx4 >> 32), d.off_lo, d.off_hi,
+                                  d.seed_lo, d.seed_hi);
+    return (r[0] >= d.thresh ? 1u : 0u) | (r[1] >= d.thresh ? 2u : 0u) | (r[2] >= d.thresh ? 4u : 0u) |
+           (r[3] >= d.thresh ? 8u : 0u);
+}
 // Single element `e` (0..3) of group idx4.
 __device__ __forceinline__ float dropout_mult1(const DropoutCfg& d, uint64_t idx4, int e) {
     const u32x4 r = philox4x32_10((uint32_t)idx4, (uint32_t)(idx4 >> 32), d.off_lo, d.off_hi,
@@ -129,12 +136,26 @@ __device__ __forceinline__ float dropout_mult1(const DropoutCfg& d, uint64_t idx
 // ---------------------------------------------------------------------------------------------
 // exact erf GELU (model/layer.py:31-37) and its derivative
 // ---------------------------------------------------------------------------------------------
+// Phi(x) = 0.5*(1+erf(x/sqrt2)) and phi(x) = exp(-x^2/2)/sqrt(2 pi) from ONE exponential:
+// erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1/(1 + p z)  (Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7,
+// far below the bf16 resolution of the stored result) with z = |x|/sqrt2, so exp(-z^2) = exp(-x^2/2) serves both.
+__device__ __forceinline__ void normal_cdf_pdf(float x, float& cdf, float& pdf) {
+    const float ax = fabsf(x);
+    const float e = __expf(-0.5f * ax * ax);
+    const float t = __frcp_rn(1.0f + 0.23164189f * ax);          // p / sqrt2 = 0.3275911 / 1.41421356
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float tail = 0.5f * poly * e;                            // = 0.5 * erfc(|x| / sqrt2)
+    cdf = x >= 0.f ? 1.0f - tail : tail;
+    pdf = 0.39894228040143267794f * e;
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-    return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    float cdf, pdf;
+    normal_cdf_pdf(x, cdf, pdf);
+    return x * cdf;
 }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    float cdf, pdf;
+    normal_cdf_pdf(x, cdf, pdf);
     return cdf + x * pdf;
 }
 

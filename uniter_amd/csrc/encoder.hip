@@ -40,7 +40,7 @@ ActLayout act_layout(const UniterEncoderShape& s) {
 }
 
 struct ScratchLayout {
-    size_t bufA, bufB, dd, dctx, dqkv, dpre, red, red_bytes, wg, wg_bytes, total;
+    size_t bufA, bufB, dd, dd1, dctx, dqkv, dpre, red, red2, red_bytes, wg, wg_bytes, total;
 };
 ScratchLayout scratch_layout(const UniterEncoderShape& s) {
     const size_t T = (size_t)s.B * s.L, H = s.H, I = s.I;
@@ -50,6 +50,7 @@ ScratchLayout scratch_layout(const UniterEncoderShape& s) {
     l.bufA = take(T * H * 2);
     l.bufB = take(T * H * 2);
     l.dd = take(T * H * 2);
+    l.dd1 = take(T * H * 2);
     l.dctx = take(T * H * 2);
     l.dqkv = take(T * 3 * H * 2);
     l.dpre = take(T * I * 2);
@@ -60,6 +61,7 @@ ScratchLayout scratch_layout(const UniterEncoderShape& s) {
     if (c2 > red) red = c2;
     l.red_bytes = red;
     l.red = take(red);
+    l.red2 = take(red);
     // split-K partials: up to 8 slices of the largest weight gradient
     size_t big = 3 * H * H;
     if (I * H > big) big = I * H;
@@ -68,6 +70,35 @@ ScratchLayout scratch_layout(const UniterEncoderShape& s) {
     l.total = o;
     return l;
 }
+
+// ---- second stream for the weight-gradient GEMMs ------------------------------------------------------
+// dgrad(l) and wgrad(l) both need only dY(l); nothing downstream of backward needs the weight gradients
+// until the optimizer.  Running every wgrad / bias column-sum on a side stream lets them fill the CUs the
+// (small, 144-576 workgroup) dgrad chain leaves idle.  Ordering is by events only, no host synchronisation.
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t main_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // recorded on the caller's stream
+    hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // recorded on the side stream
+    hipEvent_t done = nullptr;
+    int device = -1;
+};
+thread_local SideStream g_side;
+
+int side_init() {
+    int dev = 0;
+    UH_CHECK_HIP(hipGetDevice(&dev));
+    if (g_side.stream != nullptr && g_side.device == dev) return 0;
+    UH_CHECK_HIP(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; ++i) {
+        UH_CHECK_HIP(hipEventCreateWithFlags(&g_side.main_ev[i], hipEventDisableTiming));
+        UH_CHECK_HIP(hipEventCreateWithFlags(&g_side.side_ev[i], hipEventDisableTiming));
+    }
+    UH_CHECK_HIP(hipEventCreateWithFlags(&g_side.done, hipEventDisableTiming));
+    g_side.device = dev;
+    return 0;
+}
+
+int g_use_side_stream = 1;
 
 int check_shape(const UniterEncoderShape* s) {
     if (s == nullptr) { uh_set_error("encoder: null shape"); return -1; }
@@ -153,13 +184,42 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
     char* S = (char*)scratch;
     char* bufA = S + sl.bufA;
     char* bufB = S + sl.bufB;
-    char* ddb = S + sl.dd;
+    char* ddb2 = S + sl.dd;
+    char* ddb1 = S + sl.dd1;
     char* dctx = S + sl.dctx;
     char* dqkv = S + sl.dqkv;
     char* dpre = S + sl.dpre;
     void* red = S + sl.red;
+    void* red2 = S + sl.red2;
     void* wg = S + sl.wg;
     const bool hdrop = s->p_hidden > 0.f;
+    const bool side = g_use_side_stream != 0;
+    hipStream_t ss = st;
+    if (side) {
+        RC(side_init());
+        ss = g_side.stream;
+    }
+    // slot k: main_ev[k] = "input of side job k is ready", side_ev[k] = "side job k has finished reading its input".
+    // jobs: 0 = wgrad W2 (reads dd2), 1 = colsum + wgrad W1 (reads dpre), 2 = wgrad Wo (reads dd1), 3 = colsum + wgrad Wqkv (reads dqkv)
+    bool side_pending[4] = {false, false, false, false};
+    auto fork = [&](int k) -> int {            // side stream may start job k once the main stream reaches this point
+        if (!side) return 0;
+        UH_CHECK_HIP(hipEventRecord(g_side.main_ev[k], st));
+        UH_CHECK_HIP(hipStreamWaitEvent(ss, g_side.main_ev[k], 0));
+        return 0;
+    };
+    auto joined = [&](int k) -> int {          // side job k enqueued: remember that its input buffer is busy
+        if (!side) return 0;
+        UH_CHECK_HIP(hipEventRecord(g_side.side_ev[k], ss));
+        side_pending[k] = true;
+        return 0;
+    };
+    auto before_overwrite = [&](int k) -> int { // main stream is about to overwrite the input buffer of side job k
+        if (!side || !side_pending[k]) return 0;
+        UH_CHECK_HIP(hipStreamWaitEvent(st, g_side.side_ev[k], 0));
+        side_pending[k] = false;
+        return 0;
+    };
     const char* dyl = (const char*)dy;
     for (int l = layer_end - 1; l >= layer_begin; --l) {
         const UniterLayerParams& P = layers[l];
@@ -172,32 +232,58 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         const DropoutCfg d_h2 = make_dropout(s->p_hidden, seed, off + 2);
 
         // ---- BertOutput backward (model/layer.py:152-156) ----
+        // without dropout the masked gradient IS dz (bufA): side jobs 0 / 2 then read bufA
+        RC(before_overwrite(0));
+        if (!hdrop) RC(before_overwrite(2));
         RC(uh::layernorm_bwd(dyl, nullptr, A + al.z2, (const float*)(A + al.mean2), (const float*)(A + al.rstd2), P.ln2_g,
-                             bufA, hdrop ? ddb : nullptr, P.g_ln2_g, P.g_ln2_b, P.g_b2, T, H, 1, d_h2, 0,
+                             bufA, hdrop ? ddb2 : nullptr, P.g_ln2_g, P.g_ln2_b, P.g_b2, T, H, 1, d_h2, 0,
                              red, sl.red_bytes, st));
-        const char* dd2 = hdrop ? ddb : bufA;
+        const char* dd2 = hdrop ? ddb2 : bufA;
+        RC(fork(0));
+        RC(uh::gemm_wgrad(dd2, A + al.g, P.g_w2, T, H, I, 1, wg, sl.wg_bytes, ss));
+        RC(joined(0));
+        RC(before_overwrite(1));
         RC(uh::gemm_dgrad(uh::GEMM_EPI_GELU_BWD, dd2, P.w2, A + al.u, dpre, T, H, I, st));
-        RC(uh::gemm_wgrad(dd2, A + al.g, P.g_w2, T, H, I, 1, wg, sl.wg_bytes, st));
         // ---- BertIntermediate backward (model/layer.py:139-142) ----
-        RC(uh::colsum(dpre, P.g_b1, T, I, 1, red, sl.red_bytes, st));
-        RC(uh::gemm_wgrad(dpre, A + al.a, P.g_w1, T, I, H, 1, wg, sl.wg_bytes, st));
+        RC(fork(1));
+        RC(uh::colsum(dpre, P.g_b1, T, I, 1, side ? red2 : red, sl.red_bytes, ss));
+        RC(uh::gemm_wgrad(dpre, A + al.a, P.g_w1, T, I, H, 1, wg, sl.wg_bytes, ss));
+        RC(joined(1));
         RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dpre, P.w1, bufA, bufB, T, I, H, st));          // da = dpre*W1 + dz2
         // ---- BertSelfOutput backward (model/layer.py:111-115) ----
+        RC(before_overwrite(2));
+        if (!hdrop) RC(before_overwrite(0));
         RC(uh::layernorm_bwd(bufB, nullptr, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1), P.ln1_g,
-                             bufA, hdrop ? ddb : nullptr, P.g_ln1_g, P.g_ln1_b, P.g_bo, T, H, 1, d_h1, 0,
+                             bufA, hdrop ? ddb1 : nullptr, P.g_ln1_g, P.g_ln1_b, P.g_bo, T, H, 1, d_h1, 0,
                              red, sl.red_bytes, st));
-        const char* dd1 = hdrop ? ddb : bufA;
+        const char* dd1 = hdrop ? ddb1 : bufA;
+        RC(fork(2));
+        RC(uh::gemm_wgrad(dd1, A + al.ctx, P.g_wo, T, H, H, 1, wg, sl.wg_bytes, ss));
+        RC(joined(2));
         RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dd1, P.wo, nullptr, dctx, T, H, H, st));
-        RC(uh::gemm_wgrad(dd1, A + al.ctx, P.g_wo, T, H, H, 1, wg, sl.wg_bytes, st));
         // ---- BertSelfAttention backward (model/layer.py:75-101) ----
+        RC(before_overwrite(3));
         RC(uh::attention_bwd(A + al.qkv, mask_bias, A + al.ctx, (const float*)(A + al.lse), dctx, dqkv,
                              s->B, s->L, s->heads, d_attn, st));
-        RC(uh::colsum(dqkv, P.g_bqkv, T, 3 * H, 1, red, sl.red_bytes, st));
-        RC(uh::gemm_wgrad(dqkv, xin, P.g_wqkv, T, 3 * H, H, 1, wg, sl.wg_bytes, st));
+        RC(fork(3));
+        RC(uh::colsum(dqkv, P.g_bqkv, T, 3 * H, 1, side ? red2 : red, sl.red_bytes, ss));
+        RC(uh::gemm_wgrad(dqkv, xin, P.g_wqkv, T, 3 * H, H, 1, wg, sl.wg_bytes, ss));
+        RC(joined(3));
         char* dxl = (l == layer_begin) ? (char*)dx : bufB;
         RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dqkv, P.wqkv, bufA, dxl, T, 3 * H, H, st));     // dx = dqkv*Wqkv + dz1
         dyl = dxl;
     }
+    if (side) {
+        // every weight gradient is complete (and the scratch buffers are free) once the caller's stream passes this point
+        UH_CHECK_HIP(hipEventRecord(g_side.done, ss));
+        UH_CHECK_HIP(hipStreamWaitEvent(st, g_side.done, 0));
+    }
+    return 0;
+}
+
+// test / tuning hook: 0 = run the weight-gradient GEMMs on the caller's stream, 1 = on the library's side stream
+int uniter_encoder_debug_side_stream(int enable) {
+    g_use_side_stream = enable;
     return 0;
 }
 

@@ -11,8 +11,9 @@
 // Tile BM x BN x 64, 256 threads = 4 waves (2 x 2), v_mfma_f32_16x16x32_bf16.  The N side feeds the
 // MFMA "A" operand and the M side the "B" operand, so every lane ends up with 4 consecutive output
 // columns of one output row (8-byte bf16 stores, 16-byte fp32 partial stores).
-// LDS: double buffered, register-staged (global_load_dwordx4 -> ds_write_b128), one barrier per
-// K tile.  K-contiguous tiles are stored [rows][64] with a 16-byte-chunk XOR swizzle so ds_read_b128
+// LDS: double buffered, filled by direct global->LDS DMA (global_load_lds_dwordx4; partial K tiles fall back
+// to register staging with zero fill), one barrier per K tile with the next tile's DMA in flight under the
+// MFMAs.  K-contiguous tiles are stored [rows][64] with a 16-byte-chunk XOR swizzle so ds_read_b128
 // fragment reads are bank-conflict free; K-strided ("transposed") tiles are stored [64][W] and read
 // with ds_read_b64_tr_b16, with a 32-byte-block XOR swizzle that makes those reads conflict free.
 #include "common.cuh"
@@ -137,6 +138,49 @@ struct StageKS {
     }
 };
 
+// ---- direct global -> LDS staging (global_load_lds_dwordx4) ---------------------------------------
+// One wave instruction moves 64 lanes x 16 B = 1 KiB to LDS base + lane*16 (the destination is lane-linear by
+// hardware), so the XOR swizzle is applied on the SOURCE address: lane l, which lands in physical 16-byte
+// chunk c' of row r, fetches the logical chunk c = c' ^ swz(r).  Lanes of one row still read one contiguous
+// 128/256-byte row segment, so HBM/L2 coalescing is unchanged.  Rows beyond the matrix are clamped to the last
+// valid row (their products land in output rows the epilogue never stores); partial K tiles do not use this
+// path (they need zero fill).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void global_void_t;
+
+__device__ __forceinline__ void glds16(const bf16_t* src, bf16_t* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((global_void_t*)src, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+
+// K-contiguous tile [ROWS][64]: instruction j covers rows 8j..8j+7.
+template <int ROWS>
+__device__ __forceinline__ void glds_kc(bf16_t* tile, const bf16_t* base, int64_t ld, int row0, int rows_total,
+                                        int k0, int wid, int lane) {
+#pragma unroll
+    for (int it = 0; it < ROWS / 32; ++it) {
+        const int j = it * 4 + wid;
+        const int r = 8 * j + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int gr = row0 + r;
+        gr = gr < rows_total ? gr : rows_total - 1;
+        glds16(base + (int64_t)gr * ld + k0 + c * 8, tile + j * 512);
+    }
+}
+// K-strided tile [64][W]: W = 128 -> 4 rows per instruction, W = 64 -> 8 rows per instruction.
+template <int W>
+__device__ __forceinline__ void glds_ks(bf16_t* tile, const bf16_t* base, int64_t ld, int col0, int k0, int wid, int lane) {
+    constexpr int RPI = 1024 / (2 * W);          // rows per instruction
+    constexpr int NI = 64 / RPI;                 // instructions per tile
+    constexpr int CPR = W / 8;                   // 16-byte chunks per row
+#pragma unroll
+    for (int it = 0; it < NI / 4; ++it) {
+        const int j = it * 4 + wid;
+        const int r = RPI * j + lane / CPR;
+        const int c = (lane % CPR) ^ (ks_swz<W>(r) << 1);
+        glds16(base + (int64_t)(k0 + r) * ld + col0 + c * 8, tile + j * 512);
+    }
+}
+
 template <int ROWS, bool TR>
 struct Stage;
 template <int ROWS>
@@ -177,7 +221,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     Stage<BM, TRA> sr;
     Stage<BN, TRB> sc;
 
-    auto do_load = [&](int kt) {
+    auto do_load = [&](int kt) {               // register-staged path (partial K tiles only)
         const int k0 = k_begin + kt * 64;
         if constexpr (TRA) sr.load(p.R, p.ldr, m0, k0, k_end, t);
         else               sr.load(p.R, p.ldr, m0, p.M, k0, k_end, t);
@@ -188,6 +232,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         sr.store(smem + buf * (TILE_R + TILE_C), t);
         sc.store(smem + buf * (TILE_R + TILE_C) + TILE_R, t);
     };
+    auto do_glds = [&](int kt, int buf) {       // direct-to-LDS path (full K tiles)
+        const int k0 = k_begin + kt * 64;
+        bf16_t* tr_ = smem + buf * (TILE_R + TILE_C);
+        bf16_t* tc_ = tr_ + TILE_R;
+        if constexpr (TRA) glds_ks<BM>(tr_, p.R, p.ldr, m0, k0, wid, lane);
+        else               glds_kc<BM>(tr_, p.R, p.ldr, m0, p.M, k0, wid, lane);
+        if constexpr (TRB) glds_ks<BN>(tc_, p.Cc, p.ldcc, n0, k0, wid, lane);
+        else               glds_kc<BN>(tc_, p.Cc, p.ldcc, n0, p.N, k0, wid, lane);
+    };
+    auto is_full = [&](int kt) { return k_begin + kt * 64 + 64 <= k_end; };
 
     f32x4 acc[NI][MI];
 #pragma unroll
@@ -196,14 +250,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (nk > 0) {
-        do_load(0);
-        do_store(0);
+        if (is_full(0)) {
+            do_glds(0, 0);
+        } else {
+            do_load(0);
+            do_store(0);
+        }
     }
-    __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed (the barrier's fence drains this wave's outstanding LDS-DMA) and every wave is done
+        // reading the buffer the next tile is about to overwrite
+        __syncthreads();
         const bool more = (kt + 1 < nk);
-        if (more) do_load(kt + 1);
+        const bool next_full = more && is_full(kt + 1);
+        if (more) {
+            if (next_full) do_glds(kt + 1, (kt + 1) & 1);
+            else           do_load(kt + 1);
+        }
 
         const bf16_t* tr = smem + (kt & 1) * (TILE_R + TILE_C);
         const bf16_t* tc = tr + TILE_R;
@@ -227,8 +291,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[a], fr[b], acc[a][b], 0, 0, 0);
         }
 
-        if (more) do_store((kt + 1) & 1);
-        __syncthreads();
+        if (more && !next_full) do_store((kt + 1) & 1);
     }
 
     // ---- epilogue: lane holds C[m][n..n+3], m = m0 + wm*WM + b*16 + i, n = n0 + wn*WN + a*16 + 4g ----
