@@ -213,6 +213,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue every step eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -256,22 +257,44 @@ def main():
     optimizer.step()                                                     # train_nlvr2.py:150-151 dummy step (no-op)
     global_step = 0
 
-    def train_step():
+    def schedule_lr():                        # train_nlvr2.py:174-178 (host side, before the update)
         nonlocal global_step
+        global_step += 1
+        lr_this_step = get_lr_sched(global_step, opts)
+        for group in optimizer.param_groups:
+            group['lr'] = lr_this_step
+
+    def device_step():                        # everything that runs on the GPU for one optimizer step
         if reducer is not None:
             reducer.begin()
         loss = model(batch, compute_loss=True)
         loss = loss.mean()
         loss.backward()
         scale = reducer.finish() if reducer is not None else 1.0
-        global_step += 1
-        lr_this_step = get_lr_sched(global_step, opts)
-        for group in optimizer.param_groups:
-            group['lr'] = lr_this_step
         clip_grad_norm_(optimizer, opts.grad_norm, grad_scale=scale)
         optimizer.step()
         optimizer.zero_grad()
         return loss
+
+    # N == 1: the whole step is captured once into a hipGraph and replayed (one launch per step instead of ~550);
+    # N > 1 stays eager so that the bucketed RCCL allreduce keeps overlapping with backward outside of capture.
+    mode = "eager"
+    train_step = None
+    if world == 1 and not args.no_graph:
+        from uniter_amd.utils.graph import GraphedStep
+        try:
+            graphed = GraphedStep(device_step, optimizer, device, warmup=3, pre_step=schedule_lr).capture()
+            train_step = graphed
+            mode = "hipgraph"
+        except Exception as e:                                  # pragma: no cover - depends on the runtime
+            sys.stderr.write("hipGraph capture failed (%s: %s); falling back to eager steps\n" % (type(e).__name__, e))
+            from uniter_amd import ops as _ops
+            _ops.disable_graph_rng()
+            optimizer._graph = None
+    if train_step is None:
+        def train_step():
+            schedule_lr()
+            return device_step()
 
     for _ in range(args.warmup):
         train_step()
@@ -315,7 +338,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "UNITER-base NLVR2 paired-attn finetune step (config/train-nlvr2-base-1gpu.json shapes): "
                                    "fwd+bwd+clip+fused AdamW, dropout 0.1, random-init weights",
-                       "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world,
+                       "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world, "launch": mode,
                        "examples": "encoder sequences (32/GPU = 16 NLVR2 pairs)"},
             "final_loss": round(final_loss, 4),
             "roofline": roofline,

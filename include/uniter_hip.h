@@ -40,6 +40,12 @@ const char* uniter_hip_last_error(void);
 /* Writes device facts of the current HIP device: [0]=CU count, [1]=wavefront size, [2]=LDS bytes/CU,
  * [3]=gfx arch number (950).  Returns 0 / hipError_t. */
 int uniter_hip_device_info(int32_t out[4]);
+/* hipGraph support for dropout: when a device counter is registered, every dropout kernel adds *dev_counter to its
+ * Philox offset at run time, so a captured graph draws fresh masks on each replay once the counter is advanced
+ * (uniter_hip_counter_add, itself capturable).  NULL restores the purely host-supplied offsets. */
+int uniter_hip_set_dropout_offset_ptr(const uint64_t* dev_counter);
+int uniter_hip_counter_add(uint64_t* dev_counter, uint64_t inc, void* stream);
+
 /* Test / tuning hook: force the GEMM tile (0=128x128, 1=128x64, 2=64x128, 3=64x64; -1 = heuristic)
  * and the wgrad split-K factor (-1 = heuristic). */
 int uniter_gemm_debug_force(int cfg, int splits);
@@ -51,6 +57,13 @@ int uniter_gemm_debug_force(int cfg, int splits);
  *   M = rows (tokens, B*L), K = in_features, N = out_features for the forward layer.
  *   Requirements: N % 64 == 0, K % 64 == 0 for fwd/dgrad shapes; wgrad needs N % 64 == 0 and K % 64 == 0.
  * ---------------------------------------------------------------------------------------------- */
+
+/* Empirical tile selection (SYNCHRONOUS, allocates scratch: set-up time only): times every legal tile shape — and
+ * split-K factor for wgrad — of one GEMM and caches the winner for (kind, M, N, K); later launches of that shape use
+ * it.  kind 0 = forward, 1 = dgrad, 2 = wgrad, with M, N, K as in the corresponding call below.
+ * uniter_gemm_tuned_choice reports the cached (tile index, splits) or (-1, -1). */
+int uniter_gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, void* stream);
+int uniter_gemm_tuned_choice(int kind, int64_t M, int64_t N, int64_t K, int32_t out[2]);
 
 /* y[M,N] = x[M,K] * w[N,K]^T + bias[N]        (bias may be NULL)                 layer.py:76-78 */
 int uniter_gemm_bias_fwd(const void* x, const void* w, const void* bias, void* y,
@@ -240,6 +253,10 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
                             const void* x_in, const float* mask_bias, const void* dy, void* dx,
                             void* acts, void* scratch, uint64_t seed, uint64_t offset, void* stream);
 
+/* Autotune the 12 GEMM shapes (4 forward, 4 dgrad, 4 wgrad) of one BertLayer for this (B, L, H, I): synchronous,
+ * call once per shape at set-up time (the Python side does it on the first forward of a new shape). */
+int uniter_encoder_autotune(const UniterEncoderShape* s, void* stream);
+
 /* Test / tuning hook: backward runs the weight-gradient GEMMs and bias column sums on an internal side stream
  * (ordered against `stream` purely by events) unless disabled with 0. */
 int uniter_encoder_debug_side_stream(int enable);
@@ -278,6 +295,12 @@ int uniter_adamw_grad_norm(void* plan, float grad_scale, float max_norm, float* 
  * multiplies every gradient element on the fly (fused clipping). */
 int uniter_adamw_step(void* plan, const UniterAdamGroup* groups, int32_t n_groups,
                       const float* clip_coef, void* stream);
+
+/* Same update with the per-group hyper-parameters read from DEVICE memory: dev_hyper = n_groups x 6 floats
+ * {lr, beta1, beta2, eps, weight_decay, step_size}, step_size = lr*sqrt(1-b2^t)/(1-b1^t) (or lr without bias
+ * correction).  Lets a captured hipGraph follow the LR schedule: the host refreshes a pinned buffer, a captured
+ * H2D copy moves it before the kernel. */
+int uniter_adamw_step_dev(void* plan, const float* dev_hyper, int32_t n_groups, const float* clip_coef, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * RCCL communicator (one process per GPU).                              utils/distributed.py:16-209

@@ -241,8 +241,16 @@ static void host_gemm_nt(const std::vector<float>& X, const std::vector<float>& 
         }
 }
 
+// mirror of kTiles in gemm.hip (tile index -> BM x BN)
+static const int kTileBM[] = {128, 128, 64, 64, 96, 192, 192, 128, 96, 128, 96, 96, 192};
+static const int kTileBN[] = {128, 64, 128, 64, 192, 96, 128, 192, 128, 96, 96, 64, 64};
+static const int kNumTiles = 13;
+
 static void test_gemm(int M, int N, int K, int cfg, int splits) {
     char tag[128];
+    const bool pow2_bn = cfg < 0 || kTileBN[cfg] == 64 || kTileBN[cfg] == 128;
+    const bool pow2_bm = cfg < 0 || kTileBM[cfg] == 64 || kTileBM[cfg] == 128;
+    if (cfg >= 0 && N % kTileBN[cfg] != 0) { printf("  (skip cfg%d for N=%d)\n", cfg, N); return; }
     HostBf X, W, Bv, R, DY;
     X.fill((size_t)M * K, 1.f); W.fill((size_t)N * K, 0.5f); Bv.fill(N, 1.f); R.fill((size_t)M * N, 1.f); DY.fill((size_t)M * N, 1.f);
     uint16_t *dX = upload(X), *dW = upload(W), *dB = upload(Bv), *dR = upload(R), *dDY = upload(DY);
@@ -284,8 +292,8 @@ static void test_gemm(int M, int N, int K, int cfg, int splits) {
         snprintf(tag, sizeof tag, "gemm_bias_dropout_residual_fwd p=%.2f cfg%d", p, cfg);
         check(tag, download_bf(dY, (size_t)M * N), rz, 0.06f, 0.01f);
     }
-    // --- dgrad: dx[M,K] = dy[M,N] * w[N,K] (+resid) ---  (needs K % 64 == 0)
-    if (K % 64 == 0) {
+    // --- dgrad: dx[M,K] = dy[M,N] * w[N,K] (+resid) ---  (needs K % 64 == 0; the K-strided weight side needs a 64/128 tile)
+    if (K % 64 == 0 && pow2_bn && (cfg < 0 || K % kTileBN[cfg] == 0)) {
         uint16_t* dDX = dalloc<uint16_t>((size_t)M * K);
         HostBf RX, U;
         RX.fill((size_t)M * K, 1.f); U.fill((size_t)M * K, 2.f);
@@ -316,7 +324,7 @@ static void test_gemm(int M, int N, int K, int cfg, int splits) {
         HIPCHK(hipFree(dDX)); HIPCHK(hipFree(dRX)); HIPCHK(hipFree(dU));
     }
     // --- wgrad: dw[N,K] (+)= dy^T x ; db = colsum(dy) ---
-    if (K % 64 == 0) {
+    if (K % 64 == 0 && pow2_bn && pow2_bm && (cfg < 0 || (N % kTileBM[cfg] == 0 && K % kTileBN[cfg] == 0))) {
         const size_t wsb = uniter_gemm_wgrad_workspace_bytes(M, N, K);
         void* ws = dalloc<char>(wsb);
         HostBf Old, OldB;
@@ -610,16 +618,27 @@ static void bench(int B, int L, int H, int heads, int I, int layers) {
         {"qkv   ", T, 3 * (int64_t)H, H}, {"out   ", T, H, H}, {"ffn1  ", T, I, H}, {"ffn2  ", T, H, I}};
     for (auto& s : shapes) {
         const double fl = 2.0 * s.M * s.N * s.K;
-        for (int cfg = -1; cfg < 4; ++cfg) {
-            uniter_gemm_debug_force(cfg, -1);
-            double t1 = tm.run([&] { UHCHK(uniter_gemm_bias_fwd(dX, dW, dB, dY, s.M, s.N, s.K, 0)); });
-            double t2 = tm.run([&] { UHCHK(uniter_gemm_dgrad(dY, dW, nullptr, dY2, s.M, s.N, s.K, 0)); });
-            printf("  %s cfg%2d  fwd %8.1f us %7.1f TF | dgrad %8.1f us %7.1f TF", s.name, cfg, t1, fl / t1 * 1e-6, t2, fl / t2 * 1e-6);
-            for (int sp : {1, 2, 4, 8}) {
-                uniter_gemm_debug_force(cfg, cfg < 0 ? -1 : sp);
-                double t3 = tm.run([&] { UHCHK(uniter_gemm_wgrad(dY, dX, dG, nullptr, s.M, s.N, s.K, 1, ws, wsb, 0)); });
-                printf(" | wgrad s%d %7.1f us %6.1f TF", cfg < 0 ? -1 : sp, t3, fl / t3 * 1e-6);
-                if (cfg < 0) break;
+        for (int cfg = -1; cfg < kNumTiles; ++cfg) {
+            const int bm = cfg < 0 ? 0 : kTileBM[cfg], bn = cfg < 0 ? 0 : kTileBN[cfg];
+            const bool p2n = cfg < 0 || bn == 64 || bn == 128, p2m = cfg < 0 || bm == 64 || bm == 128;
+            printf("  %s cfg%2d %3dx%3d", s.name, cfg, bm, bn);
+            if (cfg < 0 || s.N % bn == 0) {
+                uniter_gemm_debug_force(cfg, -1);
+                double t1 = tm.run([&] { UHCHK(uniter_gemm_bias_fwd(dX, dW, dB, dY, s.M, s.N, s.K, 0)); });
+                printf("  fwd %6.1f us %6.1f TF", t1, fl / t1 * 1e-6);
+            } else printf("  fwd      -            ");
+            if (p2n && (cfg < 0 || s.K % bn == 0)) {
+                uniter_gemm_debug_force(cfg, -1);
+                double t2 = tm.run([&] { UHCHK(uniter_gemm_dgrad(dY, dW, nullptr, dY2, s.M, s.N, s.K, 0)); });
+                printf(" | dgrad %6.1f us %6.1f TF", t2, fl / t2 * 1e-6);
+            } else printf(" | dgrad      -            ");
+            if (p2n && p2m && (cfg < 0 || (s.N % bm == 0 && s.K % bn == 0))) {
+                for (int sp : {1, 2, 4}) {
+                    uniter_gemm_debug_force(cfg, cfg < 0 ? -1 : sp);
+                    double t3 = tm.run([&] { UHCHK(uniter_gemm_wgrad(dY, dX, dG, nullptr, s.M, s.N, s.K, 1, ws, wsb, 0)); });
+                    printf(" | wgrad s%d %6.1f us %5.1f TF", cfg < 0 ? -1 : sp, t3, fl / t3 * 1e-6);
+                    if (cfg < 0) break;
+                }
             }
             printf("\n");
         }
@@ -673,6 +692,21 @@ static void bench(int B, int L, int H, int heads, int I, int layers) {
         float* dMask = dalloc<float>((size_t)B * L);
         HIPCHK(hipMemset(dMask, 0, (size_t)B * L * 4));
         uint16_t* dDx = dalloc<uint16_t>((size_t)T * H);
+        {
+            double tf0 = tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 10);
+            double tb0 = tm.run([&] { UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0)); }, 2, 10);
+            printf("  (cost-model tiles: fwd %.1f us, bwd %.1f us)\n", tf0, tb0);
+            UHCHK(uniter_encoder_autotune(&sh, 0));
+            const int64_t shp[4][2] = {{3 * (int64_t)H, H}, {H, H}, {I, H}, {H, I}};
+            const char* kn[3] = {"fwd", "dgrad", "wgrad"};
+            for (int kind = 0; kind < 3; ++kind)
+                for (int gi = 0; gi < 4; ++gi) {
+                    int32_t ch[2];
+                    UHCHK(uniter_gemm_tuned_choice(kind, T, shp[gi][0], shp[gi][1], ch));
+                    printf("  autotune %-5s N%lld K%lld -> tile %dx%d splits %d\n", kn[kind], (long long)shp[gi][0], (long long)shp[gi][1],
+                           ch[0] >= 0 ? kTileBM[ch[0]] : -1, ch[0] >= 0 ? kTileBN[ch[0]] : -1, ch[1]);
+                }
+        }
         double tf = tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 10);
         double tb = tm.run([&] { UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0)); }, 2, 10);
         uniter_encoder_debug_side_stream(0);
@@ -731,6 +765,7 @@ int main(int argc, char** argv) {
     run_probes();
     printf("== gemm ==\n");
     for (int cfg = 0; cfg < 4; ++cfg) test_gemm(200, 256, 128, cfg, cfg == 0 ? 1 : 2);
+    for (int cfg = 4; cfg < kNumTiles; ++cfg) test_gemm(300, 384, 128, cfg, 1);
     test_gemm(77, 128, 192, 3, 3);
     test_gemm(384, 384, 320, -1, -1);
     if (!quick) test_gemm(1000, 768, 768, -1, -1);

@@ -442,3 +442,83 @@ def test_arena_training_step_matches_unflattened(golden):
         results.append({n: p.detach().float().cpu().clone() for n, p in model.named_parameters()})
     for n in results[0]:
         assert rel_l2(results[1][n], results[0][n]) < 1e-3, n
+
+
+# --------------------------------------------------------------------------------------------------------------
+# whole-step hipGraph capture
+# --------------------------------------------------------------------------------------------------------------
+def test_graphed_step_matches_eager(golden):
+    """3 optimizer steps replayed from a captured hipGraph == 3 eager steps (dropout 0, LR schedule active), and with
+    dropout on, consecutive replays draw different masks (device-side Philox counter)."""
+    from uniter_amd import ops
+    from uniter_amd.model.pretrain import UniterForPretraining
+    from uniter_amd.optim import build_optimizer, clip_grad_norm_
+    from uniter_amd.utils.arena import flatten_model
+    from uniter_amd.utils.graph import GraphedStep
+    from uniter_amd.utils.misc import Struct, set_dropout
+    # ITM: no boolean-mask row selection (a device->host sync, not capturable) in the head
+    batch = _to_dev(golden.batch('itm'))
+    opts = Struct(dict(optim='adamw', learning_rate=1e-3, betas=(0.9, 0.98), weight_decay=0.01))
+    results = []
+    try:
+        for graphed in (False, True):
+            model = _prep(UniterForPretraining.from_pretrained(TINY_CONFIG, golden.pretrain_sd(), img_dim=IMG_DIM,
+                                                               img_label_dim=LABEL_DIM))
+            flatten_model(model)
+            opt = build_optimizer(model, opts)
+            n = [0]
+
+            def sched():
+                n[0] += 1
+                for grp in opt.param_groups:
+                    grp['lr'] = 1e-3 * n[0] / 4.0
+
+            def dev_step():
+                loss = model(batch, task='itm', compute_loss=True)[0].mean()
+                loss.backward()
+                clip_grad_norm_(opt, 1.0)
+                opt.step()
+                opt.zero_grad()
+                return loss
+
+            if graphed:
+                # GraphedStep's warm-up steps would already train the model: snapshot / restore around it
+                snap = {k: v.detach().clone() for k, v in model.state_dict().items()}
+                step = GraphedStep(dev_step, opt, _dev(), warmup=2, pre_step=sched).capture()
+                model.load_state_dict(snap)
+                for p in model.parameters():
+                    st = opt.state[p]
+                    if st:
+                        st['step'] = 0
+                        st['exp_avg'].zero_(); st['exp_avg_sq'].zero_()
+                        if 'master' in st:
+                            st['master'].copy_(p.data)
+                n[0] = 0
+                losses = [float(step()) for _ in range(3)]
+            else:
+                losses = []
+                for _ in range(3):
+                    sched()
+                    losses.append(float(dev_step()))
+            results.append((losses, {k: v.detach().float().cpu().clone() for k, v in model.named_parameters()}))
+        for a, b in zip(results[0][0], results[1][0]):
+            assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (results[0][0], results[1][0])
+        for k in results[0][1]:
+            assert rel_l2(results[1][1][k], results[0][1][k]) < 2e-3, k
+        # dropout under replay: fresh masks every replay
+        model = _prep(UniterForPretraining.from_pretrained(TINY_CONFIG, golden.pretrain_sd(), img_dim=IMG_DIM, img_label_dim=LABEL_DIM))
+        set_dropout(model, 0.3)
+        opt = build_optimizer(model, Struct(dict(optim='adamw', learning_rate=0.0, betas=(0.9, 0.98), weight_decay=0.0)))
+
+        def dev_step2():
+            loss = model(batch, task='itm', compute_loss=True)[0].mean()
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            return loss
+
+        step = GraphedStep(dev_step2, opt, _dev(), warmup=2).capture()
+        vals = [float(step()) for _ in range(4)]                   # lr = 0: weights frozen, only the masks change
+        assert len(set(round(v, 4) for v in vals)) >= 3, vals
+    finally:
+        ops.disable_graph_rng()

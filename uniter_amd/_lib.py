@@ -46,7 +46,11 @@ SIGNATURES = {
     "uniter_hip_abi_version": (c_int, []),
     "uniter_hip_last_error": (c_char_p, []),
     "uniter_hip_device_info": (c_int, [POINTER(c_int32)]),
+    "uniter_hip_set_dropout_offset_ptr": (c_int, [_P]),
+    "uniter_hip_counter_add": (c_int, [_P, c_uint64, _P]),
     "uniter_gemm_debug_force": (c_int, [c_int, c_int]),
+    "uniter_gemm_autotune": (c_int, [c_int, _I, _I, _I, _P]),
+    "uniter_gemm_tuned_choice": (c_int, [c_int, _I, _I, _I, POINTER(c_int32)]),
     "uniter_gemm_bias_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "uniter_gemm_bias_gelu_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "uniter_gemm_bias_dropout_residual_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
@@ -81,11 +85,13 @@ SIGNATURES = {
                                        _P, _P, _P, _P, c_uint64, c_uint64, _P]),
     "uniter_encoder_backward": (c_int, [POINTER(UniterEncoderShape), POINTER(UniterLayerParams), c_int32, c_int32,
                                         _P, _P, _P, _P, _P, _P, c_uint64, c_uint64, _P]),
+    "uniter_encoder_autotune": (c_int, [POINTER(UniterEncoderShape), _P]),
     "uniter_encoder_debug_side_stream": (c_int, [c_int]),
     "uniter_adamw_plan_create": (c_int, [POINTER(UniterAdamTensor), _I, POINTER(c_void_p)]),
     "uniter_adamw_plan_destroy": (c_int, [_P]),
     "uniter_adamw_grad_norm": (c_int, [_P, c_float, c_float, _P, _P]),
     "uniter_adamw_step": (c_int, [_P, POINTER(UniterAdamGroup), c_int32, _P, _P]),
+    "uniter_adamw_step_dev": (c_int, [_P, _P, c_int32, _P, _P]),
     "uniter_comm_unique_id": (c_int, [POINTER(c_uint8)]),
     "uniter_comm_init": (c_int, [POINTER(c_uint8), c_int32, c_int32, POINTER(c_void_p)]),
     "uniter_comm_destroy": (c_int, [_P]),

@@ -51,12 +51,13 @@ struct Plan {
 
 __global__ __launch_bounds__(256) void adamw_kernel(const DevTensor* __restrict__ tensors,
                                                     const ChunkRef* __restrict__ chunks, int64_t n_chunks,
-                                                    const HyperTable hyp, const float* __restrict__ clip_coef) {
+                                                    const HyperTable hyp, const GroupHyper* __restrict__ hyp_dev,
+                                                    const float* __restrict__ clip_coef) {
     const float coef = clip_coef ? *clip_coef : 1.0f;
     for (int64_t ci = blockIdx.x; ci < n_chunks; ci += gridDim.x) {
         const ChunkRef cr = chunks[ci];
         const DevTensor t = tensors[cr.tensor];
-        const GroupHyper h = hyp.g[t.group];
+        const GroupHyper h = hyp_dev ? hyp_dev[t.group] : hyp.g[t.group];
         const int64_t base = (int64_t)cr.chunk * CHUNK;
 #pragma unroll
         for (int it = 0; it < CHUNK / (256 * 4); ++it) {
@@ -248,7 +249,21 @@ int uniter_adamw_step(void* plan, const UniterAdamGroup* groups, int32_t n_group
     // enough blocks to fill the chip several times over; chunks are grid-strided
     int64_t blocks = p->n_chunks < 8192 ? p->n_chunks : 8192;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const DevTensor*)p->d_tensors, (const ChunkRef*)p->d_chunks, p->n_chunks, ht, clip_coef);
+                       (const DevTensor*)p->d_tensors, (const ChunkRef*)p->d_chunks, p->n_chunks, ht, (const GroupHyper*)nullptr,
+                       clip_coef);
+    UH_LAUNCH_CHECK();
+    return 0;
+}
+
+int uniter_adamw_step_dev(void* plan, const float* dev_hyper, int32_t n_groups, const float* clip_coef, void* stream) {
+    UH_CHECK_ARG(plan != nullptr && dev_hyper != nullptr, "null pointer");
+    UH_CHECK_ARG(n_groups > 0 && n_groups <= MAX_GROUPS, "1..16 parameter groups supported");
+    Plan* p = (Plan*)plan;
+    HyperTable ht{};
+    int64_t blocks = p->n_chunks < 8192 ? p->n_chunks : 8192;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const DevTensor*)p->d_tensors, (const ChunkRef*)p->d_chunks, p->n_chunks, ht,
+                       (const GroupHyper*)dev_hyper, clip_coef);
     UH_LAUNCH_CHECK();
     return 0;
 }

@@ -9,7 +9,11 @@
 
 namespace {
 thread_local char g_err[512] = {0};
+
+__global__ void counter_add_kernel(unsigned long long* c, unsigned long long inc) { *c += inc; }
 }
+
+const unsigned long long* uh_drop_offset_ptr = nullptr;
 
 void uh_set_error(const char* fmt, ...) {
     va_list ap;
@@ -48,9 +52,34 @@ int uniter_hip_device_info(int32_t out[4]) {
     return 0;
 }
 
+int uniter_hip_set_dropout_offset_ptr(const uint64_t* dev_counter) {
+    uh_drop_offset_ptr = (const unsigned long long*)dev_counter;
+    return 0;
+}
+
+int uniter_hip_counter_add(uint64_t* dev_counter, uint64_t inc, void* stream) {
+    UH_CHECK_ARG(dev_counter != nullptr, "null pointer");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)dev_counter,
+                       (unsigned long long)inc);
+    UH_LAUNCH_CHECK();
+    return 0;
+}
+
 // test / tuning hook: force a GEMM tile config (0..3, -1 = heuristic) and split count (-1 = heuristic)
 int uniter_gemm_debug_force(int cfg, int splits) {
     uh::gemm_debug_force(cfg, splits);
+    return 0;
+}
+
+int uniter_gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, void* stream) {
+    return uh::gemm_autotune(kind, M, N, K, (hipStream_t)stream);
+}
+
+int uniter_gemm_tuned_choice(int kind, int64_t M, int64_t N, int64_t K, int32_t out[2]) {
+    UH_CHECK_ARG(out != nullptr, "null pointer");
+    int cfg = -1, sp = -1;
+    if (uh::gemm_tuned_choice(kind, M, N, K, &cfg, &sp)) { out[0] = -1; out[1] = -1; return 0; }
+    out[0] = cfg; out[1] = sp;
     return 0;
 }
 

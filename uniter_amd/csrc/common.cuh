@@ -96,7 +96,12 @@ struct DropoutCfg {
     uint32_t thresh;     // keep iff rnd >= thresh ; thresh = p * 2^32
     uint32_t seed_lo, seed_hi;
     uint32_t off_lo, off_hi;
+    // optional device-resident base offset added to (off_hi:off_lo) at run time: lets a captured hipGraph draw fresh
+    // masks on every replay (the host-side offset is baked into the graph, the device counter is not)
+    const unsigned long long* off_ptr;
 };
+
+extern const unsigned long long* uh_drop_offset_ptr;   // set through uniter_hip_set_dropout_offset_ptr (capi.hip)
 
 static inline DropoutCfg make_dropout(float p, uint64_t seed, uint64_t offset) {
     DropoutCfg d;
@@ -108,27 +113,38 @@ static inline DropoutCfg make_dropout(float p, uint64_t seed, uint64_t offset) {
     d.thresh = (uint32_t)t;
     d.seed_lo = (uint32_t)seed; d.seed_hi = (uint32_t)(seed >> 32);
     d.off_lo = (uint32_t)offset; d.off_hi = (uint32_t)(offset >> 32);
+    d.off_ptr = p > 0.f ? uh_drop_offset_ptr : nullptr;
     return d;
+}
+
+__device__ __forceinline__ void dropout_offset(const DropoutCfg& d, uint32_t& lo, uint32_t& hi) {
+    unsigned long long o = ((unsigned long long)d.off_hi << 32) | (unsigned long long)d.off_lo;
+    if (d.off_ptr != nullptr) o += *d.off_ptr;
+    lo = (uint32_t)o;
+    hi = (uint32_t)(o >> 32);
 }
 
 // Keep-multipliers (0 or 1/(1-p)) for the 4 consecutive elements of group `idx4` (= element index / 4).
 __device__ __forceinline__ void dropout_mult4(const DropoutCfg& d, uint64_t idx4, float (&m)[4]) {
-    const u32x4 r = philox4x32_10((uint32_t)idx4, (uint32_t)(idx4 >> 32), d.off_lo, d.off_hi,
-                                  d.seed_lo, d.seed_hi);
+    uint32_t olo, ohi;
+    dropout_offset(d, olo, ohi);
+    const u32x4 r = philox4x32_10((uint32_t)idx4, (uint32_t)(idx4 >> 32), olo, ohi, d.seed_lo, d.seed_hi);
 #pragma unroll
     for (int i = 0; i < 4; ++i) m[i] = (r[i] >= d.thresh) ? d.scale : 0.f;
 }
 // Keep bits (bit e set = element e of the group survives) for the 4 consecutive elements of group `idx4`.
 __device__ __forceinline__ uint32_t dropout_keep4(const DropoutCfg& d, uint64_t idx4) {
-    const u32x4 r = philox4x32_10((uint32_t)idx4, (uint32_t)(idx4 >> 32), d.off_lo, d.off_hi,
-                                  d.seed_lo, d.seed_hi);
+    uint32_t olo, ohi;
+    dropout_offset(d, olo, ohi);
+    const u32x4 r = philox4x32_10((uint32_t)idx4, (uint32_t)(idx4 >> 32), olo, ohi, d.seed_lo, d.seed_hi);
     return (r[0] >= d.thresh ? 1u : 0u) | (r[1] >= d.thresh ? 2u : 0u) | (r[2] >= d.thresh ? 4u : 0u) |
            (r[3] >= d.thresh ? 8u : 0u);
 }
 // Single element `e` (0..3) of group idx4.
 __device__ __forceinline__ float dropout_mult1(const DropoutCfg& d, uint64_t idx4, int e) {
-    const u32x4 r = philox4x32_10((uint32_t)idx4, (uint32_t)(idx4 >> 32), d.off_lo, d.off_hi,
-                                  d.seed_lo, d.seed_hi);
+    uint32_t olo, ohi;
+    dropout_offset(d, olo, ohi);
+    const u32x4 r = philox4x32_10((uint32_t)idx4, (uint32_t)(idx4 >> 32), olo, ohi, d.seed_lo, d.seed_hi);
     const uint32_t v = e == 0 ? r[0] : (e == 1 ? r[1] : (e == 2 ? r[2] : r[3]));
     return (v >= d.thresh) ? d.scale : 0.f;
 }

@@ -281,6 +281,17 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
     return 0;
 }
 
+// Time every legal tile shape for the 12 GEMMs of one layer at this (B, L, H, I) and cache the winners (synchronous).
+int uniter_encoder_autotune(const UniterEncoderShape* s, void* stream) {
+    RC(check_shape(s));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t T = s->B * s->L, H = s->H, I = s->I;
+    const int64_t shapes[4][2] = {{3 * H, H}, {H, H}, {I, H}, {H, I}};      // (N = out features, K = in features)
+    for (int kind = 0; kind < 3; ++kind)
+        for (int g = 0; g < 4; ++g) RC(uh::gemm_autotune(kind, T, shapes[g][0], shapes[g][1], st));
+    return 0;
+}
+
 // test / tuning hook: 0 = run the weight-gradient GEMMs on the caller's stream, 1 = on the library's side stream
 int uniter_encoder_debug_side_stream(int enable) {
     g_use_side_stream = enable;

@@ -19,6 +19,8 @@ size_t gemm_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int gemm_wgrad(const void* dy, const void* x, void* dw, int64_t M, int64_t N, int64_t K, int accumulate,
                void* workspace, size_t ws_bytes, hipStream_t st);
 void gemm_debug_force(int cfg, int splits);
+int gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, hipStream_t st);
+int gemm_tuned_choice(int kind, int64_t M, int64_t N, int64_t K, int* cfg, int* splits);
 void gemm_set_num_cus(int n);
 
 // ---- attention.hip ----

@@ -228,6 +228,12 @@ class BertLayer(nn.Module):
         self.intermediate = BertIntermediate(config)
         self.output = BertOutput(config)
         self._enc_cfg = _encoder_cfg(config)
+        self._ptr_cache = None         # device-pointer row cached by ops._layer_row
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .bfloat16() re-allocate every parameter: forget cached device pointers
+        self._ptr_cache = None
+        return super(BertLayer, self)._apply(fn, *args, **kwargs)
 
     def forward(self, hidden_states, attention_mask):
         return run_layers([self], hidden_states, attention_mask)

@@ -26,9 +26,34 @@ class _Rng(threading.local):
     def __init__(self):
         self.seed = None
         self.offset = 0
+        self.counter = None        # device uint64 step counter (hipGraph mode), see enable_graph_rng
 
 
 _rng = _Rng()
+GRAPH_RNG_STRIDE = 1 << 24         # offsets reserved per training step in graph mode
+
+
+def enable_graph_rng(device):
+    """hipGraph-friendly dropout stream: host offsets restart at 0 every step (so a captured step replays with
+    identical kernel arguments) and a DEVICE counter, advanced by `graph_rng_step()` inside the captured step,
+    is added by the kernels at run time — every replay draws fresh masks without touching kernel arguments."""
+    if _rng.counter is None or _rng.counter.device != torch.device(device):
+        _rng.counter = torch.zeros(1, dtype=torch.int64, device=device)
+    C.uniter_hip_set_dropout_offset_ptr(_rng.counter.data_ptr())
+    return _rng.counter
+
+
+def disable_graph_rng():
+    C.uniter_hip_set_dropout_offset_ptr(None)
+    _rng.counter = None
+
+
+def graph_rng_step():
+    """Call once at the start of every (captured or eager) training step while graph RNG is enabled."""
+    if _rng.counter is None:
+        return
+    _rng.offset = 0
+    C.uniter_hip_counter_add(_rng.counter.data_ptr(), GRAPH_RNG_STRIDE, _lib.stream_ptr())
 
 
 def manual_seed(seed):
@@ -124,26 +149,64 @@ class LayerView(object):
         return out
 
 
+def _layer_row(lay, with_grads, pool):
+    """Device pointers of one BertLayer (12 params [+ 12 grads]), cached on the module.
+
+    Building a row costs ~40 tensor-metadata calls, so it is cached and re-validated cheaply: parameter storages
+    can only move through nn.Module._apply (.to / .bfloat16 — BertLayer._apply drops the cache) or through
+    ParamArena (which also drops it); gradients are re-created when someone sets them to None, which is caught by
+    an identity check of every cached grad tensor."""
+    cache = getattr(lay, "_ptr_cache", None)
+    if cache is not None:
+        ps, pptrs, gs, gptrs, owners = cache
+        ok = ps[2].data_ptr() == pptrs[2] and lay.attention.self.query.weight.data_ptr() == pptrs[0]
+        if ok and with_grads:
+            if gs is None:
+                ok = False
+            else:
+                for p, g in owners:
+                    if p.grad is not g:
+                        ok = False
+                        break
+        if ok:
+            return pptrs, gptrs, (ps, gs)
+    view = LayerView(lay)
+    ps = view.params()
+    for t in ps:
+        _check_dev(t, "encoder parameter")
+        if not t.is_contiguous():
+            raise _lib.UniterHipError("encoder parameters must be contiguous")
+    pptrs = [t.data_ptr() for t in ps]
+    gs = gptrs = None
+    owners = []
+    if with_grads:
+        gs = view.grads(pool)
+        gptrs = [t.data_ptr() for t in gs]
+        att = lay.attention.self
+        for m in (att.query, att.key, att.value, lay.attention.output.dense, lay.attention.output.LayerNorm,
+                  lay.intermediate.dense, lay.output.dense, lay.output.LayerNorm):
+            for p in (m.weight, m.bias):
+                if p.requires_grad:
+                    owners.append((p, p.grad))
+    lay._ptr_cache = (ps, pptrs, gs, gptrs, owners)
+    return pptrs, gptrs, (ps, gs)
+
+
 def _layer_table(layers, with_grads):
     n = len(layers)
     table = (UniterLayerParams * n)()
     keep = []
     pool = {}
+    names = LayerView.NAMES
     for i, lay in enumerate(layers):
-        view = LayerView(lay)
-        ps = view.params()
-        for t in ps:
-            _check_dev(t, "encoder parameter")
-            if not t.is_contiguous():
-                raise _lib.UniterHipError("encoder parameters must be contiguous")
-        keep.append(ps)
-        for name, t in zip(LayerView.NAMES, ps):
-            setattr(table[i], name, t.data_ptr())
+        pptrs, gptrs, alive = _layer_row(lay, with_grads, pool)
+        keep.append(alive)
+        row = table[i]
+        for name, v in zip(names, pptrs):
+            setattr(row, name, v)
         if with_grads:
-            gs = view.grads(pool)
-            keep.append(gs)
-            for name, t in zip(LayerView.NAMES, gs):
-                setattr(table[i], "g_" + name, t.data_ptr())
+            for name, v in zip(names, gptrs):
+                setattr(row, "g_" + name, v)
     return table, keep
 
 
@@ -155,6 +218,24 @@ def _shape(cfg_like, B, L, training):
     s.ln_eps = float(cfg_like["ln_eps"])
     s.training = 1 if training else 0
     return s
+
+
+_autotuned = set()
+
+
+def _maybe_autotune(s, training):
+    """First training-mode call of a new (B, L, H, I): let the library time its GEMM tile shapes for exactly these sizes
+    (one-off, synchronous, ~0.1 s).  UNITER_AMD_AUTOTUNE=0 keeps the built-in cost model (run-to-run identical tiles)."""
+    key = (int(s.B), int(s.L), int(s.H), int(s.I))
+    if key in _autotuned:
+        return
+    _autotuned.add(key)
+    import os
+    if os.environ.get("UNITER_AMD_AUTOTUNE", "1") == "0" or not training:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return
+    C.uniter_encoder_autotune(ctypes.byref(s), _lib.stream_ptr())
 
 
 class _EncoderFn(torch.autograd.Function):
@@ -169,6 +250,7 @@ class _EncoderFn(torch.autograd.Function):
         if act_bytes == 0:
             raise _lib.UniterHipError("bad encoder shape: " + _lib.load().uniter_hip_last_error().decode())
         out_off = C.uniter_encoder_layer_out_offset(ctypes.byref(s))
+        _maybe_autotune(s, training)
         acts = torch.empty(n * act_bytes, dtype=torch.uint8, device=x.device)
         table, keep = _layer_table(layers, with_grads=False)
         seed, off = _next_offsets(n * 8) if training else (0, 0)
@@ -251,14 +333,16 @@ def encoder_forward(layers, x, mask_bias, cfg_like, training, need_all=False, ho
     if mask_bias.numel() != B * L:
         raise _lib.UniterHipError("attention_mask must have B*L elements (got %d for B=%d L=%d)" % (mask_bias.numel(), B, L))
     mask_bias = mask_bias.reshape(B, L).contiguous()
-    params = []
-    for lay in layers:
-        params.extend(p for p in lay.parameters() if p.requires_grad)
     track = torch.is_grad_enabled() and training
     if not track:
         with torch.no_grad():
             return _EncoderFn.apply(x, mask_bias, list(layers), cfg_like, False, need_all, None)
-    return _EncoderFn.apply(x, mask_bias, list(layers), cfg_like, True, need_all, hook, *params)
+    # one parameter is enough to make the output require grad (gradients are written straight into .grad)
+    anchor = layers[0].output.dense.weight
+    if not anchor.requires_grad:
+        anchor = next((p for lay in layers for p in lay.parameters() if p.requires_grad), None)
+    extra = () if anchor is None else (anchor,)
+    return _EncoderFn.apply(x, mask_bias, list(layers), cfg_like, True, need_all, hook, *extra)
 
 
 # ----------------------------------------------------------------------------------------------------

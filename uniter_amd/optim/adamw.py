@@ -16,6 +16,7 @@ MI355X specifics:
     reads the gradients — identical to scaling the gradients in place first.
 """
 import ctypes
+import math
 
 import torch
 from torch.optim import Optimizer
@@ -52,6 +53,7 @@ class AdamW(Optimizer):
         self._keep = None
         self._clip = None             # device tensor [norm, coef] left by clip_grad_norm_
         self._norm_buf = None
+        self._graph = None            # (pinned host hyper table, device hyper table) in hipGraph mode
 
     # ---- plan management ------------------------------------------------------------------------------
     def _active(self):
@@ -137,6 +139,29 @@ class AdamW(Optimizer):
             pass
 
     def _ensure_plan(self):
+        """(Re)build the device-side tensor table when the set of (parameter, gradient) storages changed.
+
+        Full validation (two data_ptr() calls per tensor, ~0.5 ms for 230 tensors) runs every 32nd call; in between a
+        cheap check catches the two things that happen in practice: a gradient tensor was replaced (set_to_none,
+        first backward) -> identity test per parameter, or the parameter groups were edited."""
+        self._calls = getattr(self, '_calls', 0) + 1
+        if self._plan is not None and (self._calls & 31):
+            refs = self._plan_refs
+            n = 0
+            ok = True
+            for group in self.param_groups:
+                for p in group['params']:
+                    g = p.grad
+                    if g is None:
+                        continue
+                    if n >= len(refs) or refs[n][0] is not p or refs[n][1] is not g:
+                        ok = False
+                        break
+                    n += 1
+                if not ok:
+                    break
+            if ok and n == len(refs):
+                return True
         active = self._active()
         if not active:
             return False
@@ -144,6 +169,8 @@ class AdamW(Optimizer):
         if self._plan is None or key != self._plan_key:
             self._build_plan(active)
             self._plan_key = key
+        self._plan_refs = [(p, p.grad) for _, p in active]
+        self._flat_grads = None
         return True
 
     # ---- public API -----------------------------------------------------------------------------------
@@ -159,6 +186,33 @@ class AdamW(Optimizer):
         self._clip = self._norm_buf
         return self._norm_buf[0]
 
+    # ---- hipGraph mode ----------------------------------------------------------------------------------
+    def enable_graph_mode(self):
+        """Make step() capturable: hyper-parameters travel through a pinned host table + captured H2D copy instead of
+        kernel arguments.  Protocol per training step: `graph_prepare()` on the host (advances state['step'], folds the
+        current param_groups' lr / betas / ... into the pinned table), then step() — eagerly, under capture, or as part
+        of a graph replay."""
+        if not self._ensure_plan():
+            raise _lib.UniterHipError("enable_graph_mode needs gradients to exist (run one eager backward first)")
+        dev = self._plan_groups[0][1][0].device
+        host = torch.zeros(16, 6, dtype=torch.float32).pin_memory()
+        self._graph = (host, torch.zeros(16, 6, dtype=torch.float32, device=dev))
+
+    def graph_prepare(self):
+        host = self._graph[0]
+        for ig, (gi, plist) in enumerate(self._plan_groups):
+            group = self.param_groups[gi]
+            for p in plist:
+                self.state[p]['step'] += 1
+            t = int(self.state[plist[0]]['step'])
+            b1, b2 = float(group['betas'][0]), float(group['betas'][1])
+            lr = float(group['lr'])
+            step_size = lr
+            if group['correct_bias']:
+                step_size = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+            host[ig, 0], host[ig, 1], host[ig, 2] = lr, b1, b2
+            host[ig, 3], host[ig, 4], host[ig, 5] = float(group['eps']), float(group['weight_decay']), step_size
+
     def step(self, closure=None):
         """One optimisation step over every parameter that has a gradient."""
         loss = None
@@ -166,6 +220,14 @@ class AdamW(Optimizer):
             loss = closure()
         if not self._ensure_plan():
             return loss           # nothing has a gradient: no-op, like the reference's dummy first step (pretrain.py:261-263)
+        if self._graph is not None:
+            host, dev = self._graph
+            dev.copy_(host, non_blocking=True)
+            clip = self._clip
+            self._clip = None
+            C.uniter_adamw_step_dev(self._plan, ptr(dev), len(self._plan_groups), ptr(clip[1:]) if clip is not None else None,
+                                    _lib.stream_ptr())
+            return loss
         hyper = (UniterAdamGroup * len(self._plan_groups))()
         for ig, (gi, plist) in enumerate(self._plan_groups):
             group = self.param_groups[gi]
@@ -186,7 +248,15 @@ class AdamW(Optimizer):
         """Zero the gradients IN PLACE by default: the kernels accumulate into `.grad` storages that may be views of
         one flat arena (utils.arena), which must survive the step."""
         if set_to_none:
+            self._flat_grads = None
             return super(AdamW, self).zero_grad(set_to_none=True)
+        flats = getattr(self, '_flat_grads', None)
+        if flats is not None and self._plan is not None:
+            for f in flats:                      # fast path: everything lives in flat arenas found earlier
+                f.zero_()
+            return
+        all_flat = True
+        bases = []
         seen = set()
         for group in self.param_groups:
             for p in group['params']:
@@ -197,8 +267,11 @@ class AdamW(Optimizer):
                         if key not in seen:
                             seen.add(key)
                             base.zero_()
+                            bases.append(base)
                     else:
+                        all_flat = False
                         p.grad.zero_()
+        self._flat_grads = bases if (all_flat and bases) else None
 
 
 def clip_grad_norm_(parameters_or_optimizer, max_norm, grad_scale=1.0):

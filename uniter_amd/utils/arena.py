@@ -88,6 +88,9 @@ class ParamArena(object):
                     if p.grad is not None:
                         g.copy_(p.grad)
                     p.grad = g
+        for m in model.modules():                      # parameter storages moved: drop cached device pointers
+            if hasattr(m, "_ptr_cache"):
+                m._ptr_cache = None
 
     def span(self, params):
         """(start, end) element range of the arena covering the given parameters (must be arena members)."""
