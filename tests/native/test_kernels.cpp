@@ -242,9 +242,9 @@ static void host_gemm_nt(const std::vector<float>& X, const std::vector<float>& 
 }
 
 // mirror of kTiles in gemm.hip (tile index -> BM x BN)
-static const int kTileBM[] = {128, 128, 64, 64, 96, 192, 192, 128, 96, 128, 96, 96, 192};
-static const int kTileBN[] = {128, 64, 128, 64, 192, 96, 128, 192, 128, 96, 96, 64, 64};
-static const int kNumTiles = 13;
+static const int kTileBM[] = {128, 128, 64, 64, 96, 192, 192, 128, 96, 128, 96, 96, 192, 128, 64, 64, 96, 96, 96, 128};
+static const int kTileBN[] = {128, 64, 128, 64, 192, 96, 128, 192, 128, 96, 96, 64, 64, 64, 128, 64, 96, 64, 128, 96};
+static const int kNumTiles = 20;     // 13.. are 3-stage rings
 
 static void test_gemm(int M, int N, int K, int cfg, int splits) {
     char tag[128];
@@ -720,6 +720,9 @@ static void bench(int B, int L, int H, int heads, int I, int layers) {
     }
 }
 
+#ifdef UNITER_GEMM_PROBE
+extern "C" int uniter_gemm_debug_probe(unsigned long long* dev);
+#endif
 // --one <fwd|gelu|dgrad|wgrad> M N K cfg splits iters : launch one GEMM flavour repeatedly (for rocprofv3 --pmc runs)
 static int run_one(int argc, char** argv, int at) {
     if (at + 7 > argc) { fprintf(stderr, "usage: --one kind M N K cfg splits iters\n"); return 2; }
@@ -742,6 +745,45 @@ static int run_one(int argc, char** argv, int at) {
         else if (kind == "dgrad") UHCHK(uniter_gemm_dgrad(dX, dW, nullptr, dY, M, N, K, 0));
         else UHCHK(uniter_gemm_wgrad(dX, dY, dW, nullptr, M, N, K, 1, ws, wsb, 0));
     };
+#ifdef UNITER_GEMM_PROBE
+    {
+        const int nblk = 4096;
+        unsigned long long* dpr = dalloc<unsigned long long>((size_t)nblk * 64 * 5);
+        for (int i = 0; i < 3; ++i) fn();
+        HIPCHK(hipMemset(dpr, 0, (size_t)nblk * 64 * 5 * 8));
+        uniter_gemm_debug_probe(dpr);
+        fn();
+        HIPCHK(hipDeviceSynchronize());
+        uniter_gemm_debug_probe(nullptr);
+        std::vector<unsigned long long> h((size_t)nblk * 64 * 5);
+        HIPCHK(hipMemcpy(h.data(), dpr, h.size() * 8, hipMemcpyDeviceToHost));
+        const int nkt = (int)std::min<int64_t>((kind == "wgrad" ? M : (kind == "dgrad" ? N : K)) / 64, 63);
+        double ph[4] = {0, 0, 0, 0}, tot = 0, gap = 0; long cnt = 0, gcnt = 0;
+        unsigned long long tmin = ~0ull, tmax = 0;
+        for (int b = 0; b < nblk; ++b) {
+            if (h[(size_t)b * 320] == 0) continue;
+            for (int k = 0; k < nkt; ++k) {
+                const unsigned long long* r = &h[((size_t)b * 64 + k) * 5];
+                if (r[4] == 0) continue;
+                for (int q = 0; q < 4; ++q) ph[q] += (double)(r[q + 1] - r[q]);
+                tot += (double)(r[4] - r[0]); ++cnt;
+                if (k + 1 < nkt && r[9] != 0) { gap += (double)(r[5] - r[4]); ++gcnt; }
+                tmin = std::min(tmin, r[0]); tmax = std::max(tmax, r[4]);
+            }
+        }
+        printf("   probe: %ld iterations; cycles/iter: dma-wait %.0f | barrier %.0f | dma-issue %.0f | lds+mfma %.0f | total %.0f (+%.0f between) ; kernel span %.0f kcycles\n",
+               cnt, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, tot / cnt, gcnt ? gap / gcnt : 0.0, (double)(tmax - tmin) / 1e3);
+        // per-block span distribution
+        std::vector<double> spans;
+        for (int b = 0; b < nblk; ++b) {
+            const unsigned long long* r0 = &h[(size_t)b * 320];
+            const unsigned long long* r1 = &h[((size_t)b * 64 + nkt - 1) * 5];
+            if (r0[0] && r1[4]) spans.push_back((double)(r1[4] - r0[0]));
+        }
+        std::sort(spans.begin(), spans.end());
+        if (!spans.empty()) printf("   probe: main-loop span per block: min %.0f median %.0f max %.0f cycles (%zu blocks)\n", spans.front(), spans[spans.size() / 2], spans.back(), spans.size());
+    }
+#endif
     const double us = tm.run(fn, 3, iters);
     printf("%s M%lld N%lld K%lld cfg%d splits%d: %.2f us  %.1f TF\n", kind.c_str(), (long long)M, (long long)N, (long long)K, cfg,
            splits, us, 2.0 * M * N * K / us * 1e-6);

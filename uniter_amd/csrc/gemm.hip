@@ -43,6 +43,9 @@ struct GemmArgs {
     int k_per_split;      // multiple of 64
     int accumulate;       // EPI_WGRAD, splits == 1: C += result
     int xr;               // 2-D XCD blocking: rows of the XCD grid (0 = 1-D contiguous ranges)
+#ifdef UNITER_GEMM_PROBE
+    unsigned long long* probe;   // cycle stamps of wave 0 of every workgroup: [block][kt][5] (profiling builds only)
+#endif
     DropoutCfg drop;
 };
 
@@ -203,11 +206,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return start + loc;
 }
 
-template <int BM, int BN, bool TRA, bool TRB, int EPI>
+template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
     constexpr int TILE_R = BM * 64, TILE_C = BN * 64;   // elements per LDS tile
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];     // 2 x (TILE_R + TILE_C) bf16, sized at launch
+    constexpr int STAGE = TILE_R + TILE_C;               // elements per pipeline stage
+    constexpr int G = BM / 32 + BN / 32;                 // LDS-DMA instructions per wave per K tile
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];     // NSTAGE x STAGE bf16, sized at launch
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
 
     const int t = threadIdx.x;
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     Stage<BM, TRA> sr;
     Stage<BN, TRB> sc;
 
-    auto do_load = [&](int kt) {               // register-staged path (partial K tiles only)
+    auto do_load = [&](int kt) {               // register-staged path (the partial K tile at the end, if any)
         const int k0 = k_begin + kt * 64;
         if constexpr (TRA) sr.load(p.R, p.ldr, m0, k0, k_end, t);
         else               sr.load(p.R, p.ldr, m0, p.M, k0, k_end, t);
@@ -249,19 +254,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         else               sc.load(p.Cc, p.ldcc, n0, p.N, k0, k_end, t);
     };
     auto do_store = [&](int buf) {
-        sr.store(smem + buf * (TILE_R + TILE_C), t);
-        sc.store(smem + buf * (TILE_R + TILE_C) + TILE_R, t);
+        sr.store(smem + buf * STAGE, t);
+        sc.store(smem + buf * STAGE + TILE_R, t);
     };
     auto do_glds = [&](int kt, int buf) {       // direct-to-LDS path (full K tiles)
         const int k0 = k_begin + kt * 64;
-        bf16_t* tr_ = smem + buf * (TILE_R + TILE_C);
+        bf16_t* tr_ = smem + buf * STAGE;
         bf16_t* tc_ = tr_ + TILE_R;
         if constexpr (TRA) glds_ks<BM>(tr_, p.R, p.ldr, m0, k0, wid, lane);
         else               glds_kc<BM>(tr_, p.R, p.ldr, m0, p.M, k0, wid, lane);
         if constexpr (TRB) glds_ks<BN>(tc_, p.Cc, p.ldcc, n0, k0, wid, lane);
         else               glds_kc<BN>(tc_, p.Cc, p.ldcc, n0, p.N, k0, wid, lane);
     };
-    auto is_full = [&](int kt) { return k_begin + kt * 64 + 64 <= k_end; };
 
     f32x4 acc[NI][MI];
 #pragma unroll
@@ -269,27 +273,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (nk > 0) {
-        if (is_full(0)) {
-            do_glds(0, 0);
-        } else {
-            do_load(0);
-            do_store(0);
-        }
-    }
-
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt has landed (the barrier's fence drains this wave's outstanding LDS-DMA) and every wave is done
-        // reading the buffer the next tile is about to overwrite
-        __syncthreads();
-        const bool more = (kt + 1 < nk);
-        const bool next_full = more && is_full(kt + 1);
-        if (more) {
-            if (next_full) do_glds(kt + 1, (kt + 1) & 1);
-            else           do_load(kt + 1);
-        }
-
-        const bf16_t* tr = smem + (kt & 1) * (TILE_R + TILE_C);
+    auto compute = [&](int buf) {
+        const bf16_t* tr = smem + buf * STAGE;
         const bf16_t* tc = tr + TILE_R;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -310,8 +295,52 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                 for (int b = 0; b < MI; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[a], fr[b], acc[a][b], 0, 0, 0);
         }
+    };
 
-        if (more && !next_full) do_store((kt + 1) & 1);
+    // ---- main loop over the full K tiles: NSTAGE-deep ring of LDS buffers filled by LDS-DMA -----------------------
+    // Up to NSTAGE-1 tiles are in flight.  vmcnt counts this wave's DMA instructions in issue order, so
+    // "vmcnt(G * tiles_allowed_in_flight)" means "my share of tile kt has landed"; the raw s_barrier then makes
+    // every wave's share visible and also proves that all waves are done reading the buffer tile kt+NSTAGE-1 is
+    // about to overwrite (it held tile kt-1).  No __syncthreads() here: its fence would drain the DMA queue.
+    const int nfull = (k_end > k_begin) ? ((k_end - k_begin) >> 6) : 0;
+#pragma unroll
+    for (int d = 0; d < NSTAGE - 1; ++d)
+        if (d < nfull) do_glds(d, d);
+    int buf = 0;                  // kt % NSTAGE
+    int pre = NSTAGE - 1;         // (kt + NSTAGE - 1) % NSTAGE
+    for (int kt = 0; kt < nfull; ++kt) {
+#ifdef UNITER_GEMM_PROBE
+        unsigned long long* pr = p.probe ? p.probe + ((size_t)blockIdx.x * 64 + (kt < 63 ? kt : 63)) * 5 : nullptr;
+        const bool rec = pr != nullptr && t == 0;
+        if (rec) pr[0] = __builtin_readcyclecounter();
+#endif
+        if (NSTAGE == 3 && kt + 1 < nfull) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+        else                               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef UNITER_GEMM_PROBE
+        if (rec) pr[1] = __builtin_readcyclecounter();
+#endif
+        __builtin_amdgcn_s_barrier();
+#ifdef UNITER_GEMM_PROBE
+        if (rec) pr[2] = __builtin_readcyclecounter();
+#endif
+        if (kt + NSTAGE - 1 < nfull) do_glds(kt + NSTAGE - 1, pre);
+#ifdef UNITER_GEMM_PROBE
+        if (rec) pr[3] = __builtin_readcyclecounter();
+#endif
+        compute(buf);
+#ifdef UNITER_GEMM_PROBE
+        if (rec) { asm volatile("s_nop 0" ::: "memory"); pr[4] = __builtin_readcyclecounter(); }
+#endif
+        buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+        pre = (pre + 1 == NSTAGE) ? 0 : pre + 1;
+    }
+    // ---- partial K tile (contraction length not a multiple of 64): zero-filled register staging --------------------
+    if (nk > nfull) {
+        __syncthreads();          // everyone is done with the ring
+        do_load(nfull);
+        do_store(0);
+        __syncthreads();
+        compute(0);
     }
 
     // ---- epilogue: lane holds C[m][n..n+3], m = m0 + wm*WM + b*16 + i, n = n0 + wn*WN + a*16 + 4g ----
@@ -401,6 +430,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *reinterpret_cast<u32x2*>(out + idx) = pack4(v);
 }
 
+#ifdef UNITER_GEMM_PROBE
+unsigned long long* g_probe = nullptr;
+#endif
+
 // XCD grid for the 2-D mapping: the factorisation xr x xc = 8 that divides the tile grid and minimises the operand
 // bytes one XCD touches (sub_m*BM + sub_n*BN rows of K elements); 0 if none divides.
 int pick_xr(int tiles_m, int tiles_n, int bm, int bn) {
@@ -415,20 +448,23 @@ int pick_xr(int tiles_m, int tiles_n, int bm, int bn) {
     return best;
 }
 
-template <int BM, int BN, bool TRA, bool TRB, int EPI>
+template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE>
 int launch_cfg(const GemmArgs& a_in, int splits, hipStream_t st) {
     GemmArgs a = a_in;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
     a.xr = pick_xr(tiles_m, tiles_n, BM, BN);
-    constexpr size_t lds = (size_t)2 * (BM + BN) * 64 * sizeof(bf16_t);
+#ifdef UNITER_GEMM_PROBE
+    a.probe = g_probe;
+#endif
+    constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * 64 * sizeof(bf16_t);
     static bool attr_done = false;
     if (lds > 64 * 1024 && !attr_done) {
-        UH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, TRA, TRB, EPI>),
+        UH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, TRA, TRB, EPI, NSTAGE>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     dim3 grid(tiles_m * tiles_n, splits, 1);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, TRA, TRB, EPI>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, TRA, TRB, EPI, NSTAGE>), grid, dim3(256), lds, st, a);
     UH_LAUNCH_CHECK();
     return 0;
 }
@@ -436,9 +472,12 @@ int launch_cfg(const GemmArgs& a_in, int splits, hipStream_t st) {
 // Tile shapes.  Index 0..3 are the power-of-two tiles every layout supports; 4.. are the 96/192 shapes that let a
 // 3072-wide problem fill the 512 resident workgroup slots (256 CUs x 2) in ONE round.  K-strided operands (dgrad's
 // weight, both wgrad operands) need a 64- or 128-wide tile on their side (LDS swizzle / 1 KiB DMA granularity).
-struct TileShape { int bm, bn; };
-constexpr TileShape kTiles[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {96, 192}, {192, 96}, {192, 128},
-                                {128, 192}, {96, 128}, {128, 96}, {96, 96}, {96, 64}, {192, 64}};
+struct TileShape { int bm, bn, stages; };
+constexpr TileShape kTiles[] = {{128, 128, 2}, {128, 64, 2}, {64, 128, 2}, {64, 64, 2}, {96, 192, 2}, {192, 96, 2}, {192, 128, 2},
+                                {128, 192, 2}, {96, 128, 2}, {128, 96, 2}, {96, 96, 2}, {96, 64, 2}, {192, 64, 2},
+                                // 3-stage rings (two tiles in flight) for the shapes whose three stages still let two
+                                // workgroups share a CU (<= 80 KiB each)
+                                {128, 64, 3}, {64, 128, 3}, {64, 64, 3}, {96, 96, 3}, {96, 64, 3}, {96, 128, 3}, {128, 96, 3}};
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <bool TRA, bool TRB>
@@ -452,7 +491,7 @@ constexpr bool tile_ok(int idx) {
 template <bool TRA, bool TRB, int EPI, int IDX>
 int launch_idx(const GemmArgs& a, int splits, hipStream_t st) {
     if constexpr (tile_ok<TRA, TRB>(IDX)) {
-        return launch_cfg<kTiles[IDX].bm, kTiles[IDX].bn, TRA, TRB, EPI>(a, splits, st);
+        return launch_cfg<kTiles[IDX].bm, kTiles[IDX].bn, TRA, TRB, EPI, kTiles[IDX].stages>(a, splits, st);
     } else {
         uh_set_error("gemm: tile shape %d is not available for this operand layout", IDX);
         return -1;
@@ -475,6 +514,13 @@ int launch_gemm(const GemmArgs& a, int cfg, int splits, hipStream_t st) {
         case 10: return launch_idx<TRA, TRB, EPI, 10>(a, splits, st);
         case 11: return launch_idx<TRA, TRB, EPI, 11>(a, splits, st);
         case 12: return launch_idx<TRA, TRB, EPI, 12>(a, splits, st);
+        case 13: return launch_idx<TRA, TRB, EPI, 13>(a, splits, st);
+        case 14: return launch_idx<TRA, TRB, EPI, 14>(a, splits, st);
+        case 15: return launch_idx<TRA, TRB, EPI, 15>(a, splits, st);
+        case 16: return launch_idx<TRA, TRB, EPI, 16>(a, splits, st);
+        case 17: return launch_idx<TRA, TRB, EPI, 17>(a, splits, st);
+        case 18: return launch_idx<TRA, TRB, EPI, 18>(a, splits, st);
+        case 19: return launch_idx<TRA, TRB, EPI, 19>(a, splits, st);
         default: uh_set_error("gemm: bad tile index %d", cfg); return -1;
     }
 }
@@ -509,7 +555,7 @@ int pick_cfg(int M, int N, bool trm, bool trn) {
         if (trm && (M % bm != 0 || !(bm == 64 || bm == 128))) continue;
         if (trn && !(bn == 64 || bn == 128)) continue;
         const long tiles = (long)((M + bm - 1) / bm) * (N / bn);
-        const int lds = 2 * (bm + bn) * 128;
+        const int lds = kTiles[i].stages * (bm + bn) * 128;
         int per_cu = 163840 / lds;
         if (per_cu > 4) per_cu = 4;
         const long slots = (long)g_num_cus * per_cu;
@@ -517,6 +563,7 @@ int pick_cfg(int M, int N, bool trm, bool trn) {
         const double resident = (double)tiles / (double)(rounds * g_num_cus);     // workgroups per CU in a typical round
         const double intensity = (double)bm * bn / (bm + bn);                     // 64 for 128x128
         double cost = (double)rounds * ((double)bm * bn * (1.0 + 24.0 / intensity) + 6000.0);   // + fixed prologue/epilogue
+        if (kTiles[i].stages == 3) cost *= 1.02;     // untuned default stays on the 2-stage ring; the autotuner decides
         if (resident < 1.5) cost *= 1.35;
         if (resident < 0.75) cost *= 1.5;
         if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
@@ -529,6 +576,9 @@ int pick_cfg(int M, int N, bool trm, bool trn) {
 namespace uh {
 
 void gemm_debug_force(int cfg, int splits) { g_force_cfg = cfg; g_force_splits = splits; }
+#ifdef UNITER_GEMM_PROBE
+extern "C" int uniter_gemm_debug_probe(unsigned long long* dev) { g_probe = dev; return 0; }
+#endif
 void gemm_set_num_cus(int n) { if (n > 0) g_num_cus = n; }
 
 static int check_common(int64_t M, int64_t N, int64_t K) {
