@@ -213,7 +213,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="issue every step eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole optimizer step into a hipGraph and replay it (N=1 only); measured slower than "
+                         "eager issue on ROCm 7.2 (8.65 vs 8.27 ms), so it is opt-in")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -276,11 +278,11 @@ def main():
         optimizer.zero_grad()
         return loss
 
-    # N == 1: the whole step is captured once into a hipGraph and replayed (one launch per step instead of ~550);
-    # N > 1 stays eager so that the bucketed RCCL allreduce keeps overlapping with backward outside of capture.
+    # --graph (N == 1): the whole step is captured once into a hipGraph and replayed (one launch per step instead of
+    # ~550).  Default is eager issue: the step is GPU-bound and graph replay measured slower on this ROCm.
     mode = "eager"
     train_step = None
-    if world == 1 and not args.no_graph:
+    if world == 1 and args.graph:
         from uniter_amd.utils.graph import GraphedStep
         try:
             graphed = GraphedStep(device_step, optimizer, device, warmup=3, pre_step=schedule_lr).capture()

@@ -242,9 +242,13 @@ static void host_gemm_nt(const std::vector<float>& X, const std::vector<float>& 
 }
 
 // mirror of kTiles in gemm.hip (tile index -> BM x BN)
-static const int kTileBM[] = {128, 128, 64, 64, 96, 192, 192, 128, 96, 128, 96, 96, 192, 128, 64, 64, 96, 96, 96, 128};
-static const int kTileBN[] = {128, 64, 128, 64, 192, 96, 128, 192, 128, 96, 96, 64, 64, 64, 128, 64, 96, 64, 128, 96};
-static const int kNumTiles = 20;     // 13.. are 3-stage rings
+static const int kTileBM[] = {128, 128, 64, 64, 96, 192, 192, 128, 96, 128, 96, 96, 192, 128, 64, 64, 96, 96, 96, 128,
+                              128, 96, 192, 128, 64, 96, 128, 64, 96, 64,
+                              96, 96, 128, 128, 64, 96, 128, 64, 96, 192};
+static const int kTileBN[] = {128, 64, 128, 64, 192, 96, 128, 192, 128, 96, 96, 64, 64, 64, 128, 64, 96, 64, 128, 96,
+                              128, 192, 96, 64, 128, 96, 64, 128, 96, 64,
+                              64, 128, 96, 128, 64, 64, 64, 128, 96, 64};
+static const int kNumTiles = 40;     // 13..19 are 3-stage rings, 20..29 wave-specialised (4 compute + 4 loader waves)
 
 static void test_gemm(int M, int N, int K, int cfg, int splits) {
     char tag[128];
@@ -807,7 +811,7 @@ int main(int argc, char** argv) {
     run_probes();
     printf("== gemm ==\n");
     for (int cfg = 0; cfg < 4; ++cfg) test_gemm(200, 256, 128, cfg, cfg == 0 ? 1 : 2);
-    for (int cfg = 4; cfg < kNumTiles; ++cfg) test_gemm(300, 384, 128, cfg, 1);
+    for (int cfg = 4; cfg < kNumTiles; ++cfg) test_gemm(cfg >= 20 ? 320 : 300, 384, 128, cfg, 1);   // WS: contraction % 64 == 0 (wgrad contracts over M)
     test_gemm(77, 128, 192, 3, 3);
     test_gemm(384, 384, 320, -1, -1);
     if (!quick) test_gemm(1000, 768, 768, -1, -1);

@@ -206,8 +206,22 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return start + loc;
 }
 
-template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+// Wait until this wave's DMA share of the current tile has landed while the younger tiles of the ring (at most
+// NSTAGE-2 of them, `later` = tiles still to come after this one) stay in flight: vmcnt counts outstanding VMEM
+// instructions in issue order and every tile is G instructions per wave.
+template <int NSTAGE, int G>
+__device__ __forceinline__ void wait_tile(int later) {
+    if (NSTAGE >= 4 && later >= 2)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+    else if (NSTAGE >= 3 && later >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+    else                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// WS ("wave specialised"): 8 waves per workgroup — waves 0-3 only read LDS and issue MFMAs, waves 4-7 only issue
+// the LDS-DMA for the next tile and wait for it.  In the unspecialised kernel every wave spends ~470 cycles per K tile
+// issuing its 8 DMA instructions and ~490 waiting for them (cycle stamps, tests/native/build_probe.sh) before it can
+// start the ~940 cycles of LDS reads + MFMAs; with dedicated loader waves those phases run concurrently.
+template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, bool WS>
+__global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 1) void gemm_kernel(const GemmArgs p) {
     constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
     constexpr int TILE_R = BM * 64, TILE_C = BN * 64;   // elements per LDS tile
     constexpr int STAGE = TILE_R + TILE_C;               // elements per pipeline stage
@@ -303,39 +317,71 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     // every wave's share visible and also proves that all waves are done reading the buffer tile kt+NSTAGE-1 is
     // about to overwrite (it held tile kt-1).  No __syncthreads() here: its fence would drain the DMA queue.
     const int nfull = (k_end > k_begin) ? ((k_end - k_begin) >> 6) : 0;
+    if constexpr (WS) {
+        if (wid >= 4) {
+            // ---- loader waves: one barrier per tile, shared with the compute waves ----
+            const int lw = wid - 4;
+            auto ws_glds = [&](int kt, int b) {
+                const int k0 = k_begin + kt * 64;
+                bf16_t* tr_ = smem + b * STAGE;
+                bf16_t* tc_ = tr_ + TILE_R;
+                if constexpr (TRA) glds_ks<BM>(tr_, p.R, p.ldr, m0, k0, lw, lane);
+                else               glds_kc<BM>(tr_, p.R, p.ldr, m0, p.M, k0, lw, lane);
+                if constexpr (TRB) glds_ks<BN>(tc_, p.Cc, p.ldcc, n0, k0, lw, lane);
+                else               glds_kc<BN>(tc_, p.Cc, p.ldcc, n0, p.N, k0, lw, lane);
+            };
 #pragma unroll
-    for (int d = 0; d < NSTAGE - 1; ++d)
-        if (d < nfull) do_glds(d, d);
-    int buf = 0;                  // kt % NSTAGE
-    int pre = NSTAGE - 1;         // (kt + NSTAGE - 1) % NSTAGE
-    for (int kt = 0; kt < nfull; ++kt) {
+            for (int d = 0; d < NSTAGE - 1; ++d)
+                if (d < nfull) ws_glds(d, d);
+            int pre = NSTAGE - 1;
+            for (int kt = 0; kt < nfull; ++kt) {
+                wait_tile<NSTAGE, G>(nfull - 1 - kt);
+                __builtin_amdgcn_s_barrier();
+                if (kt + NSTAGE - 1 < nfull) ws_glds(kt + NSTAGE - 1, pre);
+                pre = (pre + 1 == NSTAGE) ? 0 : pre + 1;
+            }
+            return;
+        }
+        int buf = 0;
+        for (int kt = 0; kt < nfull; ++kt) {
+            __builtin_amdgcn_s_barrier();
+            compute(buf);
+            buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < NSTAGE - 1; ++d)
+            if (d < nfull) do_glds(d, d);
+        int buf = 0;                  // kt % NSTAGE
+        int pre = NSTAGE - 1;         // (kt + NSTAGE - 1) % NSTAGE
+        for (int kt = 0; kt < nfull; ++kt) {
 #ifdef UNITER_GEMM_PROBE
-        unsigned long long* pr = p.probe ? p.probe + ((size_t)blockIdx.x * 64 + (kt < 63 ? kt : 63)) * 5 : nullptr;
-        const bool rec = pr != nullptr && t == 0;
-        if (rec) pr[0] = __builtin_readcyclecounter();
+            unsigned long long* pr = p.probe ? p.probe + ((size_t)blockIdx.x * 64 + (kt < 63 ? kt : 63)) * 5 : nullptr;
+            const bool rec = pr != nullptr && t == 0;
+            if (rec) pr[0] = __builtin_readcyclecounter();
 #endif
-        if (NSTAGE == 3 && kt + 1 < nfull) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-        else                               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_tile<NSTAGE, G>(nfull - 1 - kt);
 #ifdef UNITER_GEMM_PROBE
-        if (rec) pr[1] = __builtin_readcyclecounter();
+            if (rec) pr[1] = __builtin_readcyclecounter();
 #endif
-        __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
 #ifdef UNITER_GEMM_PROBE
-        if (rec) pr[2] = __builtin_readcyclecounter();
+            if (rec) pr[2] = __builtin_readcyclecounter();
 #endif
-        if (kt + NSTAGE - 1 < nfull) do_glds(kt + NSTAGE - 1, pre);
+            if (kt + NSTAGE - 1 < nfull) do_glds(kt + NSTAGE - 1, pre);
 #ifdef UNITER_GEMM_PROBE
-        if (rec) pr[3] = __builtin_readcyclecounter();
+            if (rec) pr[3] = __builtin_readcyclecounter();
 #endif
-        compute(buf);
+            compute(buf);
 #ifdef UNITER_GEMM_PROBE
-        if (rec) { asm volatile("s_nop 0" ::: "memory"); pr[4] = __builtin_readcyclecounter(); }
+            if (rec) { asm volatile("s_nop 0" ::: "memory"); pr[4] = __builtin_readcyclecounter(); }
 #endif
-        buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
-        pre = (pre + 1 == NSTAGE) ? 0 : pre + 1;
+            buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+            pre = (pre + 1 == NSTAGE) ? 0 : pre + 1;
+        }
     }
     // ---- partial K tile (contraction length not a multiple of 64): zero-filled register staging --------------------
-    if (nk > nfull) {
+    if (!WS && nk > nfull) {
         __syncthreads();          // everyone is done with the ring
         do_load(nfull);
         do_store(0);
@@ -448,9 +494,13 @@ int pick_xr(int tiles_m, int tiles_n, int bm, int bn) {
     return best;
 }
 
-template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE>
+template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, bool WS>
 int launch_cfg(const GemmArgs& a_in, int splits, hipStream_t st) {
     GemmArgs a = a_in;
+    if (WS && (a.K % 64 != 0 || a.k_per_split % 64 != 0)) {
+        uh_set_error("gemm: the wave-specialised tiles need a contraction length that is a multiple of 64");
+        return -1;
+    }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
     a.xr = pick_xr(tiles_m, tiles_n, BM, BN);
 #ifdef UNITER_GEMM_PROBE
@@ -459,12 +509,12 @@ int launch_cfg(const GemmArgs& a_in, int splits, hipStream_t st) {
     constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * 64 * sizeof(bf16_t);
     static bool attr_done = false;
     if (lds > 64 * 1024 && !attr_done) {
-        UH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, TRA, TRB, EPI, NSTAGE>),
+        UH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, TRA, TRB, EPI, NSTAGE, WS>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     dim3 grid(tiles_m * tiles_n, splits, 1);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, TRA, TRB, EPI, NSTAGE>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, TRA, TRB, EPI, NSTAGE, WS>), grid, dim3(WS ? 512 : 256), lds, st, a);
     UH_LAUNCH_CHECK();
     return 0;
 }
@@ -472,12 +522,20 @@ int launch_cfg(const GemmArgs& a_in, int splits, hipStream_t st) {
 // Tile shapes.  Index 0..3 are the power-of-two tiles every layout supports; 4.. are the 96/192 shapes that let a
 // 3072-wide problem fill the 512 resident workgroup slots (256 CUs x 2) in ONE round.  K-strided operands (dgrad's
 // weight, both wgrad operands) need a 64- or 128-wide tile on their side (LDS swizzle / 1 KiB DMA granularity).
-struct TileShape { int bm, bn, stages; };
-constexpr TileShape kTiles[] = {{128, 128, 2}, {128, 64, 2}, {64, 128, 2}, {64, 64, 2}, {96, 192, 2}, {192, 96, 2}, {192, 128, 2},
-                                {128, 192, 2}, {96, 128, 2}, {128, 96, 2}, {96, 96, 2}, {96, 64, 2}, {192, 64, 2},
-                                // 3-stage rings (two tiles in flight) for the shapes whose three stages still let two
+struct TileShape { int bm, bn, stages, ws; };
+constexpr TileShape kTiles[] = {{128, 128, 2, 0}, {128, 64, 2, 0}, {64, 128, 2, 0}, {64, 64, 2, 0}, {96, 192, 2, 0}, {192, 96, 2, 0},
+                                {192, 128, 2, 0}, {128, 192, 2, 0}, {96, 128, 2, 0}, {128, 96, 2, 0}, {96, 96, 2, 0}, {96, 64, 2, 0},
+                                {192, 64, 2, 0},
+                                // 3-stage rings (two tiles in flight) for shapes whose three stages still let two
                                 // workgroups share a CU (<= 80 KiB each)
-                                {128, 64, 3}, {64, 128, 3}, {64, 64, 3}, {96, 96, 3}, {96, 64, 3}, {96, 128, 3}, {128, 96, 3}};
+                                {128, 64, 3, 0}, {64, 128, 3, 0}, {64, 64, 3, 0}, {96, 96, 3, 0}, {96, 64, 3, 0}, {96, 128, 3, 0},
+                                {128, 96, 3, 0},
+                                // wave-specialised (4 compute + 4 loader waves)
+                                {128, 128, 2, 1}, {96, 192, 2, 1}, {192, 96, 2, 1}, {128, 64, 2, 1}, {64, 128, 2, 1}, {96, 96, 2, 1},
+                                {128, 64, 3, 1}, {64, 128, 3, 1}, {96, 96, 3, 1}, {64, 64, 3, 1},
+                                // deeper / other wave-specialised rings
+                                {96, 64, 3, 1}, {96, 128, 3, 1}, {128, 96, 3, 1}, {128, 128, 3, 1}, {64, 64, 4, 1}, {96, 64, 4, 1},
+                                {128, 64, 4, 1}, {64, 128, 4, 1}, {96, 96, 4, 1}, {192, 64, 3, 1}};
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <bool TRA, bool TRB>
@@ -491,7 +549,7 @@ constexpr bool tile_ok(int idx) {
 template <bool TRA, bool TRB, int EPI, int IDX>
 int launch_idx(const GemmArgs& a, int splits, hipStream_t st) {
     if constexpr (tile_ok<TRA, TRB>(IDX)) {
-        return launch_cfg<kTiles[IDX].bm, kTiles[IDX].bn, TRA, TRB, EPI, kTiles[IDX].stages>(a, splits, st);
+        return launch_cfg<kTiles[IDX].bm, kTiles[IDX].bn, TRA, TRB, EPI, kTiles[IDX].stages, kTiles[IDX].ws != 0>(a, splits, st);
     } else {
         uh_set_error("gemm: tile shape %d is not available for this operand layout", IDX);
         return -1;
@@ -521,6 +579,26 @@ int launch_gemm(const GemmArgs& a, int cfg, int splits, hipStream_t st) {
         case 17: return launch_idx<TRA, TRB, EPI, 17>(a, splits, st);
         case 18: return launch_idx<TRA, TRB, EPI, 18>(a, splits, st);
         case 19: return launch_idx<TRA, TRB, EPI, 19>(a, splits, st);
+        case 20: return launch_idx<TRA, TRB, EPI, 20>(a, splits, st);
+        case 21: return launch_idx<TRA, TRB, EPI, 21>(a, splits, st);
+        case 22: return launch_idx<TRA, TRB, EPI, 22>(a, splits, st);
+        case 23: return launch_idx<TRA, TRB, EPI, 23>(a, splits, st);
+        case 24: return launch_idx<TRA, TRB, EPI, 24>(a, splits, st);
+        case 25: return launch_idx<TRA, TRB, EPI, 25>(a, splits, st);
+        case 26: return launch_idx<TRA, TRB, EPI, 26>(a, splits, st);
+        case 27: return launch_idx<TRA, TRB, EPI, 27>(a, splits, st);
+        case 28: return launch_idx<TRA, TRB, EPI, 28>(a, splits, st);
+        case 29: return launch_idx<TRA, TRB, EPI, 29>(a, splits, st);
+        case 30: return launch_idx<TRA, TRB, EPI, 30>(a, splits, st);
+        case 31: return launch_idx<TRA, TRB, EPI, 31>(a, splits, st);
+        case 32: return launch_idx<TRA, TRB, EPI, 32>(a, splits, st);
+        case 33: return launch_idx<TRA, TRB, EPI, 33>(a, splits, st);
+        case 34: return launch_idx<TRA, TRB, EPI, 34>(a, splits, st);
+        case 35: return launch_idx<TRA, TRB, EPI, 35>(a, splits, st);
+        case 36: return launch_idx<TRA, TRB, EPI, 36>(a, splits, st);
+        case 37: return launch_idx<TRA, TRB, EPI, 37>(a, splits, st);
+        case 38: return launch_idx<TRA, TRB, EPI, 38>(a, splits, st);
+        case 39: return launch_idx<TRA, TRB, EPI, 39>(a, splits, st);
         default: uh_set_error("gemm: bad tile index %d", cfg); return -1;
     }
 }
@@ -545,12 +623,13 @@ bool tuned_lookup(int kind, int64_t M, int64_t N, int64_t K, Tuned* out) {
     return true;
 }
 
-int pick_cfg(int M, int N, bool trm, bool trn) {
+int pick_cfg(int M, int N, bool trm, bool trn, bool k_mult64 = false) {
     if (g_force_cfg >= 0) return g_force_cfg;
     int best = -1;
     double best_cost = 0;
     for (int i = 0; i < kNumTiles; ++i) {
         const int bm = kTiles[i].bm, bn = kTiles[i].bn;
+        if (kTiles[i].ws && (!k_mult64 || kTiles[i].stages != 3)) continue;   // un-tuned default: 3-stage WS rings only
         if (N % bn != 0) continue;
         if (trm && (M % bm != 0 || !(bm == 64 || bm == 128))) continue;
         if (trn && !(bn == 64 || bn == 128)) continue;
@@ -563,7 +642,8 @@ int pick_cfg(int M, int N, bool trm, bool trn) {
         const double resident = (double)tiles / (double)(rounds * g_num_cus);     // workgroups per CU in a typical round
         const double intensity = (double)bm * bn / (bm + bn);                     // 64 for 128x128
         double cost = (double)rounds * ((double)bm * bn * (1.0 + 24.0 / intensity) + 6000.0);   // + fixed prologue/epilogue
-        if (kTiles[i].stages == 3) cost *= 1.02;     // untuned default stays on the 2-stage ring; the autotuner decides
+        if (kTiles[i].ws) cost *= 0.8;               // measured: loader waves hide the DMA issue + wait phases
+        else if (kTiles[i].stages == 3) cost *= 1.02;
         if (resident < 1.5) cost *= 1.35;
         if (resident < 0.75) cost *= 1.5;
         if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
@@ -602,7 +682,7 @@ int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void
     a.k_per_split = (int)((K + 63) / 64 * 64);
     a.accumulate = 0;
     a.drop = drop;
-    int cfg = pick_cfg((int)M, (int)N, false, false);
+    int cfg = pick_cfg((int)M, (int)N, false, false, K % 64 == 0);
     Tuned tn;
     if (g_force_cfg < 0 && tuned_lookup(0, M, N, K, &tn)) cfg = tn.cfg;
     switch (epi) {
@@ -629,7 +709,7 @@ int gemm_dgrad(int epi, const void* dy, const void* w, const void* aux, void* dx
     a.k_per_split = (int)((N + 63) / 64 * 64);
     a.accumulate = 0;
     a.drop = make_dropout(0.f, 0, 0);
-    int cfg = pick_cfg((int)M, (int)K, false, true);
+    int cfg = pick_cfg((int)M, (int)K, false, true, N % 64 == 0);
     Tuned tn;
     if (g_force_cfg < 0 && tuned_lookup(1, M, N, K, &tn)) cfg = tn.cfg;
     if (epi == EPI_RES) return launch_gemm<false, true, EPI_RES>(a, cfg, 1, st);
@@ -666,7 +746,7 @@ int gemm_wgrad(const void* dy, const void* x, void* dw, int64_t M, int64_t N, in
     a.M = (int)N; a.N = (int)K; a.K = (int)M;
     a.accumulate = accumulate;
     a.drop = make_dropout(0.f, 0, 0);
-    int cfg = pick_cfg((int)N, (int)K, true, true);
+    int cfg = pick_cfg((int)N, (int)K, true, true, M % 64 == 0);
     int splits = wgrad_splits(M, N, K, cfg);
     Tuned tn;
     if (g_force_cfg < 0 && g_force_splits < 0 && tuned_lookup(2, M, N, K, &tn)) { cfg = tn.cfg; splits = tn.splits; }
@@ -728,6 +808,8 @@ int gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, hipStream_t st) {
     for (int cfg = 0; cfg < kNumTiles && rc == 0; ++cfg) {
         const int bm = kTiles[cfg].bm, bn = kTiles[cfg].bn;
         const bool p2m = bm == 64 || bm == 128, p2n = bn == 64 || bn == 128;
+        const int64_t contraction = kind == 0 ? K : (kind == 1 ? N : M);
+        if (kTiles[cfg].ws && contraction % 64 != 0) continue;
         if (kind == 0 && N % bn != 0) continue;
         if (kind == 1 && (!p2n || K % bn != 0)) continue;
         if (kind == 2 && (!p2m || !p2n || N % bm != 0 || K % bn != 0)) continue;
