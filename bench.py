@@ -13,10 +13,12 @@ accumulation 1), bf16 parameters/activations with fp32 master weights and fp32 A
 Prints ONE JSON line (rank 0).  `value` counts encoder sequences ("examples") per second over all GPUs.
 
 Extra objects on the line:
-  roofline      the dominant HIP kernel (largest share of the step by launches x duration) timed live with HIP
-                events on the stream the kernels run on; algorithmic FLOP / average launch duration vs the dense
-                bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).  `step` adds the whole-step figure
-                (encoder fwd+bwd algorithmic FLOP / step time).
+  roofline      the dominant HIP kernel (largest summed in-situ duration per step) timed live with HIP events that the
+                library records around every launch on the stream it is launched on, over extra optimizer steps right
+                after the timed region; algorithmic FLOP / average launch duration vs the dense bf16 MFMA peak
+                (2.5 PFLOP/s, MI355X_MICROARCH.md).  `traffic` = HBM bytes per launch from the committed PMC passes
+                (profiles/*_pmc_traffic.json).  `step` adds the whole-step figure (encoder fwd+bwd algorithmic FLOP /
+                step time).
   cpu_baseline  the CPU oracle (oracle/uniter_oracle.py, a port of the reference path) timed on this box's host
                 cores on the same workload — a reported baseline, not the target.
 """
@@ -63,55 +65,57 @@ def build_model(device, cfg_path, seed):
     return model
 
 
-def time_kernels(device):
-    """Live HIP-event timing of the GEMM kernels of one encoder layer at the benchmark shape."""
-    from uniter_amd._lib import C, ptr, stream_ptr
-    B, L, H, I = TRAIN['batch'], TRAIN['max_txt_len'] + TRAIN['num_bb'], BASE_CFG['hidden_size'], BASE_CFG['intermediate_size']
-    T = B * L
-    bf = torch.bfloat16
-    g = torch.Generator(device='cpu').manual_seed(0)
+def kernel_flop(rec):
+    """Algorithmic FLOP of one launch of a timed kernel (None for the HBM-bound ones)."""
+    k, M, N, K = rec["kind_id"], rec["M"], rec["N"], rec["K"]
+    if k <= 5:
+        return 2.0 * M * N * K                     # every GEMM flavour: M tokens x N out x K in (C-ABI argument order)
+    if k == 6:
+        return 4.0 * M * N * N * K * 64            # attention fwd: B=M, L=N, heads=K, d=64: QK^T + PV
+    if k == 7:
+        return 8.0 * M * N * N * K * 64            # attention bwd: dV, dP, dQ, dK (algorithmic 2x forward)
+    return None
 
-    def rnd(*shape, scale=1.0):
-        return (torch.randn(*shape, generator=g) * scale).to(device=device, dtype=bf)
 
-    x_h, x_i = rnd(T, H), rnd(T, I)
-    w_qkv, w_o, w_1, w_2 = rnd(3 * H, H, scale=0.02), rnd(H, H, scale=0.02), rnd(I, H, scale=0.02), rnd(H, I, scale=0.02)
-    bias = rnd(I, scale=0.1)
-    y_3h, y_h, y_i, y_i2 = rnd(T, 3 * H), rnd(T, H), rnd(T, I), rnd(T, I)
-    gw = torch.zeros(I * H, dtype=bf, device=device)
-    wsb = C.uniter_gemm_wgrad_workspace_bytes(T, I, H)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=device)
-    st = stream_ptr()
-    n_layers = BASE_CFG['num_hidden_layers']
-    # (name, launches per step, FLOP per launch, thunk)
-    kernels = [
-        ("gemm fwd qkv   [T,3H]x[H]", n_layers, 2.0 * T * 3 * H * H, lambda: C.uniter_gemm_bias_fwd(ptr(x_h), ptr(w_qkv), ptr(bias), ptr(y_3h), T, 3 * H, H, st)),
-        ("gemm fwd out   [T,H]x[H]+drop+res", n_layers, 2.0 * T * H * H, lambda: C.uniter_gemm_bias_dropout_residual_fwd(ptr(x_h), ptr(w_o), ptr(bias), ptr(x_h), ptr(y_h), T, H, H, 0.1, 1, 2, st)),
-        ("gemm fwd ffn1  [T,I]x[H]+gelu", n_layers, 2.0 * T * I * H, lambda: C.uniter_gemm_bias_gelu_fwd(ptr(x_h), ptr(w_1), ptr(bias), ptr(y_i), ptr(y_i2), T, I, H, st)),
-        ("gemm fwd ffn2  [T,H]x[I]+drop+res", n_layers, 2.0 * T * H * I, lambda: C.uniter_gemm_bias_dropout_residual_fwd(ptr(x_i), ptr(w_2), ptr(bias), ptr(x_h), ptr(y_h), T, H, I, 0.1, 1, 2, st)),
-        ("gemm dgrad ffn2 +gelu'", n_layers, 2.0 * T * H * I, lambda: C.uniter_gemm_dgrad_gelu(ptr(x_h), ptr(w_2), ptr(x_i), ptr(y_i), T, H, I, st)),
-        ("gemm dgrad ffn1 +res", n_layers, 2.0 * T * I * H, lambda: C.uniter_gemm_dgrad(ptr(x_i), ptr(w_1), ptr(x_h), ptr(y_h), T, I, H, st)),
-        ("gemm dgrad out", n_layers, 2.0 * T * H * H, lambda: C.uniter_gemm_dgrad(ptr(x_h), ptr(w_o), None, ptr(y_h), T, H, H, st)),
-        ("gemm dgrad qkv +res", n_layers, 2.0 * T * 3 * H * H, lambda: C.uniter_gemm_dgrad(ptr(y_3h), ptr(w_qkv), ptr(x_h), ptr(y_h), T, 3 * H, H, st)),
-        ("gemm wgrad ffn2", n_layers, 2.0 * T * H * I, lambda: C.uniter_gemm_wgrad(ptr(x_h), ptr(x_i), ptr(gw), None, T, H, I, 1, ptr(ws), wsb, st)),
-        ("gemm wgrad ffn1", n_layers, 2.0 * T * I * H, lambda: C.uniter_gemm_wgrad(ptr(x_i), ptr(x_h), ptr(gw), None, T, I, H, 1, ptr(ws), wsb, st)),
-        ("gemm wgrad out", n_layers, 2.0 * T * H * H, lambda: C.uniter_gemm_wgrad(ptr(y_h), ptr(x_h), ptr(gw), None, T, H, H, 1, ptr(ws), wsb, st)),
-        ("gemm wgrad qkv", n_layers, 2.0 * T * 3 * H * H, lambda: C.uniter_gemm_wgrad(ptr(y_3h), ptr(x_h), ptr(gw), None, T, 3 * H, H, 1, ptr(ws), wsb, st)),
-    ]
-    out = []
-    for name, per_step, flop, fn in kernels:
-        for _ in range(3):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        iters = 20
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        e1.synchronize()
-        us = e0.elapsed_time(e1) * 1000.0 / iters
-        out.append({"kernel": name, "launches_per_step": per_step, "us": round(us, 2), "tflops": round(flop / us * 1e-6, 1)})
-    return out
+def timed_pass(train_step, steps):
+    """Run `steps` more optimizer steps with the library's per-launch HIP events enabled (events are recorded on the
+    stream each kernel is launched on — the main stream or the backward's wgrad side stream) and return one row per
+    (kind, shape): launches per step, average launch duration in situ, achieved TFLOP/s."""
+    from uniter_amd import _lib
+    torch.cuda.synchronize()
+    _lib.timing_begin()
+    for _ in range(steps):
+        train_step()
+    recs = _lib.timing_end()
+    rows = []
+    for r in recs:
+        us = r["total_us"] / max(r["calls"], 1)
+        fl = kernel_flop(r)
+        rows.append({"kernel": r["kind"], "kind_id": r["kind_id"], "shape": [r["M"], r["N"], r["K"]],
+                     "launches_per_step": round(r["calls"] / steps, 2), "us": round(us, 2),
+                     "us_per_step": round(r["total_us"] / steps, 1),
+                     "tflops": None if fl is None else round(fl / us * 1e-6, 1)})
+    rows.sort(key=lambda x: -x["us_per_step"])
+    return rows
+
+
+def pmc_traffic(kind_id):
+    """HBM bytes per launch of a GEMM flavour from the committed PMC passes (profiles/*_pmc_traffic.json, produced by
+    scripts/profile_round.sh + scripts/summarize_profile.py; rocprofv3 cannot run inside this process).  None if the
+    passes are absent or the flavour runs at more than one shape (the kernel name does not carry the shape)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        by_kind = json.load(open(files[-1])).get("by_kind", {})
+    except (OSError, ValueError):
+        return None
+    e = by_kind.get(str(kind_id))
+    if not e or not e.get("single_shape"):
+        return None
+    return {"hbm_bytes": e["hbm_bytes"], "hbm_read_bytes": e["hbm_read_bytes"], "hbm_write_bytes": e["hbm_write_bytes"],
+            "source": os.path.basename(files[-1])}
 
 
 def usable_cores():
@@ -325,12 +329,22 @@ def main():
         step_tf = flop_step / (ms * 1e-3) * 1e-12
         roofline = None
         kernels = None
-        if not args.no_kernel_timing:
-            kernels = time_kernels(device)
-            dom = max(kernels, key=lambda k: k["us"] * k["launches_per_step"])
-            roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        if not args.no_kernel_timing and mode == "eager":
+            tsteps = max(1, min(args.steps, 5))
+            kernels = timed_pass(train_step, tsteps)
+            mfma = [k for k in kernels if k["tflops"] is not None]
+            dom = max(mfma, key=lambda k: k["us_per_step"])
+            M, N, K = dom["shape"]
+            traffic = pmc_traffic(dom["kind_id"])
+            # algorithmic HBM bytes of the dominant kernel for reference (bf16 operands + output [+ aux read])
+            roofline = {"bound": "mfma", "kernel": "%s M%d N%d K%d" % (dom["kernel"], M, N, K), "achieved": dom["tflops"],
+                        "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4),
+                        "traffic": None if traffic is None else traffic["hbm_bytes"],
+                        "traffic_detail": traffic,
                         "avg_launch_us": dom["us"], "launches_per_step": dom["launches_per_step"],
+                        "measured": "HIP events around every launch on its own stream during %d extra optimizer steps; in the "
+                                    "backward pass this kernel shares the GPU with the wgrad side stream, so the in-situ "
+                                    "duration is longer than the kernel alone (DESIGN.md section 5)" % tsteps,
                         "step": {"algorithmic_tflop_per_step": round(flop_step * 1e-12, 4), "achieved": round(step_tf, 1),
                                  "frac": round(step_tf / MFMA_PEAK_TFLOPS, 4),
                                  "note": "encoder fwd+bwd algorithmic FLOP (heads, embeddings, optimizer excluded) / whole step time"}}

@@ -46,6 +46,23 @@ int uniter_hip_device_info(int32_t out[4]);
 int uniter_hip_set_dropout_offset_ptr(const uint64_t* dev_counter);
 int uniter_hip_counter_add(uint64_t* dev_counter, uint64_t inc, void* stream);
 
+/* ---- optional per-launch timing (bench.py's roofline object) ------------------------------------------------
+ * Between _begin and _end every GEMM / attention / LayerNorm / column-sum / AdamW entry point brackets its launches
+ * with two HIP events on the stream it launches on.  _end synchronises the device and reports one record per
+ * (kind, M, N, K): number of launches and their summed duration.  Not usable during stream capture.
+ * kind: 0 gemm fwd +bias, 1 gemm fwd +bias+gelu, 2 gemm fwd +bias+dropout+residual, 3 gemm dgrad, 4 gemm dgrad x gelu',
+ *       5 gemm wgrad (incl. split-K reduce), 6 attention fwd, 7 attention bwd, 8 layernorm fwd, 9 layernorm bwd,
+ *       10 column sum, 11 AdamW, 12 layernorm bwd column sums (dgamma/dbeta/dbias; kind 9 is then the row half).
+ *       The reference has no counterpart (it profiles with nvprof / apex timers). */
+typedef struct {
+    int32_t kind;
+    int32_t calls;
+    int64_t M, N, K;
+    double total_us;
+} UniterTimingRecord;
+int uniter_hip_timing_begin(void);
+int uniter_hip_timing_end(UniterTimingRecord* out, int32_t cap, int32_t* n_out);
+
 /* Test / tuning hook: force the GEMM tile (0=128x128, 1=128x64, 2=64x128, 3=64x64; -1 = heuristic)
  * and the wgrad split-K factor (-1 = heuristic). */
 int uniter_gemm_debug_force(int cfg, int splits);
@@ -61,8 +78,11 @@ int uniter_gemm_debug_force(int cfg, int splits);
 /* Empirical tile selection (SYNCHRONOUS, allocates scratch: set-up time only): times every legal tile shape — and
  * split-K factor for wgrad — of one GEMM and caches the winner for (kind, M, N, K); later launches of that shape use
  * it.  kind 0 = forward, 1 = dgrad, 2 = wgrad, with M, N, K as in the corresponding call below.
- * uniter_gemm_tuned_choice reports the cached (tile index, splits) or (-1, -1). */
+ * uniter_gemm_tuned_choice reports the cached (tile index, splits) or (-1, -1); uniter_gemm_set_tuned installs a choice
+ * saved from an earlier process (checked against the same legality rules the sweep uses), so that a job can skip the
+ * sweep and run-to-run kernel selection is reproducible. */
 int uniter_gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, void* stream);
+int uniter_gemm_set_tuned(int kind, int64_t M, int64_t N, int64_t K, int32_t cfg, int32_t splits);
 int uniter_gemm_tuned_choice(int kind, int64_t M, int64_t N, int64_t K, int32_t out[2]);
 
 /* y[M,N] = x[M,K] * w[N,K]^T + bias[N]        (bias may be NULL)                 layer.py:76-78 */

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): kernel-trace + stats of the bench command, then two separate PMC passes
+# (FETCH_SIZE, WRITE_SIZE — never combined with other trace domains) for the HBM-traffic figure of bench.py's
+# roofline object.  Output under gpurun_out/<tag>/ ; scripts/summarize_profile.py turns it into profiles/<tag>_*.
+set -u
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-kernel-timing"
+# pin the GEMM tile choices: the first (unprofiled) run sweeps and saves them, the profiled runs reuse them, so the
+# traces contain the step's kernels only and all passes measure the same kernels
+export UNITER_AMD_TUNE_CACHE=$OUT/tune_cache.json
+rm -f "$UNITER_AMD_TUNE_CACHE"
+timeout 300 python $ROOT/bench.py --no-cpu-baseline --steps 30 --warmup 5 > "$OUT/bench.json.log" 2> "$OUT/bench.err.log"
+echo "bench rc=$?"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python $ROOT/bench.py --no-cpu-baseline --steps 10 --warmup 3 > "$OUT/trace.log" 2>&1
+echo "trace rc=$?"
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- $BENCH --steps 3 --warmup 2 > "$OUT/pmc_fetch.log" 2>&1
+echo "pmc fetch rc=$?"
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- $BENCH --steps 3 --warmup 2 > "$OUT/pmc_write.log" 2>&1
+echo "pmc write rc=$?"
+ls -R "$OUT" | head -40

@@ -34,6 +34,11 @@ class UniterAdamTensor(Structure):
                 ("exp_avg_sq", c_void_p), ("numel", c_int64), ("group", c_int32), ("param_is_bf16", c_int32)]
 
 
+class UniterTimingRecord(Structure):
+    _fields_ = [("kind", c_int32), ("calls", c_int32), ("M", c_int64), ("N", c_int64), ("K", c_int64),
+                ("total_us", ctypes.c_double)]
+
+
 class UniterAdamGroup(Structure):
     _fields_ = [("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
                 ("weight_decay", c_float), ("correct_bias", c_int32), ("step", c_int32)]
@@ -48,8 +53,11 @@ SIGNATURES = {
     "uniter_hip_device_info": (c_int, [POINTER(c_int32)]),
     "uniter_hip_set_dropout_offset_ptr": (c_int, [_P]),
     "uniter_hip_counter_add": (c_int, [_P, c_uint64, _P]),
+    "uniter_hip_timing_begin": (c_int, []),
+    "uniter_hip_timing_end": (c_int, [POINTER(UniterTimingRecord), c_int32, POINTER(c_int32)]),
     "uniter_gemm_debug_force": (c_int, [c_int, c_int]),
     "uniter_gemm_autotune": (c_int, [c_int, _I, _I, _I, _P]),
+    "uniter_gemm_set_tuned": (c_int, [c_int, _I, _I, _I, c_int32, c_int32]),
     "uniter_gemm_tuned_choice": (c_int, [c_int, _I, _I, _I, POINTER(c_int32)]),
     "uniter_gemm_bias_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "uniter_gemm_bias_gelu_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
@@ -159,6 +167,24 @@ def ptr(t):
 def stream_ptr():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+TIMING_KINDS = ("gemm fwd +bias", "gemm fwd +bias+gelu", "gemm fwd +bias+dropout+residual", "gemm dgrad",
+                "gemm dgrad x gelu'", "gemm wgrad", "attention fwd", "attention bwd", "layernorm fwd", "layernorm bwd",
+                "column sum", "adamw", "layernorm bwd column sums")
+
+
+def timing_begin():
+    C.uniter_hip_timing_begin()
+
+
+def timing_end(cap=256):
+    """Per-(kind, M, N, K) launch counts and summed HIP-event durations since timing_begin()."""
+    recs = (UniterTimingRecord * cap)()
+    n = c_int32(0)
+    C.uniter_hip_timing_end(recs, cap, ctypes.byref(n))
+    return [{"kind": TIMING_KINDS[r.kind] if 0 <= r.kind < len(TIMING_KINDS) else str(r.kind), "kind_id": r.kind,
+             "M": r.M, "N": r.N, "K": r.K, "calls": r.calls, "total_us": r.total_us} for r in recs[:min(n.value, cap)]]
 
 
 def device_info():

@@ -248,6 +248,7 @@ int uniter_adamw_step(void* plan, const UniterAdamGroup* groups, int32_t n_group
     }
     // enough blocks to fill the chip several times over; chunks are grid-strided
     int64_t blocks = p->n_chunks < 8192 ? p->n_chunks : 8192;
+    uh::LaunchTimer lt(uh::TIME_ADAMW, p->n_chunks, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        (const DevTensor*)p->d_tensors, (const ChunkRef*)p->d_chunks, p->n_chunks, ht, (const GroupHyper*)nullptr,
                        clip_coef);
@@ -261,6 +262,7 @@ int uniter_adamw_step_dev(void* plan, const float* dev_hyper, int32_t n_groups, 
     Plan* p = (Plan*)plan;
     HyperTable ht{};
     int64_t blocks = p->n_chunks < 8192 ? p->n_chunks : 8192;
+    uh::LaunchTimer lt(uh::TIME_ADAMW, p->n_chunks, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        (const DevTensor*)p->d_tensors, (const ChunkRef*)p->d_chunks, p->n_chunks, ht,
                        (const GroupHyper*)dev_hyper, clip_coef);

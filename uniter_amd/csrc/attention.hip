@@ -378,6 +378,7 @@ static int check(int64_t B, int64_t L, int64_t heads) {
 int attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse,
                   int64_t B, int64_t L, int64_t heads, const DropoutCfg& drop, hipStream_t st) {
     if (check(B, L, heads)) return -1;
+    LaunchTimer lt(TIME_ATTN_FWD, B, L, heads, st);
     AttnArgs a{};
     a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = lse;
     a.dctx = nullptr; a.dqkv = nullptr;
@@ -409,6 +410,7 @@ int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, cons
                   const void* dctx, void* dqkv, int64_t B, int64_t L, int64_t heads,
                   const DropoutCfg& drop, hipStream_t st) {
     if (check(B, L, heads)) return -1;
+    LaunchTimer lt(TIME_ATTN_BWD, B, L, heads, st);
     AttnArgs a{};
     a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)const_cast<void*>(ctx);
     a.lse = const_cast<float*>(lse); a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv;

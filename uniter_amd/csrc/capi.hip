@@ -6,6 +6,10 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
 
 namespace {
 thread_local char g_err[512] = {0};
@@ -14,6 +18,37 @@ __global__ void counter_add_kernel(unsigned long long* c, unsigned long long inc
 }
 
 const unsigned long long* uh_drop_offset_ptr = nullptr;
+
+// ---- per-launch timing: event pairs recorded on the launch stream, resolved at uniter_hip_timing_end ----
+namespace uh {
+bool g_timing_on = false;
+namespace {
+struct TimedLaunch { int kind; int64_t M, N, K; hipEvent_t e0, e1; };
+std::vector<TimedLaunch> g_timed;
+std::vector<hipEvent_t> g_event_pool;
+std::mutex g_timing_mu;
+hipEvent_t take_event() {
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+}  // namespace
+void timing_mark(int kind, int64_t M, int64_t N, int64_t K, hipStream_t st, bool begin) {
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    if (begin) {
+        TimedLaunch t{kind, M, N, K, take_event(), take_event()};
+        if (t.e0 == nullptr || t.e1 == nullptr) return;
+        (void)hipEventRecord(t.e0, st);
+        g_timed.push_back(t);
+    } else {
+        for (size_t i = g_timed.size(); i-- > 0;) {         // innermost open bracket of this kind
+            TimedLaunch& t = g_timed[i];
+            if (t.kind == kind && t.M == M && t.N == N && t.K == K) { (void)hipEventRecord(t.e1, st); break; }
+        }
+    }
+}
+}  // namespace uh
 
 void uh_set_error(const char* fmt, ...) {
     va_list ap;
@@ -65,6 +100,46 @@ int uniter_hip_counter_add(uint64_t* dev_counter, uint64_t inc, void* stream) {
     return 0;
 }
 
+int uniter_hip_timing_begin(void) {
+    std::lock_guard<std::mutex> lk(uh::g_timing_mu);
+    for (auto& t : uh::g_timed) { uh::g_event_pool.push_back(t.e0); uh::g_event_pool.push_back(t.e1); }
+    uh::g_timed.clear();
+    uh::g_timing_on = true;
+    return 0;
+}
+
+int uniter_hip_timing_end(UniterTimingRecord* out, int32_t cap, int32_t* n_out) {
+    UH_CHECK_ARG(n_out != nullptr && (out != nullptr || cap == 0), "null pointer");
+    uh::g_timing_on = false;
+    UH_CHECK_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(uh::g_timing_mu);
+    std::map<std::tuple<int, int64_t, int64_t, int64_t>, std::pair<int, double>> agg;
+    for (auto& t : uh::g_timed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) {
+            auto& a = agg[std::make_tuple(t.kind, t.M, t.N, t.K)];
+            a.first += 1;
+            a.second += (double)ms * 1e3;
+        }
+        uh::g_event_pool.push_back(t.e0);
+        uh::g_event_pool.push_back(t.e1);
+    }
+    (void)hipGetLastError();
+    uh::g_timed.clear();
+    int32_t n = 0;
+    for (auto& kv : agg) {
+        if (n < cap) {
+            out[n].kind = std::get<0>(kv.first);
+            out[n].calls = kv.second.first;
+            out[n].M = std::get<1>(kv.first); out[n].N = std::get<2>(kv.first); out[n].K = std::get<3>(kv.first);
+            out[n].total_us = kv.second.second;
+        }
+        ++n;
+    }
+    *n_out = n;
+    return 0;
+}
+
 // test / tuning hook: force a GEMM tile config (0..3, -1 = heuristic) and split count (-1 = heuristic)
 int uniter_gemm_debug_force(int cfg, int splits) {
     uh::gemm_debug_force(cfg, splits);
@@ -73,6 +148,10 @@ int uniter_gemm_debug_force(int cfg, int splits) {
 
 int uniter_gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, void* stream) {
     return uh::gemm_autotune(kind, M, N, K, (hipStream_t)stream);
+}
+
+int uniter_gemm_set_tuned(int kind, int64_t M, int64_t N, int64_t K, int32_t cfg, int32_t splits) {
+    return uh::gemm_set_tuned(kind, M, N, K, cfg, splits);
 }
 
 int uniter_gemm_tuned_choice(int kind, int64_t M, int64_t N, int64_t K, int32_t out[2]) {

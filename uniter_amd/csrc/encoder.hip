@@ -77,8 +77,8 @@ ScratchLayout scratch_layout(const UniterEncoderShape& s) {
 // (small, 144-576 workgroup) dgrad chain leaves idle.  Ordering is by events only, no host synchronisation.
 struct SideStream {
     hipStream_t stream = nullptr;
-    hipEvent_t main_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // recorded on the caller's stream
-    hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // recorded on the side stream
+    hipEvent_t main_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // recorded on the caller's stream
+    hipEvent_t side_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // recorded on the side stream
     hipEvent_t done = nullptr;
     int device = -1;
 };
@@ -89,7 +89,7 @@ int side_init() {
     UH_CHECK_HIP(hipGetDevice(&dev));
     if (g_side.stream != nullptr && g_side.device == dev) return 0;
     UH_CHECK_HIP(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 6; ++i) {
         UH_CHECK_HIP(hipEventCreateWithFlags(&g_side.main_ev[i], hipEventDisableTiming));
         UH_CHECK_HIP(hipEventCreateWithFlags(&g_side.side_ev[i], hipEventDisableTiming));
     }
@@ -201,7 +201,8 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
     }
     // slot k: main_ev[k] = "input of side job k is ready", side_ev[k] = "side job k has finished reading its input".
     // jobs: 0 = wgrad W2 (reads dd2), 1 = colsum + wgrad W1 (reads dpre), 2 = wgrad Wo (reads dd1), 3 = colsum + wgrad Wqkv (reads dqkv)
-    bool side_pending[4] = {false, false, false, false};
+    // slots 4 / 5 only carry "the LayerNorm column sums of BertOutput / BertSelfOutput have read their dy" (bufB)
+    bool side_pending[6] = {false, false, false, false, false, false};
     auto fork = [&](int k) -> int {            // side stream may start job k once the main stream reaches this point
         if (!side) return 0;
         UH_CHECK_HIP(hipEventRecord(g_side.main_ev[k], st));
@@ -235,11 +236,16 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         // without dropout the masked gradient IS dz (bufA): side jobs 0 / 2 then read bufA
         RC(before_overwrite(0));
         if (!hdrop) RC(before_overwrite(2));
-        RC(uh::layernorm_bwd(dyl, nullptr, A + al.z2, (const float*)(A + al.mean2), (const float*)(A + al.rstd2), P.ln2_g,
-                             bufA, hdrop ? ddb2 : nullptr, P.g_ln2_g, P.g_ln2_b, P.g_b2, T, H, 1, d_h2, 0,
-                             red, sl.red_bytes, st));
+        // LayerNorm backward is split: the row half (dz, dd) stays on the critical path, the column sums
+        // (dgamma, dbeta and the dense bias gradient) go to the side stream together with the weight gradient.
+        RC(uh::layernorm_bwd_rows(dyl, nullptr, A + al.z2, (const float*)(A + al.mean2), (const float*)(A + al.rstd2),
+                                  P.ln2_g, bufA, hdrop ? ddb2 : nullptr, T, H, d_h2, 0, st));
         const char* dd2 = hdrop ? ddb2 : bufA;
         RC(fork(0));
+        RC(uh::layernorm_bwd_cols(dyl, nullptr, A + al.z2, (const float*)(A + al.mean2), (const float*)(A + al.rstd2),
+                                  bufA, hdrop ? ddb2 : nullptr, P.g_ln2_g, P.g_ln2_b, P.g_b2, T, H, 1, d_h2, 0,
+                                  side ? red2 : red, sl.red_bytes, ss));
+        RC(joined(4));                         // dyl (bufB below the top layer) has been read
         RC(uh::gemm_wgrad(dd2, A + al.g, P.g_w2, T, H, I, 1, wg, sl.wg_bytes, ss));
         RC(joined(0));
         RC(before_overwrite(1));
@@ -249,15 +255,19 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         RC(uh::colsum(dpre, P.g_b1, T, I, 1, side ? red2 : red, sl.red_bytes, ss));
         RC(uh::gemm_wgrad(dpre, A + al.a, P.g_w1, T, I, H, 1, wg, sl.wg_bytes, ss));
         RC(joined(1));
+        RC(before_overwrite(4));               // bufB is about to receive da
         RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dpre, P.w1, bufA, bufB, T, I, H, st));          // da = dpre*W1 + dz2
         // ---- BertSelfOutput backward (model/layer.py:111-115) ----
         RC(before_overwrite(2));
-        if (!hdrop) RC(before_overwrite(0));
-        RC(uh::layernorm_bwd(bufB, nullptr, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1), P.ln1_g,
-                             bufA, hdrop ? ddb1 : nullptr, P.g_ln1_g, P.g_ln1_b, P.g_bo, T, H, 1, d_h1, 0,
-                             red, sl.red_bytes, st));
+        if (!hdrop) RC(before_overwrite(0));   // without dropout side job 0 reads dz2 straight from bufA
+        RC(uh::layernorm_bwd_rows(bufB, nullptr, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1),
+                                  P.ln1_g, bufA, hdrop ? ddb1 : nullptr, T, H, d_h1, 0, st));
         const char* dd1 = hdrop ? ddb1 : bufA;
         RC(fork(2));
+        RC(uh::layernorm_bwd_cols(bufB, nullptr, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1),
+                                  bufA, hdrop ? ddb1 : nullptr, P.g_ln1_g, P.g_ln1_b, P.g_bo, T, H, 1, d_h1, 0,
+                                  side ? red2 : red, sl.red_bytes, ss));
+        RC(joined(5));                         // bufB (da) has been read
         RC(uh::gemm_wgrad(dd1, A + al.ctx, P.g_wo, T, H, H, 1, wg, sl.wg_bytes, ss));
         RC(joined(2));
         RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dd1, P.wo, nullptr, dctx, T, H, H, st));
@@ -270,6 +280,7 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         RC(uh::gemm_wgrad(dqkv, xin, P.g_wqkv, T, 3 * H, H, 1, wg, sl.wg_bytes, ss));
         RC(joined(3));
         char* dxl = (l == layer_begin) ? (char*)dx : bufB;
+        RC(before_overwrite(5));               // bufB is about to receive this layer's dx
         RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dqkv, P.wqkv, bufA, dxl, T, 3 * H, H, st));     // dx = dqkv*Wqkv + dz1
         dyl = dxl;
     }

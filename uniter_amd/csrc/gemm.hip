@@ -344,8 +344,19 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 1) void gemm_kernel(const 
         }
         int buf = 0;
         for (int kt = 0; kt < nfull; ++kt) {
+#ifdef UNITER_GEMM_PROBE
+            unsigned long long* pr = p.probe ? p.probe + ((size_t)blockIdx.x * 64 + (kt < 63 ? kt : 63)) * 5 : nullptr;
+            const bool rec = pr != nullptr && t == 0;
+            if (rec) pr[0] = __builtin_readcyclecounter();
+#endif
             __builtin_amdgcn_s_barrier();
+#ifdef UNITER_GEMM_PROBE
+            if (rec) pr[1] = pr[2] = pr[3] = __builtin_readcyclecounter();   // phases: [0,1] wait for the loaders' barrier
+#endif
             compute(buf);
+#ifdef UNITER_GEMM_PROBE
+            if (rec) { asm volatile("s_nop 0" ::: "memory"); pr[4] = __builtin_readcyclecounter(); }   // [3,4] lds + mfma
+#endif
             buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
         }
     } else {
@@ -535,7 +546,9 @@ constexpr TileShape kTiles[] = {{128, 128, 2, 0}, {128, 64, 2, 0}, {64, 128, 2, 
                                 {128, 64, 3, 1}, {64, 128, 3, 1}, {96, 96, 3, 1}, {64, 64, 3, 1},
                                 // deeper / other wave-specialised rings
                                 {96, 64, 3, 1}, {96, 128, 3, 1}, {128, 96, 3, 1}, {128, 128, 3, 1}, {64, 64, 4, 1}, {96, 64, 4, 1},
-                                {128, 64, 4, 1}, {64, 128, 4, 1}, {96, 96, 4, 1}, {192, 64, 3, 1}};
+                                {128, 64, 4, 1}, {64, 128, 4, 1}, {96, 96, 4, 1}, {192, 64, 3, 1},
+                                // 4-stage rings that own a CU (three tiles in flight)
+                                {96, 128, 4, 1}, {128, 96, 4, 1}, {192, 64, 4, 1}, {128, 128, 4, 1}};
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <bool TRA, bool TRB>
@@ -599,6 +612,10 @@ int launch_gemm(const GemmArgs& a, int cfg, int splits, hipStream_t st) {
         case 37: return launch_idx<TRA, TRB, EPI, 37>(a, splits, st);
         case 38: return launch_idx<TRA, TRB, EPI, 38>(a, splits, st);
         case 39: return launch_idx<TRA, TRB, EPI, 39>(a, splits, st);
+        case 40: return launch_idx<TRA, TRB, EPI, 40>(a, splits, st);
+        case 41: return launch_idx<TRA, TRB, EPI, 41>(a, splits, st);
+        case 42: return launch_idx<TRA, TRB, EPI, 42>(a, splits, st);
+        case 43: return launch_idx<TRA, TRB, EPI, 43>(a, splits, st);
         default: uh_set_error("gemm: bad tile index %d", cfg); return -1;
     }
 }
@@ -671,6 +688,7 @@ int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void
              int64_t M, int64_t N, int64_t K, const DropoutCfg& drop, hipStream_t st) {
     if (check_common(M, N, K)) return -1;
     if (N % 64 != 0 || K % 8 != 0) { uh_set_error("gemm_fwd: need N %% 64 == 0 and K %% 8 == 0 (N=%lld K=%lld)", (long long)N, (long long)K); return -1; }
+    LaunchTimer lt(epi == GEMM_EPI_BIAS ? TIME_GEMM_FWD_BIAS : (epi == GEMM_EPI_BIAS_GELU ? TIME_GEMM_FWD_GELU : TIME_GEMM_FWD_DROP_RES), M, N, K, st);
     GemmArgs a{};
     a.R = (const bf16_t*)x; a.ldr = K;
     a.Cc = (const bf16_t*)w; a.ldcc = K;
@@ -698,6 +716,7 @@ int gemm_dgrad(int epi, const void* dy, const void* w, const void* aux, void* dx
                int64_t M, int64_t N, int64_t K, hipStream_t st) {
     if (check_common(M, N, K)) return -1;
     if (K % 64 != 0 || N % 8 != 0) { uh_set_error("gemm_dgrad: need K %% 64 == 0 and N %% 8 == 0"); return -1; }
+    LaunchTimer lt(epi == GEMM_EPI_GELU_BWD ? TIME_GEMM_DGRAD_GELU : TIME_GEMM_DGRAD, M, N, K, st);
     GemmArgs a{};
     a.R = (const bf16_t*)dy; a.ldr = N;
     a.Cc = (const bf16_t*)w; a.ldcc = K;          // stored [contraction = N][out cols = K]
@@ -738,6 +757,7 @@ int gemm_wgrad(const void* dy, const void* x, void* dw, int64_t M, int64_t N, in
                void* workspace, size_t ws_bytes, hipStream_t st) {
     if (check_common(M, N, K)) return -1;
     if (N % 64 != 0 || K % 64 != 0) { uh_set_error("gemm_wgrad: need N %% 64 == 0 and K %% 64 == 0 (N=%lld K=%lld)", (long long)N, (long long)K); return -1; }
+    LaunchTimer lt(TIME_GEMM_WGRAD, M, N, K, st);
     GemmArgs a{};
     a.R = (const bf16_t*)dy; a.ldr = N;           // stored [contraction = M][out rows = N]
     a.Cc = (const bf16_t*)x; a.ldcc = K;          // stored [contraction = M][out cols = K]
@@ -842,6 +862,23 @@ int gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, hipStream_t st) {
         std::lock_guard<std::mutex> lk(g_tuned_mu);
         g_tuned[std::make_tuple(kind, M, N, K)] = best;
     }
+    return 0;
+}
+
+int gemm_set_tuned(int kind, int64_t M, int64_t N, int64_t K, int cfg, int splits) {
+    if (kind < 0 || kind > 2 || cfg < 0 || cfg >= kNumTiles) { uh_set_error("gemm_set_tuned: bad kind / tile index"); return -1; }
+    if (splits < 1 || splits > 4 || (kind != 2 && splits != 1)) { uh_set_error("gemm_set_tuned: bad split count (split-K is a wgrad option, <= 4)"); return -1; }
+    // same legality rules as the autotune sweep
+    const int bm = kTiles[cfg].bm, bn = kTiles[cfg].bn;
+    const bool p2m = bm == 64 || bm == 128, p2n = bn == 64 || bn == 128;
+    const int64_t contraction = kind == 0 ? K : (kind == 1 ? N : M);
+    bool ok = !(kTiles[cfg].ws && contraction % (64 * (int64_t)splits) != 0);
+    if (kind == 0) ok = ok && N % bn == 0;
+    if (kind == 1) ok = ok && p2n && K % bn == 0;
+    if (kind == 2) ok = ok && p2m && p2n && N % bm == 0 && K % bn == 0;
+    if (!ok) { uh_set_error("gemm_set_tuned: tile %d (%dx%d) is not legal for kind %d M=%lld N=%lld K=%lld", cfg, bm, bn, kind, (long long)M, (long long)N, (long long)K); return -1; }
+    std::lock_guard<std::mutex> lk(g_tuned_mu);
+    g_tuned[std::make_tuple(kind, M, N, K)] = Tuned{cfg, splits};
     return 0;
 }
 

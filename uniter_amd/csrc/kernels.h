@@ -9,6 +9,21 @@ struct DropoutCfg;
 
 namespace uh {
 
+// ---- capi.hip: optional per-launch timing (uniter_hip_timing_begin / _end) ----
+// Kinds of timed launches; (kind, M, N, K) identifies one row of the report.
+enum { TIME_GEMM_FWD_BIAS = 0, TIME_GEMM_FWD_GELU = 1, TIME_GEMM_FWD_DROP_RES = 2, TIME_GEMM_DGRAD = 3,
+       TIME_GEMM_DGRAD_GELU = 4, TIME_GEMM_WGRAD = 5, TIME_ATTN_FWD = 6, TIME_ATTN_BWD = 7, TIME_LN_FWD = 8,
+       TIME_LN_BWD = 9, TIME_COLSUM = 10, TIME_ADAMW = 11, TIME_LN_BWD_COLS = 12 };
+extern bool g_timing_on;
+void timing_mark(int kind, int64_t M, int64_t N, int64_t K, hipStream_t st, bool begin);
+// Brackets everything launched in its scope with two events on `st` while timing is enabled (no-op otherwise).
+struct LaunchTimer {
+    int kind; int64_t M, N, K; hipStream_t st; bool on;
+    LaunchTimer(int kind_, int64_t M_, int64_t N_, int64_t K_, hipStream_t st_)
+        : kind(kind_), M(M_), N(N_), K(K_), st(st_), on(g_timing_on) { if (on) timing_mark(kind, M, N, K, st, true); }
+    ~LaunchTimer() { if (on) timing_mark(kind, M, N, K, st, false); }
+};
+
 // ---- gemm.hip ----
 enum { GEMM_EPI_BIAS = 0, GEMM_EPI_BIAS_GELU = 1, GEMM_EPI_BIAS_DROP_RES = 2, GEMM_EPI_RES = 3, GEMM_EPI_GELU_BWD = 4 };
 int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void* resid, void* y, void* y2,
@@ -21,6 +36,7 @@ int gemm_wgrad(const void* dy, const void* x, void* dw, int64_t M, int64_t N, in
 void gemm_debug_force(int cfg, int splits);
 int gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, hipStream_t st);
 int gemm_tuned_choice(int kind, int64_t M, int64_t N, int64_t K, int* cfg, int* splits);
+int gemm_set_tuned(int kind, int64_t M, int64_t N, int64_t K, int cfg, int splits);
 void gemm_set_num_cus(int n);
 
 // ---- attention.hip ----
@@ -38,6 +54,13 @@ int layernorm_bwd(const void* dy, const void* dy_extra, const void* z, const flo
                   const void* gamma, void* dz, void* dd, void* dgamma, void* dbeta, void* dbias,
                   int64_t rows, int64_t H, int accumulate, const DropoutCfg& drop, int post_drop,
                   void* workspace, size_t ws_bytes, hipStream_t st);
+int layernorm_bwd_rows(const void* dy, const void* dy_extra, const void* z, const float* mean, const float* rstd,
+                       const void* gamma, void* dz, void* dd, int64_t rows, int64_t H, const DropoutCfg& drop,
+                       int post_drop, hipStream_t st);
+int layernorm_bwd_cols(const void* dy, const void* dy_extra, const void* z, const float* mean, const float* rstd,
+                       const void* dz, const void* dd, void* dgamma, void* dbeta, void* dbias,
+                       int64_t rows, int64_t H, int accumulate, const DropoutCfg& drop, int post_drop,
+                       void* workspace, size_t ws_bytes, hipStream_t st);
 size_t colsum_workspace_bytes(int64_t rows, int64_t N);
 int colsum(const void* a, void* out, int64_t rows, int64_t N, int accumulate,
            void* workspace, size_t ws_bytes, hipStream_t st);

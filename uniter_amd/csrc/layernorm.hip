@@ -191,6 +191,167 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel2(const bf16_t* dy, cons
     LnBwd<NC, NW>::run(dy, dy_extra, z, mean_in, rstd_in, gamma, dz, dd, partial, rows, H, want_dbias, post_drop, drop, red);
 }
 
+// ---- split backward (H % 8 == 0): a row kernel on the critical path + a column-sum kernel that can run elsewhere ----
+// Row part: dz (and the dropout-masked dd) of every row; one wave per row, no cross-row traffic at all.
+template <int NC>
+__global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dy_extra,
+                                                          const bf16_t* __restrict__ z, const float* __restrict__ mean_in,
+                                                          const float* __restrict__ rstd_in, const bf16_t* __restrict__ gamma,
+                                                          bf16_t* __restrict__ dz, bf16_t* __restrict__ dd, int rows, int H,
+                                                          int post_drop, const DropoutCfg drop) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nch = H >> 2;
+    float gv[NC][4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) unpack4(*reinterpret_cast<const u32x2*>(gamma + ch * 4), gv[c]);
+        else gv[c][0] = gv[c][1] = gv[c][2] = gv[c][3] = 0.f;
+    }
+    const bool use_drop = drop.p > 0.f && !post_drop;
+    const bool use_post = drop.p > 0.f && post_drop;
+    for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4) {
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        const int64_t ro = (int64_t)row * H;
+        float xh[NC][4], gy[NC][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                float zv[4], dv[4];
+                unpack4(*reinterpret_cast<const u32x2*>(z + ro + ch * 4), zv);
+                unpack4(*reinterpret_cast<const u32x2*>(dy + ro + ch * 4), dv);
+                if (dy_extra != nullptr) {
+                    float ev[4];
+                    unpack4(*reinterpret_cast<const u32x2*>(dy_extra + ro + ch * 4), ev);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dv[e] += ev[e];
+                }
+                if (use_post) {
+                    float mult[4];
+                    dropout_mult4(drop, ((uint64_t)row * (uint64_t)H + (uint64_t)ch * 4) >> 2, mult);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dv[e] *= mult[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[c][e] = (zv[e] - mean) * rstd;
+                    gy[c][e] = dv[e] * gv[c][e];
+                    s1 += gy[c][e];
+                    s2 += gy[c][e] * xh[c][e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { xh[c][e] = 0.f; gy[c][e] = 0.f; }
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)H;
+        const float c2 = wave_sum(s2) / (float)H;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rstd * (gy[c][e] - c1 - xh[c][e] * c2);
+                const u32x2 packed = pack4(o);
+                *reinterpret_cast<u32x2*>(dz + ro + ch * 4) = packed;
+                if (use_drop && dd != nullptr) {
+                    float oq[4], mult[4];
+                    unpack4(packed, oq);
+                    dropout_mult4(drop, ((uint64_t)row * (uint64_t)H + (uint64_t)ch * 4) >> 2, mult);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) oq[e] *= mult[e];
+                    *reinterpret_cast<u32x2*>(dd + ro + ch * 4) = pack4(oq);
+                }
+            }
+        }
+    }
+}
+
+// Column part: per-block partial sums over rows of (dy*xhat, dy, d) with d = `dsrc` (the bf16 dd / dz the row kernel
+// wrote; masked on the fly when `mask_dsrc`).  Grid (strips of 512 columns, row blocks); partial [gridDim.y][3][H].
+__global__ __launch_bounds__(1024) void ln_bwd_cols_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dy_extra,
+                                                           const bf16_t* __restrict__ z, const float* __restrict__ mean_in,
+                                                           const float* __restrict__ rstd_in, const bf16_t* __restrict__ dsrc,
+                                                           float* __restrict__ partial, int rows, int H, int post_drop,
+                                                           int mask_dsrc, const DropoutCfg drop) {
+    __shared__ float red[BWD_WAVES][512];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int col = blockIdx.x * 512 + lane * 8;
+    float ag[8], ab[8], ad[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ag[e] = 0.f; ab[e] = 0.f; ad[e] = 0.f; }
+    const bool use_post = drop.p > 0.f && post_drop;
+    const bool use_mask = drop.p > 0.f && !post_drop && mask_dsrc;
+    if (col < H) {
+        for (int row = blockIdx.y * BWD_WAVES + wid; row < rows; row += gridDim.y * BWD_WAVES) {
+            const float mean = mean_in[row], rstd = rstd_in[row];
+            const int64_t o = (int64_t)row * H + col;
+            float zv[8], dv[8];
+            unpack8(*reinterpret_cast<const u32x4*>(z + o), zv);
+            unpack8(*reinterpret_cast<const u32x4*>(dy + o), dv);
+            if (dy_extra != nullptr) {
+                float ev[8];
+                unpack8(*reinterpret_cast<const u32x4*>(dy_extra + o), ev);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dv[e] += ev[e];
+            }
+            float mult[8];
+            if (use_post || use_mask) {
+                float m0[4], m1[4];
+                dropout_mult4(drop, (uint64_t)o >> 2, m0);
+                dropout_mult4(drop, ((uint64_t)o >> 2) + 1, m1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { mult[e] = m0[e]; mult[4 + e] = m1[e]; }
+            }
+            if (use_post) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dv[e] *= mult[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ag[e] += dv[e] * ((zv[e] - mean) * rstd);
+                ab[e] += dv[e];
+            }
+            if (dsrc != nullptr) {
+                float sv[8];
+                unpack8(*reinterpret_cast<const u32x4*>(dsrc + o), sv);
+                if (use_mask) {
+                    // same rounding as the row kernel's dd: mask the bf16 dz, round the product to bf16
+                    float q0[4], q1[4], r0[4], r1[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { q0[e] = sv[e] * mult[e]; q1[e] = sv[4 + e] * mult[4 + e]; }
+                    unpack4(pack4(q0), r0);
+                    unpack4(pack4(q1), r1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { sv[e] = r0[e]; sv[4 + e] = r1[e]; }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ad[e] += sv[e];
+            }
+        }
+    }
+    float* pout = partial + (int64_t)blockIdx.y * 3 * H;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wid][lane * 8 + e] = (k == 0) ? ag[e] : ((k == 1) ? ab[e] : ad[e]);
+        __syncthreads();
+        if (threadIdx.x < 512) {
+            const int gc = blockIdx.x * 512 + threadIdx.x;
+            if (gc < H) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < BWD_WAVES; ++w) s += red[w][threadIdx.x];
+                pout[k * H + gc] = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // out_k[col] (+)= sum_b partial[b][k][col]   for k < nk (nk <= 3), partial [nb][nk][H].
 // One block = 64 columns x 16 groups of partial rows (coalesced 256-byte reads), LDS tree over the groups.
 __global__ __launch_bounds__(1024) void finalize_cols_kernel(const float* __restrict__ partial, int nb, int nk, int H,
@@ -256,6 +417,14 @@ int ln_bwd_blocks(int64_t rows, int nw) {
     if (nb > cap) nb = cap;
     return (int)nb;
 }
+int ln_cols_blocks(int64_t rows, int64_t H) {
+    const int64_t strips = (H + 511) / 512;
+    int64_t nb = 256 / strips;                           // ~256 blocks x 16 waves
+    const int64_t maxb = (rows + BWD_WAVES - 1) / BWD_WAVES;
+    if (nb > maxb) nb = maxb;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
 int colsum_blocks(int64_t rows, int64_t N) {
     const int64_t strips = (N + 511) / 512;
     int64_t nb = 256 / strips;                           // ~256 blocks x 16 waves in flight
@@ -274,6 +443,7 @@ int layernorm_fwd(const void* z, const void* gamma, const void* beta, void* y, f
                   int64_t rows, int64_t H, float eps, const DropoutCfg& drop, hipStream_t st) {
     if (rows <= 0 || H <= 0 || H % 4 != 0 || H > 4096) { uh_set_error("layernorm_fwd: need H %% 4 == 0 and H <= 4096 (H=%lld)", (long long)H); return -1; }
     const int nc = (int)((H / 4 + 63) / 64);
+    LaunchTimer lt(TIME_LN_FWD, rows, H, 0, st);
     dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
 #define LN_FWD(NCV)                                                                                         \
     hipLaunchKernelGGL(ln_fwd_kernel<NCV>, grid, block, 0, st, (const bf16_t*)z, (const bf16_t*)gamma,      \
@@ -291,15 +461,81 @@ int layernorm_fwd(const void* z, const void* gamma, const void* beta, void* y, f
 
 size_t layernorm_bwd_workspace_bytes(int64_t rows, int64_t H) {
     const int nc = (int)((H / 4 + 63) / 64);
-    return (size_t)ln_bwd_blocks(rows, ln_bwd_waves(nc)) * 3 * (size_t)H * sizeof(float);
+    const size_t fused = (size_t)ln_bwd_blocks(rows, ln_bwd_waves(nc)) * 3 * (size_t)H * sizeof(float);
+    const size_t split = (size_t)ln_cols_blocks(rows, H) * 3 * (size_t)H * sizeof(float);
+    return fused > split ? fused : split;
+}
+
+static int ln_bwd_check(int64_t rows, int64_t H) {
+    if (rows <= 0 || H <= 0 || H % 4 != 0 || H > 2048) { uh_set_error("layernorm_bwd: need H %% 4 == 0 and H <= 2048 (H=%lld)", (long long)H); return -1; }
+    return 0;
+}
+
+// Row half of the split backward (H % 8 == 0): dz, and dd = dropout-masked dz when the dropout sat on the dense branch.
+int layernorm_bwd_rows(const void* dy, const void* dy_extra, const void* z, const float* mean, const float* rstd,
+                       const void* gamma, void* dz, void* dd, int64_t rows, int64_t H, const DropoutCfg& drop,
+                       int post_drop, hipStream_t st) {
+    if (ln_bwd_check(rows, H)) return -1;
+    if (H % 8 != 0) { uh_set_error("layernorm_bwd_rows: need H %% 8 == 0"); return -1; }
+    LaunchTimer lt(TIME_LN_BWD, rows, H, 0, st);
+    const int nc = (int)((H / 4 + 63) / 64);
+    int64_t nb = (rows + 3) / 4;
+    if (nb > 4096) nb = 4096;
+#define LN_ROWS(NCV)                                                                                                   \
+    hipLaunchKernelGGL(ln_bwd_rows_kernel<NCV>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)dy,              \
+                       (const bf16_t*)dy_extra, (const bf16_t*)z, mean, rstd, (const bf16_t*)gamma, (bf16_t*)dz,      \
+                       (bf16_t*)dd, (int)rows, (int)H, post_drop, drop)
+    if (nc <= 1) LN_ROWS(1);
+    else if (nc == 2) LN_ROWS(2);
+    else if (nc == 3) LN_ROWS(3);
+    else if (nc == 4) LN_ROWS(4);
+    else LN_ROWS(8);
+#undef LN_ROWS
+    UH_LAUNCH_CHECK();
+    return 0;
+}
+
+// Column half: dgamma / dbeta / dbias (+)= column sums.  `dz` and `dd` are the row half's outputs (dd may be null).
+int layernorm_bwd_cols(const void* dy, const void* dy_extra, const void* z, const float* mean, const float* rstd,
+                       const void* dz, const void* dd, void* dgamma, void* dbeta, void* dbias,
+                       int64_t rows, int64_t H, int accumulate, const DropoutCfg& drop, int post_drop,
+                       void* workspace, size_t ws_bytes, hipStream_t st) {
+    if (ln_bwd_check(rows, H)) return -1;
+    if (H % 8 != 0) { uh_set_error("layernorm_bwd_cols: need H %% 8 == 0"); return -1; }
+    const int nb = ln_cols_blocks(rows, H);
+    if (ws_bytes < (size_t)nb * 3 * (size_t)H * sizeof(float)) { uh_set_error("layernorm_bwd: workspace too small"); return -1; }
+    LaunchTimer lt(TIME_LN_BWD_COLS, rows, H, 0, st);
+    const bool masked = drop.p > 0.f && !post_drop;
+    const void* dsrc = nullptr;
+    int mask_dsrc = 0;
+    if (dbias != nullptr) {
+        if (masked && dd == nullptr) { dsrc = dz; mask_dsrc = 1; }
+        else dsrc = (masked && dd != nullptr) ? dd : dz;
+    }
+    dim3 grid((unsigned)((H + 511) / 512), nb);
+    hipLaunchKernelGGL(ln_bwd_cols_kernel, grid, dim3(64 * BWD_WAVES), 0, st, (const bf16_t*)dy, (const bf16_t*)dy_extra,
+                       (const bf16_t*)z, mean, rstd, (const bf16_t*)dsrc, (float*)workspace, (int)rows, (int)H, post_drop,
+                       mask_dsrc, drop);
+    UH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(finalize_cols_kernel, dim3((unsigned)((3 * H + 63) / 64)), dim3(1024), 0, st,
+                       (const float*)workspace, nb, 3, (int)H, (bf16_t*)dgamma, (bf16_t*)dbeta, (bf16_t*)dbias, accumulate);
+    UH_LAUNCH_CHECK();
+    return 0;
 }
 
 int layernorm_bwd(const void* dy, const void* dy_extra, const void* z, const float* mean, const float* rstd,
                   const void* gamma, void* dz, void* dd, void* dgamma, void* dbeta, void* dbias,
                   int64_t rows, int64_t H, int accumulate, const DropoutCfg& drop, int post_drop,
                   void* workspace, size_t ws_bytes, hipStream_t st) {
-    if (rows <= 0 || H <= 0 || H % 4 != 0 || H > 2048) { uh_set_error("layernorm_bwd: need H %% 4 == 0 and H <= 2048 (H=%lld)", (long long)H); return -1; }
+    if (ln_bwd_check(rows, H)) return -1;
     if (ws_bytes < layernorm_bwd_workspace_bytes(rows, H)) { uh_set_error("layernorm_bwd: workspace too small"); return -1; }
+    if (H % 8 == 0) {
+        int rc = layernorm_bwd_rows(dy, dy_extra, z, mean, rstd, gamma, dz, dd, rows, H, drop, post_drop, st);
+        if (rc) return rc;
+        return layernorm_bwd_cols(dy, dy_extra, z, mean, rstd, dz, dd, dgamma, dbeta, dbias, rows, H, accumulate, drop,
+                                  post_drop, workspace, ws_bytes, st);
+    }
+    LaunchTimer lt(TIME_LN_BWD, rows, H, 0, st);
     const int nc = (int)((H / 4 + 63) / 64);
     const int nw = ln_bwd_waves(nc);
     const int nb = ln_bwd_blocks(rows, nw);
@@ -330,6 +566,7 @@ int colsum(const void* a, void* out, int64_t rows, int64_t N, int accumulate,
            void* workspace, size_t ws_bytes, hipStream_t st) {
     if (rows <= 0 || N <= 0 || N % 8 != 0) { uh_set_error("colsum: need N %% 8 == 0"); return -1; }
     if (ws_bytes < colsum_workspace_bytes(rows, N)) { uh_set_error("colsum: workspace too small"); return -1; }
+    LaunchTimer lt(TIME_COLSUM, rows, N, 0, st);
     const int nb = colsum_blocks(rows, N);
     dim3 grid((unsigned)((N + 511) / 512), nb);
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(64 * BWD_WAVES), 0, st, (const bf16_t*)a, (float*)workspace, (int)rows, (int)N);

@@ -223,9 +223,56 @@ def _shape(cfg_like, B, L, training):
 _autotuned = set()
 
 
+def _layer_gemm_shapes(s):
+    """(kind, M, N, K) of the 12 GEMMs of one BertLayer as the C ABI sees them (kind 0 fwd, 1 dgrad, 2 wgrad)."""
+    T, H, I = int(s.B) * int(s.L), int(s.H), int(s.I)
+    return [(kind, T, n, k) for kind in range(3) for n, k in ((3 * H, H), (H, H), (I, H), (H, I))]
+
+
+def _load_tune_cache(path, s):
+    """Install tile choices saved by an earlier process.  True if every GEMM of this shape was covered."""
+    import json
+    import os
+    if not path or not os.path.exists(path):
+        return False
+    try:
+        saved = json.load(open(path))
+    except (OSError, ValueError):
+        return False
+    table = {(e["kind"], e["M"], e["N"], e["K"]): (e["cfg"], e["splits"]) for e in saved.get("gemm", [])}
+    shapes = _layer_gemm_shapes(s)
+    if any(k not in table for k in shapes):
+        return False
+    for k in shapes:
+        C.uniter_gemm_set_tuned(k[0], k[1], k[2], k[3], table[k][0], table[k][1])
+    return True
+
+
+def _save_tune_cache(path, s):
+    import json
+    import os
+    entries = []
+    if os.path.exists(path):
+        try:
+            entries = json.load(open(path)).get("gemm", [])
+        except (OSError, ValueError):
+            entries = []
+    have = {(e["kind"], e["M"], e["N"], e["K"]) for e in entries}
+    out = (ctypes.c_int32 * 2)()
+    for k in _layer_gemm_shapes(s):
+        C.uniter_gemm_tuned_choice(k[0], k[1], k[2], k[3], out)
+        if out[0] >= 0 and k not in have:
+            entries.append({"kind": k[0], "M": k[1], "N": k[2], "K": k[3], "cfg": int(out[0]), "splits": int(out[1])})
+    tmp = "%s.%d.tmp" % (path, os.getpid())
+    with open(tmp, "w") as f:
+        json.dump({"gemm": entries}, f)
+    os.replace(tmp, path)
+
+
 def _maybe_autotune(s, training):
     """First training-mode call of a new (B, L, H, I): let the library time its GEMM tile shapes for exactly these sizes
-    (one-off, synchronous, ~0.1 s).  UNITER_AMD_AUTOTUNE=0 keeps the built-in cost model (run-to-run identical tiles)."""
+    (one-off, synchronous, ~0.1 s).  UNITER_AMD_AUTOTUNE=0 keeps the built-in cost model (run-to-run identical tiles);
+    UNITER_AMD_TUNE_CACHE=<file> saves the winners and reuses them in later processes (no sweep, same kernels)."""
     key = (int(s.B), int(s.L), int(s.H), int(s.I))
     if key in _autotuned:
         return
@@ -235,7 +282,12 @@ def _maybe_autotune(s, training):
         return
     if torch.cuda.is_current_stream_capturing():
         return
+    cache = os.environ.get("UNITER_AMD_TUNE_CACHE", "")
+    if cache and _load_tune_cache(cache, s):
+        return
     C.uniter_encoder_autotune(ctypes.byref(s), _lib.stream_ptr())
+    if cache:
+        _save_tune_cache(cache, s)
 
 
 class _EncoderFn(torch.autograd.Function):
