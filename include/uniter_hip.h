@@ -117,6 +117,21 @@ int uniter_gemm_wgrad(const void* dy, const void* x, void* dw, void* db,
                       int64_t M, int64_t N, int64_t K, int accumulate,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Strided-operand variants (row stride in elements; operands may be column slices of a wider row-major matrix —
+ * e.g. the q / k|v column blocks of a packed [T,3H] projection buffer).  Used by the NLVR2 paired cross-attention
+ * head (model/nlvr2.py:170-189 + model/attention.py:86-127: q projected from one sequence, k|v from its partner):
+ *   y[M,N] (ldy)  = x[M,K] (ldx) * w[N,K]^T + bias
+ *   dx[M,K]       = dy[M,N] (lddy) * w[N,K] (+ resid[M,K])
+ *   dw[N,K] (+)=    dy[M,N]^T (lddy) * x[M,K] (ldx)
+ * ld* must be multiples of 8 elements (16-byte rows) and >= the logical width. */
+int uniter_gemm_bias_fwd_ld(const void* x, int64_t ldx, const void* w, const void* bias, void* y, int64_t ldy,
+                            int64_t M, int64_t N, int64_t K, void* stream);
+int uniter_gemm_dgrad_ld(const void* dy, int64_t lddy, const void* w, const void* resid, void* dx,
+                         int64_t M, int64_t N, int64_t K, void* stream);
+int uniter_gemm_wgrad_ld(const void* dy, int64_t lddy, const void* x, int64_t ldx, void* dw,
+                         int64_t M, int64_t N, int64_t K, int accumulate,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused self-attention (scale + additive key mask + softmax + dropout + P·V), head_dim fixed at 64,
  * L <= 256.  qkv is the fused projection output [B*L, 3H] = [Q | K | V], head h owns columns

@@ -66,6 +66,9 @@ SIGNATURES = {
     "uniter_gemm_dgrad_gelu": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "uniter_gemm_wgrad_workspace_bytes": (c_size_t, [_I, _I, _I]),
     "uniter_gemm_wgrad": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_int, _P, c_size_t, _P]),
+    "uniter_gemm_bias_fwd_ld": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "uniter_gemm_dgrad_ld": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "uniter_gemm_wgrad_ld": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, c_int, _P, c_size_t, _P]),
     "uniter_attention_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
     "uniter_attention_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
     "uniter_layernorm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, c_float, c_float, c_uint64, c_uint64, _P]),

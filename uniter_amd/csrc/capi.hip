@@ -168,6 +168,12 @@ int uniter_gemm_bias_fwd(const void* x, const void* w, const void* bias, void* y
     return uh::gemm_fwd(uh::GEMM_EPI_BIAS, x, w, bias, nullptr, y, nullptr, M, N, K, make_dropout(0.f, 0, 0), (hipStream_t)stream);
 }
 
+int uniter_gemm_bias_fwd_ld(const void* x, int64_t ldx, const void* w, const void* bias, void* y, int64_t ldy,
+                            int64_t M, int64_t N, int64_t K, void* stream) {
+    UH_CHECK_ARG(x && w && y, "null pointer");
+    return uh::gemm_fwd(uh::GEMM_EPI_BIAS, x, w, bias, nullptr, y, nullptr, M, N, K, make_dropout(0.f, 0, 0), (hipStream_t)stream, ldx, ldy);
+}
+
 int uniter_gemm_bias_gelu_fwd(const void* x, const void* w, const void* bias, void* u, void* g,
                               int64_t M, int64_t N, int64_t K, void* stream) {
     UH_CHECK_ARG(x && w && u && g, "null pointer");
@@ -187,6 +193,12 @@ int uniter_gemm_dgrad(const void* dy, const void* w, const void* resid, void* dx
                       int64_t M, int64_t N, int64_t K, void* stream) {
     UH_CHECK_ARG(dy && w && dx, "null pointer");
     return uh::gemm_dgrad(uh::GEMM_EPI_RES, dy, w, resid, dx, M, N, K, (hipStream_t)stream);
+}
+
+int uniter_gemm_dgrad_ld(const void* dy, int64_t lddy, const void* w, const void* resid, void* dx,
+                         int64_t M, int64_t N, int64_t K, void* stream) {
+    UH_CHECK_ARG(dy && w && dx, "null pointer");
+    return uh::gemm_dgrad(uh::GEMM_EPI_RES, dy, w, resid, dx, M, N, K, (hipStream_t)stream, lddy);
 }
 
 int uniter_gemm_dgrad_gelu(const void* dy, const void* w, const void* u, void* dpre,
@@ -211,6 +223,13 @@ int uniter_gemm_wgrad(const void* dy, const void* x, void* dw, void* db,
         RC(uh::colsum(dy, db, M, N, accumulate, workspace, workspace_bytes, (hipStream_t)stream));
     }
     return 0;
+}
+
+int uniter_gemm_wgrad_ld(const void* dy, int64_t lddy, const void* x, int64_t ldx, void* dw,
+                         int64_t M, int64_t N, int64_t K, int accumulate,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    UH_CHECK_ARG(dy && x && dw, "null pointer");
+    return uh::gemm_wgrad(dy, x, dw, M, N, K, accumulate, workspace, workspace_bytes, (hipStream_t)stream, lddy, ldx);
 }
 
 int uniter_attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse,

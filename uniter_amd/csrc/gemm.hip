@@ -685,14 +685,17 @@ static int check_common(int64_t M, int64_t N, int64_t K) {
 }
 
 int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void* resid, void* y, void* y2,
-             int64_t M, int64_t N, int64_t K, const DropoutCfg& drop, hipStream_t st) {
+             int64_t M, int64_t N, int64_t K, const DropoutCfg& drop, hipStream_t st, int64_t ldx, int64_t ldy) {
     if (check_common(M, N, K)) return -1;
+    if (ldx == 0) ldx = K;
+    if (ldy == 0) ldy = N;
+    if (ldx < K || ldy < N || ldx % 8 != 0 || ldy % 4 != 0) { uh_set_error("gemm_fwd: bad leading dimension"); return -1; }
     if (N % 64 != 0 || K % 8 != 0) { uh_set_error("gemm_fwd: need N %% 64 == 0 and K %% 8 == 0 (N=%lld K=%lld)", (long long)N, (long long)K); return -1; }
     LaunchTimer lt(epi == GEMM_EPI_BIAS ? TIME_GEMM_FWD_BIAS : (epi == GEMM_EPI_BIAS_GELU ? TIME_GEMM_FWD_GELU : TIME_GEMM_FWD_DROP_RES), M, N, K, st);
     GemmArgs a{};
-    a.R = (const bf16_t*)x; a.ldr = K;
+    a.R = (const bf16_t*)x; a.ldr = (int)ldx;
     a.Cc = (const bf16_t*)w; a.ldcc = K;
-    a.C = (bf16_t*)y; a.C2 = (bf16_t*)y2; a.ldc = N;
+    a.C = (bf16_t*)y; a.C2 = (bf16_t*)y2; a.ldc = (int)ldy;
     a.bias = (const bf16_t*)bias;
     a.aux = (const bf16_t*)resid; a.ldaux = N;
     a.partial = nullptr;
@@ -713,12 +716,14 @@ int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void
 
 // dx[M,K] = dy[M,N] * w[N,K]  -> output dims (M, K), contraction N
 int gemm_dgrad(int epi, const void* dy, const void* w, const void* aux, void* dx,
-               int64_t M, int64_t N, int64_t K, hipStream_t st) {
+               int64_t M, int64_t N, int64_t K, hipStream_t st, int64_t lddy) {
     if (check_common(M, N, K)) return -1;
     if (K % 64 != 0 || N % 8 != 0) { uh_set_error("gemm_dgrad: need K %% 64 == 0 and N %% 8 == 0"); return -1; }
+    if (lddy == 0) lddy = N;
+    if (lddy < N || lddy % 8 != 0) { uh_set_error("gemm_dgrad: bad leading dimension"); return -1; }
     LaunchTimer lt(epi == GEMM_EPI_GELU_BWD ? TIME_GEMM_DGRAD_GELU : TIME_GEMM_DGRAD, M, N, K, st);
     GemmArgs a{};
-    a.R = (const bf16_t*)dy; a.ldr = N;
+    a.R = (const bf16_t*)dy; a.ldr = (int)lddy;
     a.Cc = (const bf16_t*)w; a.ldcc = K;          // stored [contraction = N][out cols = K]
     a.C = (bf16_t*)dx; a.C2 = nullptr; a.ldc = K;
     a.bias = nullptr;
@@ -754,13 +759,16 @@ size_t gemm_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 
 // dw[N,K] (+)= dy[M,N]^T x[M,K] -> output dims (N, K), contraction M
 int gemm_wgrad(const void* dy, const void* x, void* dw, int64_t M, int64_t N, int64_t K, int accumulate,
-               void* workspace, size_t ws_bytes, hipStream_t st) {
+               void* workspace, size_t ws_bytes, hipStream_t st, int64_t lddy, int64_t ldx) {
     if (check_common(M, N, K)) return -1;
     if (N % 64 != 0 || K % 64 != 0) { uh_set_error("gemm_wgrad: need N %% 64 == 0 and K %% 64 == 0 (N=%lld K=%lld)", (long long)N, (long long)K); return -1; }
+    if (lddy == 0) lddy = N;
+    if (ldx == 0) ldx = K;
+    if (lddy < N || ldx < K || lddy % 8 != 0 || ldx % 8 != 0) { uh_set_error("gemm_wgrad: bad leading dimension"); return -1; }
     LaunchTimer lt(TIME_GEMM_WGRAD, M, N, K, st);
     GemmArgs a{};
-    a.R = (const bf16_t*)dy; a.ldr = N;           // stored [contraction = M][out rows = N]
-    a.Cc = (const bf16_t*)x; a.ldcc = K;          // stored [contraction = M][out cols = K]
+    a.R = (const bf16_t*)dy; a.ldr = (int)lddy;   // stored [contraction = M][out rows = N]
+    a.Cc = (const bf16_t*)x; a.ldcc = (int)ldx;   // stored [contraction = M][out cols = K]
     a.C = (bf16_t*)dw; a.C2 = nullptr; a.ldc = K;
     a.bias = nullptr; a.aux = nullptr; a.ldaux = 0;
     a.M = (int)N; a.N = (int)K; a.K = (int)M;

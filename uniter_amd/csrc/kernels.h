@@ -27,12 +27,12 @@ struct LaunchTimer {
 // ---- gemm.hip ----
 enum { GEMM_EPI_BIAS = 0, GEMM_EPI_BIAS_GELU = 1, GEMM_EPI_BIAS_DROP_RES = 2, GEMM_EPI_RES = 3, GEMM_EPI_GELU_BWD = 4 };
 int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void* resid, void* y, void* y2,
-             int64_t M, int64_t N, int64_t K, const DropoutCfg& drop, hipStream_t st);
+             int64_t M, int64_t N, int64_t K, const DropoutCfg& drop, hipStream_t st, int64_t ldx = 0, int64_t ldy = 0);
 int gemm_dgrad(int epi, const void* dy, const void* w, const void* aux, void* dx,
-               int64_t M, int64_t N, int64_t K, hipStream_t st);
+               int64_t M, int64_t N, int64_t K, hipStream_t st, int64_t lddy = 0);
 size_t gemm_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int gemm_wgrad(const void* dy, const void* x, void* dw, int64_t M, int64_t N, int64_t K, int accumulate,
-               void* workspace, size_t ws_bytes, hipStream_t st);
+               void* workspace, size_t ws_bytes, hipStream_t st, int64_t lddy = 0, int64_t ldx = 0);
 void gemm_debug_force(int cfg, int splits);
 int gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, hipStream_t st);
 int gemm_tuned_choice(int kind, int64_t M, int64_t N, int64_t K, int* cfg, int* splits);

@@ -111,15 +111,28 @@ class UniterForNlvr2PairedAttn(_Nlvr2Base):
     def forward(self, batch, compute_loss=True):
         batch, seq = self._encode(batch)
         bs, tl, d = seq.size()
-        # rows 2i / 2i+1 are the left / right image of pair i
-        left, right = seq.contiguous().view(bs // 2, tl * 2, d).chunk(2, dim=1)
-        pad = batch['attn_masks'] == 0
-        left_pad, right_pad = pad.contiguous().view(bs // 2, tl * 2).chunk(2, dim=1)
-        left = left.transpose(0, 1)        # (L, N, E) for the attention module
-        right = right.transpose(0, 1)
-        l2r, _ = self.attn1(left, right, right, key_padding_mask=right_pad)
-        r2l, _ = self.attn2(right, left, left, key_padding_mask=left_pad)
-        left = self.fc(torch.cat([l2r, left], dim=-1)).transpose(0, 1)
-        right = self.fc(torch.cat([r2l, right], dim=-1)).transpose(0, 1)
-        pooled = torch.cat([self.attn_pool(left, left_pad), self.attn_pool(right, right_pad)], dim=-1)
+        n = bs // 2
+        # rows 2i / 2i+1 are the left / right image of pair i (model/nlvr2.py:172-176): regroup as [side, pair, L, H]
+        xs = seq.contiguous().view(n, 2, tl, d).transpose(0, 1).contiguous()
+        valid = batch['attn_masks'].contiguous().view(n, 2, tl).transpose(0, 1)         # [2, n, L]
+        pad = (valid == 0).reshape(bs, tl)                                              # left block, then right block
+        if self._fused_pair_attention(seq):
+            from .. import ops
+            # instance block 0 (left queries) attends to the right sequences and vice versa -> partner's key mask
+            att = ops.paired_cross_attention(xs, valid.flip(0).reshape(bs, tl), self.attn1, self.attn2,
+                                             self.attn1.dropout, self.training)
+        else:
+            left, right = xs[0].transpose(0, 1), xs[1].transpose(0, 1)                  # (L, N, E) module layout
+            l2r, _ = self.attn1(left, right, right, key_padding_mask=pad[n:], need_weights=False)
+            r2l, _ = self.attn2(right, left, left, key_padding_mask=pad[:n], need_weights=False)
+            att = torch.stack([l2r.transpose(0, 1), r2l.transpose(0, 1)], dim=0)
+        # both sides at once: fc(cat([attended, self])) -> masked attention pooling -> cat(left, right) -> classifier
+        hidden = self.fc(torch.cat([att, xs], dim=-1)).view(bs, tl, d)
+        pooled = self.attn_pool(hidden, pad)                                            # [2n, H]
+        pooled = pooled.view(2, n, d).transpose(0, 1).reshape(n, 2 * d)
         return self._finish(self.nlvr2_output(pooled), batch, compute_loss)
+
+    def _fused_pair_attention(self, seq):
+        """The HIP path covers the shipped configuration (bf16 on the GPU, 64-wide heads, L <= 256)."""
+        return (seq.is_cuda and seq.dtype == torch.bfloat16 and self.attn1.head_dim == 64 and seq.size(1) <= 256
+                and self.attn1.in_proj_weight.dtype == torch.bfloat16)

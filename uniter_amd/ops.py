@@ -612,3 +612,135 @@ def gather_embeddings(txt, img, gather_index):
     _check_dev(txt, "txt_emb")
     _check_dev(img, "img_emb")
     return _GatherFn.apply(txt, img, gather_index)
+
+
+# ----------------------------------------------------------------------------------------------------
+# NLVR2 paired cross attention (model/nlvr2.py:170-189 through model/attention.py:13-265)
+# ----------------------------------------------------------------------------------------------------
+class _PairedCrossAttnFn(torch.autograd.Function):
+    """attn1(left, right, right) and attn2(right, left, left) of UniterForNlvr2PairedAttn in one autograd node.
+
+    xs [2, n, L, H]: xs[0] = the "left" sequences of the n pairs, xs[1] = the "right" ones.  The four input
+    projections write column blocks of ONE packed [2nL, 3H] buffer laid out so that "attention instance" i
+    (rows i*L..) holds [q_i | k_partner(i) | v_partner(i)]: rows 0..nL = attn1 (queries from left, keys/values from
+    right), rows nL..2nL = attn2 (queries from right, keys/values from left).  The encoder's fused attention kernel
+    then runs unchanged on 2n instances, and each module's in_proj bias gradient is a plain column sum of its half.
+    mask_bias_p [2n, L] fp32 = additive key mask of the PARTNER sequence of every instance.
+    Gradients of the module parameters are accumulated straight into `.grad` (like the encoder stack).
+    """
+
+    @staticmethod
+    def forward(ctx, xs, mask_bias_p, attn1, attn2, p_drop, training, *anchor):
+        two, n, L, H = xs.shape
+        heads = attn1.num_heads
+        T2 = n * L
+        T = 2 * T2
+        dev = xs.device
+        st = _lib.stream_ptr()
+        P = torch.empty(T, 3 * H, dtype=_BF16, device=dev)
+        cx = torch.empty(T, H, dtype=_BF16, device=dev)
+        lse = torch.empty(2 * n * heads * L, dtype=torch.float32, device=dev)
+        out = torch.empty(2, n, L, H, dtype=_BF16, device=dev)
+        es = 2                                           # bytes per bf16 element
+        x_l, x_r = xs.data_ptr(), xs.data_ptr() + T2 * H * es
+        w1, w2 = attn1.in_proj_weight, attn2.in_proj_weight
+        b1, b2 = attn1.in_proj_bias, attn2.in_proj_bias
+        bp = lambda b, o: None if b is None else b.data_ptr() + o * es
+        p0, p1 = P.data_ptr(), P.data_ptr() + T2 * 3 * H * es
+        # rows 0..T2: attn1 — q from left, k|v from right;  rows T2..T: attn2 — q from right, k|v from left
+        C.uniter_gemm_bias_fwd_ld(x_l, H, w1.data_ptr(), bp(b1, 0), p0, 3 * H, T2, H, H, st)
+        C.uniter_gemm_bias_fwd_ld(x_r, H, w1.data_ptr() + H * H * es, bp(b1, H), p0 + H * es, 3 * H, T2, 2 * H, H, st)
+        C.uniter_gemm_bias_fwd_ld(x_r, H, w2.data_ptr(), bp(b2, 0), p1, 3 * H, T2, H, H, st)
+        C.uniter_gemm_bias_fwd_ld(x_l, H, w2.data_ptr() + H * H * es, bp(b2, H), p1 + H * es, 3 * H, T2, 2 * H, H, st)
+        p = float(p_drop) if training else 0.0
+        seed, off = _next_offsets(1) if p > 0.0 else (0, 0)
+        C.uniter_attention_fwd(ptr(P), ptr(mask_bias_p), ptr(cx), ptr(lse), 2 * n, L, heads, p, seed, off, st)
+        o0, o1 = out.data_ptr(), out.data_ptr() + T2 * H * es
+        c0, c1 = cx.data_ptr(), cx.data_ptr() + T2 * H * es
+        C.uniter_gemm_bias_fwd(c0, ptr(attn1.out_proj.weight), ptr(attn1.out_proj.bias), o0, T2, H, H, st)
+        C.uniter_gemm_bias_fwd(c1, ptr(attn2.out_proj.weight), ptr(attn2.out_proj.bias), o1, T2, H, H, st)
+        ctx.mods = (attn1, attn2)
+        ctx.p, ctx.seed, ctx.off = p, seed, off
+        ctx.save_for_backward(xs, mask_bias_p, P, cx, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xs, mask_bias_p, P, cx, lse = ctx.saved_tensors
+        attn1, attn2 = ctx.mods
+        two, n, L, H = xs.shape
+        heads = attn1.num_heads
+        T2 = n * L
+        T = 2 * T2
+        dev = xs.device
+        st = _lib.stream_ptr()
+        es = 2
+        dout = dout.contiguous()
+        dcx = torch.empty(T, H, dtype=_BF16, device=dev)
+        dP = torch.empty(T, 3 * H, dtype=_BF16, device=dev)
+        dxs = torch.empty_like(xs)
+        wsb = max(C.uniter_gemm_wgrad_workspace_bytes(T2, 2 * H, H), C.uniter_colsum_workspace_bytes(T2, 3 * H))
+        ws = _scratch(("pca", dev.index), wsb, dev)
+        pool = {}
+
+        def grad_of(prm):
+            if prm is None:
+                return None
+            return ensure_grad(prm) if prm.requires_grad else _dummy_grad_like(prm, pool)
+
+        half = T2 * H * es
+        # ---- out_proj (model/attention.py:257) ----
+        for i, mod in enumerate((attn1, attn2)):
+            d_o, c_i, dc_i = dout.data_ptr() + i * half, cx.data_ptr() + i * half, dcx.data_ptr() + i * half
+            C.uniter_gemm_dgrad(d_o, ptr(mod.out_proj.weight), None, dc_i, T2, H, H, st)
+            C.uniter_gemm_wgrad(d_o, c_i, ptr(grad_of(mod.out_proj.weight)), ptr(grad_of(mod.out_proj.bias)),
+                                T2, H, H, 1, ptr(ws), wsb, st)
+        # ---- attention core ----
+        C.uniter_attention_bwd(ptr(P), ptr(mask_bias_p), ptr(cx), ptr(lse), ptr(dcx), ptr(dP), 2 * n, L, heads,
+                               ctx.p, ctx.seed, ctx.off, st)
+        # ---- in_proj (model/attention.py:103-127, the kv_same branch) ----
+        x_l, x_r = xs.data_ptr(), xs.data_ptr() + half
+        dx_l, dx_r = dxs.data_ptr(), dxs.data_ptr() + half
+        d0, d1 = dP.data_ptr(), dP.data_ptr() + T2 * 3 * H * es
+        w1, w2 = attn1.in_proj_weight, attn2.in_proj_weight
+        wq1, wkv1 = w1.data_ptr(), w1.data_ptr() + H * H * es
+        wq2, wkv2 = w2.data_ptr(), w2.data_ptr() + H * H * es
+        # d_left = dq(attn1) Wq1 + dkv(attn2) Wkv2 ; d_right = dq(attn2) Wq2 + dkv(attn1) Wkv1
+        C.uniter_gemm_dgrad_ld(d0, 3 * H, wq1, None, dx_l, T2, H, H, st)
+        C.uniter_gemm_dgrad_ld(d1 + H * es, 3 * H, wkv2, dx_l, dx_l, T2, 2 * H, H, st)
+        C.uniter_gemm_dgrad_ld(d1, 3 * H, wq2, None, dx_r, T2, H, H, st)
+        C.uniter_gemm_dgrad_ld(d0 + H * es, 3 * H, wkv1, dx_r, dx_r, T2, 2 * H, H, st)
+        g1, g2 = grad_of(w1), grad_of(w2)
+        C.uniter_gemm_wgrad_ld(d0, 3 * H, x_l, H, g1.data_ptr(), T2, H, H, 1, ptr(ws), wsb, st)
+        C.uniter_gemm_wgrad_ld(d0 + H * es, 3 * H, x_r, H, g1.data_ptr() + H * H * es, T2, 2 * H, H, 1, ptr(ws), wsb, st)
+        C.uniter_gemm_wgrad_ld(d1, 3 * H, x_r, H, g2.data_ptr(), T2, H, H, 1, ptr(ws), wsb, st)
+        C.uniter_gemm_wgrad_ld(d1 + H * es, 3 * H, x_l, H, g2.data_ptr() + H * H * es, T2, 2 * H, H, 1, ptr(ws), wsb, st)
+        if attn1.in_proj_bias is not None:
+            C.uniter_colsum(d0, ptr(grad_of(attn1.in_proj_bias)), T2, 3 * H, 1, ptr(ws), wsb, st)
+        if attn2.in_proj_bias is not None:
+            C.uniter_colsum(d1, ptr(grad_of(attn2.in_proj_bias)), T2, 3 * H, 1, ptr(ws), wsb, st)
+        return (dxs if ctx.needs_input_grad[0] else None, None, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 6)
+
+
+def paired_cross_attention(xs, key_valid_partner, attn1, attn2, p_drop, training):
+    """xs [2, n, L, H] bf16 (left block, right block); key_valid_partner [2n, L] = attention mask (1 = real token) of
+    the sequence each instance attends TO.  Returns [2, n, L, H]: attn1(left->right) block, attn2(right->left) block."""
+    _check_dev(xs, "paired sequences")
+    if xs.dim() != 4 or xs.size(0) != 2:
+        raise _lib.UniterHipError("paired sequences must be [2, n, L, H]")
+    H = xs.size(3)
+    for mod in (attn1, attn2):
+        if mod.embed_dim != H or mod.head_dim != 64 or mod.out_proj.bias is None:
+            raise _lib.UniterHipError("fused paired attention needs embed_dim == H, head_dim 64 and an out_proj bias")
+        for prm in (mod.in_proj_weight, mod.in_proj_bias, mod.out_proj.weight, mod.out_proj.bias):
+            if prm is not None:
+                _check_dev(prm, "attention parameter")
+    xs = xs.contiguous()
+    mb = mask_bias(key_valid_partner)
+    track = torch.is_grad_enabled()
+    if not track:
+        with torch.no_grad():
+            return _PairedCrossAttnFn.apply(xs, mb, attn1, attn2, p_drop, training)
+    anchor = next((p for m in (attn1, attn2) for p in m.parameters() if p.requires_grad), None)
+    extra = () if anchor is None else (anchor,)
+    return _PairedCrossAttnFn.apply(xs, mb, attn1, attn2, p_drop, training, *extra)
