@@ -295,6 +295,9 @@ int uniter_encoder_autotune(const UniterEncoderShape* s, void* stream);
 /* Test / tuning hook: backward runs the weight-gradient GEMMs and bias column sums on an internal side stream
  * (ordered against `stream` purely by events) unless disabled with 0. */
 int uniter_encoder_debug_side_stream(int enable);
+/* 0 = uniter_encoder_autotune keeps the isolated per-GEMM winners; 1 (default) = it then re-picks every GEMM's tile among
+ * its fastest candidates by timing a short forward+backward stack (cold weights, wgrad side stream running). */
+int uniter_encoder_debug_tune_in_situ(int enable);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused multi-tensor AdamW + global gradient norm / clipping.                 optim/adamw.py:40-103

@@ -684,8 +684,10 @@ static void bench(int B, int L, int H, int heads, int I, int layers) {
         HostBf P;
         P.fill(per, 0.03f);
         std::vector<UniterLayerParams> lp(layers);
+        const bool share_w = getenv("UNITER_BENCH_SHARE_WEIGHTS") != nullptr;   // experiment: every layer reads the same (cache-hot) weights
+        uint16_t* p_shared = share_w ? upload(P) : nullptr;
         for (int l = 0; l < layers; ++l) {
-            uint16_t* p = upload(P);
+            uint16_t* p = share_w ? p_shared : upload(P);
             uint16_t* g = dalloc<uint16_t>(per);
             HIPCHK(hipMemset(g, 0, per * 2));
             size_t o = 0;
@@ -702,6 +704,12 @@ static void bench(int B, int L, int H, int heads, int I, int layers) {
             double tf0 = tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 10);
             double tb0 = tm.run([&] { UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0)); }, 2, 10);
             printf("  (cost-model tiles: fwd %.1f us, bwd %.1f us)\n", tf0, tb0);
+            UHCHK(uniter_encoder_debug_tune_in_situ(0));
+            UHCHK(uniter_encoder_autotune(&sh, 0));
+            double tf1 = tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 10);
+            double tb1 = tm.run([&] { UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0)); }, 2, 10);
+            printf("  (isolated-sweep tiles: fwd %.1f us, bwd %.1f us)\n", tf1, tb1);
+            UHCHK(uniter_encoder_debug_tune_in_situ(1));
             UHCHK(uniter_encoder_autotune(&sh, 0));
             const int64_t shp[4][2] = {{3 * (int64_t)H, H}, {H, H}, {I, H}, {H, I}};
             const char* kn[3] = {"fwd", "dgrad", "wgrad"};
@@ -719,6 +727,20 @@ static void bench(int B, int L, int H, int heads, int I, int layers) {
         double tb0 = tm.run([&] { UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0)); }, 2, 10);
         uniter_encoder_debug_side_stream(1);
         printf("  (backward with the wgrad side stream disabled: %.1f us)\n", tb0);
+        {   // in-situ per-launch durations (HIP events around every launch) of one forward + backward
+            static const char* kinds[] = {"gemm fwd +bias", "gemm fwd +gelu", "gemm fwd +drop+res", "gemm dgrad", "gemm dgrad gelu'", "gemm wgrad",
+                                          "attn fwd", "attn bwd", "ln fwd", "ln bwd rows", "colsum", "adamw", "ln bwd cols"};
+            UniterTimingRecord rec[64];
+            int32_t nrec = 0;
+            HIPCHK(hipDeviceSynchronize());
+            UHCHK(uniter_hip_timing_begin());
+            UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0));
+            UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0));
+            UHCHK(uniter_hip_timing_end(rec, 64, &nrec));
+            for (int i = 0; i < nrec && i < 64; ++i)
+                printf("  in-situ %-18s M%-5lld N%-5lld K%-5lld x%-3d avg %7.2f us\n", kinds[rec[i].kind], (long long)rec[i].M,
+                       (long long)rec[i].N, (long long)rec[i].K, rec[i].calls, rec[i].total_us / rec[i].calls);
+        }
         const double flf = (double)layers * (24.0 * T * H * H + 4.0 * T * L * H);
         printf("  ENCODER fwd %.1f us (%.1f TF) | bwd %.1f us (%.1f TF) | fwd+bwd %.1f us = %.1f TF = %.1f%% of 2.5 PF ; %.0f ex/s\n", tf,
                flf / tf * 1e-6, tb, 2 * flf / tb * 1e-6, tf + tb, 3 * flf / (tf + tb) * 1e-6, 3 * flf / (tf + tb) * 1e-6 / 2500 * 100,

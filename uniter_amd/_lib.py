@@ -98,6 +98,7 @@ SIGNATURES = {
                                         _P, _P, _P, _P, _P, _P, c_uint64, c_uint64, _P]),
     "uniter_encoder_autotune": (c_int, [POINTER(UniterEncoderShape), _P]),
     "uniter_encoder_debug_side_stream": (c_int, [c_int]),
+    "uniter_encoder_debug_tune_in_situ": (c_int, [c_int]),
     "uniter_adamw_plan_create": (c_int, [POINTER(UniterAdamTensor), _I, POINTER(c_void_p)]),
     "uniter_adamw_plan_destroy": (c_int, [_P]),
     "uniter_adamw_grad_norm": (c_int, [_P, c_float, c_float, _P, _P]),

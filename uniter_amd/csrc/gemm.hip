@@ -19,6 +19,7 @@
 #include "common.cuh"
 #include "kernels.h"
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -630,6 +631,7 @@ int g_num_cus = 256;
 // trm / trn: the M / N side operand is K-strided (restricts that side to 64 / 128).
 struct Tuned { int cfg, splits; };
 std::map<std::tuple<int, int64_t, int64_t, int64_t>, Tuned> g_tuned;    // (kind, M, N, K) of the public call -> best config
+std::map<std::tuple<int, int64_t, int64_t, int64_t>, std::vector<Tuned>> g_ranked;   // autotune sweep: fastest first
 std::mutex g_tuned_mu;
 
 bool tuned_lookup(int kind, int64_t M, int64_t N, int64_t K, Tuned* out) {
@@ -832,6 +834,7 @@ int gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, hipStream_t st) {
     const int save_cfg = g_force_cfg, save_sp = g_force_splits;
     Tuned best{-1, 1};
     float best_ms = 0.f;
+    std::vector<std::pair<float, Tuned>> ranked;
     const DropoutCfg nodrop = make_dropout(0.f, 0, 0);
     for (int cfg = 0; cfg < kNumTiles && rc == 0; ++cfg) {
         const int bm = kTiles[cfg].bm, bn = kTiles[cfg].bn;
@@ -859,6 +862,7 @@ int gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, hipStream_t st) {
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, e0, e1);
             if (best.cfg < 0 || ms < best_ms) { best = Tuned{cfg, sp}; best_ms = ms; }
+            ranked.push_back({ms, Tuned{cfg, sp}});
         }
     }
     g_force_cfg = save_cfg;
@@ -867,10 +871,27 @@ int gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, hipStream_t st) {
     cleanup();
     if (rc) return rc;
     if (best.cfg >= 0) {
+        std::sort(ranked.begin(), ranked.end(), [](const std::pair<float, Tuned>& x, const std::pair<float, Tuned>& y) { return x.first < y.first; });
+        std::vector<Tuned> order;
+        for (auto& r : ranked) order.push_back(r.second);
         std::lock_guard<std::mutex> lk(g_tuned_mu);
         g_tuned[std::make_tuple(kind, M, N, K)] = best;
+        g_ranked[std::make_tuple(kind, M, N, K)] = order;
     }
     return 0;
+}
+
+// The sweep's candidates for (kind, M, N, K), fastest (in isolation) first; returns how many were written.
+int gemm_autotune_candidates(int kind, int64_t M, int64_t N, int64_t K, int* cfgs, int* splits, int cap) {
+    std::lock_guard<std::mutex> lk(g_tuned_mu);
+    auto it = g_ranked.find(std::make_tuple(kind, M, N, K));
+    if (it == g_ranked.end()) return 0;
+    int n = 0;
+    for (const Tuned& t : it->second) {
+        if (n >= cap) break;
+        cfgs[n] = t.cfg; splits[n] = t.splits; ++n;
+    }
+    return n;
 }
 
 int gemm_set_tuned(int kind, int64_t M, int64_t N, int64_t K, int cfg, int splits) {

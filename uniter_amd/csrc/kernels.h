@@ -37,6 +37,7 @@ void gemm_debug_force(int cfg, int splits);
 int gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, hipStream_t st);
 int gemm_tuned_choice(int kind, int64_t M, int64_t N, int64_t K, int* cfg, int* splits);
 int gemm_set_tuned(int kind, int64_t M, int64_t N, int64_t K, int cfg, int splits);
+int gemm_autotune_candidates(int kind, int64_t M, int64_t N, int64_t K, int* cfgs, int* splits, int cap);
 void gemm_set_num_cus(int n);
 
 // ---- attention.hip ----
