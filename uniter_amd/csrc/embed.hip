@@ -37,9 +37,11 @@ __global__ __launch_bounds__(256) void embed_txt_fwd_kernel(const int64_t* __res
 // it then sums (fp32) the dz rows of every position with the same key and adds them to the table row.
 // keys: n_keys entries; the dz rows of key position k are rows {k + r*row_stride, r < reps} (reps > 1 for the
 // position table whose ids are shared by the whole batch).
+template <int NC>
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const int64_t* __restrict__ keys, int n_keys, int reps, int row_stride,
                                                            const bf16_t* __restrict__ dz, bf16_t* __restrict__ table,
                                                            int H, int64_t padding_idx) {
+    // grid (ceil(n_keys / 4), column groups): a wave covers NC chunks of 256 columns starting at blockIdx.y * NC * 256
     const int lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= n_keys) return;
@@ -50,32 +52,42 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const int64_t* __rest
     for (int q = lane; q < p; q += 64) dup |= (keys[q] == key);
     if (__any(dup)) return;
     bf16_t* trow = table + key * H;
-    for (int c0 = 0; c0 < (H >> 2); c0 += 64) {
-        const int ch = c0 + lane;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int q0 = p; q0 < n_keys; q0 += 64) {
-            const int q = q0 + lane;
-            const bool hit = (q < n_keys) && (keys[q] == key);
-            unsigned long long mask = __ballot(hit);
-            while (mask) {
-                const int b = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                const int pos = q0 + b;
-                if (ch < (H >> 2)) {
-                    for (int r = 0; r < reps; ++r) {
-                        float v[4];
-                        unpack4(*reinterpret_cast<const u32x2*>(dz + ((int64_t)pos + (int64_t)r * row_stride) * H + ch * 4), v);
+    const int nch = H >> 2;
+    const int ch0 = blockIdx.y * NC * 64 + lane;
+    float acc[NC][4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+    for (int c = 0; c < NC; ++c) acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0.f;
+    for (int q0 = p; q0 < n_keys; q0 += 64) {            // the key list is scanned once; positions are summed in order
+        const int q = q0 + lane;
+        const bool hit = (q < n_keys) && (keys[q] == key);
+        unsigned long long mask = __ballot(hit);
+        while (mask) {
+            const int b = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int pos = q0 + b;
+            for (int r = 0; r < reps; ++r) {
+                const bf16_t* src = dz + ((int64_t)pos + (int64_t)r * row_stride) * H;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const int ch = ch0 + 64 * c;
+                    if (ch < nch) {
+                        float v[4];
+                        unpack4(*reinterpret_cast<const u32x2*>(src + ch * 4), v);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[c][e] += v[e];
                     }
                 }
             }
         }
-        if (ch < (H >> 2)) {
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ch = ch0 + 64 * c;
+        if (ch < nch) {
             float o[4];
             unpack4(*reinterpret_cast<const u32x2*>(trow + ch * 4), o);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] += acc[e];
+            for (int e = 0; e < 4; ++e) o[e] += acc[c][e];
             *reinterpret_cast<u32x2*>(trow + ch * 4) = pack4(o);
         }
     }
@@ -112,12 +124,22 @@ __global__ __launch_bounds__(256) void colsum_filtered_kernel(const bf16_t* __re
         if (gc < N) partial[(int64_t)blockIdx.y * N + gc] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
     }
 }
-__global__ __launch_bounds__(256) void add_partials_kernel(const float* __restrict__ partial, int nb, int N, bf16_t* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
+// out[c] += sum_b partial[b][c]: one block = 64 columns x 16 groups of partial rows, LDS tree over the groups
+__global__ __launch_bounds__(1024) void add_partials_kernel(const float* __restrict__ partial, int nb, int N, bf16_t* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int cx = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
     float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += partial[(int64_t)b * N + c];
-    out[c] = f2bf(bf2f(out[c]) + s);
+    if (c < N)
+        for (int b = grp; b < nb; b += 16) s += partial[(int64_t)b * N + c];
+    red[grp][cx] = s;
+    __syncthreads();
+    if (grp == 0 && c < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][cx];
+        out[c] = f2bf(bf2f(out[c]) + t);
+    }
 }
 
 // ---- image ------------------------------------------------------------------------------------------
@@ -182,15 +204,24 @@ __global__ __launch_bounds__(256) void pos_linear_bwd_kernel(const void* __restr
 #pragma unroll
     for (int k = 0; k < 8; ++k) partial[((int64_t)blockIdx.y * 8 + k) * H + h] = acc[k];
 }
-__global__ __launch_bounds__(256) void pos_linear_finalize_kernel(const float* __restrict__ partial, int nb, int H,
-                                                                  bf16_t* __restrict__ dw, bf16_t* __restrict__ db) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= 8 * H) return;
-    const int k = idx / H, h = idx % H;
+__global__ __launch_bounds__(1024) void pos_linear_finalize_kernel(const float* __restrict__ partial, int nb, int H,
+                                                                   bf16_t* __restrict__ dw, bf16_t* __restrict__ db) {
+    __shared__ float red[16][64];
+    const int cx = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + cx;
     float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += partial[((int64_t)b * 8 + k) * H + h];
-    if (k < 7) { if (dw) dw[h * 7 + k] = f2bf(bf2f(dw[h * 7 + k]) + s); }
-    else if (db) db[h] = f2bf(bf2f(db[h]) + s);
+    if (idx < 8 * H)
+        for (int b = grp; b < nb; b += 16) s += partial[(int64_t)b * 8 * H + idx];      // partial[b][k][h], idx = k*H + h
+    red[grp][cx] = s;
+    __syncthreads();
+    if (grp == 0 && idx < 8 * H) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][cx];
+        const int k = idx / H, h = idx % H;
+        if (k < 7) { if (dw) dw[h * 7 + k] = f2bf(bf2f(dw[h * 7 + k]) + t); }
+        else if (db) db[h] = f2bf(bf2f(db[h]) + t);
+    }
 }
 
 __global__ __launch_bounds__(256) void img_combine_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
@@ -308,7 +339,7 @@ int uniter_embed_type_bwd(const void* dz, const int64_t* type_ids, void* dtype_t
         hipLaunchKernelGGL(colsum_filtered_kernel, dim3((unsigned)((H + 511) / 512), nb), dim3(256), 0, st, (const bf16_t*)dz,
                            type_ids, (const uint8_t*)nullptr, k, 1, (float*)workspace, (int)rows, (int)H);
         UH_LAUNCH_CHECK();
-        hipLaunchKernelGGL(add_partials_kernel, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, st, (const float*)workspace, nb,
+        hipLaunchKernelGGL(add_partials_kernel, dim3((unsigned)((H + 63) / 64)), dim3(1024), 0, st, (const float*)workspace, nb,
                            (int)H, (bf16_t*)dtype_table + k * H);
         UH_LAUNCH_CHECK();
     }
@@ -326,13 +357,21 @@ int uniter_embed_txt_bwd(const int64_t* ids, const int64_t* position_ids, const 
     const int n = (int)(B * Lt);
     if (dword) {
         // nn.Embedding(vocab, H, padding_idx=0) (model/model.py:220-221): row 0 receives no gradient
-        hipLaunchKernelGGL(scatter_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, ids, n, 1, 0, (const bf16_t*)dz,
-                           (bf16_t*)dword, (int)H, (int64_t)0);
+        // one wave per token covers the whole row (<= 4 chunks of 256 columns; wider rows add column groups)
+        const int nch256 = (int)((H / 4 + 63) / 64);
+        if (nch256 <= 4) {
+            hipLaunchKernelGGL(scatter_rows_kernel<4>, dim3((n + 3) / 4, 1), dim3(256), 0, st, ids, n, 1, 0, (const bf16_t*)dz,
+                               (bf16_t*)dword, (int)H, (int64_t)0);
+        } else {
+            hipLaunchKernelGGL(scatter_rows_kernel<4>, dim3((n + 3) / 4, (nch256 + 3) / 4), dim3(256), 0, st, ids, n, 1, 0,
+                               (const bf16_t*)dz, (bf16_t*)dword, (int)H, (int64_t)0);
+        }
         UH_LAUNCH_CHECK();
     }
     if (dpos) {
-        hipLaunchKernelGGL(scatter_rows_kernel, dim3(((int)Lt + 3) / 4), dim3(256), 0, st, position_ids, (int)Lt, (int)B, (int)Lt,
-                           (const bf16_t*)dz, (bf16_t*)dpos, (int)H, (int64_t)-1);
+        // few keys, B rows each: spread the columns over the grid instead (one 256-column chunk per wave)
+        hipLaunchKernelGGL(scatter_rows_kernel<1>, dim3(((int)Lt + 3) / 4, (unsigned)((H / 4 + 63) / 64)), dim3(256), 0, st,
+                           position_ids, (int)Lt, (int)B, (int)Lt, (const bf16_t*)dz, (bf16_t*)dpos, (int)H, (int64_t)-1);
         UH_LAUNCH_CHECK();
     }
     return 0;
@@ -372,7 +411,7 @@ int uniter_embed_pos_linear_bwd(const void* pos_feat, int feat_is_fp32, const vo
     hipLaunchKernelGGL(pos_linear_bwd_kernel, dim3((unsigned)((H + 255) / 256), rb), dim3(256), 0, st, pos_feat, feat_is_fp32,
                        (const bf16_t*)d, (float*)workspace, (int)rows, (int)H);
     UH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(pos_linear_finalize_kernel, dim3((unsigned)((8 * H + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
+    hipLaunchKernelGGL(pos_linear_finalize_kernel, dim3((unsigned)((8 * H + 63) / 64)), dim3(1024), 0, st, (const float*)workspace,
                        rb, (int)H, (bf16_t*)dwpos, (bf16_t*)dbpos);
     UH_LAUNCH_CHECK();
     return 0;
@@ -399,7 +438,7 @@ int uniter_embed_mask_bwd(const void* df, const uint8_t* img_masks, void* dmask_
     hipLaunchKernelGGL(colsum_filtered_kernel, dim3((unsigned)((D + 511) / 512), nb), dim3(256), 0, st, (const bf16_t*)df,
                        (const int64_t*)nullptr, img_masks, (int64_t)1, 0, (float*)workspace, (int)rows, (int)D);
     UH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(add_partials_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, (const float*)workspace, nb, (int)D,
+    hipLaunchKernelGGL(add_partials_kernel, dim3((unsigned)((D + 63) / 64)), dim3(1024), 0, st, (const float*)workspace, nb, (int)D,
                        (bf16_t*)dmask_row);
     UH_LAUNCH_CHECK();
     return 0;

@@ -307,7 +307,7 @@ int uniter_encoder_autotune(const UniterEncoderShape* s, void* stream) {
     // The isolated sweep times each GEMM alone on cache-hot operands.  In a training step the same kernel meets cold
     // weights and (in backward) shares the chip with the weight-gradient stream, so its best tile can differ.  Re-pick
     // each of the 12 GEMMs among its fastest isolated candidates by timing a short forward+backward stack.
-    constexpr int NL = 3, TOP = 5;
+    constexpr int NL = 3, TOP = 8;
     const ActLayout al = act_layout(*s);
     const ScratchLayout sl = scratch_layout(*s);
     const size_t per = (size_t)(3 * H * H + 3 * H + H * H + H + 2 * H + I * H + I + H * I + H + 2 * H);   // elements of one layer
@@ -370,7 +370,7 @@ int uniter_encoder_autotune(const UniterEncoderShape* s, void* stream) {
     };
     rc = run_once();                            // warm up
     float cur = rc ? 0.f : measure();
-    for (int pass = 0; pass < 2 && rc == 0; ++pass) {
+    for (int pass = 0; pass < 3 && rc == 0; ++pass) {
         bool changed = false;
         for (int kind = 0; kind < 3 && rc == 0; ++kind)
             for (int g = 0; g < 4 && rc == 0; ++g) {
