@@ -522,3 +522,178 @@ def test_graphed_step_matches_eager(golden):
         assert len(set(round(v, 4) for v in vals)) >= 3, vals
     finally:
         ops.disable_graph_rng()
+
+
+# --------------------------------------------------------------------------------------------------------------
+# (5) the other configs of SURVEY.md §8d as parity cases: uniter-large shapes, L = 128 + 50, VQA with 4 parameter groups
+# --------------------------------------------------------------------------------------------------------------
+LARGE_CFG = dict(vocab_size=28996, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
+                 hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+                 max_position_embeddings=512, type_vocab_size=2, initializer_range=0.02)
+
+
+def test_large_config_vqa_l178_vs_oracle(tmp_path):
+    """config/uniter-large.json widths (H=1024, 16 heads, I=4096) with 2 layers, ragged text up to 128 tokens + up to 50
+    regions (the large-178 shape, config/pretrain-alldata-large-16gpu.json), VQA head; then one clipped AdamW step with
+    the 4-group lr_mul optimizer of train_vqa.py:51-86 against the oracle's AdamW on the oracle's gradients."""
+    import json
+    from uniter_amd.model.vqa import UniterForVisualQuestionAnswering
+    from uniter_amd.optim import build_vqa_optimizer, clip_grad_norm_
+    from uniter_amd.utils.misc import Struct
+    from uniter_amd.utils.synthetic import make_batch
+    cfg = dict(LARGE_CFG, num_hidden_layers=2)
+    path = tmp_path / "large.json"
+    path.write_text(json.dumps(cfg))
+    torch.manual_seed(11)
+    model = UniterForVisualQuestionAnswering.from_pretrained(str(path), {}, img_dim=2048, num_answer=N_ANS)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(12)
+        for n, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn(p.shape, generator=g) * 0.02)
+            p.copy_(p.to(torch.bfloat16).float())
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    batch = make_batch('vqa', 3, max_txt_len=128, num_bb=50, seed=9, ragged=True, num_answer=N_ANS,
+                       min_txt_len=128, min_bb=20)              # full-length text, 20..50 regions: L = 178 with padding
+    assert batch['attn_masks'].shape[1] == 178
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref_loss, ref_seq = O.vqa_loss(leaf, cfg, batch)
+    (ref_loss.mean() * N_ANS).backward()                                  # train_vqa.py:188
+
+    _prep(model)
+    d = _to_dev(batch)
+    seq = model.uniter(d['input_ids'], d['position_ids'], d['img_feat'], d['img_pos_feat'], d['attn_masks'],
+                       d['gather_index'], output_all_encoded_layers=False)
+    valid = batch['attn_masks'].bool()
+    _, yseq, ygrads = _yardstick(O.vqa_loss, sd, cfg, batch)
+    _check_hidden(seq.detach()[valid.to(seq.device)], ref_seq.detach()[valid], "large-178 hidden", yseq[valid])
+    loss = model(d, compute_loss=True)
+    _check_loss(loss, ref_loss.detach(), atol=3e-2)
+    for p in model.parameters():
+        p.grad = None
+    (model(d, compute_loss=True).float().mean() * N_ANS).backward()
+    named = dict(model.named_parameters())
+    checked = 0
+    for name, p in named.items():
+        if leaf[name].grad is None or p.grad is None:
+            continue
+        yard = ygrads.get(name)
+        _check_grad(name, p.grad / N_ANS, leaf[name].grad / N_ANS, None if yard is None else yard)
+        checked += 1
+    assert checked > 40
+
+    # one optimizer step: 4 groups (vqa_output x lr_mul 10, decay / no-decay), clip 2.0 — from the ORACLE's gradients
+    opts = Struct(dict(learning_rate=8e-5, lr_mul=10.0, betas=(0.9, 0.98), weight_decay=0.01, optim='adamw'))
+    optimizer = build_vqa_optimizer(model, opts)
+    assert len(optimizer.param_groups) == 4
+    for group in optimizer.param_groups[:2]:                             # train_vqa.py:208-214
+        group['lr'] = opts.learning_rate * opts.lr_mul
+    with torch.no_grad():
+        for name, p in named.items():
+            p.grad = leaf[name].grad.to(p.device, p.dtype) if leaf[name].grad is not None else None
+    ref_grads = {n: named[n].grad.float().cpu() for n in named if named[n].grad is not None}      # bf16-rounded, as fed
+    _, coef = O.clip_coef(list(ref_grads.values()), 2.0)
+    norm = clip_grad_norm_(optimizer, 2.0)
+    total = float(torch.sqrt(sum((g.double() ** 2).sum() for g in ref_grads.values())))
+    assert abs(float(norm) - total) <= 2e-3 * total
+    optimizer.step()
+    for name, p in named.items():
+        if name not in ref_grads:
+            continue
+        lr = opts.learning_rate * (opts.lr_mul if 'vqa_output' in name else 1.0)
+        wd = 0.0 if O.no_decay(name) else opts.weight_decay
+        want, m, v = O.adamw_step(sd[name], ref_grads[name] * coef, torch.zeros_like(sd[name]), torch.zeros_like(sd[name]),
+                                  1, lr, betas=opts.betas, eps=1e-6, weight_decay=wd)
+        st = optimizer.state[p]
+        torch.testing.assert_close(st['exp_avg'].float().cpu(), m, rtol=2e-4, atol=1e-9)
+        torch.testing.assert_close(st['exp_avg_sq'].float().cpu(), v, rtol=4e-4, atol=1e-12)
+        master = st['master'].float().cpu() if 'master' in st else p.detach().float().cpu()
+        torch.testing.assert_close(master, want, rtol=1e-5, atol=1e-7)
+
+
+def test_paired_cross_attention_fused_equals_module_path(tmp_path):
+    """The fused NLVR2 cross-attention op (strided GEMMs + the encoder's attention kernel on the packed partner layout)
+    against the plain MultiheadAttention module path of the same model (torch bf16 ops), ragged pairs, base width."""
+    import json
+    from uniter_amd.model.nlvr2 import UniterForNlvr2PairedAttn
+    from uniter_amd.utils.synthetic import make_batch
+    cfg = dict(BASE_CFG, num_hidden_layers=1)
+    path = tmp_path / "pa.json"
+    path.write_text(json.dumps(cfg))
+    torch.manual_seed(3)
+    model = UniterForNlvr2PairedAttn.from_pretrained(str(path), {}, img_dim=2048)
+    model.init_type_embedding()
+    _prep(model)
+    batch = _to_dev(make_batch('nlvr2', 8, seed=4, ragged=True))
+
+    def run(fused):
+        model._fused_pair_attention = (lambda seq: fused)
+        for p in model.parameters():
+            p.grad = None
+        loss = model(batch, compute_loss=True)
+        loss.float().mean().backward()
+        return loss.detach().float().cpu(), {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters()
+                                             if p.grad is not None and n.startswith(('attn1', 'attn2', 'fc', 'uniter.encoder'))}
+
+    loss_f, g_f = run(True)
+    loss_m, g_m = run(False)
+    torch.testing.assert_close(loss_f, loss_m, rtol=2e-2, atol=2e-2)
+    assert set(g_f) == set(g_m) and len(g_f) > 20
+    for name in g_f:
+        if float(g_m[name].abs().max()) < 1e-6:
+            continue
+        assert cosine(g_f[name], g_m[name]) >= 0.99, (name, cosine(g_f[name], g_m[name]))
+        assert rel_l2(g_f[name], g_m[name]) <= 1e-1, (name, rel_l2(g_f[name], g_m[name]))
+
+
+def test_timing_records_tuned_choice_and_cache(tmp_path, monkeypatch):
+    """uniter_hip_timing_{begin,end}, uniter_gemm_set_tuned legality and the UNITER_AMD_TUNE_CACHE round trip."""
+    import ctypes
+    import json
+    from uniter_amd import _lib, ops
+    from uniter_amd._lib import C
+    dev = _dev()
+    M, N, K = 256, 128, 192
+    x = torch.randn(M, K, device=dev).bfloat16()
+    w = torch.randn(N, K, device=dev).bfloat16()
+    y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    _lib.timing_begin()
+    for _ in range(3):
+        C.uniter_gemm_bias_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), M, N, K, _lib.stream_ptr())
+    recs = _lib.timing_end()
+    mine = [r for r in recs if r["kind_id"] == 0 and (r["M"], r["N"], r["K"]) == (M, N, K)]
+    assert len(mine) == 1 and mine[0]["calls"] == 3 and 0.0 < mine[0]["total_us"] < 1e5
+    torch.testing.assert_close(y.float(), x.float() @ w.float().t(), rtol=2e-2, atol=2e-1)
+    assert _lib.timing_end() == []                                       # nothing recorded outside begin/end
+    # a 96-wide tile cannot serve a K-strided operand (dgrad), tile 3 (64x64) can
+    with pytest.raises(_lib.UniterHipError):
+        C.uniter_gemm_set_tuned(1, M, N, K, 10, 1)
+    C.uniter_gemm_set_tuned(1, M, N, K, 3, 1)
+    out = (ctypes.c_int32 * 2)()
+    C.uniter_gemm_tuned_choice(1, M, N, K, out)
+    assert (out[0], out[1]) == (3, 1)
+    with pytest.raises(_lib.UniterHipError):
+        C.uniter_gemm_set_tuned(0, M, N, K, 3, 2)                        # split-K is a wgrad-only option
+    # cache round trip for an encoder shape
+    cache = tmp_path / "tune.json"
+    monkeypatch.setenv("UNITER_AMD_TUNE_CACHE", str(cache))
+    s = ops._shape(dict(H=128, heads=2, I=256, p_hidden=0.0, p_attn=0.0, ln_eps=1e-12), 2, 32, True)
+    ops._autotuned.discard((2, 32, 128, 256))
+    ops._maybe_autotune(s, True)
+    saved = json.loads(cache.read_text())["gemm"]
+    assert len(saved) == 12 and all(e["cfg"] >= 0 for e in saved)
+    ops._autotuned.discard((2, 32, 128, 256))
+    assert ops._load_tune_cache(str(cache), s)
+
+
+def test_native_kernel_harness():
+    """The C++ harness (tests/native/test_kernels.cpp) checks every kernel against a host fp32 reference through the C
+    ABI without Python or torch in the process: GEMM epilogues x all tile shapes, attention, LayerNorm, AdamW, probes."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "build", "test_kernels")
+    if not os.path.exists(exe):
+        pytest.skip("tests/native/build/test_kernels not built (python tests/native/build.py)")
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:]
+    assert "== 0 check(s) failed ==" in res.stdout, res.stdout[-2000:]

@@ -161,3 +161,34 @@ def test_synthetic_batch_contract():
     assert set(n['img_type_ids'].unique().tolist()) == {1, 2}
     v = make_batch('vqa', 3, seed=4)
     assert v['targets'].shape == (3, 3129) and float(v['targets'].max()) <= 1.0
+
+
+def test_vqa_optimizer_has_four_groups_in_reference_order():
+    """train_vqa.py:51-86: vqa_output (decayed, not decayed) first — their lr is multiplied by lr_mul every step —
+    then the rest (decayed, not decayed).  `vqa_output.2.weight` is a LayerNorm weight inside nn.Sequential: decayed."""
+    from uniter_amd.optim.misc import NO_DECAY
+    from uniter_amd.utils.misc import Struct
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.body = torch.nn.Linear(4, 4)
+            self.LayerNorm = torch.nn.LayerNorm(4)
+            self.vqa_output = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.GELU(), torch.nn.LayerNorm(8),
+                                                  torch.nn.Linear(8, 3))
+
+    model = Toy()
+    opts = Struct(dict(learning_rate=1e-3, betas=(0.9, 0.98), weight_decay=0.01, optim='adam'))
+    from uniter_amd.optim import build_vqa_optimizer
+    opt = build_vqa_optimizer(model, opts)
+    named = dict(model.named_parameters())
+    ids = [[id(p) for p in g['params']] for g in opt.param_groups]
+    assert len(ids) == 4
+    want = [[], [], [], []]
+    for n, p in named.items():
+        top = 'vqa_output' in n
+        nd = any(t in n for t in NO_DECAY)
+        want[(0 if top else 2) + (1 if nd else 0)].append(id(p))
+    assert ids == want
+    assert id(named['vqa_output.2.weight']) in ids[0]                   # the quirk: Sequential LayerNorm weight is decayed
+    assert [g['weight_decay'] for g in opt.param_groups] == [0.01, 0.0, 0.01, 0.0]

@@ -23,3 +23,21 @@ def build_optimizer(model, opts):
     if opts.optim not in classes:
         raise ValueError('invalid optimizer')
     return classes[opts.optim](groups, lr=opts.learning_rate, betas=opts.betas)
+
+
+def build_vqa_optimizer(model, opts):
+    """Four param groups: the `vqa_output` head (decayed / not decayed) then the rest (decayed / not decayed) — the head's
+    groups get `lr * opts.lr_mul` written into them every step by the training loop (train_vqa.py:51-86,208-214)."""
+    named = list(model.named_parameters())
+    top = [(n, p) for n, p in named if 'vqa_output' in n]
+    rest = [(n, p) for n, p in named if 'vqa_output' not in n]
+    groups = []
+    for part, with_lr in ((top, True), (rest, False)):
+        for g in split_decay(part, opts.weight_decay):
+            if with_lr:
+                g['lr'] = opts.learning_rate
+            groups.append(g)
+    classes = {'adam': Adam, 'adamax': Adamax, 'adamw': AdamW}
+    if opts.optim not in classes:
+        raise ValueError('invalid optimizer')
+    return classes[opts.optim](groups, lr=opts.learning_rate, betas=opts.betas)
