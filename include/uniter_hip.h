@@ -341,6 +341,26 @@ int uniter_adamw_step(void* plan, const UniterAdamGroup* groups, int32_t n_group
 int uniter_adamw_step_dev(void* plan, const float* dev_hyper, int32_t n_groups, const float* clip_coef, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Word-region alignment loss: IPOT optimal-transport distance.
+ * Replaces model/ot.py:11-85 (cost_matrix_cosine, ipot, trace) and the un-compaction scatter of
+ * model/pretrain.py:166-181 — one workgroup per example instead of ~8 PyTorch launches x 50 iterations.
+ *   seq [B,L,H] bf16: the encoder output (compact [txt_i ; img_i ; pad] rows);
+ *   scatter [B,L] int64: destination slot of every row (data/itm.py:128-135: text slots 0..tl-1, image slots
+ *     tl..tl+il-1; other destinations are ignored);  txt_pad [B,tl], img_pad [B,il]: uint8 / bool, 1 = padded slot;
+ *   dist [B] fp32 = trace(C T) with C the cosine cost (0 at padded pairs) and T the IPOT plan after `iterations`
+ *     outer and `k` inner iterations with temperature beta (reference defaults 0.5, 50, 1);
+ *   plan [B,il,tl] fp32 = T (no gradient flows through it, as in the reference), kept for backward.
+ * Backward: dseq [B,L,H] bf16 = d(sum_b gdist[b] * dist[b]) / d seq, every row written (zeros where the row is not a
+ * non-padded text / image slot).  Needs H % 8 == 0, H <= 1024 and (2 tl il + 6 tl + 3 il) * 4 bytes <= 160 KiB of LDS.
+ * ---------------------------------------------------------------------------------------------- */
+int uniter_ot_fwd(const void* seq, const int64_t* scatter, const uint8_t* txt_pad, const uint8_t* img_pad,
+                  float* dist, float* plan, int64_t B, int64_t L, int64_t H, int64_t tl, int64_t il,
+                  float beta, int32_t iterations, int32_t k, void* stream);
+int uniter_ot_bwd(const void* seq, const int64_t* scatter, const uint8_t* txt_pad, const uint8_t* img_pad,
+                  const float* plan, const float* gdist, void* dseq,
+                  int64_t B, int64_t L, int64_t H, int64_t tl, int64_t il, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * RCCL communicator (one process per GPU).                              utils/distributed.py:16-209
  * The Python launcher exchanges the 128-byte unique id (rank 0 creates it, broadcasts it through the
  * torch.distributed store) and each rank calls uniter_comm_init.

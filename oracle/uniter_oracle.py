@@ -184,6 +184,81 @@ def itm_loss(sd, cfg, batch):
     return F.cross_entropy(scores, batch['targets'], reduction='none'), seq
 
 
+# ----------------------------------------------------------------------------------------------------
+# word-region alignment: IPOT optimal-transport distance (model/ot.py) and its wiring into ITM
+# ----------------------------------------------------------------------------------------------------
+def ot_cost_matrix_cosine(x, y, eps=1e-5):
+    """model/ot.py:11-22: 1 - cos(x_m, y_n); F.normalize divides by max(||.||, eps)."""
+    xn = x / x.norm(dim=-1, keepdim=True).clamp_min(eps)
+    yn = y / y.norm(dim=-1, keepdim=True).clamp_min(eps)
+    return 1 - xn.matmul(yn.transpose(1, 2))
+
+
+def ot_ipot(C, x_len, x_pad, y_len, y_pad, joint_pad, beta=0.5, iteration=50, k=1):
+    """model/ot.py:36-69 with bool masks (the reference's uint8 masks no longer index in torch >= 1.2).
+    C [B,M,N]; returns the transport plan T [B,N,M]; no gradient (the reference decorates it with no_grad)."""
+    with torch.no_grad():
+        b, m, n = C.shape
+        sigma = torch.ones(b, m, dtype=C.dtype) / x_len.unsqueeze(1)                    # :39-40
+        T = torch.ones(b, n, m, dtype=C.dtype)                                           # :41
+        A = torch.exp(-C.transpose(1, 2) / beta)                                         # :42
+        sigma = sigma.masked_fill(x_pad, 0)                                              # :45
+        jp = joint_pad.transpose(1, 2)                                                   # :46
+        T = T.masked_fill(jp, 0)                                                         # :47
+        A = A.masked_fill(jp, 0)                                                         # :48
+        xl = x_len.view(b, 1, 1)                                                         # :51-52
+        yl = y_len.view(b, 1, 1)
+        x_mask = (x_pad.to(C.dtype) * 1e4).unsqueeze(1)                                  # :55-56
+        y_mask = (y_pad.to(C.dtype) * 1e4).unsqueeze(1)
+        delta = None
+        for _ in range(iteration):                                                       # :58-65
+            Q = A * T
+            sigma = sigma.view(b, m, 1)
+            for _ in range(k):
+                delta = 1 / (yl * Q.matmul(sigma).view(b, 1, n) + y_mask)
+                sigma = 1 / (xl * delta.matmul(Q) + x_mask)
+            T = delta.view(b, n, 1) * Q * sigma
+        return T.masked_fill(jp, 0)                                                      # :66
+
+
+def optimal_transport_dist(txt_emb, img_emb, txt_pad, img_pad, beta=0.5, iteration=50, k=1):
+    """model/ot.py:70-85: trace(cost @ T) with T detached; gradient flows through the cosine cost only."""
+    txt_pad, img_pad = txt_pad.bool(), img_pad.bool()
+    cost = ot_cost_matrix_cosine(txt_emb, img_emb)
+    joint_pad = txt_pad.unsqueeze(-1) | img_pad.unsqueeze(-2)                            # :75
+    cost = cost.masked_fill(joint_pad, 0)                                                # :76
+    txt_len = (txt_pad.size(1) - txt_pad.sum(dim=1)).to(cost.dtype)                      # :78-81
+    img_len = (img_pad.size(1) - img_pad.sum(dim=1)).to(cost.dtype)
+    T = ot_ipot(cost.detach(), txt_len, txt_pad, img_len, img_pad, joint_pad, beta, iteration, k)
+    return torch.diagonal(cost.matmul(T), dim1=1, dim2=2).sum(-1), T                     # :83-84 (trace)
+
+
+def ot_scatter_split(seq, ot_scatter, scatter_max, tl, il):
+    """model/pretrain.py:168-181: undo the [txt_i ; img_i ; pad] compaction -> ([B,tl,H] text slots, [B,il,H] image slots)."""
+    b, _, h = seq.shape
+    max_l = max(int(scatter_max) + 1, tl + il)
+    index = ot_scatter.unsqueeze(-1).expand_as(seq)
+    ctx = torch.zeros(b, max_l, h, dtype=seq.dtype).scatter(1, index, seq)
+    return ctx[:, :tl, :], ctx[:, tl:tl + il, :]
+
+
+def itm_ot_loss(sd, cfg, batch, ot_lambda=0.1):
+    """forward_itm with ot_inputs (model/pretrain.py:156-199) and the loss mix of pretrain.py:270-290:
+    itm.mean() + lambda * (sum(pos) - sum(neg)) / (n_pos + n_neg).  Returns (scalar loss, itm losses, ot distances, seq)."""
+    seq = uniter_model(sd, cfg, batch['input_ids'], batch['position_ids'], batch['img_feat'], batch['img_pos_feat'],
+                       batch['attn_masks'], batch['gather_index'])
+    scores = linear(pooler(sd, 'uniter.pooler.', seq), sd['itm_output.weight'], sd['itm_output.bias'])
+    itm = F.cross_entropy(scores, batch['targets'], reduction='none')
+    ot = batch['ot_inputs']
+    tl, il = batch['input_ids'].size(1), batch['img_feat'].size(1)
+    txt, img = ot_scatter_split(seq, ot['ot_scatter'], ot['scatter_max'], tl, il)
+    dist, _ = optimal_transport_dist(txt, img, ot['txt_pad'], ot['img_pad'])
+    pos = dist[batch['targets'] == 1]
+    neg = dist[batch['targets'] == 0]
+    ot_loss = (pos.sum() - neg.sum()) / (pos.numel() + neg.numel())
+    return itm.mean() + ot_lambda * ot_loss, itm, dist, seq
+
+
 def vqa_loss(sd, cfg, batch):
     """model/vqa.py:30-52."""
     seq = uniter_model(sd, cfg, batch['input_ids'], batch['position_ids'], batch['img_feat'], batch['img_pos_feat'],

@@ -697,3 +697,77 @@ def test_native_kernel_harness():
     res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:]
     assert "== 0 check(s) failed ==" in res.stdout, res.stdout[-2000:]
+
+
+# --------------------------------------------------------------------------------------------------------------
+# (6) SURVEY.md §8 f-1: fused IPOT optimal-transport distance
+# --------------------------------------------------------------------------------------------------------------
+def _ot_golden(name):
+    import os
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ot_golden.npz"))
+
+    def bf(a):
+        return torch.from_numpy(a.astype(np.int16)).view(torch.bfloat16)
+
+    return {k.split("/", 1)[1]: (bf(z[k]) if k.endswith("_bf16") else torch.from_numpy(z[k])) for k in z.files
+            if k.startswith(name + "/")}
+
+
+@pytest.mark.parametrize("name", ["small", "base", "long"])
+def test_ot_kernel_vs_reference_golden(name):
+    """uniter_ot_fwd / uniter_ot_bwd against the REAL reference's cost_matrix_cosine + ipot (tests/golden/ot_golden.npz):
+    transport plan, distance, and d dist / d embeddings.  The joint sequence is [text slots ; image slots] (identity
+    scatter); the kernel's inputs are the same bf16 values the reference saw, so only fp32 summation order differs."""
+    from uniter_amd import ops
+    c = _ot_golden(name)
+    x, y = c["x_bf16"], c["y_bf16"]
+    B, M, D = x.shape
+    N = y.shape[1]
+    seq = torch.cat([x, y], dim=1).to(_dev()).requires_grad_(True)
+    scatter = torch.arange(M + N).unsqueeze(0).repeat(B, 1)
+    dist = ops.optimal_transport_dist(seq, scatter.to(_dev()), c["txt_pad"].to(_dev()), c["img_pad"].to(_dev()))
+    torch.testing.assert_close(dist.detach().cpu(), c["dist"], rtol=2e-4, atol=1e-6)
+    # the saved plan
+    plan = dist.grad_fn.saved_tensors[4].cpu()
+    torch.testing.assert_close(plan, c["T"], rtol=2e-3, atol=1e-7)
+    dist.sum().backward()
+    g = seq.grad.float().cpu()
+    for got, want, what in ((g[:, :M], c["dx"], "dx"), (g[:, M:], c["dy"], "dy")):
+        assert rel_l2(got, want) <= 1e-2, (name, what, rel_l2(got, want))                 # bf16 output rounding
+        assert cosine(got, want) >= 0.9999, (name, what)
+        assert float(got[want == 0].abs().max()) == 0.0                                  # padded slots get exact zeros
+
+
+def test_itm_ot_loss_vs_oracle(tmp_path):
+    """forward_itm with ot_inputs through the model (compact ragged sequences, real ot_scatter) and the loss mix of
+    pretrain.py:270-290 against the oracle: ITM losses, OT distances, gradients."""
+    from uniter_amd.utils.synthetic import make_batch
+    model, cfg = _base_model(tmp_path, n_layers=2)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    batch = make_batch('itm', 6, seed=21, ragged=True, with_ot=True)
+    batch['targets'] = torch.tensor([1, 0, 1, 1, 0, 0])
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != 'cls.predictions.decoder.weight'}
+    ref_loss, ref_itm, ref_dist, _ = O.itm_ot_loss(leaf, cfg, batch, ot_lambda=0.1)
+    ref_loss.backward()
+
+    _prep(model)
+    d = _to_dev(batch)
+    itm, (pos, neg) = model(d, task='itm', compute_loss=True)
+    _check_loss(itm, ref_itm.detach(), atol=3e-2)
+    tgt = batch['targets']
+    torch.testing.assert_close(pos.float().cpu(), ref_dist.detach()[tgt == 1], rtol=2e-2, atol=2e-3)
+    torch.testing.assert_close(neg.float().cpu(), ref_dist.detach()[tgt == 0], rtol=2e-2, atol=2e-3)
+    for p in model.parameters():
+        p.grad = None
+    itm, (pos, neg) = model(d, task='itm', compute_loss=True)
+    loss = itm.float().mean() + 0.1 * (pos.float().sum() - neg.float().sum()) / (pos.numel() + neg.numel())
+    loss.backward()
+    named = dict(model.named_parameters())
+    checked = 0
+    for name in ('uniter.encoder.layer.1.output.dense.weight', 'uniter.encoder.layer.1.attention.self.query.weight',
+                 'uniter.encoder.layer.0.intermediate.dense.weight', 'uniter.embeddings.word_embeddings.weight',
+                 'uniter.img_embeddings.img_linear.weight', 'itm_output.weight'):
+        _check_grad(name, named[name].grad, leaf[name].grad)
+        checked += 1
+    assert checked == 6

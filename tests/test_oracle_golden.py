@@ -125,3 +125,34 @@ def test_inplace_adamw_equals_functional():
         O.adamw_step_(p1, grad, m1, v1, step, 1e-2, (0.9, 0.98), 1e-6, 0.01)
     torch.testing.assert_close(p, p1, rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(v, v1, rtol=1e-6, atol=1e-12)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# optimal-transport distance: oracle vs the real reference's cost_matrix_cosine + ipot
+# --------------------------------------------------------------------------------------------------------------
+def _ot_case(name):
+    import os
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ot_golden.npz"))
+
+    def bf(a):
+        return torch.from_numpy(a.astype(np.int16)).view(torch.bfloat16).float()
+
+    return {k.split("/", 1)[1]: (bf(z[k]) if k.endswith("_bf16") else torch.from_numpy(z[k])) for k in z.files
+            if k.startswith(name + "/")}
+
+
+@pytest.mark.parametrize("name", ["small", "base", "long"])
+def test_optimal_transport_matches_reference(name):
+    c = _ot_case(name)
+    x = c["x_bf16"].clone().requires_grad_(True)
+    y = c["y_bf16"].clone().requires_grad_(True)
+    dist, T = O.optimal_transport_dist(x, y, c["txt_pad"], c["img_pad"])
+    torch.testing.assert_close(T, c["T"], rtol=1e-5, atol=1e-8)
+    torch.testing.assert_close(dist.detach(), c["dist"], rtol=1e-5, atol=1e-7)
+    dist.sum().backward()
+    torch.testing.assert_close(x.grad, c["dx"], rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(y.grad, c["dy"], rtol=1e-4, atol=1e-7)
+    # transport plan: rows of padded slots are exactly zero, the rest is a non-negative coupling
+    assert float(T.min()) >= 0.0
+    assert float(T[c["img_pad"]].abs().max() if c["img_pad"].any() else 0.0) == 0.0

@@ -104,6 +104,8 @@ SIGNATURES = {
     "uniter_adamw_grad_norm": (c_int, [_P, c_float, c_float, _P, _P]),
     "uniter_adamw_step": (c_int, [_P, POINTER(UniterAdamGroup), c_int32, _P, _P]),
     "uniter_adamw_step_dev": (c_int, [_P, _P, c_int32, _P, _P]),
+    "uniter_ot_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, c_float, c_int32, c_int32, _P]),
+    "uniter_ot_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "uniter_comm_unique_id": (c_int, [POINTER(c_uint8)]),
     "uniter_comm_init": (c_int, [POINTER(c_uint8), c_int32, c_int32, POINTER(c_void_p)]),
     "uniter_comm_destroy": (c_int, [_P]),

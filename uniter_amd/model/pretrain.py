@@ -118,17 +118,24 @@ class UniterForPretraining(UniterPreTrainedModel):
 
         ot_loss = None
         if ot_inputs is not None:
-            # undo the compaction: scatter the joint sequence back to [txt(max_tl) ; img] slots
-            b = sequence_output.size(0)
             tl, il = input_ids.size(1), img_feat.size(1)
-            max_l = max(ot_inputs['scatter_max'] + 1, tl + il)
-            index = ot_inputs['ot_scatter'].unsqueeze(-1).expand_as(sequence_output)
-            ctx_emb = torch.zeros(b, max_l, self.config.hidden_size, dtype=sequence_output.dtype,
-                                  device=sequence_output.device).scatter_(dim=1, index=index, src=sequence_output)
-            txt_emb, img_emb = ctx_emb[:, :tl, :], ctx_emb[:, tl:tl + il, :]
-            # fp32 for stability, as the reference does
-            ot_dist = optimal_transport_dist(txt_emb.float(), img_emb.float(), ot_inputs['txt_pad'],
-                                             ot_inputs['img_pad']).to(txt_emb)
+            if sequence_output.is_cuda and sequence_output.dtype == torch.bfloat16 and self.config.hidden_size <= 1024:
+                # fused HIP path: cosine cost, 50 IPOT iterations and trace(C T) in one workgroup per example, reading
+                # the compact sequence through ot_scatter (no un-compaction copy); distances stay fp32
+                from .. import ops
+                ot_dist = ops.optimal_transport_dist(sequence_output, ot_inputs['ot_scatter'], ot_inputs['txt_pad'],
+                                                     ot_inputs['img_pad'])
+            else:
+                # undo the compaction: scatter the joint sequence back to [txt(max_tl) ; img] slots
+                b = sequence_output.size(0)
+                max_l = max(ot_inputs['scatter_max'] + 1, tl + il)
+                index = ot_inputs['ot_scatter'].unsqueeze(-1).expand_as(sequence_output)
+                ctx_emb = torch.zeros(b, max_l, self.config.hidden_size, dtype=sequence_output.dtype,
+                                      device=sequence_output.device).scatter_(dim=1, index=index, src=sequence_output)
+                txt_emb, img_emb = ctx_emb[:, :tl, :], ctx_emb[:, tl:tl + il, :]
+                # fp32 for stability, as the reference does
+                ot_dist = optimal_transport_dist(txt_emb.float(), img_emb.float(), ot_inputs['txt_pad'],
+                                                 ot_inputs['img_pad']).to(txt_emb)
             ot_loss = (ot_dist.masked_select(targets == 1), ot_dist.masked_select(targets == 0))
 
         if not compute_loss:

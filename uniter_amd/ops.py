@@ -744,3 +744,47 @@ def paired_cross_attention(xs, key_valid_partner, attn1, attn2, p_drop, training
     anchor = next((p for m in (attn1, attn2) for p in m.parameters() if p.requires_grad), None)
     extra = () if anchor is None else (anchor,)
     return _PairedCrossAttnFn.apply(xs, mb, attn1, attn2, p_drop, training, *extra)
+
+
+# ----------------------------------------------------------------------------------------------------
+# word-region alignment: IPOT optimal-transport distance (model/ot.py:11-85, model/pretrain.py:166-188)
+# ----------------------------------------------------------------------------------------------------
+class _OtDistFn(torch.autograd.Function):
+    """dist [B] fp32 = optimal_transport_dist(text slots, image slots) of the compact joint sequence `seq`."""
+
+    @staticmethod
+    def forward(ctx, seq, scatter, txt_pad, img_pad, beta, iteration, k):
+        B, L, H = seq.shape
+        tl, il = txt_pad.size(1), img_pad.size(1)
+        dist = torch.empty(B, dtype=torch.float32, device=seq.device)
+        plan = torch.empty(B, il, tl, dtype=torch.float32, device=seq.device)
+        C.uniter_ot_fwd(ptr(seq), ptr(scatter), ptr(txt_pad), ptr(img_pad), ptr(dist), ptr(plan), B, L, H, tl, il,
+                        float(beta), int(iteration), int(k), _lib.stream_ptr())
+        ctx.save_for_backward(seq, scatter, txt_pad, img_pad, plan)
+        return dist
+
+    @staticmethod
+    def backward(ctx, gdist):
+        seq, scatter, txt_pad, img_pad, plan = ctx.saved_tensors
+        B, L, H = seq.shape
+        tl, il = txt_pad.size(1), img_pad.size(1)
+        g = gdist.contiguous().to(torch.float32)
+        dseq = torch.empty_like(seq)
+        C.uniter_ot_bwd(ptr(seq), ptr(scatter), ptr(txt_pad), ptr(img_pad), ptr(plan), ptr(g), ptr(dseq), B, L, H, tl, il,
+                        _lib.stream_ptr())
+        return dseq, None, None, None, None, None, None
+
+
+def optimal_transport_dist(seq, ot_scatter, txt_pad, img_pad, beta=0.5, iteration=50, k=1, return_plan=False):
+    """seq [B, L, H] bf16 encoder output, ot_scatter [B, L] int64, txt_pad [B, tl] / img_pad [B, il] bool (True = pad).
+    Returns the transport distances [B] in fp32 (autograd flows into `seq` through the cosine cost only)."""
+    _check_dev(seq, "sequence_output")
+    if seq.dim() != 3 or ot_scatter.shape != seq.shape[:2]:
+        raise _lib.UniterHipError("sequence_output must be [B, L, H] and ot_scatter [B, L]")
+    if txt_pad.size(0) != seq.size(0) or img_pad.size(0) != seq.size(0):
+        raise _lib.UniterHipError("padding masks must have one row per example")
+    dev = seq.device
+    sc = ot_scatter.to(device=dev, dtype=torch.int64).contiguous()
+    tp = txt_pad.to(device=dev, dtype=torch.uint8).contiguous()
+    ip = img_pad.to(device=dev, dtype=torch.uint8).contiguous()
+    return _OtDistFn.apply(seq.contiguous(), sc, tp, ip, beta, iteration, k)

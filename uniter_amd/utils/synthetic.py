@@ -27,7 +27,7 @@ def _boxes(gen, n):
 
 
 def make_batch(task, batch_size, max_txt_len=60, num_bb=36, img_dim=2048, vocab_size=28996, seed=0, ragged=False,
-               img_label_dim=1601, num_answer=3129, min_txt_len=10, min_bb=10, mask_prob=0.15):
+               img_label_dim=1601, num_answer=3129, min_txt_len=10, min_bb=10, mask_prob=0.15, with_ot=False):
     """Returns a dict of CPU tensors.  task in {mlm, mrfr, mrc, mrckl, itm, vqa, nlvr2}.
 
     nlvr2: `batch_size` rows = batch_size/2 pairs; rows 2i / 2i+1 share the text and carry img_type_ids 1 / 2."""
@@ -110,6 +110,20 @@ def make_batch(task, batch_size, max_txt_len=60, num_bb=36, img_dim=2048, vocab_
         batch['img_mask_tgt'] = img_mask_tgt
     elif task == 'itm':
         batch['targets'] = rint(0, 2, B)
+        batch['ot_inputs'] = None
+        if with_ot:
+            # word-region alignment inputs of itm_ot_collate (data/itm.py:128-184), bool pads
+            joint_len = batch['attn_masks'].size(1)
+            ot_scatter = torch.arange(0, joint_len, dtype=torch.long).unsqueeze(0).repeat(B, 1)
+            for i, tl in enumerate(txt_lens):
+                ot_scatter[i, tl:] = torch.arange(Lt, Lt + (joint_len - tl), dtype=torch.long)
+            txt_pad = torch.zeros(B, Lt, dtype=torch.bool)
+            img_pad = torch.zeros(B, Li, dtype=torch.bool)
+            for i in range(B):
+                txt_pad[i, txt_lens[i]:] = True
+                img_pad[i, num_bbs[i]:] = True
+            batch['ot_inputs'] = {'ot_scatter': ot_scatter, 'scatter_max': int(ot_scatter.max()), 'txt_pad': txt_pad,
+                                  'img_pad': img_pad}
     elif task == 'vqa':
         targets = torch.zeros(B, num_answer)
         scores = torch.tensor([0.3, 0.6, 0.9, 1.0])
