@@ -221,9 +221,21 @@ __device__ __forceinline__ void wait_tile(int later) {
 // the LDS-DMA for the next tile and wait for it.  In the unspecialised kernel every wave spends ~470 cycles per K tile
 // issuing its 8 DMA instructions and ~490 waiting for them (cycle stamps, tests/native/build_probe.sh) before it can
 // start the ~940 cycles of LDS reads + MFMAs; with dedicated loader waves those phases run concurrently.
-template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, bool WS>
-__global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 1) void gemm_kernel(const GemmArgs p) {
-    constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
+// WS = 2: eight compute waves (wave grid 2x4, or 4x2 when BN/4 is not a multiple of 16) + 4 loader waves: twice the
+// MFMA waves per tile to cover each other's LDS latency, at half the per-wave tile.
+template <int BM, int BN, int WS>
+struct WaveGrid {
+    static constexpr int GN = (WS == 2) ? (((BN / 4) % 16 == 0) ? 4 : 2) : 2;
+    static constexpr int GM = (WS == 2) ? 8 / GN : 2;
+    static constexpr int NCW = GM * GN;                    // compute waves
+    static constexpr int THREADS = (WS ? NCW + 4 : NCW) * 64;
+};
+
+template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, int WS>
+__global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS == 2 ? 3 : 1)) void gemm_kernel(const GemmArgs p) {
+    using WG = WaveGrid<BM, BN, WS>;
+    constexpr int WM = BM / WG::GM, WN = BN / WG::GN, MI = WM / 16, NI = WN / 16;
+    static_assert(WM % 16 == 0 && WN % 16 == 0, "wave tile must be a multiple of the 16x16 MFMA tile");
     constexpr int TILE_R = BM * 64, TILE_C = BN * 64;   // elements per LDS tile
     constexpr int STAGE = TILE_R + TILE_C;               // elements per pipeline stage
     constexpr int G = BM / 32 + BN / 32;                 // LDS-DMA instructions per wave per K tile
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 1) void gemm_kernel(const 
     const int t = threadIdx.x;
     const int lane = t & 63, wid = t >> 6;
     const int g = lane >> 4, i = lane & 15;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = (wid / WG::GN) % WG::GM, wn = wid % WG::GN;      // (loader waves never use these)
 
     const int tiles_n = p.N / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
@@ -318,10 +330,10 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 1) void gemm_kernel(const 
     // every wave's share visible and also proves that all waves are done reading the buffer tile kt+NSTAGE-1 is
     // about to overwrite (it held tile kt-1).  No __syncthreads() here: its fence would drain the DMA queue.
     const int nfull = (k_end > k_begin) ? ((k_end - k_begin) >> 6) : 0;
-    if constexpr (WS) {
-        if (wid >= 4) {
+    if constexpr (WS != 0) {
+        if (wid >= WG::NCW) {
             // ---- loader waves: one barrier per tile, shared with the compute waves ----
-            const int lw = wid - 4;
+            const int lw = wid - WG::NCW;
             auto ws_glds = [&](int kt, int b) {
                 const int k0 = k_begin + kt * 64;
                 bf16_t* tr_ = smem + b * STAGE;
@@ -506,7 +518,7 @@ int pick_xr(int tiles_m, int tiles_n, int bm, int bn) {
     return best;
 }
 
-template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, bool WS>
+template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, int WS>
 int launch_cfg(const GemmArgs& a_in, int splits, hipStream_t st) {
     GemmArgs a = a_in;
     if (WS && (a.K % 64 != 0 || a.k_per_split % 64 != 0)) {
@@ -526,7 +538,7 @@ int launch_cfg(const GemmArgs& a_in, int splits, hipStream_t st) {
         attr_done = true;
     }
     dim3 grid(tiles_m * tiles_n, splits, 1);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, TRA, TRB, EPI, NSTAGE, WS>), grid, dim3(WS ? 512 : 256), lds, st, a);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, TRA, TRB, EPI, NSTAGE, WS>), grid, dim3(WaveGrid<BM, BN, WS>::THREADS), lds, st, a);
     UH_LAUNCH_CHECK();
     return 0;
 }
@@ -549,7 +561,10 @@ constexpr TileShape kTiles[] = {{128, 128, 2, 0}, {128, 64, 2, 0}, {64, 128, 2, 
                                 {96, 64, 3, 1}, {96, 128, 3, 1}, {128, 96, 3, 1}, {128, 128, 3, 1}, {64, 64, 4, 1}, {96, 64, 4, 1},
                                 {128, 64, 4, 1}, {64, 128, 4, 1}, {96, 96, 4, 1}, {192, 64, 3, 1},
                                 // 4-stage rings that own a CU (three tiles in flight)
-                                {96, 128, 4, 1}, {128, 96, 4, 1}, {192, 64, 4, 1}, {128, 128, 4, 1}};
+                                {96, 128, 4, 1}, {128, 96, 4, 1}, {192, 64, 4, 1}, {128, 128, 4, 1},
+                                // 8 compute waves + 4 loader waves, one workgroup per CU
+                                {128, 128, 3, 2}, {128, 128, 4, 2}, {192, 192, 2, 2}, {96, 192, 3, 2}, {192, 96, 3, 2},
+                                {128, 192, 3, 2}, {192, 128, 3, 2}, {128, 64, 4, 2}, {64, 128, 4, 2}, {192, 64, 4, 2}};
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <bool TRA, bool TRB>
@@ -563,7 +578,7 @@ constexpr bool tile_ok(int idx) {
 template <bool TRA, bool TRB, int EPI, int IDX>
 int launch_idx(const GemmArgs& a, int splits, hipStream_t st) {
     if constexpr (tile_ok<TRA, TRB>(IDX)) {
-        return launch_cfg<kTiles[IDX].bm, kTiles[IDX].bn, TRA, TRB, EPI, kTiles[IDX].stages, kTiles[IDX].ws != 0>(a, splits, st);
+        return launch_cfg<kTiles[IDX].bm, kTiles[IDX].bn, TRA, TRB, EPI, kTiles[IDX].stages, kTiles[IDX].ws>(a, splits, st);
     } else {
         uh_set_error("gemm: tile shape %d is not available for this operand layout", IDX);
         return -1;
@@ -617,6 +632,16 @@ int launch_gemm(const GemmArgs& a, int cfg, int splits, hipStream_t st) {
         case 41: return launch_idx<TRA, TRB, EPI, 41>(a, splits, st);
         case 42: return launch_idx<TRA, TRB, EPI, 42>(a, splits, st);
         case 43: return launch_idx<TRA, TRB, EPI, 43>(a, splits, st);
+        case 44: return launch_idx<TRA, TRB, EPI, 44>(a, splits, st);
+        case 45: return launch_idx<TRA, TRB, EPI, 45>(a, splits, st);
+        case 46: return launch_idx<TRA, TRB, EPI, 46>(a, splits, st);
+        case 47: return launch_idx<TRA, TRB, EPI, 47>(a, splits, st);
+        case 48: return launch_idx<TRA, TRB, EPI, 48>(a, splits, st);
+        case 49: return launch_idx<TRA, TRB, EPI, 49>(a, splits, st);
+        case 50: return launch_idx<TRA, TRB, EPI, 50>(a, splits, st);
+        case 51: return launch_idx<TRA, TRB, EPI, 51>(a, splits, st);
+        case 52: return launch_idx<TRA, TRB, EPI, 52>(a, splits, st);
+        case 53: return launch_idx<TRA, TRB, EPI, 53>(a, splits, st);
         default: uh_set_error("gemm: bad tile index %d", cfg); return -1;
     }
 }
@@ -648,7 +673,7 @@ int pick_cfg(int M, int N, bool trm, bool trn, bool k_mult64 = false) {
     double best_cost = 0;
     for (int i = 0; i < kNumTiles; ++i) {
         const int bm = kTiles[i].bm, bn = kTiles[i].bn;
-        if (kTiles[i].ws && (!k_mult64 || kTiles[i].stages != 3)) continue;   // un-tuned default: 3-stage WS rings only
+        if (kTiles[i].ws && (!k_mult64 || kTiles[i].stages != 3 || kTiles[i].ws != 1)) continue;   // un-tuned default: 3-stage 4+4 WS rings only
         if (N % bn != 0) continue;
         if (trm && (M % bm != 0 || !(bm == 64 || bm == 128))) continue;
         if (trn && !(bn == 64 || bn == 128)) continue;
