@@ -50,7 +50,7 @@ def family(name):
     m = GEMM_RE.search(n)
     if m:
         return "%s  [tile %sx%s st%s %s]" % (EPI_KIND[int(m.group(5))], m.group(1), m.group(2), m.group(6),
-                                               "ws" if m.group(7) == "true" else "plain")
+                                               {"0": "plain", "false": "plain", "1": "ws4+4", "true": "ws4+4", "2": "ws8+4"}.get(m.group(7), m.group(7)))
     if n.startswith("Cijk_"):
         return "rocBLAS/hipBLASLt GEMM (task heads, torch)"
     if "at::native" in n:
