@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "../../include/uniter_hip.h"
@@ -743,6 +744,31 @@ static void bench(int B, int L, int H, int heads, int I, int layers) {
                 printf("  in-situ %-18s M%-5lld N%-5lld K%-5lld x%-3d avg %7.2f us\n", kinds[rec[i].kind], (long long)rec[i].M,
                        (long long)rec[i].N, (long long)rec[i].K, rec[i].calls, rec[i].total_us / rec[i].calls);
         }
+        {   // experiment: two half batches on two streams (phases of the two kernel chains are not aligned)
+            UniterEncoderShape sh2 = sh;
+            sh2.B = B / 2;
+            UHCHK(uniter_encoder_autotune(&sh2, 0));
+            const size_t act2 = uniter_encoder_layer_act_bytes(&sh2);
+            char* actsA = dalloc<char>(act2 * layers);
+            char* actsB = dalloc<char>(act2 * layers);
+            hipStream_t sA, sB;
+            HIPCHK(hipStreamCreateWithFlags(&sA, hipStreamNonBlocking));
+            HIPCHK(hipStreamCreateWithFlags(&sB, hipStreamNonBlocking));
+            const size_t half_x = (size_t)(T / 2) * H;
+            auto both = [&] {
+                UHCHK(uniter_encoder_forward(&sh2, lp.data(), 0, layers, dX, dMask, actsA, scratch, 1, 0, sA));
+                UHCHK(uniter_encoder_forward(&sh2, lp.data(), 0, layers, dX + half_x, dMask + (B / 2) * L, actsB, scratch, 1, 0, sB));
+            };
+            for (int i = 0; i < 3; ++i) both();
+            HIPCHK(hipDeviceSynchronize());
+            auto t0 = std::chrono::high_resolution_clock::now();
+            for (int i = 0; i < 10; ++i) both();
+            HIPCHK(hipDeviceSynchronize());
+            auto t1 = std::chrono::high_resolution_clock::now();
+            const double us2 = std::chrono::duration<double, std::micro>(t1 - t0).count() / 10;
+            double one = tm.run([&] { UHCHK(uniter_encoder_forward(&sh2, lp.data(), 0, layers, dX, dMask, actsA, scratch, 1, 0, 0)); }, 2, 10);
+            printf("  (experiment: forward of two B=%d halves on two streams: %.1f us; one half alone: %.1f us; full batch: %.1f us)\n", B / 2, us2, one, tf);
+        }
         const double flf = (double)layers * (24.0 * T * H * H + 4.0 * T * L * H);
         printf("  ENCODER fwd %.1f us (%.1f TF) | bwd %.1f us (%.1f TF) | fwd+bwd %.1f us = %.1f TF = %.1f%% of 2.5 PF ; %.0f ex/s\n", tf,
                flf / tf * 1e-6, tb, 2 * flf / tb * 1e-6, tf + tb, 3 * flf / (tf + tb) * 1e-6, 3 * flf / (tf + tb) * 1e-6 / 2500 * 100,
@@ -778,14 +804,14 @@ static int run_one(int argc, char** argv, int at) {
 #ifdef UNITER_GEMM_PROBE
     {
         const int nblk = 4096;
-        unsigned long long* dpr = dalloc<unsigned long long>((size_t)nblk * 64 * 5);
+        unsigned long long* dpr = dalloc<unsigned long long>((size_t)nblk * 64 * 5 + (size_t)nblk * 2);
         for (int i = 0; i < 3; ++i) fn();
-        HIPCHK(hipMemset(dpr, 0, (size_t)nblk * 64 * 5 * 8));
+        HIPCHK(hipMemset(dpr, 0, ((size_t)nblk * 64 * 5 + (size_t)nblk * 2) * 8));
         uniter_gemm_debug_probe(dpr);
         fn();
         HIPCHK(hipDeviceSynchronize());
         uniter_gemm_debug_probe(nullptr);
-        std::vector<unsigned long long> h((size_t)nblk * 64 * 5);
+        std::vector<unsigned long long> h((size_t)nblk * 64 * 5 + (size_t)nblk * 2);
         HIPCHK(hipMemcpy(h.data(), dpr, h.size() * 8, hipMemcpyDeviceToHost));
         const int nkt = (int)std::min<int64_t>((kind == "wgrad" ? M : (kind == "dgrad" ? N : K)) / 64, 63);
         double ph[4] = {0, 0, 0, 0}, tot = 0, gap = 0; long cnt = 0, gcnt = 0;
@@ -812,6 +838,26 @@ static int run_one(int argc, char** argv, int at) {
         }
         std::sort(spans.begin(), spans.end());
         if (!spans.empty()) printf("   probe: main-loop span per block: min %.0f median %.0f max %.0f cycles (%zu blocks)\n", spans.front(), spans[spans.size() / 2], spans.back(), spans.size());
+        {   // workgroup life cycle: entry -> first tile usable -> main loop end -> epilogue stored
+            const unsigned long long* life = &h[(size_t)nblk * 64 * 5];
+            unsigned long long t0 = ~0ull, t1 = 0;
+            std::vector<double> pro, epi, startoff, whole;
+            for (int b = 0; b < nblk; ++b) if (life[b * 2] && life[b * 2 + 1]) { t0 = std::min(t0, life[b * 2]); t1 = std::max(t1, life[b * 2 + 1]); }
+            for (int b = 0; b < nblk; ++b) {
+                if (!life[b * 2] || !life[b * 2 + 1]) continue;
+                const unsigned long long* r0 = &h[(size_t)b * 320];
+                const unsigned long long* r1 = &h[((size_t)b * 64 + nkt - 1) * 5];
+                if (!r0[1] || !r1[4]) continue;
+                pro.push_back((double)(r0[1] - life[b * 2]));
+                epi.push_back((double)(life[b * 2 + 1] - r1[4]));
+                startoff.push_back((double)(life[b * 2] - t0));
+                whole.push_back((double)(life[b * 2 + 1] - life[b * 2]));
+            }
+            auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+            auto mx = [](std::vector<double>& v) { return v.empty() ? 0.0 : *std::max_element(v.begin(), v.end()); };
+            printf("   probe: workgroup life (cycles): prologue median %.0f max %.0f | epilogue median %.0f max %.0f | whole median %.0f | entry offset median %.0f max %.0f | kernel first-entry..last-exit %.0f\n",
+                   med(pro), mx(pro), med(epi), mx(epi), med(whole), med(startoff), mx(startoff), (double)(t1 - t0));
+        }
     }
 #endif
     const double us = tm.run(fn, 3, iters);

@@ -245,6 +245,11 @@ __global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS 
     const int t = threadIdx.x;
     const int lane = t & 63, wid = t >> 6;
     const int g = lane >> 4, i = lane & 15;
+#ifdef UNITER_GEMM_PROBE
+    // workgroup life cycle: [4096*64*5 + block*2 + {0,1}] = cycle stamps at entry / after the epilogue (wave 0)
+    unsigned long long* life = p.probe ? p.probe + (size_t)4096 * 64 * 5 + (size_t)blockIdx.x * 2 : nullptr;
+    if (life != nullptr && t == 0 && blockIdx.x < 4096) life[0] = __builtin_readcyclecounter();
+#endif
     const int wm = (wid / WG::GN) % WG::GM, wn = wid % WG::GN;      // (loader waves never use these)
 
     const int tiles_n = p.N / BN;
@@ -413,71 +418,106 @@ __global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS 
         compute(0);
     }
 
-    // ---- epilogue: lane holds C[m][n..n+3], m = m0 + wm*WM + b*16 + i, n = n0 + wn*WN + a*16 + 4g ----
+    // ---- epilogue ---------------------------------------------------------------------------------------------------
+    // After the MFMAs a lane holds C[m][n..n+3], m = m0 + wm*WM + b*16 + i, n = n0 + wn*WN + a*16 + 4g: storing that
+    // directly is 8 bytes per lane in 32-byte row pieces, and such stores are issue-bound (cycle stamps: 2.1-2.7 us of
+    // a 9-25 us kernel).  Instead every 16-row MFMA block is staged through the (now idle) LDS ring as fp32 and read
+    // back row-contiguously, so all global traffic of the epilogue — output, residual / pre-activation reads, the
+    // accumulate read of wgrad — is 16 bytes per lane over full tile rows.  The arithmetic per element is unchanged.
+    if (EPI == EPI_WGRAD && p.partial != nullptr) {         // split-K partials: already 16-byte fp32 stores
 #pragma unroll
-    for (int b = 0; b < MI; ++b) {
-        const int m = m0 + wm * WM + b * 16 + i;
-        if (m >= p.M) continue;
+        for (int b = 0; b < MI; ++b) {
+            const int m = m0 + wm * WM + b * 16 + i;
+            if (m >= p.M) continue;
 #pragma unroll
-        for (int a = 0; a < NI; ++a) {
-            const int n = n0 + wn * WN + a * 16 + 4 * g;
-            float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
-
-            if (EPI == EPI_WGRAD && p.partial != nullptr) {
+            for (int a = 0; a < NI; ++a) {
+                const int n = n0 + wn * WN + a * 16 + 4 * g;
                 float* dst = p.partial + ((int64_t)blockIdx.y * p.M + m) * p.N + n;
-                *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-                continue;
+                *reinterpret_cast<f32x4*>(dst) = acc[a][b];
             }
-            if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RES) {
-                if (p.bias != nullptr) {
-                    float bv[4];
-                    unpack4(*reinterpret_cast<const u32x2*>(p.bias + n), bv);
+        }
+    } else {
+        constexpr int NT = WG::NCW * 64;                    // the compute waves (loader waves have exited)
+        constexpr int SROW = BN + 4;                        // fp32 row stride of the staging block (+4 spreads banks)
+        constexpr int PASS_ROWS = WG::GM * 16;              // one 16-row MFMA block of every wave row per pass
+        constexpr int CPR = BN / 8;                         // 16-byte output chunks per tile row
+        static_assert(2 * PASS_ROWS * SROW * 4 <= NSTAGE * STAGE * 2, "staging blocks must fit the LDS ring");
+        float* stage = reinterpret_cast<float*>(smem_raw);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // every wave is done reading the ring
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += bv[e];
+        for (int b = 0; b < MI; ++b) {
+            float* sb = stage + (b & 1) * PASS_ROWS * SROW;
+#pragma unroll
+            for (int a = 0; a < NI; ++a)
+                *reinterpret_cast<f32x4*>(sb + (wm * 16 + i) * SROW + wn * WN + a * 16 + 4 * g) = acc[a][b];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                   // (also orders the reads of pass b-1 before the writes of b+1)
+            for (int c = t; c < PASS_ROWS * CPR; c += NT) {
+                const int r = c / CPR, c8 = c - r * CPR;
+                const int m = m0 + (r >> 4) * WM + b * 16 + (r & 15);
+                if (m >= p.M) continue;
+                const int n = n0 + c8 * 8;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(sb + r * SROW + c8 * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(sb + r * SROW + c8 * 8 + 4);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RES) {
+                    if (p.bias != nullptr) {
+                        float bv[8];
+                        unpack8(*reinterpret_cast<const u32x4*>(p.bias + n), bv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += bv[e];
+                    }
                 }
-            }
-            bf16_t* cptr = p.C + (int64_t)m * p.ldc + n;
-            if (EPI == EPI_BIAS_GELU) {
-                *reinterpret_cast<u32x2*>(cptr) = pack4(v);   // u (pre-activation)
-                // activation is applied to the bf16-rounded u so that backward (which only has u) is consistent
-                float gq[4], uq[4];
-                unpack4(pack4(v), uq);
+                bf16_t* cptr = p.C + (int64_t)m * p.ldc + n;
+                if (EPI == EPI_BIAS_GELU) {
+                    const u32x4 uq_bits = pack8(v);
+                    *reinterpret_cast<u32x4*>(cptr) = uq_bits;                 // u (pre-activation)
+                    // activation is applied to the bf16-rounded u so that backward (which only has u) is consistent
+                    float uq[8], gq[8];
+                    unpack8(uq_bits, uq);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) gq[e] = gelu_erf(uq[e]);
-                *reinterpret_cast<u32x2*>(p.C2 + (int64_t)m * p.ldc + n) = pack4(gq);
-                continue;
-            }
-            if (EPI == EPI_BIAS_DROP_RES) {
-                if (p.drop.p > 0.f) {
-                    float mult[4];
-                    dropout_mult4(p.drop, ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 2, mult);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= mult[e];
+                    for (int e = 0; e < 8; ++e) gq[e] = gelu_erf(uq[e]);
+                    *reinterpret_cast<u32x4*>(p.C2 + (int64_t)m * p.ldc + n) = pack8(gq);
+                    continue;
                 }
-            }
-            if (EPI == EPI_BIAS_DROP_RES || EPI == EPI_RES) {
-                if (p.aux != nullptr) {
-                    float rv[4];
-                    unpack4(*reinterpret_cast<const u32x2*>(p.aux + (int64_t)m * p.ldaux + n), rv);
+                if (EPI == EPI_BIAS_DROP_RES) {
+                    if (p.drop.p > 0.f) {
+                        float m0v[4], m1v[4];
+                        const uint64_t idx4 = ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 2;
+                        dropout_mult4(p.drop, idx4, m0v);
+                        dropout_mult4(p.drop, idx4 + 1, m1v);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                        for (int e = 0; e < 4; ++e) { v[e] *= m0v[e]; v[4 + e] *= m1v[e]; }
+                    }
                 }
-            }
-            if (EPI == EPI_GELU_BWD) {
-                float uv[4];
-                unpack4(*reinterpret_cast<const u32x2*>(p.aux + (int64_t)m * p.ldaux + n), uv);
+                if (EPI == EPI_BIAS_DROP_RES || EPI == EPI_RES) {
+                    if (p.aux != nullptr) {
+                        float rv[8];
+                        unpack8(*reinterpret_cast<const u32x4*>(p.aux + (int64_t)m * p.ldaux + n), rv);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(uv[e]);
-            }
-            if (EPI == EPI_WGRAD && p.accumulate) {
-                float ov[4];
-                unpack4(*reinterpret_cast<const u32x2*>(cptr), ov);
+                        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                    }
+                }
+                if (EPI == EPI_GELU_BWD) {
+                    float uv[8];
+                    unpack8(*reinterpret_cast<const u32x4*>(p.aux + (int64_t)m * p.ldaux + n), uv);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += ov[e];
+                    for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(uv[e]);
+                }
+                if (EPI == EPI_WGRAD && p.accumulate) {
+                    float ov[8];
+                    unpack8(*reinterpret_cast<const u32x4*>(cptr), ov);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += ov[e];
+                }
+                *reinterpret_cast<u32x4*>(cptr) = pack8(v);
             }
-            *reinterpret_cast<u32x2*>(cptr) = pack4(v);
         }
     }
+#ifdef UNITER_GEMM_PROBE
+    if (life != nullptr && t == 0 && blockIdx.x < 4096) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); life[1] = __builtin_readcyclecounter(); }
+#endif
 }
 
 // out[M*N] bf16 (+)= sum_s partial[s][M*N]
@@ -716,7 +756,7 @@ int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void
     if (check_common(M, N, K)) return -1;
     if (ldx == 0) ldx = K;
     if (ldy == 0) ldy = N;
-    if (ldx < K || ldy < N || ldx % 8 != 0 || ldy % 4 != 0) { uh_set_error("gemm_fwd: bad leading dimension"); return -1; }
+    if (ldx < K || ldy < N || ldx % 8 != 0 || ldy % 8 != 0) { uh_set_error("gemm_fwd: bad leading dimension"); return -1; }
     if (N % 64 != 0 || K % 8 != 0) { uh_set_error("gemm_fwd: need N %% 64 == 0 and K %% 8 == 0 (N=%lld K=%lld)", (long long)N, (long long)K); return -1; }
     LaunchTimer lt(epi == GEMM_EPI_BIAS ? TIME_GEMM_FWD_BIAS : (epi == GEMM_EPI_BIAS_GELU ? TIME_GEMM_FWD_GELU : TIME_GEMM_FWD_DROP_RES), M, N, K, st);
     GemmArgs a{};
