@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const float v[4] = {o[dt][0], o[dt][1], o[dt][2], o[dt][3]};
-                *reinterpret_cast<u32x2*>(dst + dt * 16) = pack4(v);
+                __builtin_nontemporal_store(pack4(v), reinterpret_cast<u32x2*>(dst + dt * 16));
             }
         }
     }
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const float v[4] = {dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]};
-                *reinterpret_cast<u32x2*>(dst + dt * 16) = pack4(v);
+                __builtin_nontemporal_store(pack4(v), reinterpret_cast<u32x2*>(dst + dt * 16));
             }
         }
     }
@@ -340,8 +340,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
             for (int dt = 0; dt < 4; ++dt) {
                 const float kv[4] = {dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]};
                 const float vv[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
-                *reinterpret_cast<u32x2*>(dst + H + dt * 16) = pack4(kv);
-                *reinterpret_cast<u32x2*>(dst + 2 * H + dt * 16) = pack4(vv);
+                __builtin_nontemporal_store(pack4(kv), reinterpret_cast<u32x2*>(dst + H + dt * 16));
+                __builtin_nontemporal_store(pack4(vv), reinterpret_cast<u32x2*>(dst + 2 * H + dt * 16));
             }
         }
     }

@@ -472,13 +472,13 @@ __global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS 
                 bf16_t* cptr = p.C + (int64_t)m * p.ldc + n;
                 if (EPI == EPI_BIAS_GELU) {
                     const u32x4 uq_bits = pack8(v);
-                    *reinterpret_cast<u32x4*>(cptr) = uq_bits;                 // u (pre-activation)
+                    __builtin_nontemporal_store(uq_bits, reinterpret_cast<u32x4*>(cptr));   // u (pre-activation)
                     // activation is applied to the bf16-rounded u so that backward (which only has u) is consistent
                     float uq[8], gq[8];
                     unpack8(uq_bits, uq);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) gq[e] = gelu_erf(uq[e]);
-                    *reinterpret_cast<u32x4*>(p.C2 + (int64_t)m * p.ldc + n) = pack8(gq);
+                    __builtin_nontemporal_store(pack8(gq), reinterpret_cast<u32x4*>(p.C2 + (int64_t)m * p.ldc + n));
                     continue;
                 }
                 if (EPI == EPI_BIAS_DROP_RES) {
@@ -511,7 +511,7 @@ __global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS 
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += ov[e];
                 }
-                *reinterpret_cast<u32x4*>(cptr) = pack8(v);
+                __builtin_nontemporal_store(pack8(v), reinterpret_cast<u32x4*>(cptr));    // consumed by a later kernel from MALL/HBM, never from this L2
             }
         }
     }

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = oq[e] * mult[e];
             }
-            *reinterpret_cast<u32x2*>(yr + ch * 4) = pack4(o);
+            __builtin_nontemporal_store(pack4(o), reinterpret_cast<u32x2*>(yr + ch * 4));
         }
     }
 }
@@ -256,14 +256,14 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const bf16_t* __restri
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rstd * (gy[c][e] - c1 - xh[c][e] * c2);
                 const u32x2 packed = pack4(o);
-                *reinterpret_cast<u32x2*>(dz + ro + ch * 4) = packed;
+                __builtin_nontemporal_store(packed, reinterpret_cast<u32x2*>(dz + ro + ch * 4));
                 if (use_drop && dd != nullptr) {
                     float oq[4], mult[4];
                     unpack4(packed, oq);
                     dropout_mult4(drop, ((uint64_t)row * (uint64_t)H + (uint64_t)ch * 4) >> 2, mult);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) oq[e] *= mult[e];
-                    *reinterpret_cast<u32x2*>(dd + ro + ch * 4) = pack4(oq);
+                    __builtin_nontemporal_store(pack4(oq), reinterpret_cast<u32x2*>(dd + ro + ch * 4));
                 }
             }
         }
