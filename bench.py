@@ -220,6 +220,10 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole optimizer step into a hipGraph and replay it (N=1 only); measured slower than "
                          "eager issue on ROCm 7.2 (8.65 vs 8.27 ms), so it is opt-in")
+    ap.add_argument("--ragged", action="store_true",
+                    help="NOT the headline config: ragged synthetic batch (10-60 text tokens, 10-36 regions per sequence) "
+                         "to measure padding-free execution (SURVEY.md section 8 f-3)")
+    ap.add_argument("--pack", action="store_true", help="run the encoder on real tokens only (UniterModel.pack_padding)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -255,7 +259,10 @@ def main():
     optimizer = build_optimizer(model, opts)
     reducer = D.GradientReducer(arena, model.uniter.encoder) if world > 1 else None
     # each rank trains on its own shard (data/data.py:222): different synthetic batch per rank, resident in HBM
-    batch = to_device(make_batch('nlvr2', TRAIN['batch'], TRAIN['max_txt_len'], TRAIN['num_bb'], seed=1000 + rank), device)
+    batch = to_device(make_batch('nlvr2', TRAIN['batch'], TRAIN['max_txt_len'], TRAIN['num_bb'], seed=1000 + rank,
+                                 ragged=args.ragged), device)
+    model.uniter.pack_padding = bool(args.pack)
+    real_tokens = int(batch['attn_masks'].sum().item())
     batch['img_feat'] = batch['img_feat'].to(torch.bfloat16)            # fp16 features under amp O2 in the reference
     batch['img_pos_feat'] = batch['img_pos_feat'].to(torch.bfloat16)
 
@@ -355,6 +362,8 @@ def main():
             "config": {"workload": "UNITER-base NLVR2 paired-attn finetune step (config/train-nlvr2-base-1gpu.json shapes): "
                                    "fwd+bwd+clip+fused AdamW, dropout 0.1, random-init weights",
                        "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world, "launch": mode,
+                       "ragged": bool(args.ragged), "pack_padding": bool(args.pack),
+                       "real_token_fraction": round(real_tokens / float(B * batch['attn_masks'].size(1)), 3),
                        "examples": "encoder sequences (32/GPU = 16 NLVR2 pairs)"},
             "final_loss": round(final_loss, 4),
             "roofline": roofline,

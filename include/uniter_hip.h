@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UNITER_HIP_ABI_VERSION 1
+#define UNITER_HIP_ABI_VERSION 2
 
 /* ------------------------------------------------------------------------------------------------
  * Library
@@ -148,6 +148,16 @@ int uniter_attention_bwd(const void* qkv, const float* mask_bias, const void* ct
                          int64_t B, int64_t L, int64_t heads,
                          float p_drop, uint64_t seed, uint64_t offset, void* stream);
 
+/* Packed ("varlen") forms: qkv [total, 3H], ctx / dctx [total, H], dqkv [total, 3H]; example b owns rows
+ * cu_seqlens[b] .. cu_seqlens[b+1]-1 (device int32 [B+1]); max_len = longest example (<= 256); lse [B, heads, max_len].
+ * No key mask: only real tokens exist. */
+int uniter_attention_fwd_packed(const void* qkv, const int32_t* cu_seqlens, void* ctx, float* lse,
+                                int64_t B, int64_t max_len, int64_t heads,
+                                float p_drop, uint64_t seed, uint64_t offset, void* stream);
+int uniter_attention_bwd_packed(const void* qkv, const int32_t* cu_seqlens, const void* ctx, const float* lse,
+                                const void* dctx, void* dqkv, int64_t B, int64_t max_len, int64_t heads,
+                                float p_drop, uint64_t seed, uint64_t offset, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (apex FusedLayerNorm semantics: biased variance, eps inside the sqrt, fp32 statistics).
  * Call sites: model/layer.py:108,149 ; model/model.py:229,252,253,258.
@@ -262,6 +272,14 @@ typedef struct UniterEncoderShape {
     float p_attn;        /* attention_probs_dropout_prob  (config/uniter-base.json:2) */
     float ln_eps;        /* 1e-12 (model/layer.py:108)    */
     int32_t training;    /* 0: inference (no dropout, activations not kept) */
+    /* Padding-free ("packed") execution, SURVEY.md §8 f-3.  total_tokens == 0: dense [B, L, H] rows (every example
+     * has L rows, padded keys masked through mask_bias).  total_tokens > 0: x / y / dy / dx are [total_tokens, H], example
+     * b owns rows cu_seqlens[b] .. cu_seqlens[b+1]-1 (device int32 [B+1], cu_seqlens[B] == total_tokens), L is the
+     * longest example; mask_bias is ignored (may be NULL) — only real tokens exist.  Every GEMM / LayerNorm then runs
+     * over total_tokens rows and attention over each example's own length (data/data.py:271-279 builds exactly this
+     * compact order; data/sampler.py:31-57 batches by token count). */
+    int64_t total_tokens;
+    const int32_t* cu_seqlens;
 } UniterEncoderShape;
 
 /* Bytes of saved activations per layer / of shared scratch, for the caller to allocate. */

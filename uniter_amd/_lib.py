@@ -11,6 +11,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "build", "libuniter_hip.so")
+ABI_VERSION = 2          # UNITER_HIP_ABI_VERSION of include/uniter_hip.h (struct layouts below must match it)
 
 
 class UniterHipError(RuntimeError):
@@ -26,7 +27,8 @@ class UniterLayerParams(Structure):
 
 class UniterEncoderShape(Structure):
     _fields_ = [("B", c_int64), ("L", c_int64), ("H", c_int64), ("heads", c_int64), ("I", c_int64),
-                ("p_hidden", c_float), ("p_attn", c_float), ("ln_eps", c_float), ("training", c_int32)]
+                ("p_hidden", c_float), ("p_attn", c_float), ("ln_eps", c_float), ("training", c_int32),
+                ("total_tokens", c_int64), ("cu_seqlens", c_void_p)]
 
 
 class UniterAdamTensor(Structure):
@@ -71,6 +73,8 @@ SIGNATURES = {
     "uniter_gemm_wgrad_ld": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, c_int, _P, c_size_t, _P]),
     "uniter_attention_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
     "uniter_attention_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
+    "uniter_attention_fwd_packed": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
+    "uniter_attention_bwd_packed": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
     "uniter_layernorm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, c_float, c_float, c_uint64, c_uint64, _P]),
     "uniter_layernorm_bwd_workspace_bytes": (c_size_t, [_I, _I]),
     "uniter_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, c_int,
@@ -136,6 +140,9 @@ def load():
         fn = getattr(lib, name)      # AttributeError here = header / library mismatch
         fn.restype = res
         fn.argtypes = args
+    if lib.uniter_hip_abi_version() != ABI_VERSION:
+        raise UniterHipError("libuniter_hip.so has ABI version %d, this package needs %d — rebuild it "
+                             "(python uniter_amd/csrc/build.py --force)" % (lib.uniter_hip_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -67,7 +67,8 @@ struct AttnArgs {
     float* lse;
     const bf16_t* dctx;
     bf16_t* dqkv;
-    int B, L, heads, Lp;
+    int B, L, heads, Lp;   // L = rows per example (dense) or the longest example (packed); Lp = L rounded up to 32
+    const int32_t* cu;     // packed mode: example b owns rows cu[b] .. cu[b+1]-1 of qkv / ctx (NULL = dense [B, L])
     DropoutCfg drop;
 };
 
@@ -84,14 +85,16 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
     const int bh = blockIdx.x;
     const int b = bh / p.heads, h = bh % p.heads;
     const int H = p.heads * DH;
-    const int L = p.L, Lp = p.Lp;
+    const int Lm = p.L, Lp = p.Lp;
+    const int64_t row0 = p.cu ? (int64_t)p.cu[b] : (int64_t)b * Lm;
+    const int L = p.cu ? (p.cu[b + 1] - p.cu[b]) : Lm;         // real rows of this example
     const int64_t ld = 3 * (int64_t)H;
-    const bf16_t* base = p.qkv + (int64_t)b * L * ld + h * DH;
+    const bf16_t* base = p.qkv + row0 * ld + h * DH;
 
     load_tile(Ks, base + H, ld, L, Lp);
     load_tile(Vs, base + 2 * H, ld, L, Lp);
     for (int k = threadIdx.x; k < Lp; k += blockDim.x)
-        mb[k] = (k < L) ? p.mask_bias[(int64_t)b * L + k] : -INFINITY;
+        mb[k] = (k < L) ? (p.mask_bias ? p.mask_bias[(int64_t)b * Lm + k] : 0.f) : -INFINITY;
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -148,10 +151,10 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
         sum += __shfl_xor(sum, 16, WAVE);
         sum += __shfl_xor(sum, 32, WAVE);
         const float inv = 1.0f / sum;
-        if (g == 0 && q < L && p.lse != nullptr) p.lse[(int64_t)bh * L + q] = mx + __logf(sum);
+        if (g == 0 && q < L && p.lse != nullptr) p.lse[(int64_t)bh * Lm + q] = mx + __logf(sum);
 
         const bool drop = p.drop.p > 0.f;
-        const uint64_t drow = ((uint64_t)bh * (uint64_t)L + (uint64_t)q) * (LMAX / 4);
+        const uint64_t drow = ((uint64_t)bh * (uint64_t)Lm + (uint64_t)q) * (LMAX / 4);
 #pragma unroll
         for (int kt = 0; kt < MAXKT; ++kt) {
             if (kt < nkt) {
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
             }
         }
         if (q < L) {
-            bf16_t* dst = p.ctx + ((int64_t)b * L + q) * H + h * DH + 4 * g;
+            bf16_t* dst = p.ctx + (row0 + q) * H + h * DH + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const float v[4] = {o[dt][0], o[dt][1], o[dt][2], o[dt][3]};
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int Lp = p.Lp, L = p.L;
+    const int Lp = p.Lp, Lm = p.L;
     bf16_t* Qs = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* Ks = Qs + Lp * 64;
     bf16_t* Vs = Ks + Lp * 64;
@@ -207,17 +210,19 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
     const int b = bh / p.heads, h = bh % p.heads;
     const int H = p.heads * DH;
     const int64_t ld = 3 * (int64_t)H;
-    const bf16_t* base = p.qkv + (int64_t)b * L * ld + h * DH;
-    const bf16_t* dO = p.dctx + (int64_t)b * L * H + h * DH;
-    const bf16_t* O = p.ctx + (int64_t)b * L * H + h * DH;
+    const int64_t row0 = p.cu ? (int64_t)p.cu[b] : (int64_t)b * Lm;
+    const int L = p.cu ? (p.cu[b + 1] - p.cu[b]) : Lm;         // real rows of this example
+    const bf16_t* base = p.qkv + row0 * ld + h * DH;
+    const bf16_t* dO = p.dctx + row0 * H + h * DH;
+    const bf16_t* O = p.ctx + row0 * H + h * DH;
 
     load_tile(Qs, base, ld, L, Lp);
     load_tile(Ks, base + H, ld, L, Lp);
     load_tile(Vs, base + 2 * H, ld, L, Lp);
     load_tile(Os, dO, H, L, Lp);
     for (int k = threadIdx.x; k < Lp; k += blockDim.x) {
-        mb[k] = (k < L) ? p.mask_bias[(int64_t)b * L + k] : -INFINITY;
-        lse_s[k] = (k < L) ? p.lse[(int64_t)bh * L + k] : INFINITY;
+        mb[k] = (k < L) ? (p.mask_bias ? p.mask_bias[(int64_t)b * Lm + k] : 0.f) : -INFINITY;
+        lse_s[k] = (k < L) ? p.lse[(int64_t)bh * Lm + k] : INFINITY;
     }
     // D[q] = sum_d dO[q][d] * O[q][d]
     for (int idx = threadIdx.x; idx < Lp * 8; idx += blockDim.x) {
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
         const bf16x8 qf0 = at_frag(Qs, q, 0, g), qf1 = at_frag(Qs, q, 1, g);
         const bf16x8 of0 = at_frag(Os, q, 0, g), of1 = at_frag(Os, q, 1, g);
         const float lse_q = lse_s[q], D_q = D_s[q];
-        const uint64_t drow = ((uint64_t)bh * (uint64_t)L + (uint64_t)q) * (LMAX / 4);
+        const uint64_t drow = ((uint64_t)bh * (uint64_t)Lm + (uint64_t)q) * (LMAX / 4);
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
                 dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Ks, u, dt, g, i), dsf, dq[dt], 0, 0, 0);
         }
         if (q < L) {
-            bf16_t* dst = p.dqkv + ((int64_t)b * L + q) * ld + h * DH + 4 * g;
+            bf16_t* dst = p.dqkv + (row0 + q) * ld + h * DH + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const float v[4] = {dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]};
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
             }
         }
         if (key < L) {
-            bf16_t* dst = p.dqkv + ((int64_t)b * L + key) * ld + h * DH + 4 * g;
+            bf16_t* dst = p.dqkv + (row0 + key) * ld + h * DH + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const float kv[4] = {dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]};
@@ -376,7 +381,7 @@ static int check(int64_t B, int64_t L, int64_t heads) {
 }
 
 int attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse,
-                  int64_t B, int64_t L, int64_t heads, const DropoutCfg& drop, hipStream_t st) {
+                  int64_t B, int64_t L, int64_t heads, const DropoutCfg& drop, hipStream_t st, const int32_t* cu) {
     if (check(B, L, heads)) return -1;
     LaunchTimer lt(TIME_ATTN_FWD, B, L, heads, st);
     AttnArgs a{};
@@ -384,6 +389,8 @@ int attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse
     a.dctx = nullptr; a.dqkv = nullptr;
     a.B = (int)B; a.L = (int)L; a.heads = (int)heads; a.Lp = (int)((L + 31) / 32 * 32);
     a.drop = drop;
+    a.cu = cu;
+    if (cu == nullptr && mask_bias == nullptr) { uh_set_error("attention: dense mode needs mask_bias"); return -1; }
     const int nkt = a.Lp / 16;
     const int nw = pick_waves((int)((L + 15) / 16));
     const size_t lds = (size_t)a.Lp * 64 * 2 * 2 + (size_t)a.Lp * 4;
@@ -408,7 +415,7 @@ int attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse
 
 int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, const float* lse,
                   const void* dctx, void* dqkv, int64_t B, int64_t L, int64_t heads,
-                  const DropoutCfg& drop, hipStream_t st) {
+                  const DropoutCfg& drop, hipStream_t st, const int32_t* cu) {
     if (check(B, L, heads)) return -1;
     LaunchTimer lt(TIME_ATTN_BWD, B, L, heads, st);
     AttnArgs a{};
@@ -416,6 +423,8 @@ int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, cons
     a.lse = const_cast<float*>(lse); a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv;
     a.B = (int)B; a.L = (int)L; a.heads = (int)heads; a.Lp = (int)((L + 31) / 32 * 32);
     a.drop = drop;
+    a.cu = cu;
+    if (cu == nullptr && mask_bias == nullptr) { uh_set_error("attention: dense mode needs mask_bias"); return -1; }
     const int nw = pick_waves((int)((L + 15) / 16));
     const size_t lds = (size_t)a.Lp * 64 * 2 * 4 + (size_t)a.Lp * 4 * 3 + (size_t)a.Lp * (a.Lp / 4);
     int rc;

@@ -249,6 +249,23 @@ int uniter_attention_bwd(const void* qkv, const float* mask_bias, const void* ct
                              (hipStream_t)stream);
 }
 
+int uniter_attention_fwd_packed(const void* qkv, const int32_t* cu_seqlens, void* ctx, float* lse,
+                                int64_t B, int64_t max_len, int64_t heads,
+                                float p_drop, uint64_t seed, uint64_t offset, void* stream) {
+    UH_CHECK_ARG(qkv && cu_seqlens && ctx, "null pointer");
+    UH_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "dropout probability must be in [0,1)");
+    return uh::attention_fwd(qkv, nullptr, ctx, lse, B, max_len, heads, make_dropout(p_drop, seed, offset), (hipStream_t)stream, cu_seqlens);
+}
+
+int uniter_attention_bwd_packed(const void* qkv, const int32_t* cu_seqlens, const void* ctx, const float* lse,
+                                const void* dctx, void* dqkv, int64_t B, int64_t max_len, int64_t heads,
+                                float p_drop, uint64_t seed, uint64_t offset, void* stream) {
+    UH_CHECK_ARG(qkv && cu_seqlens && ctx && lse && dctx && dqkv, "null pointer");
+    UH_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "dropout probability must be in [0,1)");
+    return uh::attention_bwd(qkv, nullptr, ctx, lse, dctx, dqkv, B, max_len, heads, make_dropout(p_drop, seed, offset),
+                             (hipStream_t)stream, cu_seqlens);
+}
+
 int uniter_layernorm_fwd(const void* z, const void* gamma, const void* beta, void* y,
                          float* mean, float* rstd, int64_t rows, int64_t H, float eps,
                          float p_drop, uint64_t seed, uint64_t offset, void* stream) {

@@ -14,11 +14,14 @@ namespace {
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// rows every GEMM / LayerNorm works on: B*L dense, or the packed token count
+static inline size_t tokens(const UniterEncoderShape& s) { return s.total_tokens > 0 ? (size_t)s.total_tokens : (size_t)s.B * (size_t)s.L; }
+
 struct ActLayout {
     size_t qkv, lse, ctx, z1, mean1, rstd1, a, u, g, z2, mean2, rstd2, y, total;
 };
 ActLayout act_layout(const UniterEncoderShape& s) {
-    const size_t T = (size_t)s.B * s.L, H = s.H, I = s.I;
+    const size_t T = tokens(s), H = s.H, I = s.I;
     ActLayout l{};
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += align256(bytes); return r; };
@@ -43,7 +46,7 @@ struct ScratchLayout {
     size_t bufA, bufB, dd, dd1, dctx, dqkv, dpre, red, red2, red_bytes, wg, wg_bytes, total;
 };
 ScratchLayout scratch_layout(const UniterEncoderShape& s) {
-    const size_t T = (size_t)s.B * s.L, H = s.H, I = s.I;
+    const size_t T = tokens(s), H = s.H, I = s.I;
     ScratchLayout l{};
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += align256(bytes); return r; };
@@ -107,6 +110,8 @@ int check_shape(const UniterEncoderShape* s) {
     if (s->H != s->heads * 64) { uh_set_error("encoder: hidden_size must be heads*64 (H=%lld heads=%lld)", (long long)s->H, (long long)s->heads); return -1; }
     if (s->H % 64 != 0 || s->I % 64 != 0) { uh_set_error("encoder: H and I must be multiples of 64"); return -1; }
     if (s->L > 256) { uh_set_error("encoder: L=%lld > 256 unsupported", (long long)s->L); return -1; }
+    if (s->total_tokens < 0 || s->total_tokens > s->B * s->L) { uh_set_error("encoder: total_tokens must be in [0, B*L]"); return -1; }
+    if (s->total_tokens > 0 && s->cu_seqlens == nullptr) { uh_set_error("encoder: packed mode needs cu_seqlens"); return -1; }
     return 0;
 }
 
@@ -134,12 +139,13 @@ int uniter_encoder_forward(const UniterEncoderShape* s, const UniterLayerParams*
                            const void* x_in, const float* mask_bias,
                            void* acts, void* scratch, uint64_t seed, uint64_t offset, void* stream) {
     RC(check_shape(s));
-    UH_CHECK_ARG(layers != nullptr && x_in != nullptr && mask_bias != nullptr && acts != nullptr, "null pointer");
+    UH_CHECK_ARG(layers != nullptr && x_in != nullptr && acts != nullptr, "null pointer");
+    UH_CHECK_ARG(mask_bias != nullptr || s->total_tokens > 0, "dense mode needs mask_bias");
     UH_CHECK_ARG(layer_begin >= 0 && layer_end >= layer_begin, "bad layer range");
     (void)scratch;
     hipStream_t st = (hipStream_t)stream;
     const ActLayout al = act_layout(*s);
-    const int64_t T = s->B * s->L, H = s->H, I = s->I;
+    const int64_t T = (int64_t)tokens(*s), H = s->H, I = s->I;
     const bool tr = s->training != 0;
     const DropoutCfg nodrop = make_dropout(0.f, 0, 0);
     const char* x = (const char*)x_in;
@@ -153,7 +159,8 @@ int uniter_encoder_forward(const UniterEncoderShape* s, const UniterLayerParams*
         // model/layer.py:76-78  (three Linear(H,H) fused into one [3H,H] GEMM)
         RC(uh::gemm_fwd(uh::GEMM_EPI_BIAS, x, P.wqkv, P.bqkv, nullptr, A + al.qkv, nullptr, T, 3 * H, H, nodrop, st));
         // model/layer.py:80-100
-        RC(uh::attention_fwd(A + al.qkv, mask_bias, A + al.ctx, (float*)(A + al.lse), s->B, s->L, s->heads, d_attn, st));
+        RC(uh::attention_fwd(A + al.qkv, s->total_tokens > 0 ? nullptr : mask_bias, A + al.ctx, (float*)(A + al.lse), s->B, s->L, s->heads, d_attn, st,
+                             s->total_tokens > 0 ? s->cu_seqlens : nullptr));
         // model/layer.py:112-114  dense + dropout + residual
         RC(uh::gemm_fwd(uh::GEMM_EPI_BIAS_DROP_RES, A + al.ctx, P.wo, P.bo, x, A + al.z1, nullptr, T, H, H, d_h1, st));
         RC(uh::layernorm_fwd(A + al.z1, P.ln1_g, P.ln1_b, A + al.a, (float*)(A + al.mean1), (float*)(A + al.rstd1),
@@ -174,14 +181,15 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
                             const void* x_in, const float* mask_bias, const void* dy, void* dx,
                             void* acts, void* scratch, uint64_t seed, uint64_t offset, void* stream) {
     RC(check_shape(s));
-    UH_CHECK_ARG(layers != nullptr && x_in != nullptr && mask_bias != nullptr && acts != nullptr && scratch != nullptr, "null pointer");
+    UH_CHECK_ARG(layers != nullptr && x_in != nullptr && acts != nullptr && scratch != nullptr, "null pointer");
+    UH_CHECK_ARG(mask_bias != nullptr || s->total_tokens > 0, "dense mode needs mask_bias");
     UH_CHECK_ARG(dy != nullptr && dx != nullptr, "null gradient pointer");
     UH_CHECK_ARG(layer_begin >= 0 && layer_end > layer_begin, "bad layer range");
     UH_CHECK_ARG(s->training != 0, "backward needs a training-mode forward");
     hipStream_t st = (hipStream_t)stream;
     const ActLayout al = act_layout(*s);
     const ScratchLayout sl = scratch_layout(*s);
-    const int64_t T = s->B * s->L, H = s->H, I = s->I;
+    const int64_t T = (int64_t)tokens(*s), H = s->H, I = s->I;
     char* S = (char*)scratch;
     char* bufA = S + sl.bufA;
     char* bufB = S + sl.bufB;
@@ -274,8 +282,8 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dd1, P.wo, nullptr, dctx, T, H, H, st));
         // ---- BertSelfAttention backward (model/layer.py:75-101) ----
         RC(before_overwrite(3));
-        RC(uh::attention_bwd(A + al.qkv, mask_bias, A + al.ctx, (const float*)(A + al.lse), dctx, dqkv,
-                             s->B, s->L, s->heads, d_attn, st));
+        RC(uh::attention_bwd(A + al.qkv, s->total_tokens > 0 ? nullptr : mask_bias, A + al.ctx, (const float*)(A + al.lse), dctx, dqkv,
+                             s->B, s->L, s->heads, d_attn, st, s->total_tokens > 0 ? s->cu_seqlens : nullptr));
         RC(fork(3));
         RC(uh::colsum(dqkv, P.g_bqkv, T, 3 * H, 1, side ? red2 : red, sl.red_bytes, ss));
         RC(uh::gemm_wgrad(dqkv, xin, P.g_wqkv, T, 3 * H, H, 1, wg, sl.wg_bytes, ss));
@@ -297,7 +305,7 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
 int uniter_encoder_autotune(const UniterEncoderShape* s, void* stream) {
     RC(check_shape(s));
     hipStream_t st = (hipStream_t)stream;
-    const int64_t T = s->B * s->L, H = s->H, I = s->I;
+    const int64_t T = (int64_t)tokens(*s), H = s->H, I = s->I;
     const int64_t shapes[4][2] = {{3 * H, H}, {H, H}, {I, H}, {H, I}};      // (N = out features, K = in features)
     for (int kind = 0; kind < 3; ++kind)
         for (int g = 0; g < 4; ++g) RC(uh::gemm_autotune(kind, T, shapes[g][0], shapes[g][1], st));

@@ -699,12 +699,27 @@ std::map<std::tuple<int, int64_t, int64_t, int64_t>, Tuned> g_tuned;    // (kind
 std::map<std::tuple<int, int64_t, int64_t, int64_t>, std::vector<Tuned>> g_ranked;   // autotune sweep: fastest first
 std::mutex g_tuned_mu;
 
+// M only matters for wgrad, where it is the contraction length (wave-specialised tiles need whole 64-row K steps)
+bool tuned_fits(int kind, int64_t M, const Tuned& t) {
+    if (kind != 2 || t.cfg < 0 || t.cfg >= kNumTiles) return true;
+    return !(kTiles[t.cfg].ws && M % (64 * (int64_t)t.splits) != 0);
+}
+
+// Exact (kind, M, N, K) entry, else — packed batches change the token count M every step — the entry of the same
+// (kind, N, K) whose M is closest (within 2x) and whose tile is still legal for this M.
 bool tuned_lookup(int kind, int64_t M, int64_t N, int64_t K, Tuned* out) {
     std::lock_guard<std::mutex> lk(g_tuned_mu);
     auto it = g_tuned.find(std::make_tuple(kind, M, N, K));
-    if (it == g_tuned.end()) return false;
-    *out = it->second;
-    return true;
+    if (it != g_tuned.end()) { *out = it->second; return true; }
+    int64_t best_d = -1;
+    for (const auto& kv : g_tuned) {
+        if (std::get<0>(kv.first) != kind || std::get<2>(kv.first) != N || std::get<3>(kv.first) != K) continue;
+        const int64_t m2 = std::get<1>(kv.first);
+        if (m2 > 2 * M || M > 2 * m2 || !tuned_fits(kind, M, kv.second)) continue;
+        const int64_t d = m2 > M ? m2 - M : M - m2;
+        if (best_d < 0 || d < best_d) { best_d = d; *out = kv.second; }
+    }
+    return best_d >= 0;
 }
 
 int pick_cfg(int M, int N, bool trm, bool trn, bool k_mult64 = false) {

@@ -42,10 +42,11 @@ void gemm_set_num_cus(int n);
 
 // ---- attention.hip ----
 int attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse,
-                  int64_t B, int64_t L, int64_t heads, const DropoutCfg& drop, hipStream_t st);
+                  int64_t B, int64_t L, int64_t heads, const DropoutCfg& drop, hipStream_t st,
+                  const int32_t* cu = nullptr);
 int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, const float* lse,
                   const void* dctx, void* dqkv, int64_t B, int64_t L, int64_t heads,
-                  const DropoutCfg& drop, hipStream_t st);
+                  const DropoutCfg& drop, hipStream_t st, const int32_t* cu = nullptr);
 
 // ---- layernorm.hip ----
 int layernorm_fwd(const void* z, const void* gamma, const void* beta, void* y, float* mean, float* rstd,

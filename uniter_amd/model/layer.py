@@ -217,6 +217,20 @@ def run_layers(layers, hidden_states, attention_mask, output_all=False, hook=Non
     return ops.encoder_forward(layers, hidden_states, mask, cfg, training, need_all=output_all, hook=hook)
 
 
+def run_layers_packed(layers, hidden_states, cu_seqlens, n_examples, max_len, output_all=False, hook=None):
+    """Padding-free variant: hidden_states [T, H] holds only real tokens (see ops.encoder_forward_packed)."""
+    layers = list(layers)
+    first = layers[0]
+    cfg = dict(first._enc_cfg)
+    p_h, p_a = layer_dropouts(first)
+    for lay in layers[1:]:
+        if layer_dropouts(lay) != (p_h, p_a):
+            raise UniterHipError("all layers of one encoder call must share their dropout probabilities")
+    cfg["p_hidden"], cfg["p_attn"] = p_h, p_a
+    return ops.encoder_forward_packed(layers, hidden_states, cu_seqlens, n_examples, max_len, cfg, first.training,
+                                      need_all=output_all, hook=hook)
+
+
 class BertLayer(nn.Module):
     """One transformer block; forward(hidden_states, attention_mask) as model/layer.py:166-170.
 

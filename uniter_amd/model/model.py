@@ -7,6 +7,7 @@ prefix, lenient missing / unexpected keys), module attribute paths, state_dict k
 encoder stack run as HIP kernels (uniter_amd/ops.py -> include/uniter_hip.h).
 """
 import copy
+import os
 import json
 import logging
 from io import open
@@ -15,7 +16,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from .layer import BertLayer, BertLayerNorm, BertPooler, run_layers
+from .layer import run_layers_packed, BertLayer, BertLayerNorm, BertPooler, run_layers
 
 logger = logging.getLogger(__name__)
 
@@ -203,6 +204,50 @@ class UniterEncoder(nn.Module):
             return list(outs)
         return [run_layers(self.layer, input_, attention_mask, output_all=False, hook=self.grad_ready_hook)]
 
+    def forward_packed(self, input_, valid_mask, output_all_encoded_layers=True, seq_lens=None):
+        """Padding-free execution.  input_ [B, L, H]; valid_mask [B, L] (1 = real token; the real
+        tokens of every row must form a prefix, which is how gather_index lays sequences out, data/data.py:271-279).
+        Only the real tokens go through the layers; the returned [B, L, H] tensors are ZERO at padded positions (the
+        reference computes values there that no head ever reads).  With `seq_lens` (host-side list / CPU tensor of the
+        B real lengths) nothing synchronises; without it the token count is read back from the device (one sync)."""
+        B, L, H = input_.shape
+        dev = input_.device
+        if seq_lens is not None:
+            lens_host = [int(v) for v in (seq_lens.tolist() if torch.is_tensor(seq_lens) else seq_lens)]
+            if len(lens_host) != B or any(v < 0 or v > L for v in lens_host):
+                raise ValueError("seq_lens must hold B lengths in [0, L]")
+            lens = torch.tensor(lens_host, dtype=torch.int32)
+            idx = torch.cat([torch.arange(v, dtype=torch.int64) + b * L for b, v in enumerate(lens_host)])
+            total = int(idx.numel())
+            lens = lens.to(dev, non_blocking=True)
+            idx = idx.to(dev, non_blocking=True)
+        else:
+            valid = valid_mask.reshape(B, L) != 0
+            lens = valid.sum(dim=1, dtype=torch.int32)
+            idx = valid.reshape(-1).nonzero(as_tuple=False).squeeze(1)    # host sync: number of real tokens
+            total = int(idx.numel())
+        # keep the GEMM contraction (token) length a multiple of 64 for the wave-specialised wgrad tiles: the remainder
+        # becomes extra all-zero "examples" whose outputs are dropped (their gradients are exactly zero)
+        pad = (-total) % 64
+        extra = []
+        while pad > 0:
+            extra.append(min(pad, L))
+            pad -= extra[-1]
+        all_lens = torch.cat([lens, torch.tensor(extra, dtype=torch.int32, device=lens.device)]) if extra else lens
+        cu = torch.zeros(all_lens.numel() + 1, dtype=torch.int32, device=lens.device)
+        cu[1:] = torch.cumsum(all_lens, dim=0)
+        x = input_.reshape(B * L, H).index_select(0, idx)
+        if extra:
+            x = torch.cat([x, x.new_zeros(sum(extra), H)], dim=0)
+        outs = run_layers_packed(self.layer, x, cu, B + len(extra), int(L), output_all=output_all_encoded_layers,
+                                 hook=self.grad_ready_hook)
+        outs = list(outs) if output_all_encoded_layers else [outs]
+
+        def unpack(y):
+            return y.new_zeros(B * L, H).index_copy(0, idx, y[:total]).view(B, L, H)
+
+        return [unpack(y) for y in outs]
+
 
 class UniterModel(UniterPreTrainedModel):
     """Joint vision-language encoder (model/model.py:295-367)."""
@@ -213,6 +258,13 @@ class UniterModel(UniterPreTrainedModel):
         self.img_embeddings = UniterImageEmbeddings(config, img_dim)
         self.encoder = UniterEncoder(config)
         self.pooler = BertPooler(config)
+        # True: run the encoder on real tokens only (UniterEncoder.forward_packed); off by default because it costs a
+        # host sync per step and changes nothing when batches have no padding.  UNITER_AMD_PACK_PADDING=1 turns it on.
+        self.pack_padding = os.environ.get("UNITER_AMD_PACK_PADDING", "0") == "1"
+        # host-side sequence lengths of the NEXT forward (list / CPU tensor of B ints = tl + nbb, which the collate
+        # knows: data/data.py:255-279): lets the packed path build its index tables without a device sync.  The task
+        # wrappers copy batch['seq_lens'] here; consumed (reset to None) by forward.
+        self.seq_lens_hint = None
         self.apply(self.init_weights)
 
     def _compute_txt_embeddings(self, input_ids, position_ids, txt_type_ids=None):
@@ -244,8 +296,14 @@ class UniterModel(UniterPreTrainedModel):
                 input_ids, position_ids, img_feat, img_pos_feat, gather_index, img_masks, txt_type_ids,
                 img_type_ids)
 
-        encoded_layers = self.encoder(embedding_output, extended_attention_mask,
-                                      output_all_encoded_layers=output_all_encoded_layers)
+        lens_hint, self.seq_lens_hint = self.seq_lens_hint, None
+        if self.pack_padding:
+            encoded_layers = self.encoder.forward_packed(embedding_output, attention_mask,
+                                                         output_all_encoded_layers=output_all_encoded_layers,
+                                                         seq_lens=lens_hint)
+        else:
+            encoded_layers = self.encoder(embedding_output, extended_attention_mask,
+                                          output_all_encoded_layers=output_all_encoded_layers)
         if not output_all_encoded_layers:
             encoded_layers = encoded_layers[-1]
         return encoded_layers

@@ -33,6 +33,7 @@ class _Nlvr2Base(UniterPreTrainedModel):
 
     def _encode(self, batch):
         batch = defaultdict(lambda: None, batch)
+        self.uniter.seq_lens_hint = batch['seq_lens']          # optional host-side lengths (packed execution, no sync)
         seq = self.uniter(batch['input_ids'], batch['position_ids'], batch['img_feat'], batch['img_pos_feat'],
                           batch['attn_masks'], batch['gather_index'], output_all_encoded_layers=False,
                           img_type_ids=batch['img_type_ids'])

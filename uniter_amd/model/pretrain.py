@@ -68,6 +68,7 @@ class UniterForPretraining(UniterPreTrainedModel):
 
     def forward(self, batch, task, compute_loss=True):
         batch = defaultdict(lambda: None, batch)
+        self.uniter.seq_lens_hint = batch['seq_lens']          # optional host-side lengths (packed execution, no sync)
         if task == 'mlm':
             return self.forward_mlm(batch['input_ids'], batch['position_ids'], batch['img_feat'],
                                     batch['img_pos_feat'], batch['attn_masks'], batch['gather_index'],

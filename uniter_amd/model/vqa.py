@@ -20,6 +20,7 @@ class UniterForVisualQuestionAnswering(UniterPreTrainedModel):
 
     def forward(self, batch, compute_loss=True):
         batch = defaultdict(lambda: None, batch)
+        self.uniter.seq_lens_hint = batch['seq_lens']          # optional host-side lengths (packed execution, no sync)
         sequence_output = self.uniter(batch['input_ids'], batch['position_ids'], batch['img_feat'],
                                       batch['img_pos_feat'], batch['attn_masks'], batch['gather_index'],
                                       output_all_encoded_layers=False)

@@ -294,25 +294,44 @@ class _EncoderFn(torch.autograd.Function):
     """All BertLayers of a UniterEncoder in one autograd node (model/model.py:282-292)."""
 
     @staticmethod
-    def forward(ctx, x, mask_bias, layers, cfg_like, training, need_all, hook, *params):
-        B, L, H = x.shape
-        s = _shape(cfg_like, B, L, training)
+    def forward(ctx, x, mask_bias, layers, cfg_like, training, need_all, hook, packed, *params):
+        # dense: x [B, L, H], mask_bias [B, L];  packed: x [T, H], packed = (cu_seqlens int32 [B+1] on device, B, Lmax)
+        if packed is None:
+            B, L, H = x.shape
+            s = _shape(cfg_like, B, L, training)
+            out_shape = (B, L, H)
+        else:
+            cu, B, L = packed
+            H = x.shape[1]
+            s = _shape(cfg_like, B, L, training)
+            s.total_tokens = x.shape[0]
+            s.cu_seqlens = cu.data_ptr()
+            out_shape = (x.shape[0], H)
+        ctx.packed = packed
         n = len(layers)
         act_bytes = C.uniter_encoder_layer_act_bytes(ctypes.byref(s))
         if act_bytes == 0:
             raise _lib.UniterHipError("bad encoder shape: " + _lib.load().uniter_hip_last_error().decode())
         out_off = C.uniter_encoder_layer_out_offset(ctypes.byref(s))
-        _maybe_autotune(s, training)
+        if packed is None:
+            _maybe_autotune(s, training)
+        else:
+            # the token count changes every step: sweep once per power-of-two bucket on a dense stand-in shape; the
+            # library then reuses the nearest tuned M for the actual count (gemm.hip tuned_lookup)
+            bucket = 1 << max(int(x.shape[0]) - 1, 1).bit_length()
+            _maybe_autotune(_shape(cfg_like, max(bucket // 64, 1), 64, training), training)
         acts = torch.empty(n * act_bytes, dtype=torch.uint8, device=x.device)
         table, keep = _layer_table(layers, with_grads=False)
         seed, off = _next_offsets(n * 8) if training else (0, 0)
         xc = x.contiguous()
-        C.uniter_encoder_forward(ctypes.byref(s), table, 0, n, ptr(xc), ptr(mask_bias), ptr(acts), None,
-                                 seed, off, _lib.stream_ptr())
+        C.uniter_encoder_forward(ctypes.byref(s), table, 0, n, ptr(xc), None if packed is not None else ptr(mask_bias),
+                                 ptr(acts), None, seed, off, _lib.stream_ptr())
+
+        n_rows = out_shape[0] if packed is not None else B * L
 
         def layer_out(l):
             o = l * act_bytes + out_off
-            return acts[o:o + B * L * H * 2].view(_BF16).view(B, L, H)
+            return acts[o:o + n_rows * H * 2].view(_BF16).view(*out_shape)
 
         ctx.layers, ctx.cfg_like, ctx.s = layers, cfg_like, s
         ctx.acts, ctx.act_bytes = acts, act_bytes
@@ -331,7 +350,8 @@ class _EncoderFn(torch.autograd.Function):
         n = len(layers)
         if not s.training:
             raise _lib.UniterHipError("backward through an encoder forward that ran in eval mode / under no_grad")
-        B, L, H = xc.shape
+        out_shape = tuple(xc.shape)
+        H = out_shape[-1]
         scr_bytes = C.uniter_encoder_scratch_bytes(ctypes.byref(s))
         scratch = _scratch(("enc", xc.device.index), scr_bytes, xc.device)
         table, keep = _layer_table(layers, with_grads=True)
@@ -341,13 +361,13 @@ class _EncoderFn(torch.autograd.Function):
         else:
             extra = [None] * (n - 1) + [grads[0]]
         if extra[n - 1] is None:
-            extra[n - 1] = torch.zeros(B, L, H, dtype=_BF16, device=xc.device)
+            extra[n - 1] = torch.zeros(out_shape, dtype=_BF16, device=xc.device)
         dy = extra[n - 1].contiguous()
         end = n
         st = _lib.stream_ptr()
         act_bytes = ctx.act_bytes
         out_off = C.uniter_encoder_layer_out_offset(ctypes.byref(s))
-        dx = torch.empty(B, L, H, dtype=_BF16, device=xc.device)
+        dx = torch.empty(out_shape, dtype=_BF16, device=xc.device)
         cuts = set(l for l in range(n - 1) if extra[l] is not None)
         hook = ctx.hook
         while end > 0:
@@ -360,7 +380,8 @@ class _EncoderFn(torch.autograd.Function):
                 x_in = ptr(xc)
             else:
                 x_in = ctx.acts.data_ptr() + (begin - 1) * act_bytes + out_off
-            C.uniter_encoder_backward(ctypes.byref(s), table, begin, end, x_in, ptr(mask_bias), ptr(dy), ptr(dx),
+            C.uniter_encoder_backward(ctypes.byref(s), table, begin, end, x_in,
+                                      None if ctx.packed is not None else ptr(mask_bias), ptr(dy), ptr(dx),
                                       ptr(ctx.acts), ptr(scratch), ctx.seed, ctx.off, st)
             if hook is not None:
                 for l in range(end - 1, begin - 1, -1):
@@ -372,7 +393,7 @@ class _EncoderFn(torch.autograd.Function):
                     dx = dx + extra[end - 1]
                 dy, dx = dx, torch.empty_like(dx)
         del keep
-        return (dx if ctx.needs_input_grad[0] else None, None, None, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 7)
+        return (dx if ctx.needs_input_grad[0] else None, None, None, None, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 8)
 
 
 def encoder_forward(layers, x, mask_bias, cfg_like, training, need_all=False, hook=None):
@@ -388,13 +409,33 @@ def encoder_forward(layers, x, mask_bias, cfg_like, training, need_all=False, ho
     track = torch.is_grad_enabled() and training
     if not track:
         with torch.no_grad():
-            return _EncoderFn.apply(x, mask_bias, list(layers), cfg_like, False, need_all, None)
+            return _EncoderFn.apply(x, mask_bias, list(layers), cfg_like, False, need_all, None, None)
     # one parameter is enough to make the output require grad (gradients are written straight into .grad)
     anchor = layers[0].output.dense.weight
     if not anchor.requires_grad:
         anchor = next((p for lay in layers for p in lay.parameters() if p.requires_grad), None)
     extra = () if anchor is None else (anchor,)
-    return _EncoderFn.apply(x, mask_bias, list(layers), cfg_like, True, need_all, hook, *extra)
+    return _EncoderFn.apply(x, mask_bias, list(layers), cfg_like, True, need_all, hook, None, *extra)
+
+
+def encoder_forward_packed(layers, x, cu_seqlens, n_examples, max_len, cfg_like, training, need_all=False, hook=None):
+    """Padding-free form: x [T, H] bf16 holds only real tokens, example b = rows
+    cu_seqlens[b] .. cu_seqlens[b+1]-1 (int32 [n_examples+1] on the device), max_len = longest example."""
+    _check_dev(x, "hidden_states")
+    _check_dev(cu_seqlens, "cu_seqlens", torch.int32)
+    if x.dim() != 2 or cu_seqlens.numel() != n_examples + 1:
+        raise _lib.UniterHipError("packed hidden_states must be [T, H] and cu_seqlens [n_examples + 1]")
+    packed = (cu_seqlens.contiguous(), int(n_examples), int(max_len))
+    dummy_mask = cu_seqlens                      # placeholder argument of the autograd node; never handed to a kernel
+    track = torch.is_grad_enabled() and training
+    if not track:
+        with torch.no_grad():
+            return _EncoderFn.apply(x.contiguous(), dummy_mask, list(layers), cfg_like, False, need_all, None, packed)
+    anchor = layers[0].output.dense.weight
+    if not anchor.requires_grad:
+        anchor = next((p for lay in layers for p in lay.parameters() if p.requires_grad), None)
+    extra = () if anchor is None else (anchor,)
+    return _EncoderFn.apply(x.contiguous(), dummy_mask, list(layers), cfg_like, True, need_all, hook, packed, *extra)
 
 
 # ----------------------------------------------------------------------------------------------------

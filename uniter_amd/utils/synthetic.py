@@ -77,7 +77,10 @@ def make_batch(task, batch_size, max_txt_len=60, num_bb=36, img_dim=2048, vocab_
     gather_index = get_gather_index(txt_lens, num_bbs, B, Lt, out_size)
 
     batch = {'input_ids': input_ids, 'position_ids': position_ids, 'img_feat': img_feat,
-             'img_pos_feat': img_pos_feat, 'attn_masks': attn_masks, 'gather_index': gather_index}
+             'img_pos_feat': img_pos_feat, 'attn_masks': attn_masks, 'gather_index': gather_index,
+             # host-side real lengths (a python list, so to_device leaves it on the host): optional hint for the
+             # padding-free encoder path
+             'seq_lens': [tl + nbb for tl, nbb in zip(txt_lens, num_bbs)]}
 
     if task == 'mlm':
         txt_labels = torch.full((B, Lt), -1, dtype=torch.long)
