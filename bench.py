@@ -257,7 +257,8 @@ def main():
     arena = flatten_model(model)
     D.broadcast_tensors([p.data for p in model.parameters()], 0)        # train_nlvr2.py:118
     optimizer = build_optimizer(model, opts)
-    reducer = D.GradientReducer(arena, model.uniter.encoder) if world > 1 else None
+    lpb = int(os.environ.get("UNITER_BENCH_LAYERS_PER_BUCKET", "4"))
+    reducer = D.GradientReducer(arena, model.uniter.encoder, layers_per_bucket=lpb) if (world > 1 or D._on()) else None
     # each rank trains on its own shard (data/data.py:222): different synthetic batch per rank, resident in HBM
     batch = to_device(make_batch('nlvr2', TRAIN['batch'], TRAIN['max_txt_len'], TRAIN['num_bb'], seed=1000 + rank,
                                  ragged=args.ragged), device)

@@ -371,11 +371,17 @@ class _EncoderFn(torch.autograd.Function):
         cuts = set(l for l in range(n - 1) if extra[l] is not None)
         hook = ctx.hook
         while end > 0:
+            inner = [c for c in cuts if c + 1 < end]
+            begin = (max(inner) + 1) if inner else 0
             if hook is not None:
-                begin = end - 1        # per-layer calls so the hook fires as soon as a layer's gradients are enqueued
-            else:
-                inner = [c for c in cuts if c + 1 < end]
-                begin = (max(inner) + 1) if inner else 0
+                # hand control back where the hook has work (a gradient bucket completes), else after every layer
+                ready = getattr(hook, "ready_layers", None)
+                if ready is None:
+                    begin = end - 1
+                else:
+                    stops = [l for l in ready if begin < l < end]
+                    if stops:
+                        begin = max(stops)
             if begin == 0:
                 x_in = ptr(xc)
             else:

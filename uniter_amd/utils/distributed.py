@@ -35,8 +35,12 @@ def init(backend=None):
     if dist.is_available() and dist.is_initialized():
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and not _FORCE:
         return
+    if world <= 1:                     # UNITER_DIST_FORCE=1: a one-rank group, to exercise the collective path on one GPU
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_PORT", "29517")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
@@ -45,8 +49,11 @@ def init(backend=None):
     dist.init_process_group(backend=backend)
 
 
+_FORCE = os.environ.get("UNITER_DIST_FORCE", "0") == "1"
+
+
 def _on():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
 
 
 def rank():
@@ -202,6 +209,17 @@ def any_broadcast(data, root_rank):
 # ------------------------------------------------------------------------------------------------------
 # overlapped, bucketed gradient allreduce
 # ------------------------------------------------------------------------------------------------------
+class _LayerHook(object):
+    """callable(layer_index) + the set of layers at which it actually has work to do."""
+
+    def __init__(self, fn, ready_layers):
+        self.fn = fn
+        self.ready_layers = ready_layers
+
+    def __call__(self, layer_index):
+        return self.fn(layer_index)
+
+
 class GradientReducer(object):
     """Bucketed in-place sum-allreduce of a gradient arena, overlapped with backward.
 
@@ -218,7 +236,7 @@ class GradientReducer(object):
     (heads finish first in backward, embeddings last: both are small next to the encoder).
     """
 
-    def __init__(self, arena, encoder=None, layers_per_bucket=2):
+    def __init__(self, arena, encoder=None, layers_per_bucket=4):
         self.arena = arena
         self.encoder = encoder
         self.buckets = []          # (lo, hi) element ranges
@@ -238,7 +256,9 @@ class GradientReducer(object):
                 self.layer_bucket[lo_l] = len(self.buckets)     # ready once layer lo_l's backward is enqueued
                 self.buckets.append(span)
                 covered.append(span)
-            encoder.grad_ready_hook = self._on_layer
+            # backward only has to hand control back at the layers that complete a bucket (ops._EncoderFn.backward cuts
+            # the stack there instead of after every layer)
+            encoder.grad_ready_hook = _LayerHook(self._on_layer, set(self.layer_bucket.keys()))
         covered.sort()
         pos = 0
         for lo, hi in covered:
