@@ -359,6 +359,21 @@ int uniter_adamw_step(void* plan, const UniterAdamGroup* groups, int32_t n_group
 int uniter_adamw_step_dev(void* plan, const float* dev_hyper, int32_t n_groups, const float* clip_coef, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Attention pooling of the NLVR2 paired-attention head — model/nlvr2.py:110-125 (AttentionPool):
+ *   score_t = relu(x_t . w + b) - 1e4 * pad_t ; p = dropout(softmax_t(score)) ; out[B,H] = sum_t p_t x_t
+ * x [B,L,H] bf16, pad [B,L] uint8/bool (1 = padded, may be NULL), w [H] bf16 (= fc.0.weight[0]), b [1] bf16.
+ * Saved for backward (fp32 [B,L] each): raw = x_t.w + b, sm = softmax, pw = softmax * dropout multiplier.
+ * Backward: dx [B,L,H] ; dw [H], db [1] are accumulated into (+=, bf16; either may be NULL).  L <= 256, H <= 1024.
+ * ---------------------------------------------------------------------------------------------- */
+size_t uniter_attn_pool_workspace_bytes(int64_t B, int64_t H);
+int uniter_attn_pool_fwd(const void* x, const uint8_t* pad, const void* w, const void* b, void* out,
+                         float* raw, float* sm, float* pw, int64_t B, int64_t L, int64_t H,
+                         float p_drop, uint64_t seed, uint64_t offset, void* stream);
+int uniter_attn_pool_bwd(const void* x, const void* w, const float* raw, const float* sm, const float* pw,
+                         const void* dout, void* dx, void* dw, void* db, int64_t B, int64_t L, int64_t H,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Word-region alignment loss: IPOT optimal-transport distance.
  * Replaces model/ot.py:11-85 (cost_matrix_cosine, ipot, trace) and the un-compaction scatter of
  * model/pretrain.py:166-181 — one workgroup per example instead of ~8 PyTorch launches x 50 iterations.

@@ -869,3 +869,38 @@ def test_packed_attention_kernel_matches_dense_masked():
     C.uniter_attention_bwd(qkv_d.data_ptr(), mask.data_ptr(), ctx_d.data_ptr(), lse_d.data_ptr(), dctx_z.data_ptr(),
                            dqkv_z.data_ptr(), B, L, heads, 0.0, 0, 0, st)
     torch.testing.assert_close(got, dqkv_z.view(B * L, -1).index_select(0, rows).float(), rtol=0, atol=0)
+
+
+def test_attention_pool_kernel_vs_torch_fp32():
+    """uniter_attn_pool_{fwd,bwd} (model/nlvr2.py:110-125) against the same formula in torch fp32 on the bf16 inputs."""
+    from uniter_amd import ops
+    dev = _dev()
+    B, L, H = 6, 96, 768
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, L, H, generator=g).to(dev, torch.bfloat16).requires_grad_(True)
+    lin = torch.nn.Linear(H, 1).to(dev).bfloat16()
+    with torch.no_grad():
+        lin.weight.copy_((torch.randn(1, H, generator=g) * 0.05).to(dev, torch.bfloat16))
+        lin.bias.fill_(0.1)
+    pad = torch.zeros(B, L, dtype=torch.bool)
+    for b in range(1, B):
+        pad[b, 30 + 10 * b:] = True
+    pad = pad.to(dev)
+    w_out = torch.randn(B, H, generator=g).to(dev)
+    out = ops.attention_pool(x, pad, lin, 0.0, True)
+    (out.float() * w_out).sum().backward()
+    got = (out.detach().float().cpu(), x.grad.float().cpu(), lin.weight.grad.float().cpu(), lin.bias.grad.float().cpu())
+
+    xr = x.detach().float().requires_grad_(True)
+    wr = lin.weight.detach().float().requires_grad_(True)
+    br = lin.bias.detach().float().requires_grad_(True)
+    score = torch.relu(xr @ wr.t() + br).squeeze(-1) + pad.float() * -1e4
+    ref = (torch.softmax(score, dim=1).unsqueeze(1) @ xr).squeeze(1)
+    (ref * w_out).sum().backward()
+    torch.testing.assert_close(got[0], ref.detach().cpu(), rtol=1e-2, atol=1e-2)
+    assert rel_l2(got[1], xr.grad.cpu()) <= 1e-2 and cosine(got[1], xr.grad.cpu()) >= 0.9999
+    assert rel_l2(got[2], wr.grad.cpu()) <= 2e-2, rel_l2(got[2], wr.grad.cpu())
+    assert abs(float(got[3]) - float(br.grad)) <= 2e-2 * max(1.0, abs(float(br.grad)))
+    # dropout: weights are either 0 or sm / (1 - p), and the mean survives
+    out_d = ops.attention_pool(x.detach(), pad, lin, 0.5, True)
+    assert torch.isfinite(out_d.float()).all()

@@ -108,6 +108,9 @@ SIGNATURES = {
     "uniter_adamw_grad_norm": (c_int, [_P, c_float, c_float, _P, _P]),
     "uniter_adamw_step": (c_int, [_P, POINTER(UniterAdamGroup), c_int32, _P, _P]),
     "uniter_adamw_step_dev": (c_int, [_P, _P, c_int32, _P, _P]),
+    "uniter_attn_pool_workspace_bytes": (c_size_t, [_I, _I]),
+    "uniter_attn_pool_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
+    "uniter_attn_pool_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
     "uniter_ot_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, c_float, c_int32, c_int32, _P]),
     "uniter_ot_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "uniter_comm_unique_id": (c_int, [POINTER(c_uint8)]),
@@ -121,6 +124,7 @@ SIGNATURES = {
 # functions that return a size / pointer rather than a status code
 _NO_STATUS = {"uniter_hip_abi_version", "uniter_hip_last_error", "uniter_gemm_wgrad_workspace_bytes",
               "uniter_layernorm_bwd_workspace_bytes", "uniter_colsum_workspace_bytes", "uniter_embed_ws_bytes",
+              "uniter_attn_pool_workspace_bytes",
               "uniter_encoder_layer_act_bytes", "uniter_encoder_scratch_bytes", "uniter_encoder_layer_out_offset"}
 
 _lib = None

@@ -86,6 +86,10 @@ class AttentionPool(nn.Module):
 
     def forward(self, input_, mask=None):
         """input_ [B, T, D], mask [B, T] (True = padding)."""
+        if (input_.is_cuda and input_.dtype == torch.bfloat16 and input_.size(1) <= 256 and input_.size(2) <= 1024
+                and input_.size(2) % 8 == 0 and self.fc[0].weight.dtype == torch.bfloat16):
+            from .. import ops
+            return ops.attention_pool(input_, mask, self.fc[0], self.dropout.p, self.training)   # one fused kernel
         score = self.fc(input_).squeeze(-1)
         if mask is not None:
             score = score + mask.to(dtype=input_.dtype) * -1e4

@@ -835,3 +835,51 @@ def optimal_transport_dist(seq, ot_scatter, txt_pad, img_pad, beta=0.5, iteratio
     tp = txt_pad.to(device=dev, dtype=torch.uint8).contiguous()
     ip = img_pad.to(device=dev, dtype=torch.uint8).contiguous()
     return _OtDistFn.apply(seq.contiguous(), sc, tp, ip, beta, iteration, k)
+
+
+# ----------------------------------------------------------------------------------------------------
+# attention pooling of the NLVR2 paired-attention head (model/nlvr2.py:110-125)
+# ----------------------------------------------------------------------------------------------------
+class _AttnPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pad, lin, p_drop, training, *anchor):
+        B, L, H = x.shape
+        dev = x.device
+        out = torch.empty(B, H, dtype=_BF16, device=dev)
+        raw = torch.empty(B, L, dtype=torch.float32, device=dev)
+        sm = torch.empty_like(raw)
+        pw = torch.empty_like(raw)
+        p = float(p_drop) if training else 0.0
+        seed, off = _next_offsets(1) if p > 0.0 else (0, 0)
+        C.uniter_attn_pool_fwd(ptr(x), ptr(pad), ptr(lin.weight), ptr(lin.bias), ptr(out), ptr(raw), ptr(sm), ptr(pw),
+                               B, L, H, p, seed, off, _lib.stream_ptr())
+        ctx.lin = lin
+        ctx.save_for_backward(x, raw, sm, pw)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, raw, sm, pw = ctx.saved_tensors
+        lin = ctx.lin
+        B, L, H = x.shape
+        dx = torch.empty_like(x)
+        wsb = C.uniter_attn_pool_workspace_bytes(B, H)
+        ws = _scratch(("pool", x.device.index), wsb, x.device)
+        gw = ensure_grad(lin.weight) if lin.weight.requires_grad else None
+        gb = ensure_grad(lin.bias) if (lin.bias is not None and lin.bias.requires_grad) else None
+        C.uniter_attn_pool_bwd(ptr(x), ptr(lin.weight), ptr(raw), ptr(sm), ptr(pw), ptr(dout.contiguous()), ptr(dx),
+                               ptr(gw), ptr(gb), B, L, H, ptr(ws), wsb, _lib.stream_ptr())
+        return (dx if ctx.needs_input_grad[0] else None, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
+
+
+def attention_pool(x, pad, lin, p_drop, training):
+    """x [B, L, H] bf16, pad [B, L] bool (True = padding) or None, lin = the pool's nn.Linear(H, 1).  Returns [B, H]."""
+    _check_dev(x, "pool input")
+    _check_dev(lin.weight, "pool weight")
+    x = x.contiguous()
+    pad_u8 = None if pad is None else pad.to(device=x.device, dtype=torch.uint8).contiguous()
+    if not torch.is_grad_enabled():
+        return _AttnPoolFn.apply(x, pad_u8, lin, p_drop, training)
+    anchor = next((p for p in lin.parameters() if p.requires_grad), None)
+    extra = () if anchor is None else (anchor,)
+    return _AttnPoolFn.apply(x, pad_u8, lin, p_drop, training, *extra)
