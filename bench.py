@@ -99,23 +99,24 @@ def timed_pass(train_step, steps):
     return rows
 
 
-def pmc_traffic(kind_id):
-    """HBM bytes per launch of a GEMM flavour from the committed PMC passes (profiles/*_pmc_traffic.json, produced by
-    scripts/profile_round.sh + scripts/summarize_profile.py; rocprofv3 cannot run inside this process).  None if the
-    passes are absent or the flavour runs at more than one shape (the kernel name does not carry the shape)."""
+def pmc_traffic(kind_id, shape):
+    """HBM bytes per launch of one encoder GEMM (flavour = epilogue id, shape = M, N, K of the C-ABI call) from the
+    committed PMC passes (profiles/*_pmc_traffic.json, produced by scripts/profile_round.sh +
+    scripts/summarize_profile.py; rocprofv3 cannot run inside this process).  None if absent."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
         return None
     try:
-        by_kind = json.load(open(files[-1])).get("by_kind", {})
+        doc = json.load(open(files[-1]))
     except (OSError, ValueError):
         return None
-    e = by_kind.get(str(kind_id))
-    if not e or not e.get("single_shape"):
+    M, N, K = shape
+    e = doc.get("by_shape", {}).get("%d:%d:%d:%d" % (kind_id, M, N, K))
+    if e is None:
         return None
     return {"hbm_bytes": e["hbm_bytes"], "hbm_read_bytes": e["hbm_read_bytes"], "hbm_write_bytes": e["hbm_write_bytes"],
-            "source": os.path.basename(files[-1])}
+            "kernel": e["kernel"], "grid": e["grid"], "source": os.path.basename(files[-1])}
 
 
 def usable_cores():
@@ -343,7 +344,7 @@ def main():
             mfma = [k for k in kernels if k["tflops"] is not None]
             dom = max(mfma, key=lambda k: k["us_per_step"])
             M, N, K = dom["shape"]
-            traffic = pmc_traffic(dom["kind_id"])
+            traffic = pmc_traffic(dom["kind_id"], dom["shape"])
             # algorithmic HBM bytes of the dominant kernel for reference (bf16 operands + output [+ aux read])
             roofline = {"bound": "mfma", "kernel": "%s M%d N%d K%d" % (dom["kernel"], M, N, K), "achieved": dom["tflops"],
                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4),

@@ -94,9 +94,10 @@ def step_breakdown(trace, dst):
 def pmc(path, counter):
     """{(kernel short name, grid): [values]} of one counter."""
     out = collections.defaultdict(list)
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter:
-            out[(r["Kernel_Name"], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))                 # program order (needed to split shared templates)
+    for r in rows:
+        out[(r["Kernel_Name"], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
     return out
 
 
@@ -132,13 +133,79 @@ def pmc_traffic(fetch_csv, write_csv, dst):
                           "fetch_size_kib_raw": round(f_kib, 1), "write_size_kib_raw": None if w_kib is None else round(w_kib, 1),
                           "hbm_read_bytes": round(rd), "hbm_write_bytes": None if wr is None else round(wr),
                           "hbm_bytes": round(rd + (wr or 0.0))}
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over "
+    # per (kernel, grid) entries: a flavour that runs at several shapes is told apart by its dispatch grid
+    per = []
+    for (name, grid), fv in sorted(fetch.items(), key=lambda kv: (kv[0][0], kv[0][1])):
+        m = GEMM_RE.search(name.replace('(anonymous namespace)::', ''))
+        if not m:
+            continue
+        wv = write.get((name, grid), [])
+        rd = 2.0 * (sum(fv) / len(fv)) * 1024.0
+        wr = (sum(wv) / len(wv)) * 1024.0 if wv else None
+        per.append({"kind_id": int(m.group(5)), "kernel": short(name), "grid": grid, "dispatches": len(fv),
+                    "hbm_read_bytes": round(rd), "hbm_write_bytes": None if wr is None else round(wr),
+                    "hbm_bytes": round(rd + (wr or 0.0))})
+    # exact attribution to (kind, M, N, K): the tile choices the profiled runs used are in tune_cache.json, the tile table
+    # is parsed from gemm.hip, so the template arguments and the dispatch grid of every encoder GEMM are known.  Shapes
+    # that share one template + grid are told apart by program order (they alternate in a fixed per-layer sequence).
+    by_shape = {}
+    cache_path = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(fetch_csv))), "tune_cache.json")
+    tiles = parse_tiles()
+    if os.path.exists(cache_path) and tiles:
+        # per-layer launch order of the encoder (encoder.hip): (kind, EPI, N, K) with H / I recovered from the cache
+        entries = json.load(open(cache_path)).get("gemm", [])
+        hs = sorted({e["K"] for e in entries} | {e["N"] for e in entries})
+        H, I = (hs[0], hs[-1]) if hs else (0, 0)
+        order = [(0, 0, 3 * H, H), (0, 2, H, H), (0, 1, I, H), (0, 2, H, I),                       # forward
+                 (1, 4, H, I), (1, 3, I, H), (1, 3, H, H), (1, 3, 3 * H, H),                       # backward, main stream
+                 (2, 5, H, I), (2, 5, I, H), (2, 5, H, H), (2, 5, 3 * H, H)]                       # backward, side stream
+        lookup = {(e["kind"], e["N"], e["K"]): e for e in entries}
+        groups = collections.defaultdict(list)            # (kernel name, grid) -> [(epi, M, N, K)] in program order
+        names = {}
+        for kind, epi, N, K in order:
+            e = lookup.get((kind, N, K))
+            if e is None:
+                continue
+            M, cfg, splits = e["M"], e["cfg"], e["splits"]
+            bm, bn, st, ws = tiles[cfg]
+            rows, cols = (M, N) if kind == 0 else ((M, K) if kind == 1 else (N, K))      # output of the launch
+            threads = 256 if ws == 0 else (512 if ws == 1 else 768)
+            grid = ((rows + bm - 1) // bm) * (cols // bn) * threads * splits
+            layout = {0: "false, false", 1: "false, true", 2: "true, true"}[kind]
+            want = "gemm_kernel<%d, %d, %s, %d, %d, %d>" % (bm, bn, layout, epi, st, ws)
+            for (name, g2) in fetch:
+                if g2 == grid and want in name.replace('(anonymous namespace)::', ''):
+                    groups[(name, grid)].append((epi, M, N, K))
+                    names[(name, grid)] = short(name)
+        for key, shapes in groups.items():
+            fv, wv = fetch.get(key, []), write.get(key, [])
+            n = len(shapes)
+            for idx, (epi, M, N, K) in enumerate(shapes):
+                f_sel, w_sel = fv[idx::n], wv[idx::n]
+                if len(f_sel) < 8 or not w_sel:
+                    continue
+                rd = 2.0 * (sum(f_sel) / len(f_sel)) * 1024.0
+                wr = (sum(w_sel) / len(w_sel)) * 1024.0
+                by_shape["%d:%d:%d:%d" % (epi, M, N, K)] = {
+                    "kernel": names[key], "grid": key[1], "dispatches": len(f_sel), "shares_template_with": n - 1,
+                    "hbm_read_bytes": round(rd), "hbm_write_bytes": round(wr), "hbm_bytes": round(rd + wr)}
+    json.dump({"by_shape": by_shape, "per_kernel": per,
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over "
                          "`python bench.py --steps 3 --warmup 2` with pinned tile choices",
                "correction": "KiB -> bytes; FETCH_SIZE doubled on gfx950 (128-B requests of wide coalesced reads are tallied "
                              "at 64 B, MI355X_MICROARCH.md 'HBM'); WRITE_SIZE as reported; counters sit on the L2's fabric "
                              "side, so Infinity-Cache hits are included",
                "by_kind": out}, open(dst, 'w'), indent=1)
     return len(out)
+
+
+def parse_tiles():
+    """[(bm, bn, stages, ws)] from the kTiles initialiser of uniter_amd/csrc/gemm.hip."""
+    src = open(os.path.join(ROOT, "uniter_amd", "csrc", "gemm.hip")).read()
+    m = re.search(r"constexpr TileShape kTiles\[\] = \{(.*?)\};", src, re.S)
+    if not m:
+        return []
+    return [tuple(int(v) for v in t) for t in re.findall(r"\{(\d+), (\d+), (\d+), (\d+)\}", m.group(1))]
 
 
 def main():
