@@ -192,3 +192,21 @@ def test_vqa_optimizer_has_four_groups_in_reference_order():
     assert ids == want
     assert id(named['vqa_output.2.weight']) in ids[0]                   # the quirk: Sequential LayerNorm weight is decayed
     assert [g['weight_decay'] for g in opt.param_groups] == [0.01, 0.0, 0.01, 0.0]
+
+
+def test_pack_indices_layout():
+    """Host tables of the padding-free layout (UniterEncoder.forward_packed): real-token row indices in example order,
+    cumulative lengths, and all-zero dummy examples that round the row count up to a multiple of 64."""
+    from uniter_amd.model.model import pack_indices
+    idx, cu, total, extra = pack_indices([3, 0, 5], max_len=8, multiple=4)
+    assert total == 8 and extra == []
+    assert idx.tolist() == [0, 1, 2, 16, 17, 18, 19, 20]
+    assert cu.tolist() == [0, 3, 3, 8] and cu.dtype == torch.int32
+    idx, cu, total, extra = pack_indices(torch.tensor([60, 96, 41]), max_len=96)
+    assert total == 197 and extra == [59] and cu.tolist() == [0, 60, 156, 197, 256]
+    assert int(cu[-1]) % 64 == 0 and idx.numel() == total
+    # a remainder longer than one sequence becomes several dummies
+    _, cu, total, extra = pack_indices([5], max_len=16)
+    assert total == 5 and extra == [16, 16, 16, 11] and int(cu[-1]) == 64
+    with pytest.raises(ValueError):
+        pack_indices([9], max_len=8)

@@ -189,6 +189,29 @@ class UniterImageEmbeddings(nn.Module):
             "of the reference is produced inside the fused kernel here")
 
 
+def pack_indices(seq_lens, max_len, multiple=64):
+    """Host-side tables of the padding-free layout for B sequences stored as [B, max_len] rows.
+
+    Returns (idx, cu_seqlens, total, extra): `idx` int64 [total] = flat row indices (b * max_len + t) of the real
+    tokens in example order; `cu_seqlens` int32 [B + len(extra) + 1]; `extra` = lengths of the all-zero dummy examples
+    that round the packed row count up to a multiple of `multiple` (the wave-specialised wgrad tiles contract over whole
+    64-row steps); each dummy is at most max_len long."""
+    lens = [int(v) for v in (seq_lens.tolist() if torch.is_tensor(seq_lens) else seq_lens)]
+    if any(v < 0 or v > max_len for v in lens):
+        raise ValueError("sequence lengths must lie in [0, max_len]")
+    total = sum(lens)
+    parts = [torch.arange(v, dtype=torch.int64) + b * max_len for b, v in enumerate(lens) if v > 0]
+    idx = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64)
+    pad = (-total) % multiple if multiple > 1 else 0
+    extra = []
+    while pad > 0:
+        extra.append(min(pad, max_len))
+        pad -= extra[-1]
+    cu = torch.zeros(len(lens) + len(extra) + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(torch.tensor(lens + extra, dtype=torch.int64), dim=0).to(torch.int32)
+    return idx, cu, total, extra
+
+
 class UniterEncoder(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -212,30 +235,13 @@ class UniterEncoder(nn.Module):
         B real lengths) nothing synchronises; without it the token count is read back from the device (one sync)."""
         B, L, H = input_.shape
         dev = input_.device
-        if seq_lens is not None:
-            lens_host = [int(v) for v in (seq_lens.tolist() if torch.is_tensor(seq_lens) else seq_lens)]
-            if len(lens_host) != B or any(v < 0 or v > L for v in lens_host):
-                raise ValueError("seq_lens must hold B lengths in [0, L]")
-            lens = torch.tensor(lens_host, dtype=torch.int32)
-            idx = torch.cat([torch.arange(v, dtype=torch.int64) + b * L for b, v in enumerate(lens_host)])
-            total = int(idx.numel())
-            lens = lens.to(dev, non_blocking=True)
-            idx = idx.to(dev, non_blocking=True)
-        else:
-            valid = valid_mask.reshape(B, L) != 0
-            lens = valid.sum(dim=1, dtype=torch.int32)
-            idx = valid.reshape(-1).nonzero(as_tuple=False).squeeze(1)    # host sync: number of real tokens
-            total = int(idx.numel())
-        # keep the GEMM contraction (token) length a multiple of 64 for the wave-specialised wgrad tiles: the remainder
-        # becomes extra all-zero "examples" whose outputs are dropped (their gradients are exactly zero)
-        pad = (-total) % 64
-        extra = []
-        while pad > 0:
-            extra.append(min(pad, L))
-            pad -= extra[-1]
-        all_lens = torch.cat([lens, torch.tensor(extra, dtype=torch.int32, device=lens.device)]) if extra else lens
-        cu = torch.zeros(all_lens.numel() + 1, dtype=torch.int32, device=lens.device)
-        cu[1:] = torch.cumsum(all_lens, dim=0)
+        if seq_lens is None:
+            # lengths from the mask: one device -> host copy of B integers (a sync); callers that know the lengths on the
+            # host (every collate does) pass them and skip it
+            seq_lens = (valid_mask.reshape(B, L) != 0).sum(dim=1).tolist()
+        idx, cu_host, total, extra = pack_indices(seq_lens, L)
+        idx = idx.to(dev, non_blocking=True)
+        cu = cu_host.to(dev, non_blocking=True)
         x = input_.reshape(B * L, H).index_select(0, idx)
         if extra:
             x = torch.cat([x, x.new_zeros(sum(extra), H)], dim=0)
