@@ -117,6 +117,13 @@ int uniter_gemm_wgrad(const void* dy, const void* x, void* dw, void* db,
                       int64_t M, int64_t N, int64_t K, int accumulate,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Up to four weight gradients over the same M tokens in ONE launch: dw_q[N_q,K_q] (+)= dy_q[M,N_q]^T * x_q[M,K_q],
+ * q < n <= 4 (host arrays of device pointers / sizes).  The four nn.Linear weight gradients of a BertLayer
+ * (model/layer.py:64-66,112,140,153) are independent of each other; one grid pays one launch / ramp / drain and the
+ * tiles of the small problems fill the CUs the big ones leave idle.  No split-K; N_q % 64 == 0, K_q % 64 == 0. */
+int uniter_gemm_wgrad_group(int32_t n, const void* const* dy, const void* const* x, void* const* dw,
+                            int64_t M, const int64_t* N, const int64_t* K, int accumulate, void* stream);
+
 /* Strided-operand variants (row stride in elements; operands may be column slices of a wider row-major matrix —
  * e.g. the q / k|v column blocks of a packed [T,3H] projection buffer).  Used by the NLVR2 paired cross-attention
  * head (model/nlvr2.py:170-189 + model/attention.py:86-127: q projected from one sequence, k|v from its partner):
@@ -170,8 +177,8 @@ int uniter_layernorm_fwd(const void* z, const void* gamma, const void* beta, voi
 
 /* Backward of  z = dropout_p(d) + r ; y = LN(z):
  *   dz  [rows,H]  = dL/dz                       (gradient of the residual branch r)
- *   dd  [rows,H]  = dz .* keep/(1-p)            (gradient of the dense output d; NULL or p==0 -> not written,
- *                                                the caller then uses dz for both)
+ *   dd  [rows,H]  = dz .* keep/(1-p)            (gradient of the dense output d; NULL -> not written; with p == 0 it
+ *                                                is a plain copy of dz)
  *   dgamma, dbeta [H] (+)= ...                  (bf16, accumulate flag)
  *   dbias [H] (+)= column sums of dd            (bias gradient of the dense layer feeding the LN; may be NULL)
  * dy_extra (may be NULL) is added to dy first (lets a caller fold a second incoming gradient in).

@@ -467,6 +467,34 @@ static void test_attention(int B, int L, int heads, float p) {
 // ---------------------------------------------------------------------------------------------
 // LayerNorm / colsum
 // ---------------------------------------------------------------------------------------------
+// grouped weight gradients == the individual launches
+static void test_wgrad_group(int M) {
+    const int n = 4;
+    const int64_t N[4] = {128, 256, 128, 384}, K[4] = {256, 128, 128, 128};
+    HostBf DY[4], X[4], W0[4];
+    uint16_t *dDY[4], *dX[4], *dW1[4], *dW2[4];
+    size_t wsb = 0;
+    for (int q = 0; q < n; ++q) {
+        DY[q].fill((size_t)M * N[q], 1.f); X[q].fill((size_t)M * K[q], 1.f); W0[q].fill((size_t)N[q] * K[q], 0.5f);
+        dDY[q] = upload(DY[q]); dX[q] = upload(X[q]); dW1[q] = upload(W0[q]); dW2[q] = upload(W0[q]);
+        wsb = std::max(wsb, uniter_gemm_wgrad_workspace_bytes(M, N[q], K[q]));
+    }
+    void* ws = dalloc<char>(wsb);
+    uniter_gemm_debug_force(3, 1);                       // 64x64, no split: the same summation order as the grouped default
+    for (int q = 0; q < n; ++q) UHCHK(uniter_gemm_wgrad(dDY[q], dX[q], dW1[q], nullptr, M, N[q], K[q], 1, ws, wsb, 0));
+    uniter_gemm_debug_force(-1, -1);
+    const void* dyp[4] = {dDY[0], dDY[1], dDY[2], dDY[3]};
+    const void* xp[4] = {dX[0], dX[1], dX[2], dX[3]};
+    void* dwp[4] = {dW2[0], dW2[1], dW2[2], dW2[3]};
+    UHCHK(uniter_gemm_wgrad_group(n, dyp, xp, dwp, M, N, K, 1, 0));
+    HIPCHK(hipDeviceSynchronize());
+    for (int q = 0; q < n; ++q) {
+        char tag[128];
+        snprintf(tag, sizeof(tag), "wgrad group member %d (M%d N%lld K%lld, accumulate)", q, M, (long long)N[q], (long long)K[q]);
+        check(tag, download_bf(dW2[q], (size_t)N[q] * K[q]), download_bf(dW1[q], (size_t)N[q] * K[q]), 0.13f, 0.02f);
+    }
+}
+
 static void test_layernorm(int rows, int H, float p, int post) {
     char tag[128];
     HostBf Z, G, Bt, DY;
@@ -769,6 +797,24 @@ static void bench(int B, int L, int H, int heads, int I, int layers) {
             double one = tm.run([&] { UHCHK(uniter_encoder_forward(&sh2, lp.data(), 0, layers, dX, dMask, actsA, scratch, 1, 0, 0)); }, 2, 10);
             printf("  (experiment: forward of two B=%d halves on two streams: %.1f us; one half alone: %.1f us; full batch: %.1f us)\n", B / 2, us2, one, tf);
         }
+        {   // grouped weight gradients of one layer vs the four separate launches
+            const int64_t Ng[4] = {H, I, H, 3 * (int64_t)H}, Kg[4] = {I, H, H, H};
+            HostBf big; big.fill((size_t)T * I, 1.f);
+            uint16_t* dyb[4]; uint16_t* xb[4]; uint16_t* dwb[4];
+            for (int q = 0; q < 4; ++q) {
+                dyb[q] = dalloc<uint16_t>((size_t)T * Ng[q]); xb[q] = dalloc<uint16_t>((size_t)T * Kg[q]); dwb[q] = dalloc<uint16_t>((size_t)Ng[q] * Kg[q]);
+                HIPCHK(hipMemset(dyb[q], 0x3c, (size_t)T * Ng[q] * 2)); HIPCHK(hipMemset(xb[q], 0x3c, (size_t)T * Kg[q] * 2));
+                HIPCHK(hipMemset(dwb[q], 0, (size_t)Ng[q] * Kg[q] * 2));
+            }
+            const size_t wsb2 = uniter_gemm_wgrad_workspace_bytes(T, I, H);
+            void* ws2 = dalloc<char>(wsb2);
+            const void* dyp[4] = {dyb[0], dyb[1], dyb[2], dyb[3]};
+            const void* xp[4] = {xb[0], xb[1], xb[2], xb[3]};
+            void* dwp[4] = {dwb[0], dwb[1], dwb[2], dwb[3]};
+            double sep = tm.run([&] { for (int q = 0; q < 4; ++q) UHCHK(uniter_gemm_wgrad(dyb[q], xb[q], dwb[q], nullptr, T, Ng[q], Kg[q], 1, ws2, wsb2, 0)); }, 3, 20);
+            double grp = tm.run([&] { UHCHK(uniter_gemm_wgrad_group(4, dyp, xp, dwp, T, Ng, Kg, 1, 0)); }, 3, 20);
+            printf("  (four weight gradients of a layer: separate tuned launches %.1f us, one grouped launch %.1f us)\n", sep, grp);
+        }
         const double flf = (double)layers * (24.0 * T * H * H + 4.0 * T * L * H);
         printf("  ENCODER fwd %.1f us (%.1f TF) | bwd %.1f us (%.1f TF) | fwd+bwd %.1f us = %.1f TF = %.1f%% of 2.5 PF ; %.0f ex/s\n", tf,
                flf / tf * 1e-6, tb, 2 * flf / tb * 1e-6, tf + tb, 3 * flf / (tf + tb) * 1e-6, 3 * flf / (tf + tb) * 1e-6 / 2500 * 100,
@@ -895,6 +941,9 @@ int main(int argc, char** argv) {
     test_attention(1, 250, 1, 0.f);
     test_attention(2, 17, 1, 0.1f);
     printf("== layernorm ==\n");
+    printf("== grouped weight gradients ==\n");
+    test_wgrad_group(320);
+    test_wgrad_group(300);
     test_layernorm(37, 128, 0.f, 0);
     test_layernorm(300, 768, 0.2f, 0);
     test_layernorm(300, 768, 0.2f, 1);

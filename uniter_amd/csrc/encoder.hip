@@ -7,6 +7,7 @@
 // 8 GEMMs + attention + 2 LayerNorm-backward + 2 column sums backward.  Everything is asynchronous on
 // the caller's stream; activations needed by backward live in the caller-provided `acts` arena.
 #include "common.cuh"
+#include <vector>
 #include "kernels.h"
 #include "../../include/uniter_hip.h"
 
@@ -43,7 +44,7 @@ ActLayout act_layout(const UniterEncoderShape& s) {
 }
 
 struct ScratchLayout {
-    size_t bufA, bufB, dd, dd1, dctx, dqkv, dpre, red, red2, red_bytes, wg, wg_bytes, total;
+    size_t bufA, bufB, dd[2], dd1[2], dctx, dqkv[2], dpre[2], red, red2, red_bytes, wg, wg_bytes, total;
 };
 ScratchLayout scratch_layout(const UniterEncoderShape& s) {
     const size_t T = tokens(s), H = s.H, I = s.I;
@@ -52,11 +53,15 @@ ScratchLayout scratch_layout(const UniterEncoderShape& s) {
     auto take = [&](size_t bytes) { size_t r = o; o += align256(bytes); return r; };
     l.bufA = take(T * H * 2);
     l.bufB = take(T * H * 2);
-    l.dd = take(T * H * 2);
-    l.dd1 = take(T * H * 2);
+    // the four buffers the weight gradients read exist twice (even / odd layers): the grouped wgrad launch of layer l
+    // runs while layer l-1 is already producing its own
+    for (int k = 0; k < 2; ++k) {
+        l.dd[k] = take(T * H * 2);
+        l.dd1[k] = take(T * H * 2);
+        l.dqkv[k] = take(T * 3 * H * 2);
+        l.dpre[k] = take(T * I * 2);
+    }
     l.dctx = take(T * H * 2);
-    l.dqkv = take(T * 3 * H * 2);
-    l.dpre = take(T * I * 2);
     size_t red = uh::layernorm_bwd_workspace_bytes((int64_t)T, (int64_t)H);
     size_t c1 = uh::colsum_workspace_bytes((int64_t)T, (int64_t)(3 * H));
     size_t c2 = uh::colsum_workspace_bytes((int64_t)T, (int64_t)I);
@@ -103,6 +108,7 @@ int side_init() {
 
 int g_use_side_stream = 1;
 int g_tune_in_situ = 1;
+int g_group_wgrad = 1;      // 1: the four weight gradients of a layer go out as one grouped launch
 
 int check_shape(const UniterEncoderShape* s) {
     if (s == nullptr) { uh_set_error("encoder: null shape"); return -1; }
@@ -193,24 +199,22 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
     char* S = (char*)scratch;
     char* bufA = S + sl.bufA;
     char* bufB = S + sl.bufB;
-    char* ddb2 = S + sl.dd;
-    char* ddb1 = S + sl.dd1;
     char* dctx = S + sl.dctx;
-    char* dqkv = S + sl.dqkv;
-    char* dpre = S + sl.dpre;
     void* red = S + sl.red;
     void* red2 = S + sl.red2;
     void* wg = S + sl.wg;
     const bool hdrop = s->p_hidden > 0.f;
     const bool side = g_use_side_stream != 0;
+    const bool grouped = g_group_wgrad != 0;
     hipStream_t ss = st;
     if (side) {
         RC(side_init());
         ss = g_side.stream;
     }
-    // slot k: main_ev[k] = "input of side job k is ready", side_ev[k] = "side job k has finished reading its input".
-    // jobs: 0 = wgrad W2 (reads dd2), 1 = colsum + wgrad W1 (reads dpre), 2 = wgrad Wo (reads dd1), 3 = colsum + wgrad Wqkv (reads dqkv)
-    // slots 4 / 5 only carry "the LayerNorm column sums of BertOutput / BertSelfOutput have read their dy" (bufB)
+    // Event slots (main_ev[k]: "inputs of side job k are ready", side_ev[k]: "side job k has read its inputs"):
+    //   0 / 1  the weight-gradient work of even / odd layers (reads dd2, dpre, dd1, dqkv of that parity's buffer set)
+    //   2 / 3  the early column sums of the current layer (bias gradients of FFN1 / QKV read dpre / dqkv)   [ungrouped: wgrads too]
+    //   4 / 5  the LayerNorm column sums of BertOutput / BertSelfOutput (read bufB)
     bool side_pending[6] = {false, false, false, false, false, false};
     auto fork = [&](int k) -> int {            // side stream may start job k once the main stream reaches this point
         if (!side) return 0;
@@ -218,13 +222,13 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         UH_CHECK_HIP(hipStreamWaitEvent(ss, g_side.main_ev[k], 0));
         return 0;
     };
-    auto joined = [&](int k) -> int {          // side job k enqueued: remember that its input buffer is busy
+    auto joined = [&](int k) -> int {          // side job k enqueued: remember that its input buffers are busy
         if (!side) return 0;
         UH_CHECK_HIP(hipEventRecord(g_side.side_ev[k], ss));
         side_pending[k] = true;
         return 0;
     };
-    auto before_overwrite = [&](int k) -> int { // main stream is about to overwrite the input buffer of side job k
+    auto before_overwrite = [&](int k) -> int { // main stream is about to overwrite an input buffer of side job k
         if (!side || !side_pending[k]) return 0;
         UH_CHECK_HIP(hipStreamWaitEvent(st, g_side.side_ev[k], 0));
         side_pending[k] = false;
@@ -240,54 +244,67 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         const DropoutCfg d_attn = make_dropout(s->p_attn, seed, off + 0);
         const DropoutCfg d_h1 = make_dropout(s->p_hidden, seed, off + 1);
         const DropoutCfg d_h2 = make_dropout(s->p_hidden, seed, off + 2);
+        const int par = l & 1;                     // buffer set / event slot of this layer's weight-gradient work
+        char* ddb2 = S + sl.dd[par];
+        char* ddb1 = S + sl.dd1[par];
+        char* dpre = S + sl.dpre[par];
+        char* dqkv = S + sl.dqkv[par];
 
         // ---- BertOutput backward (model/layer.py:152-156) ----
-        // without dropout the masked gradient IS dz (bufA): side jobs 0 / 2 then read bufA
-        RC(before_overwrite(0));
-        if (!hdrop) RC(before_overwrite(2));
         // LayerNorm backward is split: the row half (dz, dd) stays on the critical path, the column sums
-        // (dgamma, dbeta and the dense bias gradient) go to the side stream together with the weight gradient.
+        // (dgamma, dbeta and the dense bias gradient) go to the side stream.  dd is always materialised (a copy of dz
+        // when there is no dropout) so that the weight-gradient work can read it after bufA has moved on.
+        RC(before_overwrite(par));                 // weight gradients of layer l+2 used this buffer set
         RC(uh::layernorm_bwd_rows(dyl, nullptr, A + al.z2, (const float*)(A + al.mean2), (const float*)(A + al.rstd2),
-                                  P.ln2_g, bufA, hdrop ? ddb2 : nullptr, T, H, d_h2, 0, st));
-        const char* dd2 = hdrop ? ddb2 : bufA;
-        RC(fork(0));
+                                  P.ln2_g, bufA, ddb2, T, H, d_h2, 0, st));
+        RC(fork(4));
         RC(uh::layernorm_bwd_cols(dyl, nullptr, A + al.z2, (const float*)(A + al.mean2), (const float*)(A + al.rstd2),
-                                  bufA, hdrop ? ddb2 : nullptr, P.g_ln2_g, P.g_ln2_b, P.g_b2, T, H, 1, d_h2, 0,
+                                  bufA, ddb2, P.g_ln2_g, P.g_ln2_b, P.g_b2, T, H, 1, d_h2, 0,
                                   side ? red2 : red, sl.red_bytes, ss));
         RC(joined(4));                         // dyl (bufB below the top layer) has been read
-        RC(uh::gemm_wgrad(dd2, A + al.g, P.g_w2, T, H, I, 1, wg, sl.wg_bytes, ss));
-        RC(joined(0));
-        RC(before_overwrite(1));
-        RC(uh::gemm_dgrad(uh::GEMM_EPI_GELU_BWD, dd2, P.w2, A + al.u, dpre, T, H, I, st));
+        if (!grouped) {
+            RC(uh::gemm_wgrad(ddb2, A + al.g, P.g_w2, T, H, I, 1, wg, sl.wg_bytes, ss));
+            RC(joined(par));
+        }
+        RC(uh::gemm_dgrad(uh::GEMM_EPI_GELU_BWD, ddb2, P.w2, A + al.u, dpre, T, H, I, st));
         // ---- BertIntermediate backward (model/layer.py:139-142) ----
-        RC(fork(1));
+        RC(fork(2));
         RC(uh::colsum(dpre, P.g_b1, T, I, 1, side ? red2 : red, sl.red_bytes, ss));
-        RC(uh::gemm_wgrad(dpre, A + al.a, P.g_w1, T, I, H, 1, wg, sl.wg_bytes, ss));
-        RC(joined(1));
+        if (!grouped) {
+            RC(uh::gemm_wgrad(dpre, A + al.a, P.g_w1, T, I, H, 1, wg, sl.wg_bytes, ss));
+            RC(joined(par));
+        }
         RC(before_overwrite(4));               // bufB is about to receive da
         RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dpre, P.w1, bufA, bufB, T, I, H, st));          // da = dpre*W1 + dz2
         // ---- BertSelfOutput backward (model/layer.py:111-115) ----
-        RC(before_overwrite(2));
-        if (!hdrop) RC(before_overwrite(0));   // without dropout side job 0 reads dz2 straight from bufA
         RC(uh::layernorm_bwd_rows(bufB, nullptr, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1),
-                                  P.ln1_g, bufA, hdrop ? ddb1 : nullptr, T, H, d_h1, 0, st));
-        const char* dd1 = hdrop ? ddb1 : bufA;
-        RC(fork(2));
+                                  P.ln1_g, bufA, ddb1, T, H, d_h1, 0, st));
+        RC(fork(5));
         RC(uh::layernorm_bwd_cols(bufB, nullptr, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1),
-                                  bufA, hdrop ? ddb1 : nullptr, P.g_ln1_g, P.g_ln1_b, P.g_bo, T, H, 1, d_h1, 0,
+                                  bufA, ddb1, P.g_ln1_g, P.g_ln1_b, P.g_bo, T, H, 1, d_h1, 0,
                                   side ? red2 : red, sl.red_bytes, ss));
         RC(joined(5));                         // bufB (da) has been read
-        RC(uh::gemm_wgrad(dd1, A + al.ctx, P.g_wo, T, H, H, 1, wg, sl.wg_bytes, ss));
-        RC(joined(2));
-        RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dd1, P.wo, nullptr, dctx, T, H, H, st));
+        if (!grouped) {
+            RC(uh::gemm_wgrad(ddb1, A + al.ctx, P.g_wo, T, H, H, 1, wg, sl.wg_bytes, ss));
+            RC(joined(par));
+        }
+        RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, ddb1, P.wo, nullptr, dctx, T, H, H, st));
         // ---- BertSelfAttention backward (model/layer.py:75-101) ----
-        RC(before_overwrite(3));
         RC(uh::attention_bwd(A + al.qkv, s->total_tokens > 0 ? nullptr : mask_bias, A + al.ctx, (const float*)(A + al.lse), dctx, dqkv,
                              s->B, s->L, s->heads, d_attn, st, s->total_tokens > 0 ? s->cu_seqlens : nullptr));
         RC(fork(3));
         RC(uh::colsum(dqkv, P.g_bqkv, T, 3 * H, 1, side ? red2 : red, sl.red_bytes, ss));
-        RC(uh::gemm_wgrad(dqkv, xin, P.g_wqkv, T, 3 * H, H, 1, wg, sl.wg_bytes, ss));
-        RC(joined(3));
+        if (grouped) {
+            // the four weight gradients of the layer in one launch (their inputs are all final now)
+            const void* gdy[4] = {ddb2, dpre, ddb1, dqkv};
+            const void* gx[4] = {A + al.g, A + al.a, A + al.ctx, xin};
+            void* gdw[4] = {P.g_w2, P.g_w1, P.g_wo, P.g_wqkv};
+            const int64_t gN[4] = {H, I, H, 3 * H}, gK[4] = {I, H, H, H};
+            RC(uh::gemm_wgrad_group(4, gdy, gx, gdw, T, gN, gK, 1, ss));
+        } else {
+            RC(uh::gemm_wgrad(dqkv, xin, P.g_wqkv, T, 3 * H, H, 1, wg, sl.wg_bytes, ss));
+        }
+        RC(joined(par));
         char* dxl = (l == layer_begin) ? (char*)dx : bufB;
         RC(before_overwrite(5));               // bufB is about to receive this layer's dx
         RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dqkv, P.wqkv, bufA, dxl, T, 3 * H, H, st));     // dx = dqkv*Wqkv + dz1
@@ -307,8 +324,12 @@ int uniter_encoder_autotune(const UniterEncoderShape* s, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int64_t T = (int64_t)tokens(*s), H = s->H, I = s->I;
     const int64_t shapes[4][2] = {{3 * H, H}, {H, H}, {I, H}, {H, I}};      // (N = out features, K = in features)
-    for (int kind = 0; kind < 3; ++kind)
+    for (int kind = 0; kind < (g_group_wgrad ? 2 : 3); ++kind)
         for (int g = 0; g < 4; ++g) RC(uh::gemm_autotune(kind, T, shapes[g][0], shapes[g][1], st));
+    // the grouped launch of the four weight gradients (order of uniter_encoder_backward: W2, W1, Wo, Wqkv)
+    const int64_t gN[4] = {H, I, H, 3 * H}, gK[4] = {I, H, H, H};
+    const int64_t gNs = gN[0] + gN[1] + gN[2] + gN[3], gKs = gK[0] + gK[1] + gK[2] + gK[3];
+    if (g_group_wgrad) RC(uh::gemm_group_autotune(4, T, gN, gK, st));
     if (s->training == 0 || g_tune_in_situ == 0) return 0;
 
     // ---- second phase: coordinate descent on the real thing ------------------------------------------------------
@@ -378,22 +399,29 @@ int uniter_encoder_autotune(const UniterEncoderShape* s, void* stream) {
     };
     rc = run_once();                            // warm up
     float cur = rc ? 0.f : measure();
+    // items of the descent: the 12 GEMMs of a layer (kinds 0..2; with grouping the four separate wgrads are unused and
+    // skipped) plus the grouped weight-gradient launch (kind 3)
+    struct Item { int kind; int64_t N, K; };
+    std::vector<Item> items;
+    for (int kind = 0; kind < (g_group_wgrad ? 2 : 3); ++kind)
+        for (int g = 0; g < 4; ++g) items.push_back(Item{kind, shapes[g][0], shapes[g][1]});
+    if (g_group_wgrad) items.push_back(Item{3, gNs, gKs});
     for (int pass = 0; pass < 3 && rc == 0; ++pass) {
         bool changed = false;
-        for (int kind = 0; kind < 3 && rc == 0; ++kind)
-            for (int g = 0; g < 4 && rc == 0; ++g) {
-                int cfgs[TOP], sps[TOP];
-                const int nc = uh::gemm_autotune_candidates(kind, T, shapes[g][0], shapes[g][1], cfgs, sps, TOP);
-                int keep_cfg = -1, keep_sp = 1;
-                if (uh::gemm_tuned_choice(kind, T, shapes[g][0], shapes[g][1], &keep_cfg, &keep_sp)) continue;
-                for (int c = 0; c < nc && rc == 0; ++c) {
-                    if (cfgs[c] == keep_cfg && sps[c] == keep_sp) continue;
-                    if (uh::gemm_set_tuned(kind, T, shapes[g][0], shapes[g][1], cfgs[c], sps[c])) continue;
-                    const float ms = measure();
-                    if (rc == 0 && ms < cur * 0.995f) { cur = ms; keep_cfg = cfgs[c]; keep_sp = sps[c]; changed = true; }
-                }
-                (void)uh::gemm_set_tuned(kind, T, shapes[g][0], shapes[g][1], keep_cfg, keep_sp);
+        for (const Item& it : items) {
+            if (rc) break;
+            int cfgs[TOP], sps[TOP];
+            const int nc = uh::gemm_autotune_candidates(it.kind, T, it.N, it.K, cfgs, sps, TOP);
+            int keep_cfg = -1, keep_sp = 1;
+            if (uh::gemm_tuned_choice(it.kind, T, it.N, it.K, &keep_cfg, &keep_sp)) continue;
+            for (int c = 0; c < nc && rc == 0; ++c) {
+                if (cfgs[c] == keep_cfg && sps[c] == keep_sp) continue;
+                if (uh::gemm_set_tuned(it.kind, T, it.N, it.K, cfgs[c], sps[c])) continue;
+                const float ms = measure();
+                if (rc == 0 && ms < cur * 0.995f) { cur = ms; keep_cfg = cfgs[c]; keep_sp = sps[c]; changed = true; }
             }
+            (void)uh::gemm_set_tuned(it.kind, T, it.N, it.K, keep_cfg, keep_sp);
+        }
         if (!changed) break;
     }
 #undef TN_HIP

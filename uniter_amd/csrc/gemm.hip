@@ -231,24 +231,25 @@ struct WaveGrid {
     static constexpr int THREADS = (WS ? NCW + 4 : NCW) * 64;
 };
 
+// One output tile (bx = tile slot of the launch, by = split-K slice).  Shared by the plain kernel (one problem per
+// launch) and the grouped kernel (several problems of one layout in one launch).
 template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, int WS>
-__global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS == 2 ? 3 : 1)) void gemm_kernel(const GemmArgs p) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const int by, char* smem_raw) {
     using WG = WaveGrid<BM, BN, WS>;
     constexpr int WM = BM / WG::GM, WN = BN / WG::GN, MI = WM / 16, NI = WN / 16;
     static_assert(WM % 16 == 0 && WN % 16 == 0, "wave tile must be a multiple of the 16x16 MFMA tile");
     constexpr int TILE_R = BM * 64, TILE_C = BN * 64;   // elements per LDS tile
     constexpr int STAGE = TILE_R + TILE_C;               // elements per pipeline stage
     constexpr int G = BM / 32 + BN / 32;                 // LDS-DMA instructions per wave per K tile
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];     // NSTAGE x STAGE bf16, sized at launch
-    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);                 // NSTAGE x STAGE bf16, sized at launch
 
     const int t = threadIdx.x;
     const int lane = t & 63, wid = t >> 6;
     const int g = lane >> 4, i = lane & 15;
 #ifdef UNITER_GEMM_PROBE
     // workgroup life cycle: [4096*64*5 + block*2 + {0,1}] = cycle stamps at entry / after the epilogue (wave 0)
-    unsigned long long* life = p.probe ? p.probe + (size_t)4096 * 64 * 5 + (size_t)blockIdx.x * 2 : nullptr;
-    if (life != nullptr && t == 0 && blockIdx.x < 4096) life[0] = __builtin_readcyclecounter();
+    unsigned long long* life = p.probe ? p.probe + (size_t)4096 * 64 * 5 + (size_t)bx * 2 : nullptr;
+    if (life != nullptr && t == 0 && bx < 4096) life[0] = __builtin_readcyclecounter();
 #endif
     const int wm = (wid / WG::GN) % WG::GM, wn = wid % WG::GN;      // (loader waves never use these)
 
@@ -258,20 +259,20 @@ __global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS 
     if (p.xr > 0) {
         // 2-D XCD blocking: hardware block b runs on XCD b % 8; XCD (xi, xj) of an xr x xc grid owns a
         // (tiles_m/xr) x (tiles_n/xc) sub-block of tiles, so its private L2 holds only that sub-block's operand rows
-        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        const int xcd = bx & 7, loc = bx >> 3;
         const int xc = 8 / p.xr;
         const int sub_m = tiles_m / p.xr, sub_n = tiles_n / xc;
         const int xi = xcd / xc, xj = xcd % xc;
         tm = xi * sub_m + loc / sub_n;
         tn = xj * sub_n + loc % sub_n;
     } else {
-        const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+        const int tile = xcd_remap(bx, tiles_m * tiles_n);
         tm = tile / tiles_n;
         tn = tile % tiles_n;
     }
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const int k_begin = blockIdx.y * p.k_per_split;
+    const int k_begin = by * p.k_per_split;
     const int k_end = min(p.K, k_begin + p.k_per_split);
     const int nk = (k_end - k_begin + 63) >> 6;
 
@@ -363,7 +364,7 @@ __global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS 
         int buf = 0;
         for (int kt = 0; kt < nfull; ++kt) {
 #ifdef UNITER_GEMM_PROBE
-            unsigned long long* pr = p.probe ? p.probe + ((size_t)blockIdx.x * 64 + (kt < 63 ? kt : 63)) * 5 : nullptr;
+            unsigned long long* pr = p.probe ? p.probe + ((size_t)bx * 64 + (kt < 63 ? kt : 63)) * 5 : nullptr;
             const bool rec = pr != nullptr && t == 0;
             if (rec) pr[0] = __builtin_readcyclecounter();
 #endif
@@ -385,7 +386,7 @@ __global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS 
         int pre = NSTAGE - 1;         // (kt + NSTAGE - 1) % NSTAGE
         for (int kt = 0; kt < nfull; ++kt) {
 #ifdef UNITER_GEMM_PROBE
-            unsigned long long* pr = p.probe ? p.probe + ((size_t)blockIdx.x * 64 + (kt < 63 ? kt : 63)) * 5 : nullptr;
+            unsigned long long* pr = p.probe ? p.probe + ((size_t)bx * 64 + (kt < 63 ? kt : 63)) * 5 : nullptr;
             const bool rec = pr != nullptr && t == 0;
             if (rec) pr[0] = __builtin_readcyclecounter();
 #endif
@@ -432,7 +433,7 @@ __global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS 
 #pragma unroll
             for (int a = 0; a < NI; ++a) {
                 const int n = n0 + wn * WN + a * 16 + 4 * g;
-                float* dst = p.partial + ((int64_t)blockIdx.y * p.M + m) * p.N + n;
+                float* dst = p.partial + ((int64_t)by * p.M + m) * p.N + n;
                 *reinterpret_cast<f32x4*>(dst) = acc[a][b];
             }
         }
@@ -516,8 +517,37 @@ __global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS 
         }
     }
 #ifdef UNITER_GEMM_PROBE
-    if (life != nullptr && t == 0 && blockIdx.x < 4096) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); life[1] = __builtin_readcyclecounter(); }
+    if (life != nullptr && t == 0 && bx < 4096) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); life[1] = __builtin_readcyclecounter(); }
 #endif
+}
+
+template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, int WS>
+__global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS == 2 ? 3 : 1)) void gemm_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    gemm_tile<BM, BN, TRA, TRB, EPI, NSTAGE, WS>(p, (int)blockIdx.x, (int)blockIdx.y, smem_raw);
+}
+
+// Grouped launch: up to 4 problems of the same operand layout (the four weight gradients of a BertLayer) share one
+// grid — one set of launch / ramp / drain costs instead of four, and the tiles of small problems fill the CUs the big
+// ones leave idle.  Problem q owns grid slots [start[q], start[q+1]); starts are multiples of 8 so that the slot -> XCD
+// relation of the 2-D tile mapping is preserved.
+struct GemmGroupArgs {
+    GemmArgs g[4];
+    int start[5];
+    int n;
+};
+template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, int WS>
+__global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS == 2 ? 3 : 1)) void gemm_group_kernel(const GemmGroupArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int b = (int)blockIdx.x;
+    int q = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < ga.n && b >= ga.start[k]) q = k;
+    const GemmArgs& p = ga.g[q];
+    const int bx = b - ga.start[q];
+    if (bx >= ((p.M + BM - 1) / BM) * (p.N / BN)) return;        // padding slot
+    gemm_tile<BM, BN, TRA, TRB, EPI, NSTAGE, WS>(p, bx, 0, smem_raw);
 }
 
 // out[M*N] bf16 (+)= sum_s partial[s][M*N]
@@ -683,6 +713,55 @@ int launch_gemm(const GemmArgs& a, int cfg, int splits, hipStream_t st) {
         case 52: return launch_idx<TRA, TRB, EPI, 52>(a, splits, st);
         case 53: return launch_idx<TRA, TRB, EPI, 53>(a, splits, st);
         default: uh_set_error("gemm: bad tile index %d", cfg); return -1;
+    }
+}
+
+// ---- grouped weight-gradient launch ------------------------------------------------------------------------------
+template <int IDX>
+int launch_group_idx(GemmGroupArgs& ga, hipStream_t st) {
+    if constexpr (tile_ok<true, true>(IDX)) {
+        constexpr int BM = kTiles[IDX].bm, BN = kTiles[IDX].bn, NSTAGE = kTiles[IDX].stages, WS = kTiles[IDX].ws;
+        int total = 0;
+        for (int q = 0; q < ga.n; ++q) {
+            GemmArgs& a = ga.g[q];
+            if (a.M % BM != 0 || a.N % BN != 0 || (WS && a.K % 64 != 0)) {
+                uh_set_error("gemm group: tile %dx%d does not divide problem %d", BM, BN, q);
+                return -1;
+            }
+            const int tiles_m = a.M / BM, tiles_n = a.N / BN;
+            a.xr = pick_xr(tiles_m, tiles_n, BM, BN);
+            a.k_per_split = (a.K + 63) / 64 * 64;
+            a.partial = nullptr;
+            ga.start[q] = total;
+            total += (tiles_m * tiles_n + 7) / 8 * 8;
+        }
+        ga.start[ga.n] = total;
+        constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * 64 * sizeof(bf16_t);
+        static bool attr_done = false;
+        if (lds > 64 * 1024 && !attr_done) {
+            UH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_group_kernel<BM, BN, true, true, EPI_WGRAD, NSTAGE, WS>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((gemm_group_kernel<BM, BN, true, true, EPI_WGRAD, NSTAGE, WS>), dim3(total), dim3(WaveGrid<BM, BN, WS>::THREADS),
+                           lds, st, ga);
+        UH_LAUNCH_CHECK();
+        return 0;
+    } else {
+        uh_set_error("gemm group: tile shape %d is not available for the wgrad layout", IDX);
+        return -1;
+    }
+}
+
+int launch_group(GemmGroupArgs& ga, int cfg, hipStream_t st) {
+    switch (cfg) {
+#define UH_GROUP_CASE(I) case I: return launch_group_idx<I>(ga, st);
+        UH_GROUP_CASE(0) UH_GROUP_CASE(1) UH_GROUP_CASE(2) UH_GROUP_CASE(3) UH_GROUP_CASE(13) UH_GROUP_CASE(14) UH_GROUP_CASE(15)
+        UH_GROUP_CASE(20) UH_GROUP_CASE(23) UH_GROUP_CASE(24) UH_GROUP_CASE(26) UH_GROUP_CASE(27) UH_GROUP_CASE(29) UH_GROUP_CASE(33)
+        UH_GROUP_CASE(34) UH_GROUP_CASE(36) UH_GROUP_CASE(37) UH_GROUP_CASE(43) UH_GROUP_CASE(44) UH_GROUP_CASE(45) UH_GROUP_CASE(51)
+        UH_GROUP_CASE(52)
+#undef UH_GROUP_CASE
+        default: uh_set_error("gemm group: tile index %d is not a wgrad tile", cfg); return -1;
     }
 }
 
@@ -876,6 +955,105 @@ int gemm_wgrad(const void* dy, const void* x, void* dw, int64_t M, int64_t N, in
     return 0;
 }
 
+// Up to four weight gradients dw_q[N_q,K_q] (+)= dy_q[M,N_q]^T x_q[M,K_q] over the same M tokens in ONE launch.
+static const int kGroupCfgs[] = {0, 1, 2, 3, 13, 14, 15, 20, 23, 24, 26, 27, 29, 33, 34, 36, 37, 43, 44, 45, 51, 52};
+static bool group_cfg_ok(int cfg, int n, int64_t M, const int64_t* N, const int64_t* K) {
+    const int bm = kTiles[cfg].bm, bn = kTiles[cfg].bn;
+    if (kTiles[cfg].ws && M % 64 != 0) return false;
+    for (int q = 0; q < n; ++q)
+        if (N[q] % bm != 0 || K[q] % bn != 0) return false;
+    return true;
+}
+static int64_t group_sum(int n, const int64_t* v) { int64_t s = 0; for (int q = 0; q < n; ++q) s += v[q]; return s; }
+
+int gemm_wgrad_group(int n, const void* const* dy, const void* const* x, void* const* dw, int64_t M, const int64_t* N,
+                     const int64_t* K, int accumulate, hipStream_t st, int cfg_override) {
+    if (n < 1 || n > 4) { uh_set_error("gemm_wgrad_group: 1..4 problems"); return -1; }
+    for (int q = 0; q < n; ++q) {
+        if (check_common(M, N[q], K[q])) return -1;
+        if (N[q] % 64 != 0 || K[q] % 64 != 0) { uh_set_error("gemm_wgrad_group: need N %% 64 == 0 and K %% 64 == 0"); return -1; }
+        if (dy[q] == nullptr || x[q] == nullptr || dw[q] == nullptr) { uh_set_error("gemm_wgrad_group: null pointer"); return -1; }
+    }
+    GemmGroupArgs ga{};
+    ga.n = n;
+    for (int q = 0; q < n; ++q) {
+        GemmArgs& a = ga.g[q];
+        a.R = (const bf16_t*)dy[q]; a.ldr = N[q];
+        a.Cc = (const bf16_t*)x[q]; a.ldcc = K[q];
+        a.C = (bf16_t*)dw[q]; a.C2 = nullptr; a.ldc = K[q];
+        a.bias = nullptr; a.aux = nullptr; a.ldaux = 0;
+        a.M = (int)N[q]; a.N = (int)K[q]; a.K = (int)M;
+        a.accumulate = accumulate;
+        a.drop = make_dropout(0.f, 0, 0);
+    }
+    int cfg = cfg_override;
+    if (cfg < 0) {
+        Tuned tn;
+        if (tuned_lookup(3, M, group_sum(n, N), group_sum(n, K), &tn) && group_cfg_ok(tn.cfg, n, M, N, K)) cfg = tn.cfg;
+        else {
+            const int prefer[] = {33, 29, 0, 3};                      // 128x128 ws, 64x64 ws, then the plain tiles
+            for (int c : prefer)
+                if (group_cfg_ok(c, n, M, N, K)) { cfg = c; break; }
+        }
+    }
+    if (cfg < 0 || !group_cfg_ok(cfg, n, M, N, K)) { uh_set_error("gemm_wgrad_group: no legal tile"); return -1; }
+    LaunchTimer lt(TIME_GEMM_WGRAD, M, group_sum(n, N), group_sum(n, K), st);
+    return launch_group(ga, cfg, st);
+}
+
+// Times every legal tile for the grouped launch on scratch buffers; winner cached under kind 3, (M, sum N, sum K).
+int gemm_group_autotune(int n, int64_t M, const int64_t* N, const int64_t* K, hipStream_t st) {
+    {
+        Tuned t;
+        if (tuned_lookup(3, M, group_sum(n, N), group_sum(n, K), &t) && g_ranked.count(std::make_tuple(3, M, group_sum(n, N), group_sum(n, K)))) return 0;
+    }
+    void *dyb[4] = {nullptr, nullptr, nullptr, nullptr}, *xb[4] = {nullptr, nullptr, nullptr, nullptr}, *dwb[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() {
+        for (int q = 0; q < 4; ++q) { if (dyb[q]) (void)hipFree(dyb[q]); if (xb[q]) (void)hipFree(xb[q]); if (dwb[q]) (void)hipFree(dwb[q]); }
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+#define GT_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { uh_set_error("gemm_group_autotune: %s -> %s", #expr, hipGetErrorString(_e)); cleanup(); return (int)_e; } } while (0)
+    for (int q = 0; q < n; ++q) {
+        GT_HIP(hipMalloc(&dyb[q], (size_t)M * N[q] * 2));
+        GT_HIP(hipMalloc(&xb[q], (size_t)M * K[q] * 2));
+        GT_HIP(hipMalloc(&dwb[q], (size_t)N[q] * K[q] * 2));
+        GT_HIP(hipMemsetAsync(dyb[q], 0x3c, (size_t)M * N[q] * 2, st));
+        GT_HIP(hipMemsetAsync(xb[q], 0x3c, (size_t)M * K[q] * 2, st));
+        GT_HIP(hipMemsetAsync(dwb[q], 0, (size_t)N[q] * K[q] * 2, st));
+    }
+    GT_HIP(hipEventCreate(&e0));
+    GT_HIP(hipEventCreate(&e1));
+    std::vector<std::pair<float, Tuned>> ranked;
+    int rc = 0;
+    for (int cfg : kGroupCfgs) {
+        if (!group_cfg_ok(cfg, n, M, N, K)) continue;
+        auto run = [&]() { return gemm_wgrad_group(n, dyb, xb, dwb, M, N, K, 0, st, cfg); };
+        for (int i = 0; i < 2 && rc == 0; ++i) rc = run();
+        if (rc) break;
+        (void)hipEventRecord(e0, st);
+        for (int i = 0; i < 6 && rc == 0; ++i) rc = run();
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) { rc = -3; break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        ranked.push_back({ms, Tuned{cfg, 1}});
+    }
+#undef GT_HIP
+    cleanup();
+    if (rc) return rc;
+    if (!ranked.empty()) {
+        std::sort(ranked.begin(), ranked.end(), [](const std::pair<float, Tuned>& a, const std::pair<float, Tuned>& b) { return a.first < b.first; });
+        std::vector<Tuned> order;
+        for (auto& r : ranked) order.push_back(r.second);
+        std::lock_guard<std::mutex> lk(g_tuned_mu);
+        g_tuned[std::make_tuple(3, M, group_sum(n, N), group_sum(n, K))] = order[0];
+        g_ranked[std::make_tuple(3, M, group_sum(n, N), group_sum(n, K))] = order;
+    }
+    return 0;
+}
+
 // Empirical tile selection: time every legal tile shape (and split-K factor for wgrad) of one GEMM on scratch buffers and
 // remember the winner for (kind, M, N, K).  Synchronous (uses hipEvents + hipMalloc): call it at set-up time, not in a
 // training step.  kind: 0 = fwd (y = x w^T), 1 = dgrad (dx = dy w), 2 = wgrad (dw = dy^T x); M, N, K as in those calls.
@@ -975,6 +1153,12 @@ int gemm_autotune_candidates(int kind, int64_t M, int64_t N, int64_t K, int* cfg
 }
 
 int gemm_set_tuned(int kind, int64_t M, int64_t N, int64_t K, int cfg, int splits) {
+    if (kind == 3) {            // grouped wgrad: (M, sum N, sum K); legality is re-checked at launch against the members
+        if (cfg < 0 || cfg >= kNumTiles || splits != 1) { uh_set_error("gemm_set_tuned: bad grouped-wgrad tile"); return -1; }
+        std::lock_guard<std::mutex> lk(g_tuned_mu);
+        g_tuned[std::make_tuple(kind, M, N, K)] = Tuned{cfg, splits};
+        return 0;
+    }
     if (kind < 0 || kind > 2 || cfg < 0 || cfg >= kNumTiles) { uh_set_error("gemm_set_tuned: bad kind / tile index"); return -1; }
     if (splits < 1 || splits > 4 || (kind != 2 && splits != 1)) { uh_set_error("gemm_set_tuned: bad split count (split-K is a wgrad option, <= 4)"); return -1; }
     // same legality rules as the autotune sweep

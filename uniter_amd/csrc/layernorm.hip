@@ -150,11 +150,14 @@ struct LnBwd {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { oq[e] *= mult[e]; ad[c][e] += oq[e]; }
                         if (dd != nullptr) *reinterpret_cast<u32x2*>(dd + ro + ch * 4) = pack4(oq);
-                    } else if (want_dbias) {
-                        float oq[4];
-                        unpack4(packed, oq);
+                    } else {
+                        if (dd != nullptr) *reinterpret_cast<u32x2*>(dd + ro + ch * 4) = packed;   // no dropout: dd = dz
+                        if (want_dbias) {
+                            float oq[4];
+                            unpack4(packed, oq);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) ad[c][e] += oq[e];
+                            for (int e = 0; e < 4; ++e) ad[c][e] += oq[e];
+                        }
                     }
                 }
             }
@@ -257,13 +260,17 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const bf16_t* __restri
                 for (int e = 0; e < 4; ++e) o[e] = rstd * (gy[c][e] - c1 - xh[c][e] * c2);
                 const u32x2 packed = pack4(o);
                 __builtin_nontemporal_store(packed, reinterpret_cast<u32x2*>(dz + ro + ch * 4));
-                if (use_drop && dd != nullptr) {
-                    float oq[4], mult[4];
-                    unpack4(packed, oq);
-                    dropout_mult4(drop, ((uint64_t)row * (uint64_t)H + (uint64_t)ch * 4) >> 2, mult);
+                if (dd != nullptr) {            // dd = dropout-masked dz (a plain copy when there is no dropout)
+                    u32x2 dpk = packed;
+                    if (use_drop) {
+                        float oq[4], mult[4];
+                        unpack4(packed, oq);
+                        dropout_mult4(drop, ((uint64_t)row * (uint64_t)H + (uint64_t)ch * 4) >> 2, mult);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) oq[e] *= mult[e];
-                    __builtin_nontemporal_store(pack4(oq), reinterpret_cast<u32x2*>(dd + ro + ch * 4));
+                        for (int e = 0; e < 4; ++e) oq[e] *= mult[e];
+                        dpk = pack4(oq);
+                    }
+                    __builtin_nontemporal_store(dpk, reinterpret_cast<u32x2*>(dd + ro + ch * 4));
                 }
             }
         }
@@ -509,8 +516,8 @@ int layernorm_bwd_cols(const void* dy, const void* dy_extra, const void* z, cons
     const void* dsrc = nullptr;
     int mask_dsrc = 0;
     if (dbias != nullptr) {
-        if (masked && dd == nullptr) { dsrc = dz; mask_dsrc = 1; }
-        else dsrc = (masked && dd != nullptr) ? dd : dz;
+        if (dd != nullptr) dsrc = dd;                        // the row half's (masked) copy: never the reusable dz buffer
+        else { dsrc = dz; mask_dsrc = masked ? 1 : 0; }
     }
     dim3 grid((unsigned)((H + 511) / 512), nb);
     hipLaunchKernelGGL(ln_bwd_cols_kernel, grid, dim3(64 * BWD_WAVES), 0, st, (const bf16_t*)dy, (const bf16_t*)dy_extra,

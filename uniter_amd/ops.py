@@ -224,9 +224,12 @@ _autotuned = set()
 
 
 def _layer_gemm_shapes(s):
-    """(kind, M, N, K) of the 12 GEMMs of one BertLayer as the C ABI sees them (kind 0 fwd, 1 dgrad, 2 wgrad)."""
+    """(kind, M, N, K) of the tuned launches of one BertLayer as the C ABI sees them: kind 0 forward and 1 dgrad for the
+    four linear layers, kind 3 = the grouped launch of the four weight gradients, keyed (T, sum N, sum K)."""
     T, H, I = int(s.B) * int(s.L), int(s.H), int(s.I)
-    return [(kind, T, n, k) for kind in range(3) for n, k in ((3 * H, H), (H, H), (I, H), (H, I))]
+    shapes = [(kind, T, n, k) for kind in range(2) for n, k in ((3 * H, H), (H, H), (I, H), (H, I))]
+    shapes.append((3, T, 5 * H + I, 3 * H + I))
+    return shapes
 
 
 def _load_tune_cache(path, s):
