@@ -70,6 +70,8 @@ def kernel_flop(rec):
     k, M, N, K = rec["kind_id"], rec["M"], rec["N"], rec["K"]
     if k <= 5:
         return 2.0 * M * N * K                     # every GEMM flavour: M tokens x N out x K in (C-ABI argument order)
+    if k == 13:
+        return 2.0 * M * N                         # grouped wgrad: N = sum_i N_i*K_i weight elements (include/uniter_hip.h)
     if k == 6:
         return 4.0 * M * N * N * K * 64            # attention fwd: B=M, L=N, heads=K, d=64: QK^T + PV
     if k == 7:

@@ -52,7 +52,9 @@ int uniter_hip_counter_add(uint64_t* dev_counter, uint64_t inc, void* stream);
  * (kind, M, N, K): number of launches and their summed duration.  Not usable during stream capture.
  * kind: 0 gemm fwd +bias, 1 gemm fwd +bias+gelu, 2 gemm fwd +bias+dropout+residual, 3 gemm dgrad, 4 gemm dgrad x gelu',
  *       5 gemm wgrad (incl. split-K reduce), 6 attention fwd, 7 attention bwd, 8 layernorm fwd, 9 layernorm bwd,
- *       10 column sum, 11 AdamW, 12 layernorm bwd column sums (dgamma/dbeta/dbias; kind 9 is then the row half).
+ *       10 column sum, 11 AdamW, 12 layernorm bwd column sums (dgamma/dbeta/dbias; kind 9 is then the row half),
+ *       13 grouped gemm wgrad (uniter_gemm_wgrad_group): there N = sum_i N_i*K_i (weight-gradient elements produced, so
+ *       the launch's FLOP is 2*M*N) and K = the number of problems in the group.
  *       The reference has no counterpart (it profiles with nvprof / apex timers). */
 typedef struct {
     int32_t kind;

@@ -154,7 +154,7 @@ def pmc_traffic(fetch_csv, write_csv, dst):
     if os.path.exists(cache_path) and tiles:
         # per-layer launch order of the encoder (encoder.hip): (kind, EPI, N, K) with H / I recovered from the cache
         entries = json.load(open(cache_path)).get("gemm", [])
-        hs = sorted({e["K"] for e in entries} | {e["N"] for e in entries})
+        hs = sorted({e["K"] for e in entries if e["kind"] < 3} | {e["N"] for e in entries if e["kind"] < 3})
         H, I = (hs[0], hs[-1]) if hs else (0, 0)
         order = [(0, 0, 3 * H, H), (0, 2, H, H), (0, 1, I, H), (0, 2, H, I),                       # forward
                  (1, 4, H, I), (1, 3, I, H), (1, 3, H, H), (1, 3, 3 * H, H),                       # backward, main stream
@@ -188,6 +188,21 @@ def pmc_traffic(fetch_csv, write_csv, dst):
                 wr = (sum(w_sel) / len(w_sel)) * 1024.0
                 by_shape["%d:%d:%d:%d" % (epi, M, N, K)] = {
                     "kernel": names[key], "grid": key[1], "dispatches": len(f_sel), "shares_template_with": n - 1,
+                    "hbm_read_bytes": round(rd), "hbm_write_bytes": round(wr), "hbm_bytes": round(rd + wr)}
+        # the grouped weight-gradient launch (timing kind 13: N = sum N_i*K_i weight elements, K = problems per group)
+        g3 = [e for e in entries if e["kind"] == 3]
+        if g3 and H and I:
+            welems = H * I + I * H + H * H + 3 * H * H
+            for (name, grid), fv in fetch.items():
+                if "gemm_group_kernel<" not in name:
+                    continue
+                wv = write.get((name, grid), [])
+                if len(fv) < 8 or not wv:
+                    continue
+                rd = 2.0 * (sum(fv) / len(fv)) * 1024.0
+                wr = (sum(wv) / len(wv)) * 1024.0
+                by_shape["13:%d:%d:4" % (g3[0]["M"], welems)] = {
+                    "kernel": short(name), "grid": grid, "dispatches": len(fv), "shares_template_with": 0,
                     "hbm_read_bytes": round(rd), "hbm_write_bytes": round(wr), "hbm_bytes": round(rd + wr)}
     json.dump({"by_shape": by_shape, "per_kernel": per,
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over "

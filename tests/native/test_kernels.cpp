@@ -752,6 +752,11 @@ static void bench(int B, int L, int H, int heads, int I, int layers) {
                            ch[0] >= 0 ? kTileBM[ch[0]] : -1, ch[0] >= 0 ? kTileBN[ch[0]] : -1, ch[1]);
                 }
         }
+        {
+            int32_t ch[2];
+            UHCHK(uniter_gemm_tuned_choice(3, T, 5 * (int64_t)H + I, 3 * (int64_t)H + I, ch));
+            printf("  autotune grouped wgrad -> tile %dx%d (config %d)\n", ch[0] >= 0 ? kTileBM[ch[0]] : -1, ch[0] >= 0 ? kTileBN[ch[0]] : -1, ch[0]);
+        }
         double tf = tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 10);
         double tb = tm.run([&] { UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0)); }, 2, 10);
         uniter_encoder_debug_side_stream(0);

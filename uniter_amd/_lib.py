@@ -189,7 +189,7 @@ def stream_ptr():
 
 TIMING_KINDS = ("gemm fwd +bias", "gemm fwd +bias+gelu", "gemm fwd +bias+dropout+residual", "gemm dgrad",
                 "gemm dgrad x gelu'", "gemm wgrad", "attention fwd", "attention bwd", "layernorm fwd", "layernorm bwd",
-                "column sum", "adamw", "layernorm bwd column sums")
+                "column sum", "adamw", "layernorm bwd column sums", "gemm wgrad grouped")
 
 
 def timing_begin():

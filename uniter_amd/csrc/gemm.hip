@@ -997,7 +997,9 @@ int gemm_wgrad_group(int n, const void* const* dy, const void* const* x, void* c
         }
     }
     if (cfg < 0 || !group_cfg_ok(cfg, n, M, N, K)) { uh_set_error("gemm_wgrad_group: no legal tile"); return -1; }
-    LaunchTimer lt(TIME_GEMM_WGRAD, M, group_sum(n, N), group_sum(n, K), st);
+    int64_t welems = 0;
+    for (int i = 0; i < n; ++i) welems += N[i] * K[i];
+    LaunchTimer lt(TIME_GEMM_WGRAD_GROUP, M, welems, n, st);
     return launch_group(ga, cfg, st);
 }
 

@@ -13,7 +13,7 @@ namespace uh {
 // Kinds of timed launches; (kind, M, N, K) identifies one row of the report.
 enum { TIME_GEMM_FWD_BIAS = 0, TIME_GEMM_FWD_GELU = 1, TIME_GEMM_FWD_DROP_RES = 2, TIME_GEMM_DGRAD = 3,
        TIME_GEMM_DGRAD_GELU = 4, TIME_GEMM_WGRAD = 5, TIME_ATTN_FWD = 6, TIME_ATTN_BWD = 7, TIME_LN_FWD = 8,
-       TIME_LN_BWD = 9, TIME_COLSUM = 10, TIME_ADAMW = 11, TIME_LN_BWD_COLS = 12 };
+       TIME_LN_BWD = 9, TIME_COLSUM = 10, TIME_ADAMW = 11, TIME_LN_BWD_COLS = 12, TIME_GEMM_WGRAD_GROUP = 13 };
 extern bool g_timing_on;
 void timing_mark(int kind, int64_t M, int64_t N, int64_t K, hipStream_t st, bool begin);
 // Brackets everything launched in its scope with two events on `st` while timing is enabled (no-op otherwise).
