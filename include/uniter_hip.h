@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UNITER_HIP_ABI_VERSION 2
+#define UNITER_HIP_ABI_VERSION 3
 
 /* ------------------------------------------------------------------------------------------------
  * Library
@@ -122,8 +122,11 @@ int uniter_gemm_wgrad(const void* dy, const void* x, void* dw, void* db,
 /* Up to four weight gradients over the same M tokens in ONE launch: dw_q[N_q,K_q] (+)= dy_q[M,N_q]^T * x_q[M,K_q],
  * q < n <= 4 (host arrays of device pointers / sizes).  The four nn.Linear weight gradients of a BertLayer
  * (model/layer.py:64-66,112,140,153) are independent of each other; one grid pays one launch / ramp / drain and the
- * tiles of the small problems fill the CUs the big ones leave idle.  No split-K; N_q % 64 == 0, K_q % 64 == 0. */
-int uniter_gemm_wgrad_group(int32_t n, const void* const* dy, const void* const* x, void* const* dw,
+ * tiles of the small problems fill the CUs the big ones leave idle.  No split-K; N_q % 64 == 0, K_q % 64 == 0.
+ * db (host array, may be NULL; entries may be NULL): db_q[N_q] (+)= column sums of dy_q — the nn.Linear bias gradients.
+ * They come out of the same launch: the tiles of the first tile column multiply the dy fragments they already hold by a
+ * fragment of ones (one extra MFMA each), so no separate reduction kernel reads dy again. */
+int uniter_gemm_wgrad_group(int32_t n, const void* const* dy, const void* const* x, void* const* dw, void* const* db,
                             int64_t M, const int64_t* N, const int64_t* K, int accumulate, void* stream);
 
 /* Strided-operand variants (row stride in elements; operands may be column slices of a wider row-major matrix —

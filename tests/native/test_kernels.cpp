@@ -4,6 +4,9 @@
 // Every check compares the HIP kernel with a plain fp32 host loop on bf16-rounded inputs (the host
 // reference lives in THIS file, it is test code).  Exit code = number of failed checks.
 #include <hip/hip_runtime.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -471,27 +474,32 @@ static void test_attention(int B, int L, int heads, float p) {
 static void test_wgrad_group(int M) {
     const int n = 4;
     const int64_t N[4] = {128, 256, 128, 384}, K[4] = {256, 128, 128, 128};
-    HostBf DY[4], X[4], W0[4];
-    uint16_t *dDY[4], *dX[4], *dW1[4], *dW2[4];
+    HostBf DY[4], X[4], W0[4], B0[4];
+    uint16_t *dDY[4], *dX[4], *dW1[4], *dW2[4], *dB1[4], *dB2[4];
     size_t wsb = 0;
     for (int q = 0; q < n; ++q) {
         DY[q].fill((size_t)M * N[q], 1.f); X[q].fill((size_t)M * K[q], 1.f); W0[q].fill((size_t)N[q] * K[q], 0.5f);
         dDY[q] = upload(DY[q]); dX[q] = upload(X[q]); dW1[q] = upload(W0[q]); dW2[q] = upload(W0[q]);
+        B0[q].fill((size_t)N[q], 0.5f); dB1[q] = upload(B0[q]); dB2[q] = upload(B0[q]);
         wsb = std::max(wsb, uniter_gemm_wgrad_workspace_bytes(M, N[q], K[q]));
     }
     void* ws = dalloc<char>(wsb);
     uniter_gemm_debug_force(3, 1);                       // 64x64, no split: the same summation order as the grouped default
-    for (int q = 0; q < n; ++q) UHCHK(uniter_gemm_wgrad(dDY[q], dX[q], dW1[q], nullptr, M, N[q], K[q], 1, ws, wsb, 0));
+    for (int q = 0; q < n; ++q) UHCHK(uniter_gemm_wgrad(dDY[q], dX[q], dW1[q], dB1[q], M, N[q], K[q], 1, ws, wsb, 0));
     uniter_gemm_debug_force(-1, -1);
     const void* dyp[4] = {dDY[0], dDY[1], dDY[2], dDY[3]};
     const void* xp[4] = {dX[0], dX[1], dX[2], dX[3]};
     void* dwp[4] = {dW2[0], dW2[1], dW2[2], dW2[3]};
-    UHCHK(uniter_gemm_wgrad_group(n, dyp, xp, dwp, M, N, K, 1, 0));
+    void* dbp[4] = {dB2[0], dB2[1], nullptr, dB2[3]};   // member 2 without a bias gradient: its buffer must stay untouched
+    UHCHK(uniter_gemm_wgrad_group(n, dyp, xp, dwp, dbp, M, N, K, 1, 0));
     HIPCHK(hipDeviceSynchronize());
     for (int q = 0; q < n; ++q) {
         char tag[128];
         snprintf(tag, sizeof(tag), "wgrad group member %d (M%d N%lld K%lld, accumulate)", q, M, (long long)N[q], (long long)K[q]);
         check(tag, download_bf(dW2[q], (size_t)N[q] * K[q]), download_bf(dW1[q], (size_t)N[q] * K[q]), 0.13f, 0.02f);
+        snprintf(tag, sizeof(tag), "wgrad group member %d bias gradient (column sums of dy, accumulate)", q);
+        if (q == 2) check(tag, download_bf(dB2[q], (size_t)N[q]), B0[q].v, 0.f, 0.f);
+        else check(tag, download_bf(dB2[q], (size_t)N[q]), download_bf(dB1[q], (size_t)N[q]), 0.13f, 0.02f);
     }
 }
 
@@ -765,7 +773,8 @@ static void bench(int B, int L, int H, int heads, int I, int layers) {
         printf("  (backward with the wgrad side stream disabled: %.1f us)\n", tb0);
         {   // in-situ per-launch durations (HIP events around every launch) of one forward + backward
             static const char* kinds[] = {"gemm fwd +bias", "gemm fwd +gelu", "gemm fwd +drop+res", "gemm dgrad", "gemm dgrad gelu'", "gemm wgrad",
-                                          "attn fwd", "attn bwd", "ln fwd", "ln bwd rows", "colsum", "adamw", "ln bwd cols"};
+                                          "attn fwd", "attn bwd", "ln fwd", "ln bwd rows", "colsum", "adamw", "ln bwd cols", "gemm wgrad group"};
+            const int nkinds = (int)(sizeof(kinds) / sizeof(kinds[0]));
             UniterTimingRecord rec[64];
             int32_t nrec = 0;
             HIPCHK(hipDeviceSynchronize());
@@ -774,7 +783,7 @@ static void bench(int B, int L, int H, int heads, int I, int layers) {
             UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0));
             UHCHK(uniter_hip_timing_end(rec, 64, &nrec));
             for (int i = 0; i < nrec && i < 64; ++i)
-                printf("  in-situ %-18s M%-5lld N%-5lld K%-5lld x%-3d avg %7.2f us\n", kinds[rec[i].kind], (long long)rec[i].M,
+                printf("  in-situ %-18s M%-5lld N%-5lld K%-5lld x%-3d avg %7.2f us\n", rec[i].kind >= 0 && rec[i].kind < nkinds ? kinds[rec[i].kind] : "?", (long long)rec[i].M,
                        (long long)rec[i].N, (long long)rec[i].K, rec[i].calls, rec[i].total_us / rec[i].calls);
         }
         {   // experiment: two half batches on two streams (phases of the two kernel chains are not aligned)
@@ -816,9 +825,13 @@ static void bench(int B, int L, int H, int heads, int I, int layers) {
             const void* dyp[4] = {dyb[0], dyb[1], dyb[2], dyb[3]};
             const void* xp[4] = {xb[0], xb[1], xb[2], xb[3]};
             void* dwp[4] = {dwb[0], dwb[1], dwb[2], dwb[3]};
+            uint16_t* dbb[4];
+            for (int q = 0; q < 4; ++q) { dbb[q] = dalloc<uint16_t>((size_t)Ng[q]); HIPCHK(hipMemset(dbb[q], 0, (size_t)Ng[q] * 2)); }
+            void* dbp[4] = {dbb[0], dbb[1], dbb[2], dbb[3]};
             double sep = tm.run([&] { for (int q = 0; q < 4; ++q) UHCHK(uniter_gemm_wgrad(dyb[q], xb[q], dwb[q], nullptr, T, Ng[q], Kg[q], 1, ws2, wsb2, 0)); }, 3, 20);
-            double grp = tm.run([&] { UHCHK(uniter_gemm_wgrad_group(4, dyp, xp, dwp, T, Ng, Kg, 1, 0)); }, 3, 20);
-            printf("  (four weight gradients of a layer: separate tuned launches %.1f us, one grouped launch %.1f us)\n", sep, grp);
+            double grp = tm.run([&] { UHCHK(uniter_gemm_wgrad_group(4, dyp, xp, dwp, nullptr, T, Ng, Kg, 1, 0)); }, 3, 20);
+            double grb = tm.run([&] { UHCHK(uniter_gemm_wgrad_group(4, dyp, xp, dwp, dbp, T, Ng, Kg, 1, 0)); }, 3, 20);
+            printf("  (four weight gradients of a layer: separate tuned launches %.1f us, one grouped launch %.1f us, grouped with the four bias gradients %.1f us)\n", sep, grp, grb);
         }
         const double flf = (double)layers * (24.0 * T * H * H + 4.0 * T * L * H);
         printf("  ENCODER fwd %.1f us (%.1f TF) | bwd %.1f us (%.1f TF) | fwd+bwd %.1f us = %.1f TF = %.1f%% of 2.5 PF ; %.0f ex/s\n", tf,
@@ -917,7 +930,16 @@ static int run_one(int argc, char** argv, int at) {
     return 0;
 }
 
+static void on_segv(int) {                 // where did it die: raw return addresses + symbols to stderr
+    void* bt[48];
+    const int n = backtrace(bt, 48);
+    backtrace_symbols_fd(bt, n, 2);
+    _exit(139);
+}
+
 int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);   // keep the log complete if a later test dies
+    signal(SIGSEGV, on_segv);
     bool do_bench = false, quick = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--bench")) do_bench = true;

@@ -11,7 +11,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "build", "libuniter_hip.so")
-ABI_VERSION = 2          # UNITER_HIP_ABI_VERSION of include/uniter_hip.h (struct layouts below must match it)
+ABI_VERSION = 3          # UNITER_HIP_ABI_VERSION of include/uniter_hip.h (struct layouts below must match it)
 
 
 class UniterHipError(RuntimeError):
@@ -71,7 +71,7 @@ SIGNATURES = {
     "uniter_gemm_bias_fwd_ld": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "uniter_gemm_dgrad_ld": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "uniter_gemm_wgrad_ld": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, c_int, _P, c_size_t, _P]),
-    "uniter_gemm_wgrad_group": (c_int, [c_int32, _P, _P, _P, _I, _P, _P, c_int, _P]),
+    "uniter_gemm_wgrad_group": (c_int, [c_int32, _P, _P, _P, _P, _I, _P, _P, c_int, _P]),
     "uniter_attention_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
     "uniter_attention_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
     "uniter_attention_fwd_packed": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),

@@ -60,6 +60,28 @@ __device__ __forceinline__ void load_tile(bf16_t* tile, const bf16_t* src, int64
     }
 }
 
+// A workgroup stages its [Lp x 64] operand tiles with at most TILE_IT 16-byte chunks per thread and tile (the launch
+// picks the wave count so that this holds).  ALL global loads of the prologue are issued before the first LDS write:
+// a load -> wait -> write loop would pay one full memory round trip per iteration and tile (measured: 10 serialized
+// round trips were most of the backward kernel's 20 us).
+constexpr int TILE_IT = 4;
+__device__ __forceinline__ void tile_fetch(u32x4 (&r)[TILE_IT], const bf16_t* src, int64_t ld, int L, int Lp) {
+#pragma unroll
+    for (int it = 0; it < TILE_IT; ++it) {
+        const int idx = threadIdx.x + it * blockDim.x;
+        const int row = idx >> 3, c = idx & 7;
+        r[it] = u32x4{0u, 0u, 0u, 0u};
+        if (idx < Lp * 8 && row < L) r[it] = *reinterpret_cast<const u32x4*>(src + (int64_t)row * ld + c * 8);
+    }
+}
+__device__ __forceinline__ void tile_commit(bf16_t* tile, const u32x4 (&r)[TILE_IT], int Lp) {
+#pragma unroll
+    for (int it = 0; it < TILE_IT; ++it) {
+        const int idx = threadIdx.x + it * blockDim.x;
+        if (idx < Lp * 8) *reinterpret_cast<u32x4*>(tile + at_off8(idx >> 3, 2 * (idx & 7))) = r[it];
+    }
+}
+
 struct AttnArgs {
     const bf16_t* qkv;
     const float* mask_bias;
@@ -91,26 +113,46 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
     const int64_t ld = 3 * (int64_t)H;
     const bf16_t* base = p.qkv + row0 * ld + h * DH;
 
-    load_tile(Ks, base + H, ld, L, Lp);
-    load_tile(Vs, base + 2 * H, ld, L, Lp);
-    for (int k = threadIdx.x; k < Lp; k += blockDim.x)
-        mb[k] = (k < L) ? (p.mask_bias ? p.mask_bias[(int64_t)b * Lm + k] : 0.f) : -INFINITY;
-    __syncthreads();
-
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int g = lane >> 4, i = lane & 15;
     const int nkt = Lp >> 4;           // key tiles (even)
     const int nqt = (L + 15) >> 4;
 
-    for (int qt = wid; qt < nqt; qt += nw) {
+    // prologue: the wave's first Q fragment, the K and V tiles and the mask all leave in one burst
+    auto fetch_q = [&](int qt, bf16x8 (&qf)[2]) {
         const int q = qt * 16 + i;
-        bf16x8 qf[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             u32x4 v = {0u, 0u, 0u, 0u};
             if (q < L) v = *reinterpret_cast<const u32x4*>(base + (int64_t)q * ld + ks * 32 + g * 8);
             qf[ks] = __builtin_bit_cast(bf16x8, v);
         }
+    };
+    bf16x8 qf[2] = {};
+    if (wid < nqt) fetch_q(wid, qf);
+    {
+        u32x4 rk[TILE_IT], rv[TILE_IT];
+        tile_fetch(rk, base + H, ld, L, Lp);
+        tile_fetch(rv, base + 2 * H, ld, L, Lp);
+        float mbv[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int k = threadIdx.x + it * blockDim.x;
+            mbv[it] = (k < L) ? (p.mask_bias ? p.mask_bias[(int64_t)b * Lm + k] : 0.f) : -INFINITY;
+        }
+        tile_commit(Ks, rk, Lp);
+        tile_commit(Vs, rv, Lp);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int k = threadIdx.x + it * blockDim.x;
+            if (k < Lp) mb[k] = mbv[it];
+        }
+    }
+    __syncthreads();
+
+    for (int qt = wid; qt < nqt; qt += nw) {
+        const int q = qt * 16 + i;
+        if (qt != wid) fetch_q(qt, qf);
         // S^T tiles: lane holds keys kt*16+4g+{0..3} of query i
         f32x4 s[MAXKT];
 #pragma unroll
@@ -216,29 +258,47 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
     const bf16_t* dO = p.dctx + row0 * H + h * DH;
     const bf16_t* O = p.ctx + row0 * H + h * DH;
 
-    load_tile(Qs, base, ld, L, Lp);
-    load_tile(Ks, base + H, ld, L, Lp);
-    load_tile(Vs, base + 2 * H, ld, L, Lp);
-    load_tile(Os, dO, H, L, Lp);
-    for (int k = threadIdx.x; k < Lp; k += blockDim.x) {
-        mb[k] = (k < L) ? (p.mask_bias ? p.mask_bias[(int64_t)b * Lm + k] : 0.f) : -INFINITY;
-        lse_s[k] = (k < L) ? p.lse[(int64_t)bh * Lm + k] : INFINITY;
-    }
-    // D[q] = sum_d dO[q][d] * O[q][d]
-    for (int idx = threadIdx.x; idx < Lp * 8; idx += blockDim.x) {
-        const int row = idx >> 3, c = idx & 7;
-        float part = 0.f;
-        if (row < L) {
-            float a[8], o[8];
-            unpack8(*reinterpret_cast<const u32x4*>(dO + (int64_t)row * H + c * 8), a);
-            unpack8(*reinterpret_cast<const u32x4*>(O + (int64_t)row * H + c * 8), o);
+    {
+        // prologue: Q, K, V, dO, O, the mask and lse all leave in one burst, then go to LDS (see tile_fetch)
+        u32x4 rq[TILE_IT], rk[TILE_IT], rv[TILE_IT], rdo[TILE_IT], ro[TILE_IT];
+        tile_fetch(rq, base, ld, L, Lp);
+        tile_fetch(rk, base + H, ld, L, Lp);
+        tile_fetch(rv, base + 2 * H, ld, L, Lp);
+        tile_fetch(rdo, dO, H, L, Lp);
+        tile_fetch(ro, O, H, L, Lp);
+        float mbv[2], lsv[2];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) part += a[e] * o[e];
+        for (int it = 0; it < 2; ++it) {
+            const int k = threadIdx.x + it * blockDim.x;
+            mbv[it] = (k < L) ? (p.mask_bias ? p.mask_bias[(int64_t)b * Lm + k] : 0.f) : -INFINITY;
+            lsv[it] = (k < L) ? p.lse[(int64_t)bh * Lm + k] : INFINITY;
         }
-        part += __shfl_xor(part, 1, WAVE);
-        part += __shfl_xor(part, 2, WAVE);
-        part += __shfl_xor(part, 4, WAVE);
-        if (c == 0) D_s[row] = part;
+        tile_commit(Qs, rq, Lp);
+        tile_commit(Ks, rk, Lp);
+        tile_commit(Vs, rv, Lp);
+        tile_commit(Os, rdo, Lp);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int k = threadIdx.x + it * blockDim.x;
+            if (k < Lp) { mb[k] = mbv[it]; lse_s[k] = lsv[it]; }
+        }
+        // D[q] = sum_d dO[q][d] * O[q][d]   (rows >= L were fetched as zeros; whole waves are in or out of range)
+#pragma unroll
+        for (int it = 0; it < TILE_IT; ++it) {
+            const int idx = threadIdx.x + it * blockDim.x;
+            if (idx < Lp * 8) {
+                float a[8], o[8];
+                unpack8(rdo[it], a);
+                unpack8(ro[it], o);
+                float part = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) part += a[e] * o[e];
+                part += __shfl_xor(part, 1, WAVE);
+                part += __shfl_xor(part, 2, WAVE);
+                part += __shfl_xor(part, 4, WAVE);
+                if ((idx & 7) == 0) D_s[idx >> 3] = part;
+            }
+        }
     }
     __syncthreads();
 
@@ -393,6 +453,7 @@ int attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse
     if (cu == nullptr && mask_bias == nullptr) { uh_set_error("attention: dense mode needs mask_bias"); return -1; }
     const int nkt = a.Lp / 16;
     const int nw = pick_waves((int)((L + 15) / 16));
+    if (a.Lp * 8 > TILE_IT * nw * 64 || a.Lp > 2 * nw * 64) { uh_set_error("attention: prologue staging does not cover L=%lld with %d waves", (long long)L, nw); return -1; }
     const size_t lds = (size_t)a.Lp * 64 * 2 * 2 + (size_t)a.Lp * 4;
     dim3 grid((unsigned)(B * heads)), block(nw * 64);
     int rc;
@@ -426,6 +487,7 @@ int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, cons
     a.cu = cu;
     if (cu == nullptr && mask_bias == nullptr) { uh_set_error("attention: dense mode needs mask_bias"); return -1; }
     const int nw = pick_waves((int)((L + 15) / 16));
+    if (a.Lp * 8 > TILE_IT * nw * 64 || a.Lp > 2 * nw * 64) { uh_set_error("attention: prologue staging does not cover L=%lld with %d waves", (long long)L, nw); return -1; }
     const size_t lds = (size_t)a.Lp * 64 * 2 * 4 + (size_t)a.Lp * 4 * 3 + (size_t)a.Lp * (a.Lp / 4);
     int rc;
     if ((rc = set_lds(attn_bwd_kernel, lds))) return rc;

@@ -232,10 +232,10 @@ int uniter_gemm_wgrad_ld(const void* dy, int64_t lddy, const void* x, int64_t ld
     return uh::gemm_wgrad(dy, x, dw, M, N, K, accumulate, workspace, workspace_bytes, (hipStream_t)stream, lddy, ldx);
 }
 
-int uniter_gemm_wgrad_group(int32_t n, const void* const* dy, const void* const* x, void* const* dw,
+int uniter_gemm_wgrad_group(int32_t n, const void* const* dy, const void* const* x, void* const* dw, void* const* db,
                             int64_t M, const int64_t* N, const int64_t* K, int accumulate, void* stream) {
     UH_CHECK_ARG(dy && x && dw && N && K, "null pointer");
-    return uh::gemm_wgrad_group(n, dy, x, dw, M, N, K, accumulate, (hipStream_t)stream);
+    return uh::gemm_wgrad_group(n, dy, x, dw, db, M, N, K, accumulate, (hipStream_t)stream);
 }
 
 int uniter_attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse,

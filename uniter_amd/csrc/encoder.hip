@@ -109,6 +109,11 @@ int side_init() {
 int g_use_side_stream = 1;
 int g_tune_in_situ = 1;
 int g_group_wgrad = 1;      // 1: the four weight gradients of a layer go out as one grouped launch
+// How many main-stream kernels after a layer's attention backward the grouped launch is released to the side stream
+// (0 = immediately, 1 = after the layer's last dgrad, 2 = after the next layer's first LayerNorm row kernel, ...).
+// The grouped kernel shares the CUs with whatever the main stream runs meanwhile; which neighbours it slows least is
+// an empirical question.  UNITER_AMD_WGRAD_DEFER overrides it.
+int g_group_defer = [] { const char* e = getenv("UNITER_AMD_WGRAD_DEFER"); return e ? atoi(e) : 0; }();
 
 int check_shape(const UniterEncoderShape* s) {
     if (s == nullptr) { uh_set_error("encoder: null shape"); return -1; }
@@ -235,6 +240,33 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         return 0;
     };
     const char* dyl = (const char*)dy;
+    // the grouped weight-gradient launch of layer lg: its four weight gradients AND their four bias gradients (column
+    // sums of the same dy operands), released to the side stream g_group_defer main-stream kernels after lg's
+    // attention backward
+    auto group_launch = [&](int lg) -> int {
+        const UniterLayerParams& Pg = layers[lg];
+        char* Ag = (char*)acts + (size_t)lg * al.total;
+        const char* xg = (lg == layer_begin) ? (const char*)x_in : ((char*)acts + (size_t)(lg - 1) * al.total + al.y);
+        const int pg = lg & 1;
+        const void* gdy[4] = {S + sl.dd[pg], S + sl.dpre[pg], S + sl.dd1[pg], S + sl.dqkv[pg]};
+        const void* gx[4] = {Ag + al.g, Ag + al.a, Ag + al.ctx, xg};
+        void* gdw[4] = {Pg.g_w2, Pg.g_w1, Pg.g_wo, Pg.g_wqkv};
+        void* gdb[4] = {Pg.g_b2, Pg.g_b1, Pg.g_bo, Pg.g_bqkv};
+        const int64_t gN[4] = {H, I, H, 3 * H}, gK[4] = {I, H, H, H};
+        RC(fork(3));
+        RC(uh::gemm_wgrad_group(4, gdy, gx, gdw, gdb, T, gN, gK, 1, ss));
+        RC(joined(pg));
+        return 0;
+    };
+    int pending = -1, countdown = 0;
+    auto tick = [&]() -> int {                 // one main-stream kernel has been enqueued
+        if (pending >= 0 && --countdown <= 0) {
+            const int lg = pending;
+            pending = -1;
+            return group_launch(lg);
+        }
+        return 0;
+    };
     for (int l = layer_end - 1; l >= layer_begin; --l) {
         const UniterLayerParams& P = layers[l];
         char* A = (char*)acts + (size_t)l * al.total;
@@ -257,9 +289,10 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         RC(before_overwrite(par));                 // weight gradients of layer l+2 used this buffer set
         RC(uh::layernorm_bwd_rows(dyl, nullptr, A + al.z2, (const float*)(A + al.mean2), (const float*)(A + al.rstd2),
                                   P.ln2_g, bufA, ddb2, T, H, d_h2, 0, st));
+        RC(tick());
         RC(fork(4));
         RC(uh::layernorm_bwd_cols(dyl, nullptr, A + al.z2, (const float*)(A + al.mean2), (const float*)(A + al.rstd2),
-                                  bufA, ddb2, P.g_ln2_g, P.g_ln2_b, P.g_b2, T, H, 1, d_h2, 0,
+                                  bufA, ddb2, P.g_ln2_g, P.g_ln2_b, grouped ? nullptr : P.g_b2, T, H, 1, d_h2, 0,
                                   side ? red2 : red, sl.red_bytes, ss));
         RC(joined(4));                         // dyl (bufB below the top layer) has been read
         if (!grouped) {
@@ -267,21 +300,24 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
             RC(joined(par));
         }
         RC(uh::gemm_dgrad(uh::GEMM_EPI_GELU_BWD, ddb2, P.w2, A + al.u, dpre, T, H, I, st));
+        RC(tick());
         // ---- BertIntermediate backward (model/layer.py:139-142) ----
-        RC(fork(2));
-        RC(uh::colsum(dpre, P.g_b1, T, I, 1, side ? red2 : red, sl.red_bytes, ss));
         if (!grouped) {
+            RC(fork(2));
+            RC(uh::colsum(dpre, P.g_b1, T, I, 1, side ? red2 : red, sl.red_bytes, ss));
             RC(uh::gemm_wgrad(dpre, A + al.a, P.g_w1, T, I, H, 1, wg, sl.wg_bytes, ss));
             RC(joined(par));
         }
         RC(before_overwrite(4));               // bufB is about to receive da
         RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dpre, P.w1, bufA, bufB, T, I, H, st));          // da = dpre*W1 + dz2
+        RC(tick());
         // ---- BertSelfOutput backward (model/layer.py:111-115) ----
         RC(uh::layernorm_bwd_rows(bufB, nullptr, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1),
                                   P.ln1_g, bufA, ddb1, T, H, d_h1, 0, st));
+        RC(tick());
         RC(fork(5));
         RC(uh::layernorm_bwd_cols(bufB, nullptr, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1),
-                                  bufA, ddb1, P.g_ln1_g, P.g_ln1_b, P.g_bo, T, H, 1, d_h1, 0,
+                                  bufA, ddb1, P.g_ln1_g, P.g_ln1_b, grouped ? nullptr : P.g_bo, T, H, 1, d_h1, 0,
                                   side ? red2 : red, sl.red_bytes, ss));
         RC(joined(5));                         // bufB (da) has been read
         if (!grouped) {
@@ -289,27 +325,29 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
             RC(joined(par));
         }
         RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, ddb1, P.wo, nullptr, dctx, T, H, H, st));
+        RC(tick());
         // ---- BertSelfAttention backward (model/layer.py:75-101) ----
         RC(uh::attention_bwd(A + al.qkv, s->total_tokens > 0 ? nullptr : mask_bias, A + al.ctx, (const float*)(A + al.lse), dctx, dqkv,
                              s->B, s->L, s->heads, d_attn, st, s->total_tokens > 0 ? s->cu_seqlens : nullptr));
-        RC(fork(3));
-        RC(uh::colsum(dqkv, P.g_bqkv, T, 3 * H, 1, side ? red2 : red, sl.red_bytes, ss));
         if (grouped) {
-            // the four weight gradients of the layer in one launch (their inputs are all final now)
-            const void* gdy[4] = {ddb2, dpre, ddb1, dqkv};
-            const void* gx[4] = {A + al.g, A + al.a, A + al.ctx, xin};
-            void* gdw[4] = {P.g_w2, P.g_w1, P.g_wo, P.g_wqkv};
-            const int64_t gN[4] = {H, I, H, 3 * H}, gK[4] = {I, H, H, H};
-            RC(uh::gemm_wgrad_group(4, gdy, gx, gdw, T, gN, gK, 1, ss));
+            RC(tick());                        // (a still-pending earlier layer goes first)
+            if (pending >= 0) RC(group_launch(pending));
+            pending = l;                       // this layer's inputs are all final now
+            countdown = side ? g_group_defer : 0;
+            if (countdown <= 0) { pending = -1; RC(group_launch(l)); }
         } else {
+            RC(fork(3));
+            RC(uh::colsum(dqkv, P.g_bqkv, T, 3 * H, 1, side ? red2 : red, sl.red_bytes, ss));
             RC(uh::gemm_wgrad(dqkv, xin, P.g_wqkv, T, 3 * H, H, 1, wg, sl.wg_bytes, ss));
+            RC(joined(par));
         }
-        RC(joined(par));
         char* dxl = (l == layer_begin) ? (char*)dx : bufB;
         RC(before_overwrite(5));               // bufB is about to receive this layer's dx
         RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dqkv, P.wqkv, bufA, dxl, T, 3 * H, H, st));     // dx = dqkv*Wqkv + dz1
+        RC(tick());
         dyl = dxl;
     }
+    if (pending >= 0) RC(group_launch(pending));
     if (side) {
         // every weight gradient is complete (and the scratch buffers are free) once the caller's stream passes this point
         UH_CHECK_HIP(hipEventRecord(g_side.done, ss));

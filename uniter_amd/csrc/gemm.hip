@@ -34,7 +34,8 @@ struct GemmArgs {
     const bf16_t* Cc;     // N-side operand
     int64_t ldr, ldcc;    // leading dimensions (elements)
     bf16_t* C;            // output [M][N]
-    bf16_t* C2;           // second output (EPI_BIAS_GELU: g)
+    bf16_t* C2;           // second output (EPI_BIAS_GELU: g; EPI_WGRAD: db[M] = sums of the M-side operand over the
+                          // contraction, i.e. the bias gradient that belongs to this weight gradient; nullptr = none)
     int64_t ldc;
     const bf16_t* bias;   // [N] or nullptr
     const bf16_t* aux;    // residual [M][N] / pre-activation u [M][N] / nullptr
@@ -306,6 +307,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 #pragma unroll
         for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // EPI_WGRAD with a bias-gradient output: the first tile column also sums its M-side operand (dy) over the
+    // contraction — one extra MFMA per fragment against a fragment of ones, on operands that are in registers anyway —
+    // so the separate column-sum kernels over dy disappear.  All four rows of the result tile are the same sum.
+    const bool rowsum = (EPI == EPI_WGRAD) && p.C2 != nullptr && tn == 0 && wn == 0;
+    f32x4 bacc[MI];
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#pragma unroll
+    for (int b = 0; b < MI; ++b) bacc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
     auto compute = [&](int buf) {
         const bf16_t* tr = smem + buf * STAGE;
         const bf16_t* tc = tr + TILE_R;
@@ -316,6 +328,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
             for (int b = 0; b < MI; ++b) {
                 if constexpr (TRA) fr[b] = frag_ks<BM>(tr, wm * WM + b * 16, ks, g, i);
                 else               fr[b] = frag_kc(tr, wm * WM + b * 16 + i, ks, g);
+            }
+            if constexpr (EPI == EPI_WGRAD) {
+                if (rowsum) {
+#pragma unroll
+                    for (int b = 0; b < MI; ++b)
+                        bacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fr[b], bacc[b], 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int a = 0; a < NI; ++a) {
@@ -425,6 +444,19 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     // a 9-25 us kernel).  Instead every 16-row MFMA block is staged through the (now idle) LDS ring as fp32 and read
     // back row-contiguously, so all global traffic of the epilogue — output, residual / pre-activation reads, the
     // accumulate read of wgrad — is 16 bytes per lane over full tile rows.  The arithmetic per element is unchanged.
+    if constexpr (EPI == EPI_WGRAD) {
+        if (rowsum && g == 0) {                             // lane i of the first lane group holds the sum of row m
+#pragma unroll
+            for (int b = 0; b < MI; ++b) {
+                const int m = m0 + wm * WM + b * 16 + i;
+                if (m < p.M) {
+                    float v = bacc[b][0];
+                    if (p.accumulate) v += bf2f(p.C2[m]);
+                    p.C2[m] = f2bf(v);
+                }
+            }
+        }
+    }
     if (EPI == EPI_WGRAD && p.partial != nullptr) {         // split-K partials: already 16-byte fp32 stores
 #pragma unroll
         for (int b = 0; b < MI; ++b) {
@@ -966,8 +998,8 @@ static bool group_cfg_ok(int cfg, int n, int64_t M, const int64_t* N, const int6
 }
 static int64_t group_sum(int n, const int64_t* v) { int64_t s = 0; for (int q = 0; q < n; ++q) s += v[q]; return s; }
 
-int gemm_wgrad_group(int n, const void* const* dy, const void* const* x, void* const* dw, int64_t M, const int64_t* N,
-                     const int64_t* K, int accumulate, hipStream_t st, int cfg_override) {
+int gemm_wgrad_group(int n, const void* const* dy, const void* const* x, void* const* dw, void* const* db, int64_t M,
+                     const int64_t* N, const int64_t* K, int accumulate, hipStream_t st, int cfg_override) {
     if (n < 1 || n > 4) { uh_set_error("gemm_wgrad_group: 1..4 problems"); return -1; }
     for (int q = 0; q < n; ++q) {
         if (check_common(M, N[q], K[q])) return -1;
@@ -980,7 +1012,7 @@ int gemm_wgrad_group(int n, const void* const* dy, const void* const* x, void* c
         GemmArgs& a = ga.g[q];
         a.R = (const bf16_t*)dy[q]; a.ldr = N[q];
         a.Cc = (const bf16_t*)x[q]; a.ldcc = K[q];
-        a.C = (bf16_t*)dw[q]; a.C2 = nullptr; a.ldc = K[q];
+        a.C = (bf16_t*)dw[q]; a.C2 = db != nullptr ? (bf16_t*)db[q] : nullptr; a.ldc = K[q];
         a.bias = nullptr; a.aux = nullptr; a.ldaux = 0;
         a.M = (int)N[q]; a.N = (int)K[q]; a.K = (int)M;
         a.accumulate = accumulate;
@@ -1010,9 +1042,10 @@ int gemm_group_autotune(int n, int64_t M, const int64_t* N, const int64_t* K, hi
         if (tuned_lookup(3, M, group_sum(n, N), group_sum(n, K), &t) && g_ranked.count(std::make_tuple(3, M, group_sum(n, N), group_sum(n, K)))) return 0;
     }
     void *dyb[4] = {nullptr, nullptr, nullptr, nullptr}, *xb[4] = {nullptr, nullptr, nullptr, nullptr}, *dwb[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* dbb[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto cleanup = [&]() {
-        for (int q = 0; q < 4; ++q) { if (dyb[q]) (void)hipFree(dyb[q]); if (xb[q]) (void)hipFree(xb[q]); if (dwb[q]) (void)hipFree(dwb[q]); }
+        for (int q = 0; q < 4; ++q) { if (dyb[q]) (void)hipFree(dyb[q]); if (xb[q]) (void)hipFree(xb[q]); if (dwb[q]) (void)hipFree(dwb[q]); if (dbb[q]) (void)hipFree(dbb[q]); }
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
     };
@@ -1024,6 +1057,8 @@ int gemm_group_autotune(int n, int64_t M, const int64_t* N, const int64_t* K, hi
         GT_HIP(hipMemsetAsync(dyb[q], 0x3c, (size_t)M * N[q] * 2, st));
         GT_HIP(hipMemsetAsync(xb[q], 0x3c, (size_t)M * K[q] * 2, st));
         GT_HIP(hipMemsetAsync(dwb[q], 0, (size_t)N[q] * K[q] * 2, st));
+        GT_HIP(hipMalloc(&dbb[q], (size_t)N[q] * 2));
+        GT_HIP(hipMemsetAsync(dbb[q], 0, (size_t)N[q] * 2, st));
     }
     GT_HIP(hipEventCreate(&e0));
     GT_HIP(hipEventCreate(&e1));
@@ -1031,7 +1066,7 @@ int gemm_group_autotune(int n, int64_t M, const int64_t* N, const int64_t* K, hi
     int rc = 0;
     for (int cfg : kGroupCfgs) {
         if (!group_cfg_ok(cfg, n, M, N, K)) continue;
-        auto run = [&]() { return gemm_wgrad_group(n, dyb, xb, dwb, M, N, K, 0, st, cfg); };
+        auto run = [&]() { return gemm_wgrad_group(n, dyb, xb, dwb, dbb, M, N, K, 0, st, cfg); };
         for (int i = 0; i < 2 && rc == 0; ++i) rc = run();
         if (rc) break;
         (void)hipEventRecord(e0, st);
