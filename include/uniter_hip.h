@@ -140,7 +140,7 @@ int uniter_gemm_bias_fwd_ld(const void* x, int64_t ldx, const void* w, const voi
                             int64_t M, int64_t N, int64_t K, void* stream);
 int uniter_gemm_dgrad_ld(const void* dy, int64_t lddy, const void* w, const void* resid, void* dx,
                          int64_t M, int64_t N, int64_t K, void* stream);
-int uniter_gemm_wgrad_ld(const void* dy, int64_t lddy, const void* x, int64_t ldx, void* dw,
+int uniter_gemm_wgrad_ld(const void* dy, int64_t lddy, const void* x, int64_t ldx, void* dw, void* db,
                          int64_t M, int64_t N, int64_t K, int accumulate,
                          void* workspace, size_t workspace_bytes, void* stream);
 
@@ -199,6 +199,56 @@ int uniter_layernorm_bwd(const void* dy, const void* dy_extra, const void* z, co
                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* out[N] (+)= column sums of a[rows,N] (bias gradients of QKV / FFN1).  autograd of layer.py:76-78,140 */
+/* Split-K input gradient dx[M,K] = dy[M,N] * w[N,K] for a short M against a long contraction N (the MLM decoder:
+ * a few hundred masked rows x 28996 classes, model/layer.py:205-222): slices of the contraction fill the chip, fp32
+ * partials in `workspace` (>= uniter_gemm_dgrad_splitk_workspace_bytes) are then summed.  N % 64 == 0, K % 64 == 0. */
+size_t uniter_gemm_dgrad_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int uniter_gemm_dgrad_splitk(const void* dy, int64_t lddy, const void* w, void* dx, int64_t M, int64_t N, int64_t K,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pre-training output heads          model/layer.py:188-222, model/pretrain.py:36-47
+ * The heads' GEMMs are the entry points above (strided variants over a padded logits buffer); these are the
+ * HBM-bound pieces around them.
+ * uniter_ce_fwd: F.cross_entropy(logits.float(), labels, ignore_index=-1, reduction='none') (model/pretrain.py:129-133)
+ *   over bf16 logits [n, V] with row stride ld (elements, ld % 8 == 0 for the vector path): loss[n], lse[n] (saved).
+ *   Rows whose label is < 0 get loss 0.
+ * uniter_ce_bwd: overwrites the logits with d loss / d logits = (softmax - one_hot(label)) * gout[row] (0 for
+ *   ignored rows); columns >= V of the buffer are left untouched.
+ * uniter_gelu_bwd: dx = dy .* gelu'(u), the element-wise backward of the transform's GELU (model/layer.py:188-203). */
+int uniter_ce_fwd(const void* logits, int64_t ld, const int64_t* labels, float* loss, float* lse,
+                  int64_t n, int64_t V, void* stream);
+int uniter_ce_bwd(void* logits, int64_t ld, const int64_t* labels, const float* lse, const float* gout,
+                  int64_t n, int64_t V, void* stream);
+int uniter_gelu_bwd(const void* dy, const void* u, void* dx, int64_t numel, void* stream);
+
+/* The whole head in one call each way (all launches issued from C++, like the encoder):
+ *   t = LayerNorm(gelu(x * dense_w^T + dense_b)) ; logits = t * proj_w^T + proj_b ; loss = cross_entropy(logits, labels)
+ * = BertLMPredictionHead + F.cross_entropy(reduction='none') for MLM (model/layer.py:188-222, model/pretrain.py:129-133;
+ * proj_w is then the word-embedding table, V = 28996) and RegionClassification + hard-label cross entropy for MRC
+ * (model/pretrain.py:36-47,222-229; V = 1601).  x [n, H] bf16, labels [n] (negative = ignored row), loss [n] fp32.
+ * `save` (>= uniter_head_ce_save_bytes) carries the activations and the bf16 logits to the backward call, which turns the
+ * logits into d loss / d logits in place, accumulates every parameter gradient into g_* (all required except g_proj_b,
+ * which may be NULL together with proj_b) and writes dx [n, H] (may be NULL).  V need not be a multiple of the GEMM tile:
+ * the last V % 64 classes are handled exactly by sliver kernels.  A saved forward can be back-propagated once. */
+typedef struct {
+    const void *dense_w, *dense_b, *ln_g, *ln_b, *proj_w, *proj_b;
+    void *g_dense_w, *g_dense_b, *g_ln_g, *g_ln_b, *g_proj_w, *g_proj_b;
+} UniterHeadParams;
+size_t uniter_head_ce_save_bytes(int64_t n, int64_t H, int64_t V);
+size_t uniter_head_ce_workspace_bytes(int64_t n, int64_t H, int64_t V);
+int uniter_head_ce_fwd(const UniterHeadParams* p, const void* x, const int64_t* labels, float* loss, void* save,
+                       int64_t n, int64_t H, int64_t V, float eps, void* stream);
+int uniter_head_ce_bwd(const UniterHeadParams* p, const void* x, const int64_t* labels, const float* gloss, void* dx,
+                       void* save, void* workspace, size_t workspace_bytes, int64_t n, int64_t H, int64_t V, void* stream);
+/* Same head with the MRC-KL loss (model/pretrain.py:217-221): loss[n, V] fp32 = F.kl_div(log_softmax(logits), target,
+ * reduction='none') element-wise against fp32 soft labels target[n, V] (contiguous); the backward call takes the
+ * element-wise gradient gloss[n, V].  save / workspace sizes as for the cross-entropy pair. */
+int uniter_head_kl_fwd(const UniterHeadParams* p, const void* x, const float* target, float* loss, void* save,
+                       int64_t n, int64_t H, int64_t V, float eps, void* stream);
+int uniter_head_kl_bwd(const UniterHeadParams* p, const void* x, const float* target, const float* gloss, void* dx,
+                       void* save, void* workspace, size_t workspace_bytes, int64_t n, int64_t H, int64_t V, void* stream);
+
 size_t uniter_colsum_workspace_bytes(int64_t rows, int64_t N);
 int uniter_colsum(const void* a, void* out, int64_t rows, int64_t N, int accumulate,
                   void* workspace, size_t workspace_bytes, void* stream);

@@ -904,3 +904,106 @@ def test_attention_pool_kernel_vs_torch_fp32():
     # dropout: weights are either 0 or sm / (1 - p), and the mean survives
     out_d = ops.attention_pool(x.detach(), pad, lin, 0.5, True)
     assert torch.isfinite(out_d.float()).all()
+
+
+@pytest.mark.gpu
+def test_mlm_head_fused_vs_torch_fp32():
+    """transform + tied 28996-way decoder + cross entropy through the HIP path
+    (ops.mlm_head_loss: library GEMMs over a padded bf16 logits buffer + uniter_ce_fwd/_bwd + uniter_gelu_bwd)
+    against the module formula (model/layer.py:188-222, model/pretrain.py:129-133) in torch fp32 on the same bf16
+    parameters: losses, the gradient into the encoder output, and every parameter gradient incl. the tied embedding."""
+    from uniter_amd import ops
+    from uniter_amd.model.layer import BertOnlyMLMHead
+    from uniter_amd.model.model import UniterConfig
+    dev = _dev()
+    V, H, n = 28996, 768, 339
+    g = torch.Generator().manual_seed(11)
+    emb = torch.nn.Parameter((torch.randn(V, H, generator=g) * 0.05).to(dev, torch.bfloat16))
+    head = BertOnlyMLMHead(UniterConfig(V, hidden_size=H, num_hidden_layers=1), emb).to(dev).bfloat16()
+    pr = head.predictions
+    with torch.no_grad():
+        pr.transform.dense.weight.copy_((torch.randn(H, H, generator=g) * 0.05).to(dev, torch.bfloat16))
+        pr.transform.dense.bias.copy_((torch.randn(H, generator=g) * 0.1).to(dev, torch.bfloat16))
+        pr.transform.LayerNorm.weight.copy_((1 + 0.1 * torch.randn(H, generator=g)).to(dev, torch.bfloat16))
+        pr.transform.LayerNorm.bias.copy_((0.1 * torch.randn(H, generator=g)).to(dev, torch.bfloat16))
+        pr.bias.copy_((0.1 * torch.randn(V, generator=g)).to(dev, torch.bfloat16))
+    assert pr.decoder.weight is emb
+    x = torch.randn(n, H, generator=g).to(dev, torch.bfloat16).requires_grad_(True)
+    labels = torch.randint(0, V, (n,), generator=g)
+    labels[:3] = torch.tensor([V - 1, V - 2, V - 4])          # classes in the sliver beyond the last full GEMM tile
+    labels[5] = -1                                             # an ignored row
+    labels = labels.to(dev)
+    wrow = torch.rand(n, generator=g).to(dev)
+
+    loss = ops.mlm_head_loss(x, labels, pr)
+    assert loss.shape == (n,) and loss.dtype == torch.float32
+    (loss * wrow).sum().backward()
+    params = [pr.transform.dense.weight, pr.transform.dense.bias, pr.transform.LayerNorm.weight, pr.transform.LayerNorm.bias,
+              emb, pr.bias]
+    got = [loss.detach().cpu(), x.grad.float().cpu()] + [p.grad.float().cpu() for p in params]
+
+    # fp32 reference on the same (bf16-valued) parameters
+    xr = x.detach().float().requires_grad_(True)
+    pf = [p.detach().float().requires_grad_(True) for p in params]
+    h = xr @ pf[0].t() + pf[1]
+    h = h * 0.5 * (1.0 + torch.erf(h / 2.0 ** 0.5))
+    h = torch.nn.functional.layer_norm(h, (H,), pf[2], pf[3], eps=1e-12)
+    logits = h @ pf[4].t() + pf[5]
+    ref = torch.nn.functional.cross_entropy(logits, labels, ignore_index=-1, reduction='none')
+    (ref * wrow).sum().backward()
+    assert float(got[0][5]) == 0.0 and float(ref.detach()[5]) == 0.0
+    torch.testing.assert_close(got[0], ref.detach().cpu(), rtol=2e-2, atol=5e-2)
+    assert rel_l2(got[1], xr.grad.cpu()) <= 3e-2 and cosine(got[1], xr.grad.cpu()) >= 0.999, rel_l2(got[1], xr.grad.cpu())
+    names = ["dense.weight", "dense.bias", "LayerNorm.weight", "LayerNorm.bias", "word_embeddings (tied decoder)", "decoder bias"]
+    for name, a, b in zip(names, got[2:], [p.grad.cpu() for p in pf]):
+        assert rel_l2(a, b) <= 4e-2 and cosine(a, b) >= 0.999, (name, rel_l2(a, b), cosine(a, b))
+    # the last rows of the embedding gradient (classes beyond the last full 64-wide tile) are covered
+    assert float(got[6][V - 4:].abs().sum()) > 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["kl", "ce"])
+def test_region_classification_head_fused_vs_torch_fp32(kind):
+    """SURVEY.md section 8 f-2, MRC / MRC-KL (model/pretrain.py:36-47,206-229): dense+GELU+LN+Linear(1601) + loss through
+    ops.head_kl_div / ops.head_cross_entropy against the module formula in torch fp32 (1601 = 25 GEMM tiles + 1 class)."""
+    from uniter_amd import ops
+    from uniter_amd.model.pretrain import RegionClassification
+    dev = _dev()
+    V, H, n = 1601, 768, 173
+    g = torch.Generator().manual_seed(13)
+    head = RegionClassification(H, V).to(dev).bfloat16()
+    with torch.no_grad():
+        for p in head.parameters():
+            p.copy_((torch.randn(p.shape, generator=g) * (0.05 if p.dim() == 2 else 0.1)).to(dev, torch.bfloat16))
+        head.net[2].weight.add_(1.0)
+    x = torch.randn(n, H, generator=g).to(dev, torch.bfloat16).requires_grad_(True)
+    soft = torch.softmax(torch.randn(n, V, generator=g) * 2.0, dim=-1).to(dev)
+    wel = torch.rand(n, V, generator=g).to(dev)
+    net = head.net
+    if kind == "kl":
+        loss = ops.head_kl_div(x, soft, net[0], net[2], net[3].weight, net[3].bias)
+        assert loss.shape == (n, V)
+        (loss * wel).sum().backward()
+    else:
+        hard = torch.max(soft[:, 1:], dim=-1)[1] + 1
+        hard[0] = V - 1                                          # the class beyond the last full tile
+        loss = ops.head_cross_entropy(x, hard, net[0], net[2], net[3].weight, net[3].bias)
+        assert loss.shape == (n,)
+        (loss * wel[:, 0]).sum().backward()
+    params = list(head.parameters())
+    got = [loss.detach().cpu(), x.grad.float().cpu()] + [p.grad.float().cpu() for p in params]
+
+    xr = x.detach().float().requires_grad_(True)
+    ref_head = RegionClassification(H, V).to(dev).float()
+    ref_head.load_state_dict({k: v.float() for k, v in head.state_dict().items()})
+    scores = ref_head(xr)
+    if kind == "kl":
+        ref = torch.nn.functional.kl_div(torch.log_softmax(scores, dim=-1), soft, reduction='none')
+        (ref * wel).sum().backward()
+    else:
+        ref = torch.nn.functional.cross_entropy(scores, hard, ignore_index=0, reduction='none')
+        (ref * wel[:, 0]).sum().backward()
+    torch.testing.assert_close(got[0], ref.detach().cpu(), rtol=3e-2, atol=(2e-3 if kind == "kl" else 5e-2))
+    assert rel_l2(got[1], xr.grad.cpu()) <= 3e-2 and cosine(got[1], xr.grad.cpu()) >= 0.999, rel_l2(got[1], xr.grad.cpu())
+    for (name, _), a, b in zip(head.named_parameters(), got[2:], [p.grad.cpu() for p in ref_head.parameters()]):
+        assert rel_l2(a, b) <= 4e-2 and cosine(a, b) >= 0.999, (name, rel_l2(a, b), cosine(a, b))

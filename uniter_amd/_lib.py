@@ -25,6 +25,12 @@ class UniterLayerParams(Structure):
         "g_ln2_g", "g_ln2_b")]
 
 
+class UniterHeadParams(Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "dense_w", "dense_b", "ln_g", "ln_b", "proj_w", "proj_b",
+        "g_dense_w", "g_dense_b", "g_ln_g", "g_ln_b", "g_proj_w", "g_proj_b")]
+
+
 class UniterEncoderShape(Structure):
     _fields_ = [("B", c_int64), ("L", c_int64), ("H", c_int64), ("heads", c_int64), ("I", c_int64),
                 ("p_hidden", c_float), ("p_attn", c_float), ("ln_eps", c_float), ("training", c_int32),
@@ -68,9 +74,20 @@ SIGNATURES = {
     "uniter_gemm_dgrad_gelu": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "uniter_gemm_wgrad_workspace_bytes": (c_size_t, [_I, _I, _I]),
     "uniter_gemm_wgrad": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_int, _P, c_size_t, _P]),
+    "uniter_gemm_dgrad_splitk_workspace_bytes": (c_size_t, [_I, _I, _I]),
+    "uniter_gemm_dgrad_splitk": (c_int, [_P, _I, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
+    "uniter_head_ce_save_bytes": (c_size_t, [_I, _I, _I]),
+    "uniter_head_ce_workspace_bytes": (c_size_t, [_I, _I, _I]),
+    "uniter_head_ce_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, c_float, _P]),
+    "uniter_head_ce_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_size_t, _I, _I, _I, _P]),
+    "uniter_ce_fwd": (c_int, [_P, _I, _P, _P, _P, _I, _I, _P]),
+    "uniter_ce_bwd": (c_int, [_P, _I, _P, _P, _P, _I, _I, _P]),
+    "uniter_head_kl_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, c_float, _P]),
+    "uniter_head_kl_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_size_t, _I, _I, _I, _P]),
+    "uniter_gelu_bwd": (c_int, [_P, _P, _P, _I, _P]),
     "uniter_gemm_bias_fwd_ld": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "uniter_gemm_dgrad_ld": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
-    "uniter_gemm_wgrad_ld": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, c_int, _P, c_size_t, _P]),
+    "uniter_gemm_wgrad_ld": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, c_int, _P, c_size_t, _P]),
     "uniter_gemm_wgrad_group": (c_int, [c_int32, _P, _P, _P, _P, _I, _P, _P, c_int, _P]),
     "uniter_attention_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
     "uniter_attention_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
@@ -124,6 +141,7 @@ SIGNATURES = {
 
 # functions that return a size / pointer rather than a status code
 _NO_STATUS = {"uniter_hip_abi_version", "uniter_hip_last_error", "uniter_gemm_wgrad_workspace_bytes",
+              "uniter_gemm_dgrad_splitk_workspace_bytes", "uniter_head_ce_save_bytes", "uniter_head_ce_workspace_bytes",
               "uniter_layernorm_bwd_workspace_bytes", "uniter_colsum_workspace_bytes", "uniter_embed_ws_bytes",
               "uniter_attn_pool_workspace_bytes",
               "uniter_encoder_layer_act_bytes", "uniter_encoder_scratch_bytes", "uniter_encoder_layer_out_offset"}

@@ -225,11 +225,20 @@ int uniter_gemm_wgrad(const void* dy, const void* x, void* dw, void* db,
     return 0;
 }
 
-int uniter_gemm_wgrad_ld(const void* dy, int64_t lddy, const void* x, int64_t ldx, void* dw,
+int uniter_gemm_wgrad_ld(const void* dy, int64_t lddy, const void* x, int64_t ldx, void* dw, void* db,
                          int64_t M, int64_t N, int64_t K, int accumulate,
                          void* workspace, size_t workspace_bytes, void* stream) {
     UH_CHECK_ARG(dy && x && dw, "null pointer");
-    return uh::gemm_wgrad(dy, x, dw, M, N, K, accumulate, workspace, workspace_bytes, (hipStream_t)stream, lddy, ldx);
+    return uh::gemm_wgrad(dy, x, dw, M, N, K, accumulate, workspace, workspace_bytes, (hipStream_t)stream, lddy, ldx, db);
+}
+
+size_t uniter_gemm_dgrad_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    return uh::gemm_dgrad_splitk_workspace_bytes(M, N, K);
+}
+int uniter_gemm_dgrad_splitk(const void* dy, int64_t lddy, const void* w, void* dx, int64_t M, int64_t N, int64_t K,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    UH_CHECK_ARG(dy && w && dx && workspace, "null pointer");
+    return uh::gemm_dgrad_splitk(dy, w, dx, M, N, K, workspace, workspace_bytes, (hipStream_t)stream, lddy);
 }
 
 int uniter_gemm_wgrad_group(int32_t n, const void* const* dy, const void* const* x, void* const* dw, void* const* db,

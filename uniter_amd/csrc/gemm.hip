@@ -57,6 +57,8 @@ __device__ __forceinline__ int kc_off(int row, int chunk) {
     return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
 // K-strided tile: [64][W] bf16 (W = 64 or 128).  8-byte chunk ch of row r stored at ch ^ (h(r) << 2).
+// A 192-wide K-strided tile is a [64][128] sub-tile followed by a [64][64] sub-tile (columns 128..191), each in its
+// own swizzle; only the N-side operand may be 192 wide (dgrad with 192x192 / 128x192 / 96x192 tiles).
 template <int W>
 __device__ __forceinline__ int ks_swz(int r) {
     if (W == 128) return (r & 3) | (((r >> 3) & 1) << 2);
@@ -82,6 +84,10 @@ __device__ __forceinline__ bf16x8 frag_kc(const bf16_t* tile, int row, int ks, i
 // same from a K-strided tile: lane (g, i = 4j+q) supplies row ks*32+8g+j (+4), cols cb+4q..
 template <int W>
 __device__ __forceinline__ bf16x8 frag_ks(const bf16_t* tile, int cb, int ks, int g, int i) {
+    if constexpr (W == 192) {
+        if (cb < 128) return frag_ks<128>(tile, cb, ks, g, i);
+        return frag_ks<64>(tile + 64 * 128, cb - 128, ks, g, i);
+    }
     const int j = i >> 2, q = i & 3;
     const int r0 = ks * 32 + 8 * g + j;
     const int ch = (cb >> 2) + q;
@@ -180,6 +186,11 @@ __device__ __forceinline__ void glds_kc(bf16_t* tile, const bf16_t* base, int64_
 // K-strided tile [64][W]: W = 128 -> 4 rows per instruction, W = 64 -> 8 rows per instruction.
 template <int W>
 __device__ __forceinline__ void glds_ks(bf16_t* tile, const bf16_t* base, int64_t ld, int col0, int k0, int wid, int lane) {
+    if constexpr (W == 192) {
+        glds_ks<128>(tile, base, ld, col0, k0, wid, lane);
+        glds_ks<64>(tile + 64 * 128, base, ld, col0 + 128, k0, wid, lane);
+        return;
+    }
     constexpr int RPI = 1024 / (2 * W);          // rows per instruction
     constexpr int NI = 64 / RPI;                 // instructions per tile
     constexpr int CPR = W / 8;                   // 16-byte chunks per row
@@ -198,6 +209,19 @@ template <int ROWS>
 struct Stage<ROWS, false> : StageKC<ROWS> {};
 template <int ROWS>
 struct Stage<ROWS, true> : StageKS<ROWS> {};
+template <>
+struct Stage<192, true> {                       // [64][128] + [64][64] sub-tiles
+    StageKS<128> a;
+    StageKS<64> b;
+    __device__ __forceinline__ void load(const bf16_t* base, int64_t ld, int col0, int k0, int k_end, int t) {
+        a.load(base, ld, col0, k0, k_end, t);
+        b.load(base, ld, col0 + 128, k0, k_end, t);
+    }
+    __device__ __forceinline__ void store(bf16_t* tile, int t) const {
+        a.store(tile, t);
+        b.store(tile + 64 * 128, t);
+    }
+};
 
 // bijective XCD-aware block remap (cdna_hip_programming.md T1): consecutive hardware block ids go to
 // different XCDs; give each XCD a contiguous range of logical tiles so neighbours share an L2.
@@ -457,7 +481,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
             }
         }
     }
-    if (EPI == EPI_WGRAD && p.partial != nullptr) {         // split-K partials: already 16-byte fp32 stores
+    if ((EPI == EPI_WGRAD || EPI == EPI_RES) && p.partial != nullptr) {   // split-K partials: already 16-byte fp32 stores
 #pragma unroll
         for (int b = 0; b < MI; ++b) {
             const int m = m0 + wm * WM + b * 16 + i;
@@ -673,7 +697,7 @@ template <bool TRA, bool TRB>
 constexpr bool tile_ok(int idx) {
     const int bm = kTiles[idx].bm, bn = kTiles[idx].bn;
     if (TRA && !(bm == 64 || bm == 128)) return false;
-    if (TRB && !(bn == 64 || bn == 128)) return false;
+    if (TRB && !(bn == 64 || bn == 128 || bn == 192)) return false;
     return true;
 }
 
@@ -842,7 +866,7 @@ int pick_cfg(int M, int N, bool trm, bool trn, bool k_mult64 = false) {
         if (kTiles[i].ws && (!k_mult64 || kTiles[i].stages != 3 || kTiles[i].ws != 1)) continue;   // un-tuned default: 3-stage 4+4 WS rings only
         if (N % bn != 0) continue;
         if (trm && (M % bm != 0 || !(bm == 64 || bm == 128))) continue;
-        if (trn && !(bn == 64 || bn == 128)) continue;
+        if (trn && !(bn == 64 || bn == 128 || bn == 192)) continue;
         const long tiles = (long)((M + bm - 1) / bm) * (N / bn);
         const int lds = kTiles[i].stages * (bm + bn) * 128;
         int per_cu = 163840 / lds;
@@ -935,6 +959,51 @@ int gemm_dgrad(int epi, const void* dy, const void* w, const void* aux, void* dx
     return -1;
 }
 
+// Split-K form of dx[M,K] = dy[M,N] * w[N,K] for a short M against a long contraction N (the MLM decoder's input
+// gradient: a few hundred rows x 28996 classes): `splits` slices of the contraction fill the chip, fp32 partials are
+// summed by splitk_reduce_kernel.  No residual operand.
+size_t gemm_dgrad_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    (void)N;
+    return (size_t)32 * (size_t)M * (size_t)K * sizeof(float);
+}
+int gemm_dgrad_splitk(const void* dy, const void* w, void* dx, int64_t M, int64_t N, int64_t K, void* workspace,
+                      size_t ws_bytes, hipStream_t st, int64_t lddy) {
+    if (check_common(M, N, K)) return -1;
+    if (K % 64 != 0 || N % 64 != 0) { uh_set_error("gemm_dgrad_splitk: need K %% 64 == 0 and N %% 64 == 0"); return -1; }
+    if (lddy == 0) lddy = N;
+    if (lddy < N || lddy % 8 != 0) { uh_set_error("gemm_dgrad_splitk: bad leading dimension"); return -1; }
+    LaunchTimer lt(TIME_GEMM_DGRAD, M, N, K, st);
+    GemmArgs a{};
+    a.R = (const bf16_t*)dy; a.ldr = (int)lddy;
+    a.Cc = (const bf16_t*)w; a.ldcc = K;
+    a.C = (bf16_t*)dx; a.C2 = nullptr; a.ldc = K;
+    a.bias = nullptr; a.aux = nullptr; a.ldaux = K;
+    a.M = (int)M; a.N = (int)K; a.K = (int)N;
+    a.accumulate = 0;
+    a.drop = make_dropout(0.f, 0, 0);
+    const int cfg = (K % 128 == 0) ? 31 : 30;                 // 96x128 / 96x64, 3-stage ring, 4 compute + 4 loader waves
+    const int64_t tiles = ((M + kTiles[cfg].bm - 1) / kTiles[cfg].bm) * (K / kTiles[cfg].bn);
+    const int64_t ktiles = N / 64;
+    int64_t splits = (2 * (int64_t)g_num_cus + tiles - 1) / tiles;
+    if (splits > 32) splits = 32;
+    if (splits > ktiles / 4) splits = ktiles / 4;
+    if (splits < 1) splits = 1;
+    while (splits > 1 && (size_t)splits * M * K * sizeof(float) > ws_bytes) --splits;
+    const int64_t per = (ktiles + splits - 1) / splits;
+    splits = (ktiles + per - 1) / per;
+    a.k_per_split = (int)(per * 64);
+    a.partial = splits > 1 ? (float*)workspace : nullptr;
+    int rc = launch_gemm<false, true, EPI_RES>(a, cfg, (int)splits, st);
+    if (rc) return rc;
+    if (splits > 1) {
+        const int64_t mn = M * K;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, st,
+                           (const float*)workspace, (bf16_t*)dx, mn, (int)splits, 0);
+        UH_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 static int wgrad_splits(int64_t M, int64_t N, int64_t K, int cfg) {
     if (g_force_splits > 0) return g_force_splits;
     const int bm = kTiles[cfg].bm, bn = kTiles[cfg].bn;
@@ -952,7 +1021,7 @@ size_t gemm_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 
 // dw[N,K] (+)= dy[M,N]^T x[M,K] -> output dims (N, K), contraction M
 int gemm_wgrad(const void* dy, const void* x, void* dw, int64_t M, int64_t N, int64_t K, int accumulate,
-               void* workspace, size_t ws_bytes, hipStream_t st, int64_t lddy, int64_t ldx) {
+               void* workspace, size_t ws_bytes, hipStream_t st, int64_t lddy, int64_t ldx, void* db) {
     if (check_common(M, N, K)) return -1;
     if (N % 64 != 0 || K % 64 != 0) { uh_set_error("gemm_wgrad: need N %% 64 == 0 and K %% 64 == 0 (N=%lld K=%lld)", (long long)N, (long long)K); return -1; }
     if (lddy == 0) lddy = N;
@@ -962,7 +1031,7 @@ int gemm_wgrad(const void* dy, const void* x, void* dw, int64_t M, int64_t N, in
     GemmArgs a{};
     a.R = (const bf16_t*)dy; a.ldr = (int)lddy;   // stored [contraction = M][out rows = N]
     a.Cc = (const bf16_t*)x; a.ldcc = (int)ldx;   // stored [contraction = M][out cols = K]
-    a.C = (bf16_t*)dw; a.C2 = nullptr; a.ldc = K;
+    a.C = (bf16_t*)dw; a.C2 = (bf16_t*)db; a.ldc = K;    // db: the bias gradient rides along (no split-K then)
     a.bias = nullptr; a.aux = nullptr; a.ldaux = 0;
     a.M = (int)N; a.N = (int)K; a.K = (int)M;
     a.accumulate = accumulate;
@@ -971,6 +1040,7 @@ int gemm_wgrad(const void* dy, const void* x, void* dw, int64_t M, int64_t N, in
     int splits = wgrad_splits(M, N, K, cfg);
     Tuned tn;
     if (g_force_cfg < 0 && g_force_splits < 0 && tuned_lookup(2, M, N, K, &tn)) { cfg = tn.cfg; splits = tn.splits; }
+    if (db != nullptr) splits = 1;
     while (splits > 1 && (size_t)splits * N * K * sizeof(float) > ws_bytes) splits >>= 1;
     const int64_t ktiles = (M + 63) / 64;
     a.k_per_split = (int)(((ktiles + splits - 1) / splits) * 64);
@@ -1133,7 +1203,7 @@ int gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, hipStream_t st) {
     const DropoutCfg nodrop = make_dropout(0.f, 0, 0);
     for (int cfg = 0; cfg < kNumTiles && rc == 0; ++cfg) {
         const int bm = kTiles[cfg].bm, bn = kTiles[cfg].bn;
-        const bool p2m = bm == 64 || bm == 128, p2n = bn == 64 || bn == 128;
+        const bool p2m = bm == 64 || bm == 128, p2n = bn == 64 || bn == 128 || bn == 192;
         const int64_t contraction = kind == 0 ? K : (kind == 1 ? N : M);
         if (kTiles[cfg].ws && contraction % 64 != 0) continue;
         if (kind == 0 && N % bn != 0) continue;
@@ -1200,7 +1270,7 @@ int gemm_set_tuned(int kind, int64_t M, int64_t N, int64_t K, int cfg, int split
     if (splits < 1 || splits > 4 || (kind != 2 && splits != 1)) { uh_set_error("gemm_set_tuned: bad split count (split-K is a wgrad option, <= 4)"); return -1; }
     // same legality rules as the autotune sweep
     const int bm = kTiles[cfg].bm, bn = kTiles[cfg].bn;
-    const bool p2m = bm == 64 || bm == 128, p2n = bn == 64 || bn == 128;
+    const bool p2m = bm == 64 || bm == 128, p2n = bn == 64 || bn == 128 || bn == 192;
     const int64_t contraction = kind == 0 ? K : (kind == 1 ? N : M);
     bool ok = !(kTiles[cfg].ws && contraction % (64 * (int64_t)splits) != 0);
     if (kind == 0) ok = ok && N % bn == 0;

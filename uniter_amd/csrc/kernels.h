@@ -30,9 +30,12 @@ int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void
              int64_t M, int64_t N, int64_t K, const DropoutCfg& drop, hipStream_t st, int64_t ldx = 0, int64_t ldy = 0);
 int gemm_dgrad(int epi, const void* dy, const void* w, const void* aux, void* dx,
                int64_t M, int64_t N, int64_t K, hipStream_t st, int64_t lddy = 0);
+size_t gemm_dgrad_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int gemm_dgrad_splitk(const void* dy, const void* w, void* dx, int64_t M, int64_t N, int64_t K, void* workspace,
+                      size_t ws_bytes, hipStream_t st, int64_t lddy = 0);
 size_t gemm_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int gemm_wgrad(const void* dy, const void* x, void* dw, int64_t M, int64_t N, int64_t K, int accumulate,
-               void* workspace, size_t ws_bytes, hipStream_t st, int64_t lddy = 0, int64_t ldx = 0);
+               void* workspace, size_t ws_bytes, hipStream_t st, int64_t lddy = 0, int64_t ldx = 0, void* db = nullptr);
 int gemm_wgrad_group(int n, const void* const* dy, const void* const* x, void* const* dw, void* const* db, int64_t M,
                      const int64_t* N, const int64_t* K, int accumulate, hipStream_t st, int cfg_override = -1);
 int gemm_group_autotune(int n, int64_t M, const int64_t* N, const int64_t* K, hipStream_t st);

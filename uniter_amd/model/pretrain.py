@@ -12,7 +12,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from .layer import GELU, BertLayerNorm as LayerNorm, BertOnlyMLMHead
+from .layer import GELU, BertLayerNorm as LayerNorm, BertOnlyMLMHead, gelu
 from .model import UniterModel, UniterPreTrainedModel
 from .ot import optimal_transport_dist
 
@@ -94,10 +94,21 @@ class UniterForPretraining(UniterPreTrainedModel):
                                       gather_index, output_all_encoded_layers=False)
         txt_part = sequence_output[:, :input_ids.size(1), :]
         picked = txt_labels != -1
-        prediction_scores = self.cls(_rows_where(txt_part, picked))
+        rows = _rows_where(txt_part, picked)
+        if compute_loss and self._fused_heads(rows):
+            from .. import ops
+            # transform + tied 28996-way decoder + cross entropy without an fp32 logits tensor (ops._HeadCeFn)
+            return ops.mlm_head_loss(rows, txt_labels[picked], self.cls.predictions)
+        prediction_scores = self.cls(rows)
         if not compute_loss:
             return prediction_scores
         return F.cross_entropy(prediction_scores.float(), txt_labels[picked], reduction='none')
+
+    def _fused_heads(self, rows):
+        """The HIP head path covers the shipped configuration: bf16 on the GPU, erf-GELU transform."""
+        tr = self.cls.predictions.transform
+        return (rows.is_cuda and rows.dtype == torch.bfloat16 and tr.transform_act_fn is gelu
+                and tr.dense.weight.dtype == torch.bfloat16 and rows.size(1) % 64 == 0)
 
     def _compute_masked_hidden(self, hidden, mask):
         return _rows_where(hidden, mask)
@@ -147,7 +158,16 @@ class UniterForPretraining(UniterPreTrainedModel):
                     img_masks, img_mask_tgt, label_targets, task, compute_loss=True):
         sequence_output = self.uniter(input_ids, position_ids, img_feat, img_pos_feat, attention_mask,
                                       gather_index, output_all_encoded_layers=False, img_masks=img_masks)
-        prediction_soft_label = self.region_classifier(_rows_where(sequence_output, img_mask_tgt))
+        rows = _rows_where(sequence_output, img_mask_tgt)
+        net = self.region_classifier.net
+        if compute_loss and self._fused_heads(rows) and net[3].weight.dtype == torch.bfloat16:
+            from .. import ops
+            # dense+GELU+LN+Linear(1601)+loss in one call each way (ops._HeadLossFn), no fp32 logits / log-probs
+            if "kl" in task:
+                return ops.head_kl_div(rows, label_targets, net[0], net[2], net[3].weight, net[3].bias)
+            hard = torch.max(label_targets[:, 1:], dim=-1)[1] + 1           # never 0, so ignore_index=0 is moot
+            return ops.head_cross_entropy(rows, hard, net[0], net[2], net[3].weight, net[3].bias)
+        prediction_soft_label = self.region_classifier(rows)
         if not compute_loss:
             return prediction_soft_label
         if "kl" in task:

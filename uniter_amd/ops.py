@@ -761,10 +761,10 @@ class _PairedCrossAttnFn(torch.autograd.Function):
         C.uniter_gemm_dgrad_ld(d1, 3 * H, wq2, None, dx_r, T2, H, H, st)
         C.uniter_gemm_dgrad_ld(d0 + H * es, 3 * H, wkv1, dx_r, dx_r, T2, 2 * H, H, st)
         g1, g2 = grad_of(w1), grad_of(w2)
-        C.uniter_gemm_wgrad_ld(d0, 3 * H, x_l, H, g1.data_ptr(), T2, H, H, 1, ptr(ws), wsb, st)
-        C.uniter_gemm_wgrad_ld(d0 + H * es, 3 * H, x_r, H, g1.data_ptr() + H * H * es, T2, 2 * H, H, 1, ptr(ws), wsb, st)
-        C.uniter_gemm_wgrad_ld(d1, 3 * H, x_r, H, g2.data_ptr(), T2, H, H, 1, ptr(ws), wsb, st)
-        C.uniter_gemm_wgrad_ld(d1 + H * es, 3 * H, x_l, H, g2.data_ptr() + H * H * es, T2, 2 * H, H, 1, ptr(ws), wsb, st)
+        C.uniter_gemm_wgrad_ld(d0, 3 * H, x_l, H, g1.data_ptr(), None, T2, H, H, 1, ptr(ws), wsb, st)
+        C.uniter_gemm_wgrad_ld(d0 + H * es, 3 * H, x_r, H, g1.data_ptr() + H * H * es, None, T2, 2 * H, H, 1, ptr(ws), wsb, st)
+        C.uniter_gemm_wgrad_ld(d1, 3 * H, x_r, H, g2.data_ptr(), None, T2, H, H, 1, ptr(ws), wsb, st)
+        C.uniter_gemm_wgrad_ld(d1 + H * es, 3 * H, x_l, H, g2.data_ptr() + H * H * es, None, T2, 2 * H, H, 1, ptr(ws), wsb, st)
         if attn1.in_proj_bias is not None:
             C.uniter_colsum(d0, ptr(grad_of(attn1.in_proj_bias)), T2, 3 * H, 1, ptr(ws), wsb, st)
         if attn2.in_proj_bias is not None:
@@ -838,6 +838,100 @@ def optimal_transport_dist(seq, ot_scatter, txt_pad, img_pad, beta=0.5, iteratio
     tp = txt_pad.to(device=dev, dtype=torch.uint8).contiguous()
     ip = img_pad.to(device=dev, dtype=torch.uint8).contiguous()
     return _OtDistFn.apply(seq.contiguous(), sc, tp, ip, beta, iteration, k)
+
+
+# ----------------------------------------------------------------------------------------------------
+# pre-training output heads: dense -> GELU -> LayerNorm -> projection to V classes -> cross entropy
+# (MLM: model/layer.py:188-222 + model/pretrain.py:129-133, V = 28996 tied to the word embeddings;
+#  MRC with hard labels: model/pretrain.py:36-47,206-229, V = 1601)                      SURVEY.md section 8 f-2
+# ----------------------------------------------------------------------------------------------------
+class _HeadLossFn(torch.autograd.Function):
+    """One C-ABI call each way (uniter_head_ce_* / uniter_head_kl_*): fp32 logits never exist — the projection GEMM writes
+    bf16 logits into a buffer whose row stride is V rounded up to 64, one kernel turns them into the loss (+ log-sum-exp),
+    the backward kernel overwrites them with d loss / d logits, and those feed the weight-gradient GEMM in place.
+    `target` is int64 [n] (cross entropy, negative = ignored) or fp32 [n, V] (element-wise KL divergence)."""
+
+    @staticmethod
+    def forward(ctx, x, target, dense, ln, w, b, *anchor):
+        n, H = x.shape
+        V = w.size(0)
+        dev = x.device
+        hp = _lib.UniterHeadParams()
+        hp.dense_w, hp.dense_b = dense.weight.data_ptr(), dense.bias.data_ptr()
+        hp.ln_g, hp.ln_b = ln.weight.data_ptr(), ln.bias.data_ptr()
+        hp.proj_w, hp.proj_b = w.data_ptr(), (b.data_ptr() if b is not None else None)
+        save = torch.empty(C.uniter_head_ce_save_bytes(n, H, V), dtype=torch.uint8, device=dev)
+        kl = target.dtype == torch.float32
+        loss = torch.empty((n, V) if kl else (n,), dtype=torch.float32, device=dev)
+        fwd = C.uniter_head_kl_fwd if kl else C.uniter_head_ce_fwd
+        fwd(ctypes.byref(hp), ptr(x), ptr(target), ptr(loss), ptr(save), n, H, V, float(ln.eps), _lib.stream_ptr())
+        ctx.mods = (dense, ln, w, b)
+        ctx.hp = hp
+        ctx.kl = kl
+        ctx.save_for_backward(x, target, save)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        x, target, save = ctx.saved_tensors
+        dense, ln, w, b = ctx.mods
+        hp = ctx.hp
+        n, H = x.shape
+        V = w.size(0)
+        dev = x.device
+        pool = {}
+
+        def grad_of(p):
+            return (ensure_grad(p) if p.requires_grad else _dummy_grad_like(p, pool)).data_ptr()
+        hp.g_dense_w, hp.g_dense_b = grad_of(dense.weight), grad_of(dense.bias)
+        hp.g_ln_g, hp.g_ln_b = grad_of(ln.weight), grad_of(ln.bias)
+        hp.g_proj_w = grad_of(w)
+        hp.g_proj_b = grad_of(b) if b is not None else None
+        wsb = C.uniter_head_ce_workspace_bytes(n, H, V)
+        ws = _scratch(("headce", dev.index), wsb, dev)
+        gl = gloss.to(torch.float32).contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        bwd = C.uniter_head_kl_bwd if ctx.kl else C.uniter_head_ce_bwd
+        bwd(ctypes.byref(hp), ptr(x), ptr(target), ptr(gl), ptr(dx), ptr(save), ptr(ws), wsb, n, H, V, _lib.stream_ptr())
+        return (dx, None, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 6)
+
+
+def _head_loss(x, target, dense, ln, weight, bias):
+    _check_dev(x, "head input")
+    _check_dev(weight, "projection weight")
+    _check_dev(dense.weight, "transform weight")
+    if bias is not None:
+        _check_dev(bias, "projection bias")
+    if x.dim() != 2 or x.size(1) % 64 != 0 or dense.weight.shape != (x.size(1), x.size(1)) or weight.size(1) != x.size(1):
+        raise _lib.UniterHipError("head loss: x must be [n, H] with H % 64 == 0, dense H->H, weight [V, H]")
+    params = [p for p in (dense.weight, dense.bias, ln.weight, ln.bias, weight, bias) if p is not None and p.requires_grad]
+    extra = tuple(params[:1]) if torch.is_grad_enabled() else ()
+    return _HeadLossFn.apply(x.contiguous(), target, dense, ln, weight, bias, *extra)
+
+
+def head_cross_entropy(x, labels, dense, ln, weight, bias):
+    """loss[n] = cross_entropy(LN(gelu(dense(x))) @ weight^T + bias, labels) with reduction 'none'; rows whose label is
+    negative are ignored (loss 0, no gradient).  x [n, H] bf16, labels [n] int64, dense = nn.Linear(H, H),
+    ln = nn.LayerNorm(H), weight [V, H] bf16, bias [V] bf16.  Parameter gradients are accumulated into `.grad`.
+    The backward pass reuses the logits buffer for d loss / d logits, so a graph can be back-propagated once."""
+    if x.size(0) == 0:
+        return x.float().sum(1)
+    return _head_loss(x, labels.to(device=x.device, dtype=torch.int64).contiguous(), dense, ln, weight, bias)
+
+
+def head_kl_div(x, soft_targets, dense, ln, weight, bias):
+    """loss[n, V] = F.kl_div(log_softmax(LN(gelu(dense(x))) @ weight^T + bias), soft_targets, reduction='none')."""
+    if x.size(0) == 0:
+        return x.new_zeros(0, weight.size(0), dtype=torch.float32)
+    if soft_targets.shape != (x.size(0), weight.size(0)):
+        raise _lib.UniterHipError("head_kl_div: soft targets must be [n, V]")
+    return _head_loss(x, soft_targets.to(device=x.device, dtype=torch.float32).contiguous(), dense, ln, weight, bias)
+
+
+def mlm_head_loss(x, labels, predictions):
+    """BertLMPredictionHead + F.cross_entropy(reduction='none') on the masked rows (model/pretrain.py:129-133)."""
+    tr = predictions.transform
+    return head_cross_entropy(x, labels, tr.dense, tr.LayerNorm, predictions.decoder.weight, predictions.bias)
 
 
 # ----------------------------------------------------------------------------------------------------
