@@ -115,10 +115,10 @@ static bool check(const char* name, const std::vector<float>& got, const std::ve
     return ok;
 }
 
-// host Philox4x32-10, identical to common.cuh
+// host Philox4x32-7 and the dropout field layout, identical to common.cuh
 static void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < 7; ++r) {
         const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
         const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
         const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
@@ -129,12 +129,19 @@ static void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t 
 }
 static float drop_mult(float p, uint64_t seed, uint64_t offset, uint64_t elem) {
     if (p <= 0.f) return 1.f;
-    double t = (double)p * 4294967296.0;
-    const uint32_t thresh = (uint32_t)std::min(t, 4294967295.0);
+    const uint32_t thresh = (uint32_t)std::min((double)p * 65536.0 + 0.5, 65535.0);
     uint32_t r[4];
-    const uint64_t idx4 = elem >> 2;
-    philox((uint32_t)idx4, (uint32_t)(idx4 >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
-    return r[elem & 3] >= thresh ? 1.0f / (1.0f - p) : 0.f;
+    const uint64_t idx8 = elem >> 3;
+    philox((uint32_t)idx8, (uint32_t)(idx8 >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const int e = (int)(elem & 7);
+    const uint32_t field = (r[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+    return field >= thresh ? 65536.0f / (65536.0f - (float)thresh) : 0.f;
+}
+// element index of attention probability (row = (b,h,query), key j) in the dropout stream: one 8-element group holds the
+// 4 keys 4g..4g+3 of both tiles of a key-tile pair (attention.hip)
+static uint64_t attn_drop_elem(uint64_t row, int j) {
+    const int u = j >> 5, hf = (j >> 4) & 1, g = (j & 15) >> 2, r = j & 3;
+    return ((row * 8 + (uint64_t)u) * 4 + (uint64_t)g) * 8 + (uint64_t)(4 * hf + r);
 }
 static float gelu_h(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
 static float gelu_grad_h(float x) {
@@ -420,7 +427,7 @@ static void test_attention(int B, int L, int heads, float p) {
                 lse_ref[(size_t)bh * L + i] = mx + logf(sum);
                 for (int j = 0; j < L; ++j) {
                     P[(size_t)i * L + j] /= sum;
-                    const uint64_t elem = ((uint64_t)bh * L + i) * 256 + j;
+                    const uint64_t elem = attn_drop_elem((uint64_t)bh * L + i, j);
                     Pd[(size_t)i * L + j] = P[(size_t)i * L + j] * drop_mult(p, seed, off, elem);
                 }
                 for (int d = 0; d < 64; ++d) {
@@ -436,7 +443,7 @@ static void test_attention(int B, int L, int heads, float p) {
                 for (int j = 0; j < L; ++j) {
                     float dp = 0;
                     for (int d = 0; d < 64; ++d) dp += DO.v[((size_t)b * L + i) * H + h * 64 + d] * v(j, d);
-                    const uint64_t elem = ((uint64_t)bh * L + i) * 256 + j;
+                    const uint64_t elem = attn_drop_elem((uint64_t)bh * L + i, j);
                     const float mult = drop_mult(p, seed, off, elem);
                     dPd[(size_t)i * L + j] = P[(size_t)i * L + j] * (dp * mult - Di) * 0.125f;   // dS * scale
                 }

@@ -195,15 +195,20 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
         const float inv = 1.0f / sum;
         if (g == 0 && q < L && p.lse != nullptr) p.lse[(int64_t)bh * Lm + q] = mx + __logf(sum);
 
+        // dropout: one Philox call covers this lane's 4 keys in BOTH tiles of a key-tile pair (element group
+        // ((b,h,q) * 8 + pair) * 4 + g; fields 0-3 = tile 2u, 4-7 = tile 2u+1) — the backward pass indexes the same way
         const bool drop = p.drop.p > 0.f;
-        const uint64_t drow = ((uint64_t)bh * (uint64_t)Lm + (uint64_t)q) * (LMAX / 4);
+        const uint64_t drow = ((uint64_t)bh * (uint64_t)Lm + (uint64_t)q) * (LMAX / 32);
 #pragma unroll
-        for (int kt = 0; kt < MAXKT; ++kt) {
-            if (kt < nkt) {
-                float mult[4] = {1.f, 1.f, 1.f, 1.f};
-                if (drop) dropout_mult4(p.drop, drow + (uint64_t)(kt * 4 + g), mult);
+        for (int u = 0; u < MAXKT / 2; ++u) {
+            if (2 * u < nkt) {
+                float mult[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+                if (drop) dropout_mult8(p.drop, (drow + (uint64_t)u) * 4 + (uint64_t)g, mult);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s[kt][r] = s[kt][r] * inv * mult[r];
+                for (int r = 0; r < 4; ++r) {
+                    s[2 * u][r] = s[2 * u][r] * inv * mult[r];
+                    s[2 * u + 1][r] = s[2 * u + 1][r] * inv * mult[4 + r];
+                }
             }
         }
         // O^T[d][query] = sum_keys V^T[d][key] * P^T[key][query]
@@ -314,12 +319,14 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
         const bf16x8 qf0 = at_frag(Qs, q, 0, g), qf1 = at_frag(Qs, q, 1, g);
         const bf16x8 of0 = at_frag(Os, q, 0, g), of1 = at_frag(Os, q, 1, g);
         const float lse_q = lse_s[q], D_q = D_s[q];
-        const uint64_t drow = ((uint64_t)bh * (uint64_t)Lm + (uint64_t)q) * (LMAX / 4);
+        const uint64_t drow = ((uint64_t)bh * (uint64_t)Lm + (uint64_t)q) * (LMAX / 32);
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int u = 0; u < npair; ++u) {
             float ds[2][4];
+            // one Philox call per key-tile pair (same element groups as the forward kernel)
+            const uint32_t keep8 = drop ? dropout_keep8(p.drop, (drow + (uint64_t)u) * 4 + (uint64_t)g) : 0xffu;
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int kt = 2 * u + hf;
@@ -331,8 +338,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
                 const f32x4 mv = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
                 float mult[4] = {1.f, 1.f, 1.f, 1.f};
                 if (drop) {
-                    // one Philox call per 4 keys; the keep bits are parked in LDS for the key-owner sweep
-                    const uint32_t keep = dropout_keep4(p.drop, drow + (uint64_t)(kt * 4 + g));
+                    // the keep bits are parked in LDS for the key-owner sweep
+                    const uint32_t keep = (keep8 >> (4 * hf)) & 0xfu;
                     keep_s[q * kstride + kt * 4 + g] = (uint8_t)keep;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) mult[r] = ((keep >> r) & 1u) ? p.drop.scale : 0.f;

@@ -68,16 +68,22 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Philox4x32-10 counter-based RNG.  One call gives 4 x 32 random bits for counter (c0..c3) under
-// key (k0,k1).  Dropout sites use: key = seed, counter = (element_index/4 lo, hi, site offset lo, hi).
+// Philox4x32 counter-based RNG (Salmon et al., SC'11).  One call gives 4 x 32 random bits for counter (c0..c3) under
+// key (k0,k1).  Dropout draws its masks from the 7-round variant (the fewest rounds that pass BigCrush in that paper;
+// 10 is the library default with extra margin) and spends 16 bits per element, so ONE call covers 8 consecutive
+// elements: key = seed, counter = (element_index/8 lo, hi, site offset lo, hi); element e of the group keeps iff its
+// 16-bit field (word e/2, half e%2) >= thresh16 = round(p * 65536), and survivors are scaled by 65536 / (65536 - thresh16)
+// (exactly unbiased for the quantised p; p = 0.1 becomes 0.100006).  The multiplies are quarter-rate instructions and
+// dominate a call, which is why the call count matters for the VALU-bound attention / LayerNorm kernels.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                               uint32_t k0, uint32_t k1) {
+constexpr int PHILOX_DROPOUT_ROUNDS = 7;
+
+template <int ROUNDS>
+__device__ __forceinline__ u32x4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        // one 32x32->64 multiply per product (v_mad_u64_u32) instead of a v_mul_hi_u32 + v_mul_lo_u32 pair: the
-        // multiplies are quarter-rate and dominate the cost of a call
+    for (int r = 0; r < ROUNDS; ++r) {
+        // one 32x32->64 multiply per product (v_mad_u64_u32) instead of a v_mul_hi_u32 + v_mul_lo_u32 pair
         const uint64_t p0 = (uint64_t)M0 * (uint64_t)c0, p1 = (uint64_t)M1 * (uint64_t)c2;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
@@ -95,8 +101,8 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 
 struct DropoutCfg {
     float    p;          // drop probability (0 => disabled)
-    float    scale;      // 1/(1-p)
-    uint32_t thresh;     // keep iff rnd >= thresh ; thresh = p * 2^32
+    float    scale;      // 65536 / (65536 - thresh)
+    uint32_t thresh;     // keep iff the element's 16-bit field >= thresh ; thresh = round(p * 65536)
     uint32_t seed_lo, seed_hi;
     uint32_t off_lo, off_hi;
     // optional device-resident base offset added to (off_hi:off_lo) at run time: lets a captured hipGraph draw fresh
@@ -109,11 +115,11 @@ extern const unsigned long long* uh_drop_offset_ptr;   // set through uniter_hip
 static inline DropoutCfg make_dropout(float p, uint64_t seed, uint64_t offset) {
     DropoutCfg d;
     d.p = p;
-    d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
-    double t = (double)p * 4294967296.0;
-    if (t > 4294967295.0) t = 4294967295.0;
-    if (t < 0) t = 0;
+    double t = (double)p * 65536.0 + 0.5;
+    if (t > 65535.0) t = 65535.0;
+    if (t < 0 || !(p > 0.f)) t = 0;
     d.thresh = (uint32_t)t;
+    d.scale = p > 0.f ? 65536.0f / (65536.0f - (float)d.thresh) : 1.0f;
     d.seed_lo = (uint32_t)seed; d.seed_hi = (uint32_t)(seed >> 32);
     d.off_lo = (uint32_t)offset; d.off_hi = (uint32_t)(offset >> 32);
     d.off_ptr = p > 0.f ? uh_drop_offset_ptr : nullptr;
@@ -127,29 +133,51 @@ __device__ __forceinline__ void dropout_offset(const DropoutCfg& d, uint32_t& lo
     hi = (uint32_t)(o >> 32);
 }
 
-// Keep-multipliers (0 or 1/(1-p)) for the 4 consecutive elements of group `idx4` (= element index / 4).
-__device__ __forceinline__ void dropout_mult4(const DropoutCfg& d, uint64_t idx4, float (&m)[4]) {
+// the 128 random bits of element group idx8 (= element index / 8)
+__device__ __forceinline__ u32x4 dropout_bits8(const DropoutCfg& d, uint64_t idx8) {
     uint32_t olo, ohi;
     dropout_offset(d, olo, ohi);
-    const u32x4 r = philox4x32_10((uint32_t)idx4, (uint32_t)(idx4 >> 32), olo, ohi, d.seed_lo, d.seed_hi);
+    return philox4x32<PHILOX_DROPOUT_ROUNDS>((uint32_t)idx8, (uint32_t)(idx8 >> 32), olo, ohi, d.seed_lo, d.seed_hi);
+}
+__device__ __forceinline__ bool dropout_keep_field(const DropoutCfg& d, const u32x4& r, int e) {   // e = 0..7
+    return ((r[e >> 1] >> ((e & 1) << 4)) & 0xffffu) >= d.thresh;
+}
+// Keep-multipliers (0 or scale) for the 8 consecutive elements of group `idx8`: one Philox call.
+__device__ __forceinline__ void dropout_mult8(const DropoutCfg& d, uint64_t idx8, float (&m)[8]) {
+    const u32x4 r = dropout_bits8(d, idx8);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) m[i] = (r[i] >= d.thresh) ? d.scale : 0.f;
+    for (int e = 0; e < 8; ++e) m[e] = dropout_keep_field(d, r, e) ? d.scale : 0.f;
+}
+// Keep-multipliers for the 4 consecutive elements of group `idx4` (= element index / 4): half of a call's bits.
+__device__ __forceinline__ void dropout_mult4(const DropoutCfg& d, uint64_t idx4, float (&m)[4]) {
+    const u32x4 r = dropout_bits8(d, idx4 >> 1);
+    const int h = (int)(idx4 & 1) * 2;
+    const uint32_t w0 = h ? r[2] : r[0], w1 = h ? r[3] : r[1];
+    m[0] = (w0 & 0xffffu) >= d.thresh ? d.scale : 0.f;
+    m[1] = (w0 >> 16) >= d.thresh ? d.scale : 0.f;
+    m[2] = (w1 & 0xffffu) >= d.thresh ? d.scale : 0.f;
+    m[3] = (w1 >> 16) >= d.thresh ? d.scale : 0.f;
 }
 // Keep bits (bit e set = element e of the group survives) for the 4 consecutive elements of group `idx4`.
 __device__ __forceinline__ uint32_t dropout_keep4(const DropoutCfg& d, uint64_t idx4) {
-    uint32_t olo, ohi;
-    dropout_offset(d, olo, ohi);
-    const u32x4 r = philox4x32_10((uint32_t)idx4, (uint32_t)(idx4 >> 32), olo, ohi, d.seed_lo, d.seed_hi);
-    return (r[0] >= d.thresh ? 1u : 0u) | (r[1] >= d.thresh ? 2u : 0u) | (r[2] >= d.thresh ? 4u : 0u) |
-           (r[3] >= d.thresh ? 8u : 0u);
+    const u32x4 r = dropout_bits8(d, idx4 >> 1);
+    const int h = (int)(idx4 & 1) * 2;
+    const uint32_t w0 = h ? r[2] : r[0], w1 = h ? r[3] : r[1];
+    return ((w0 & 0xffffu) >= d.thresh ? 1u : 0u) | ((w0 >> 16) >= d.thresh ? 2u : 0u) |
+           ((w1 & 0xffffu) >= d.thresh ? 4u : 0u) | ((w1 >> 16) >= d.thresh ? 8u : 0u);
+}
+// Keep bits of all 8 elements of group idx8.
+__device__ __forceinline__ uint32_t dropout_keep8(const DropoutCfg& d, uint64_t idx8) {
+    const u32x4 r = dropout_bits8(d, idx8);
+    uint32_t k = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) k |= dropout_keep_field(d, r, e) ? (1u << e) : 0u;
+    return k;
 }
 // Single element `e` (0..3) of group idx4.
 __device__ __forceinline__ float dropout_mult1(const DropoutCfg& d, uint64_t idx4, int e) {
-    uint32_t olo, ohi;
-    dropout_offset(d, olo, ohi);
-    const u32x4 r = philox4x32_10((uint32_t)idx4, (uint32_t)(idx4 >> 32), olo, ohi, d.seed_lo, d.seed_hi);
-    const uint32_t v = e == 0 ? r[0] : (e == 1 ? r[1] : (e == 2 ? r[2] : r[3]));
-    return (v >= d.thresh) ? d.scale : 0.f;
+    const u32x4 r = dropout_bits8(d, idx4 >> 1);
+    return dropout_keep_field(d, r, (int)(idx4 & 1) * 4 + e) ? d.scale : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -540,12 +540,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 }
                 if (EPI == EPI_BIAS_DROP_RES) {
                     if (p.drop.p > 0.f) {
-                        float m0v[4], m1v[4];
-                        const uint64_t idx4 = ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 2;
-                        dropout_mult4(p.drop, idx4, m0v);
-                        dropout_mult4(p.drop, idx4 + 1, m1v);
+                        float mv[8];
+                        dropout_mult8(p.drop, ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 3, mv);   // N % 8 == 0
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] *= m0v[e]; v[4 + e] *= m1v[e]; }
+                        for (int e = 0; e < 8; ++e) v[e] *= mv[e];
                     }
                 }
                 if (EPI == EPI_BIAS_DROP_RES || EPI == EPI_RES) {

@@ -307,11 +307,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_cols_kernel(const bf16_t* __restr
             }
             float mult[8];
             if (use_post || use_mask) {
-                float m0[4], m1[4];
-                dropout_mult4(drop, (uint64_t)o >> 2, m0);
-                dropout_mult4(drop, ((uint64_t)o >> 2) + 1, m1);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { mult[e] = m0[e]; mult[4 + e] = m1[e]; }
+                dropout_mult8(drop, (uint64_t)o >> 3, mult);       // o % 8 == 0 (H % 8 == 0, 8 columns per lane)
             }
             if (use_post) {
 #pragma unroll
