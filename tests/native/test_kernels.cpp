@@ -257,13 +257,15 @@ static const int kTileBM[] = {128, 128, 64, 64, 96, 192, 192, 128, 96, 128, 96, 
                               128, 96, 192, 128, 64, 96, 128, 64, 96, 64,
                               96, 96, 128, 128, 64, 96, 128, 64, 96, 192,
                               96, 128, 192, 128,
-                              128, 128, 192, 96, 192, 128, 192, 128, 64, 192};
+                              128, 128, 192, 96, 192, 128, 192, 128, 64, 192,
+                              96, 96, 128, 128};
 static const int kTileBN[] = {128, 64, 128, 64, 192, 96, 128, 192, 128, 96, 96, 64, 64, 64, 128, 64, 96, 64, 128, 96,
                               128, 192, 96, 64, 128, 96, 64, 128, 96, 64,
                               64, 128, 96, 128, 64, 64, 64, 128, 96, 64,
                               128, 96, 64, 128,
-                              128, 128, 192, 192, 96, 192, 128, 64, 128, 64};
-static const int kNumTiles = 54;     // 13..19 are 3-stage rings, 20..29 wave-specialised (4 compute + 4 loader waves)
+                              128, 128, 192, 192, 96, 192, 128, 64, 128, 64,
+                              128, 128, 96, 96};
+static const int kNumTiles = 58;     // 13..19 are 3-stage rings, 20..29 wave-specialised (4 compute + 4 loader waves)
 
 static void test_gemm(int M, int N, int K, int cfg, int splits) {
     char tag[128];

@@ -688,7 +688,9 @@ constexpr TileShape kTiles[] = {{128, 128, 2, 0}, {128, 64, 2, 0}, {64, 128, 2, 
                                 {96, 128, 4, 1}, {128, 96, 4, 1}, {192, 64, 4, 1}, {128, 128, 4, 1},
                                 // 8 compute waves + 4 loader waves, one workgroup per CU
                                 {128, 128, 3, 2}, {128, 128, 4, 2}, {192, 192, 2, 2}, {96, 192, 3, 2}, {192, 96, 3, 2},
-                                {128, 192, 3, 2}, {192, 128, 3, 2}, {128, 64, 4, 2}, {64, 128, 4, 2}, {192, 64, 4, 2}};
+                                {128, 192, 3, 2}, {192, 128, 3, 2}, {128, 64, 4, 2}, {64, 128, 4, 2}, {192, 64, 4, 2},
+                                // 8 + 4 waves on the 96-wide tiles of the N = 768 problems (one 96x128 tile per CU)
+                                {96, 128, 3, 2}, {96, 128, 4, 2}, {128, 96, 3, 2}, {128, 96, 4, 2}};
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <bool TRA, bool TRB>
@@ -766,6 +768,10 @@ int launch_gemm(const GemmArgs& a, int cfg, int splits, hipStream_t st) {
         case 51: return launch_idx<TRA, TRB, EPI, 51>(a, splits, st);
         case 52: return launch_idx<TRA, TRB, EPI, 52>(a, splits, st);
         case 53: return launch_idx<TRA, TRB, EPI, 53>(a, splits, st);
+        case 54: return launch_idx<TRA, TRB, EPI, 54>(a, splits, st);
+        case 55: return launch_idx<TRA, TRB, EPI, 55>(a, splits, st);
+        case 56: return launch_idx<TRA, TRB, EPI, 56>(a, splits, st);
+        case 57: return launch_idx<TRA, TRB, EPI, 57>(a, splits, st);
         default: uh_set_error("gemm: bad tile index %d", cfg); return -1;
     }
 }
