@@ -378,12 +378,19 @@ def main():
             result["cpu_baseline"] = cpu_baseline_subprocess()
         else:
             result["cpu_baseline"] = None
+        # RCCL prints its banner through C stdio, which sits in libc's buffer until exit when stdout is a pipe: flush
+        # it now so that the JSON line is the LAST line this process writes
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except (OSError, AttributeError):
+            pass
         print(json.dumps(result), flush=True)
     try:
         os.remove(cfg_path)
     except OSError:
         pass
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 
