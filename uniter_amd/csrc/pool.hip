@@ -45,17 +45,34 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-// dot of row t of x with a vector held as v[c] = 8 columns per lane-chunk; returns the full sum in every lane
-__device__ __forceinline__ float row_dot(const bf16_t* row, const bf16_t* vec, int H, int lane) {
-    float s = 0.f;
-    for (int c = lane * 8; c < H; c += 64 * 8) {
-        float a[8], b[8];
-        unpack8(*reinterpret_cast<const u32x4*>(row + c), a);
-        unpack8(*reinterpret_cast<const u32x4*>(vec + c), b);
+// dots of rows t0..t0+3 of x with a vector (H <= 1024: at most two 8-column chunks per lane); all eight row loads
+// are issued before the first reduction, so a wave pays one memory round trip per FOUR tokens instead of per token
+__device__ __forceinline__ void row_dot4(const bf16_t* x, const bf16_t* vec, int H, int L, int t0, int lane, float (&out)[4]) {
+    u32x4 xv[4][2], vv[2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += a[e] * b[e];
+    for (int j = 0; j < 2; ++j) {
+        const int c = (lane + 64 * j) * 8;
+        vv[j] = u32x4{0u, 0u, 0u, 0u};
+        if (c < H) vv[j] = *reinterpret_cast<const u32x4*>(vec + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            xv[k][j] = u32x4{0u, 0u, 0u, 0u};
+            if (c < H && t0 + k < L) xv[k][j] = *reinterpret_cast<const u32x4*>(x + (int64_t)(t0 + k) * H + c);
+        }
     }
-    return wave_sum(s);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float a[8], b[8];
+            unpack8(xv[k][j], a);
+            unpack8(vv[j], b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += a[e] * b[e];
+        }
+        out[k] = wave_sum(s);
+    }
 }
 
 __global__ __launch_bounds__(PT) void pool_fwd_kernel(const PoolArgs p) {
@@ -66,9 +83,12 @@ __global__ __launch_bounds__(PT) void pool_fwd_kernel(const PoolArgs p) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const bf16_t* x = p.x + (int64_t)b * L * H;
     const float bias = p.b ? bf2f(p.b[0]) : 0.f;
-    for (int t = wid; t < L; t += PT / 64) {
-        const float raw = row_dot(x + (int64_t)t * H, p.w, H, lane) + bias;
-        if (lane == 0) {
+    for (int t0 = wid * 4; t0 < L; t0 += (PT / 64) * 4) {
+        float dots[4];
+        row_dot4(x, p.w, H, L, t0, lane, dots);
+        if (lane < 4 && t0 + lane < L) {
+            const int t = t0 + lane;
+            const float raw = (lane == 0 ? dots[0] : (lane == 1 ? dots[1] : (lane == 2 ? dots[2] : dots[3]))) + bias;
             p.raw[(int64_t)b * L + t] = raw;
             sc[t] = fmaxf(raw, 0.f) + ((p.pad && p.pad[(int64_t)b * L + t]) ? -1e4f : 0.f);
         }
@@ -99,7 +119,7 @@ __global__ __launch_bounds__(PT) void pool_fwd_kernel(const PoolArgs p) {
     if (c < nchunk) {
         float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int t0 = half ? (L + 1) / 2 : 0, t1 = half ? L : (L + 1) / 2;
-#pragma unroll 4
+#pragma unroll 8
         for (int t = t0; t < t1; ++t) {
             float v[8];
             unpack8(*reinterpret_cast<const u32x4*>(x + (int64_t)t * H + c * 8), v);
@@ -129,9 +149,12 @@ __global__ __launch_bounds__(PT) void pool_bwd_kernel(const PoolArgs p) {
     const bf16_t* x = p.x + (int64_t)b * L * H;
     const bf16_t* dout = p.dout + (int64_t)b * H;
     // d pw_t = x_t . dout ; through dropout: d sm_t = d pw_t * (pw_t / sm_t)
-    for (int t = wid; t < L; t += PT / 64) {
-        const float d = row_dot(x + (int64_t)t * H, dout, H, lane);
-        if (lane == 0) {
+    for (int t0 = wid * 4; t0 < L; t0 += (PT / 64) * 4) {
+        float dots[4];
+        row_dot4(x, dout, H, L, t0, lane, dots);
+        if (lane < 4 && t0 + lane < L) {
+            const int t = t0 + lane;
+            const float d = lane == 0 ? dots[0] : (lane == 1 ? dots[1] : (lane == 2 ? dots[2] : dots[3]));
             const float s = p.sm[(int64_t)b * L + t], w = p.pw[(int64_t)b * L + t];
             ds[t] = (s > 0.f) ? d * (w / s) : 0.f;
             pwv[t] = w;
@@ -158,7 +181,7 @@ __global__ __launch_bounds__(PT) void pool_bwd_kernel(const PoolArgs p) {
         unpack8(*reinterpret_cast<const u32x4*>(dout + c * 8), dov);
         unpack8(*reinterpret_cast<const u32x4*>(p.w + c * 8), wv);
         const int t0 = half ? (L + 1) / 2 : 0, t1 = half ? L : (L + 1) / 2;
-#pragma unroll 4
+#pragma unroll 8
         for (int t = t0; t < t1; ++t) {
             float v[8], o[8];
             unpack8(*reinterpret_cast<const u32x4*>(x + (int64_t)t * H + c * 8), v);
