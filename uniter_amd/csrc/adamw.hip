@@ -113,27 +113,52 @@ __global__ __launch_bounds__(256) void gradsq_kernel(const DevTensor* __restrict
                                                      float* __restrict__ partial) {
     __shared__ float red[4];
     float acc = 0.f;
-    for (int64_t ci = blockIdx.x; ci < n_chunks; ci += gridDim.x) {
-        const ChunkRef cr = chunks[ci];
-        const DevTensor t = tensors[cr.tensor];
+    // The chunk descriptor (two dependent loads) of the NEXT iteration is fetched while the current chunk streams, and the
+    // four 8-byte loads of a bf16 chunk are issued together: per 8 KiB of gradients the kernel used to pay three
+    // dependent memory round trips.
+    int64_t ci = blockIdx.x;
+    ChunkRef cr{};
+    DevTensor t{};
+    if (ci < n_chunks) { cr = chunks[ci]; t = tensors[cr.tensor]; }
+    while (ci < n_chunks) {
+        const int64_t nci = ci + gridDim.x;
+        ChunkRef ncr{};
+        DevTensor nt{};
+        if (nci < n_chunks) { ncr = chunks[nci]; nt = tensors[ncr.tensor]; }
         const int64_t base = (int64_t)cr.chunk * CHUNK;
+        if (t.is_bf16) {
+            u32x2 raw[CHUNK / (256 * 4)];
 #pragma unroll
-        for (int it = 0; it < CHUNK / (256 * 4); ++it) {
-            const int64_t idx = base + ((int64_t)it * 256 + threadIdx.x) * 4;
-            if (idx >= t.numel) break;
-            const int n = (t.numel - idx >= 4) ? 4 : (int)(t.numel - idx);
-            if (n == 4) {
+            for (int it = 0; it < CHUNK / (256 * 4); ++it) {
+                const int64_t idx = base + ((int64_t)it * 256 + threadIdx.x) * 4;
+                raw[it] = u32x2{0u, 0u};
+                if (idx + 4 <= t.numel) raw[it] = *reinterpret_cast<const u32x2*>((const bf16_t*)t.grad + idx);
+            }
+#pragma unroll
+            for (int it = 0; it < CHUNK / (256 * 4); ++it) {
+                const int64_t idx = base + ((int64_t)it * 256 + threadIdx.x) * 4;
                 float g[4];
-                if (t.is_bf16) unpack4(*reinterpret_cast<const u32x2*>((const bf16_t*)t.grad + idx), g);
-                else { const f32x4 q = *reinterpret_cast<const f32x4*>((const float*)t.grad + idx); g[0] = q[0]; g[1] = q[1]; g[2] = q[2]; g[3] = q[3]; }
+                unpack4(raw[it], g);
                 acc += (g[0] * g[0] + g[1] * g[1]) + (g[2] * g[2] + g[3] * g[3]);
-            } else {
-                for (int e = 0; e < n; ++e) {
-                    const float ge = t.is_bf16 ? bf2f(((const bf16_t*)t.grad)[idx + e]) : ((const float*)t.grad)[idx + e];
-                    acc += ge * ge;
+                if (idx < t.numel && idx + 4 > t.numel) {            // ragged end of a tensor
+                    for (int64_t e = idx; e < t.numel; ++e) { const float ge = bf2f(((const bf16_t*)t.grad)[e]); acc += ge * ge; }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < CHUNK / (256 * 4); ++it) {
+                const int64_t idx = base + ((int64_t)it * 256 + threadIdx.x) * 4;
+                if (idx >= t.numel) break;
+                const int n = (t.numel - idx >= 4) ? 4 : (int)(t.numel - idx);
+                if (n == 4) {
+                    const f32x4 q = *reinterpret_cast<const f32x4*>((const float*)t.grad + idx);
+                    acc += (q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]);
+                } else {
+                    for (int e = 0; e < n; ++e) { const float ge = ((const float*)t.grad)[idx + e]; acc += ge * ge; }
                 }
             }
         }
+        ci = nci; cr = ncr; t = nt;
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
