@@ -85,6 +85,9 @@ int uniter_gemm_debug_force(int cfg, int splits);
  * sweep and run-to-run kernel selection is reproducible. */
 int uniter_gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, void* stream);
 int uniter_gemm_set_tuned(int kind, int64_t M, int64_t N, int64_t K, int32_t cfg, int32_t splits);
+/* Number of tile configurations the GEMM family was built with: saved tile choices (indices) are only valid for the
+ * build that produced them. */
+int uniter_gemm_tile_count(void);
 int uniter_gemm_tuned_choice(int kind, int64_t M, int64_t N, int64_t K, int32_t out[2]);
 
 /* y[M,N] = x[M,K] * w[N,K]^T + bias[N]        (bias may be NULL)                 layer.py:76-78 */

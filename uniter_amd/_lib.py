@@ -85,6 +85,7 @@ SIGNATURES = {
     "uniter_head_kl_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, c_float, _P]),
     "uniter_head_kl_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_size_t, _I, _I, _I, _P]),
     "uniter_gelu_bwd": (c_int, [_P, _P, _P, _I, _P]),
+    "uniter_gemm_tile_count": (c_int, []),
     "uniter_gemm_bias_fwd_ld": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "uniter_gemm_dgrad_ld": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "uniter_gemm_wgrad_ld": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, c_int, _P, c_size_t, _P]),
@@ -140,7 +141,7 @@ SIGNATURES = {
 }
 
 # functions that return a size / pointer rather than a status code
-_NO_STATUS = {"uniter_hip_abi_version", "uniter_hip_last_error", "uniter_gemm_wgrad_workspace_bytes",
+_NO_STATUS = {"uniter_hip_abi_version", "uniter_gemm_tile_count", "uniter_hip_last_error", "uniter_gemm_wgrad_workspace_bytes",
               "uniter_gemm_dgrad_splitk_workspace_bytes", "uniter_head_ce_save_bytes", "uniter_head_ce_workspace_bytes",
               "uniter_layernorm_bwd_workspace_bytes", "uniter_colsum_workspace_bytes", "uniter_embed_ws_bytes",
               "uniter_attn_pool_workspace_bytes",

@@ -154,6 +154,8 @@ int uniter_gemm_set_tuned(int kind, int64_t M, int64_t N, int64_t K, int32_t cfg
     return uh::gemm_set_tuned(kind, M, N, K, cfg, splits);
 }
 
+int uniter_gemm_tile_count(void) { return uh::gemm_tile_count(); }
+
 int uniter_gemm_tuned_choice(int kind, int64_t M, int64_t N, int64_t K, int32_t out[2]) {
     UH_CHECK_ARG(out != nullptr, "null pointer");
     int cfg = -1, sp = -1;

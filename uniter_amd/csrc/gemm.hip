@@ -1263,6 +1263,8 @@ int gemm_autotune_candidates(int kind, int64_t M, int64_t N, int64_t K, int* cfg
     return n;
 }
 
+int gemm_tile_count() { return kNumTiles; }
+
 int gemm_set_tuned(int kind, int64_t M, int64_t N, int64_t K, int cfg, int splits) {
     if (kind == 3) {            // grouped wgrad: (M, sum N, sum K); legality is re-checked at launch against the members
         if (cfg < 0 || cfg >= kNumTiles || splits != 1) { uh_set_error("gemm_set_tuned: bad grouped-wgrad tile"); return -1; }

@@ -45,6 +45,7 @@ int gemm_tuned_choice(int kind, int64_t M, int64_t N, int64_t K, int* cfg, int* 
 int gemm_set_tuned(int kind, int64_t M, int64_t N, int64_t K, int cfg, int splits);
 int gemm_autotune_candidates(int kind, int64_t M, int64_t N, int64_t K, int* cfgs, int* splits, int cap);
 void gemm_set_num_cus(int n);
+int gemm_tile_count();
 
 // ---- attention.hip ----
 int attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse,

@@ -9,6 +9,7 @@ own AccumulateGrad would, pretrain.py:298-312 sums micro-step gradients) instead
 autograd: the wgrad GEMMs fuse the accumulation, which saves one read+write of every gradient per step.
 """
 import ctypes
+import os
 import threading
 
 import torch
@@ -232,6 +233,9 @@ def _layer_gemm_shapes(s):
     return shapes
 
 
+FACTORY_TUNE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gfx950.json")
+
+
 def _load_tune_cache(path, s):
     """Install tile choices saved by an earlier process.  True if every GEMM of this shape was covered."""
     import json
@@ -242,12 +246,17 @@ def _load_tune_cache(path, s):
         saved = json.load(open(path))
     except (OSError, ValueError):
         return False
+    if saved.get("n_tiles", C.uniter_gemm_tile_count()) != C.uniter_gemm_tile_count():
+        return False                                   # tile indices of another build of the GEMM family
     table = {(e["kind"], e["M"], e["N"], e["K"]): (e["cfg"], e["splits"]) for e in saved.get("gemm", [])}
     shapes = _layer_gemm_shapes(s)
     if any(k not in table for k in shapes):
         return False
-    for k in shapes:
-        C.uniter_gemm_set_tuned(k[0], k[1], k[2], k[3], table[k][0], table[k][1])
+    try:
+        for k in shapes:
+            C.uniter_gemm_set_tuned(k[0], k[1], k[2], k[3], table[k][0], table[k][1])
+    except _lib.UniterHipError:
+        return False                                   # a choice this build rejects: tune afresh
     return True
 
 
@@ -268,7 +277,7 @@ def _save_tune_cache(path, s):
             entries.append({"kind": k[0], "M": k[1], "N": k[2], "K": k[3], "cfg": int(out[0]), "splits": int(out[1])})
     tmp = "%s.%d.tmp" % (path, os.getpid())
     with open(tmp, "w") as f:
-        json.dump({"gemm": entries}, f)
+        json.dump({"n_tiles": int(C.uniter_gemm_tile_count()), "gemm": entries}, f)
     os.replace(tmp, path)
 
 
@@ -287,6 +296,10 @@ def _maybe_autotune(s, training):
         return
     cache = os.environ.get("UNITER_AMD_TUNE_CACHE", "")
     if cache and _load_tune_cache(cache, s):
+        return
+    # tile choices shipped with the package for the reference's standard shapes (the same tuner's output, picked as the
+    # best of several independent runs by scripts/make_factory_tune.py); UNITER_AMD_FACTORY_TUNE=0 ignores them
+    if not cache and os.environ.get("UNITER_AMD_FACTORY_TUNE", "1") != "0" and _load_tune_cache(FACTORY_TUNE, s):
         return
     C.uniter_encoder_autotune(ctypes.byref(s), _lib.stream_ptr())
     if cache:
