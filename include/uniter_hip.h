@@ -129,8 +129,14 @@ int uniter_gemm_wgrad(const void* dy, const void* x, void* dw, void* db,
  * db (host array, may be NULL; entries may be NULL): db_q[N_q] (+)= column sums of dy_q — the nn.Linear bias gradients.
  * They come out of the same launch: the tiles of the first tile column multiply the dy fragments they already hold by a
  * fragment of ones (one extra MFMA each), so no separate reduction kernel reads dy again. */
-int uniter_gemm_wgrad_group(int32_t n, const void* const* dy, const void* const* x, void* const* dw, void* const* db,
-                            int64_t M, const int64_t* N, const int64_t* K, int accumulate, void* stream);
+int uniter_gemm_wgrad_group(int32_t n, const void* const* dy, const int64_t* lddy, const void* const* x, const int64_t* ldx,
+                            void* const* dw, void* const* db, int64_t M, const int64_t* N, const int64_t* K, int accumulate,
+                            void* stream);
+/* lddy / ldx (host arrays, may be NULL = contiguous; an entry of 0 = contiguous): row strides in elements when dy_q / x_q
+ * are column slices of wider matrices (the q / k|v blocks of a packed projection buffer).
+ * uniter_gemm_wgrad_group_autotune times the legal tiles of such a group once (synchronous, set-up time) and remembers
+ * the winner under kind 3, (M, sum N, sum K). */
+int uniter_gemm_wgrad_group_autotune(int32_t n, int64_t M, const int64_t* N, const int64_t* K, void* stream);
 
 /* Strided-operand variants (row stride in elements; operands may be column slices of a wider row-major matrix —
  * e.g. the q / k|v column blocks of a packed [T,3H] projection buffer).  Used by the NLVR2 paired cross-attention

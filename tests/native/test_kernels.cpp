@@ -500,7 +500,7 @@ static void test_wgrad_group(int M) {
     const void* xp[4] = {dX[0], dX[1], dX[2], dX[3]};
     void* dwp[4] = {dW2[0], dW2[1], dW2[2], dW2[3]};
     void* dbp[4] = {dB2[0], dB2[1], nullptr, dB2[3]};   // member 2 without a bias gradient: its buffer must stay untouched
-    UHCHK(uniter_gemm_wgrad_group(n, dyp, xp, dwp, dbp, M, N, K, 1, 0));
+    UHCHK(uniter_gemm_wgrad_group(n, dyp, nullptr, xp, nullptr, dwp, dbp, M, N, K, 1, 0));
     HIPCHK(hipDeviceSynchronize());
     for (int q = 0; q < n; ++q) {
         char tag[128];
@@ -856,8 +856,8 @@ static void bench(int B, int L, int H, int heads, int I, int layers) {
             for (int q = 0; q < 4; ++q) { dbb[q] = dalloc<uint16_t>((size_t)Ng[q]); HIPCHK(hipMemset(dbb[q], 0, (size_t)Ng[q] * 2)); }
             void* dbp[4] = {dbb[0], dbb[1], dbb[2], dbb[3]};
             double sep = tm.run([&] { for (int q = 0; q < 4; ++q) UHCHK(uniter_gemm_wgrad(dyb[q], xb[q], dwb[q], nullptr, T, Ng[q], Kg[q], 1, ws2, wsb2, 0)); }, 3, 20);
-            double grp = tm.run([&] { UHCHK(uniter_gemm_wgrad_group(4, dyp, xp, dwp, nullptr, T, Ng, Kg, 1, 0)); }, 3, 20);
-            double grb = tm.run([&] { UHCHK(uniter_gemm_wgrad_group(4, dyp, xp, dwp, dbp, T, Ng, Kg, 1, 0)); }, 3, 20);
+            double grp = tm.run([&] { UHCHK(uniter_gemm_wgrad_group(4, dyp, nullptr, xp, nullptr, dwp, nullptr, T, Ng, Kg, 1, 0)); }, 3, 20);
+            double grb = tm.run([&] { UHCHK(uniter_gemm_wgrad_group(4, dyp, nullptr, xp, nullptr, dwp, dbp, T, Ng, Kg, 1, 0)); }, 3, 20);
             printf("  (four weight gradients of a layer: separate tuned launches %.1f us, one grouped launch %.1f us, grouped with the four bias gradients %.1f us)\n", sep, grp, grb);
         }
         const double flf = (double)layers * (24.0 * T * H * H + 4.0 * T * L * H);

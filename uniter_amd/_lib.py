@@ -89,7 +89,8 @@ SIGNATURES = {
     "uniter_gemm_bias_fwd_ld": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "uniter_gemm_dgrad_ld": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "uniter_gemm_wgrad_ld": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, c_int, _P, c_size_t, _P]),
-    "uniter_gemm_wgrad_group": (c_int, [c_int32, _P, _P, _P, _P, _I, _P, _P, c_int, _P]),
+    "uniter_gemm_wgrad_group": (c_int, [c_int32, _P, _P, _P, _P, _P, _P, _I, _P, _P, c_int, _P]),
+    "uniter_gemm_wgrad_group_autotune": (c_int, [c_int32, _I, _P, _P, _P]),
     "uniter_attention_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
     "uniter_attention_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
     "uniter_attention_fwd_packed": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),

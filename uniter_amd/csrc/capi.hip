@@ -243,10 +243,16 @@ int uniter_gemm_dgrad_splitk(const void* dy, int64_t lddy, const void* w, void* 
     return uh::gemm_dgrad_splitk(dy, w, dx, M, N, K, workspace, workspace_bytes, (hipStream_t)stream, lddy);
 }
 
-int uniter_gemm_wgrad_group(int32_t n, const void* const* dy, const void* const* x, void* const* dw, void* const* db,
-                            int64_t M, const int64_t* N, const int64_t* K, int accumulate, void* stream) {
+int uniter_gemm_wgrad_group(int32_t n, const void* const* dy, const int64_t* lddy, const void* const* x, const int64_t* ldx,
+                            void* const* dw, void* const* db, int64_t M, const int64_t* N, const int64_t* K, int accumulate,
+                            void* stream) {
     UH_CHECK_ARG(dy && x && dw && N && K, "null pointer");
-    return uh::gemm_wgrad_group(n, dy, x, dw, db, M, N, K, accumulate, (hipStream_t)stream);
+    return uh::gemm_wgrad_group(n, dy, x, dw, db, M, N, K, accumulate, (hipStream_t)stream, -1, lddy, ldx);
+}
+
+int uniter_gemm_wgrad_group_autotune(int32_t n, int64_t M, const int64_t* N, const int64_t* K, void* stream) {
+    UH_CHECK_ARG(N && K, "null pointer");
+    return uh::gemm_group_autotune(n, M, N, K, (hipStream_t)stream);
 }
 
 int uniter_attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse,

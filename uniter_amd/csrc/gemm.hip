@@ -1073,7 +1073,8 @@ static bool group_cfg_ok(int cfg, int n, int64_t M, const int64_t* N, const int6
 static int64_t group_sum(int n, const int64_t* v) { int64_t s = 0; for (int q = 0; q < n; ++q) s += v[q]; return s; }
 
 int gemm_wgrad_group(int n, const void* const* dy, const void* const* x, void* const* dw, void* const* db, int64_t M,
-                     const int64_t* N, const int64_t* K, int accumulate, hipStream_t st, int cfg_override) {
+                     const int64_t* N, const int64_t* K, int accumulate, hipStream_t st, int cfg_override,
+                     const int64_t* lddy, const int64_t* ldx) {
     if (n < 1 || n > 4) { uh_set_error("gemm_wgrad_group: 1..4 problems"); return -1; }
     for (int q = 0; q < n; ++q) {
         if (check_common(M, N[q], K[q])) return -1;
@@ -1084,8 +1085,9 @@ int gemm_wgrad_group(int n, const void* const* dy, const void* const* x, void* c
     ga.n = n;
     for (int q = 0; q < n; ++q) {
         GemmArgs& a = ga.g[q];
-        a.R = (const bf16_t*)dy[q]; a.ldr = N[q];
-        a.Cc = (const bf16_t*)x[q]; a.ldcc = K[q];
+        a.R = (const bf16_t*)dy[q]; a.ldr = (lddy && lddy[q]) ? lddy[q] : N[q];      // operands may be column slices
+        a.Cc = (const bf16_t*)x[q]; a.ldcc = (ldx && ldx[q]) ? ldx[q] : K[q];
+        if (a.ldr < N[q] || a.ldcc < K[q] || a.ldr % 8 != 0 || a.ldcc % 8 != 0) { uh_set_error("gemm_wgrad_group: bad leading dimension"); return -1; }
         a.C = (bf16_t*)dw[q]; a.C2 = db != nullptr ? (bf16_t*)db[q] : nullptr; a.ldc = K[q];
         a.bias = nullptr; a.aux = nullptr; a.ldaux = 0;
         a.M = (int)N[q]; a.N = (int)K[q]; a.K = (int)M;

@@ -257,12 +257,20 @@ def _load_tune_cache(path, s):
             C.uniter_gemm_set_tuned(k[0], k[1], k[2], k[3], table[k][0], table[k][1])
     except _lib.UniterHipError:
         return False                                   # a choice this build rejects: tune afresh
+    for k, v in table.items():                          # auxiliary launches saved with them (task-head groups)
+        if k not in shapes:
+            try:
+                C.uniter_gemm_set_tuned(k[0], k[1], k[2], k[3], v[0], v[1])
+            except _lib.UniterHipError:
+                pass
     return True
+
+
+_aux_keys = []          # (kind, M, N, K) of tuned launches outside the encoder layers (grouped head weight gradients)
 
 
 def _save_tune_cache(path, s):
     import json
-    import os
     entries = []
     if os.path.exists(path):
         try:
@@ -271,7 +279,7 @@ def _save_tune_cache(path, s):
             entries = []
     have = {(e["kind"], e["M"], e["N"], e["K"]) for e in entries}
     out = (ctypes.c_int32 * 2)()
-    for k in _layer_gemm_shapes(s):
+    for k in (_layer_gemm_shapes(s) if s is not None else []) + list(_aux_keys):
         C.uniter_gemm_tuned_choice(k[0], k[1], k[2], k[3], out)
         if out[0] >= 0 and k not in have:
             entries.append({"kind": k[0], "M": k[1], "N": k[2], "K": k[3], "cfg": int(out[0]), "splits": int(out[1])})
@@ -471,6 +479,27 @@ def mask_bias(attention_mask):
     out = torch.empty(m.shape, dtype=torch.float32, device=m.device)
     C.uniter_mask_bias(ptr(m), ptr(out), m.numel(), _lib.stream_ptr())
     return out
+
+
+def wgrad_group(dys, lddys, xs_, ldxs, dws, dbs, M, Ns, Ks, training=True):
+    """Up to four weight gradients dw_q[N_q, K_q] += dy_q[M, N_q]^T x_q[M, K_q] (and db_q += column sums of dy_q) over the
+    same M rows in one launch (uniter_gemm_wgrad_group).  All arguments are raw device addresses / row strides."""
+    n = len(dys)
+    PA, IA = ctypes.c_void_p * n, ctypes.c_int64 * n
+    Na, Ka = IA(*Ns), IA(*Ks)
+    st = _lib.stream_ptr()
+    key = (3, int(M), int(sum(Ns)), int(sum(Ks)))
+    if key not in _aux_keys:
+        _aux_keys.append(key)
+        out = (ctypes.c_int32 * 2)()
+        C.uniter_gemm_tuned_choice(key[0], key[1], key[2], key[3], out)
+        if (out[0] < 0 and training and os.environ.get("UNITER_AMD_AUTOTUNE", "1") != "0"
+                and not torch.cuda.is_current_stream_capturing()):
+            C.uniter_gemm_wgrad_group_autotune(n, M, Na, Ka, st)          # one-off, times the legal tiles of this group
+            cache = os.environ.get("UNITER_AMD_TUNE_CACHE", "")
+            if cache:
+                _save_tune_cache(cache, None)
+    C.uniter_gemm_wgrad_group(n, PA(*dys), IA(*lddys), PA(*xs_), IA(*ldxs), PA(*dws), PA(*dbs), M, Na, Ka, 1, st)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -754,10 +783,12 @@ class _PairedCrossAttnFn(torch.autograd.Function):
         half = T2 * H * es
         # ---- out_proj (model/attention.py:257) ----
         for i, mod in enumerate((attn1, attn2)):
-            d_o, c_i, dc_i = dout.data_ptr() + i * half, cx.data_ptr() + i * half, dcx.data_ptr() + i * half
+            d_o, dc_i = dout.data_ptr() + i * half, dcx.data_ptr() + i * half
             C.uniter_gemm_dgrad(d_o, ptr(mod.out_proj.weight), None, dc_i, T2, H, H, st)
-            C.uniter_gemm_wgrad(d_o, c_i, ptr(grad_of(mod.out_proj.weight)), ptr(grad_of(mod.out_proj.bias)),
-                                T2, H, H, 1, ptr(ws), wsb, st)
+        # both out_proj weight + bias gradients in one launch
+        wgrad_group([dout.data_ptr(), dout.data_ptr() + half], [0, 0], [cx.data_ptr(), cx.data_ptr() + half], [0, 0],
+                    [ptr(grad_of(attn1.out_proj.weight)), ptr(grad_of(attn2.out_proj.weight))],
+                    [ptr(grad_of(attn1.out_proj.bias)), ptr(grad_of(attn2.out_proj.bias))], T2, [H, H], [H, H])
         # ---- attention core ----
         C.uniter_attention_bwd(ptr(P), ptr(mask_bias_p), ptr(cx), ptr(lse), ptr(dcx), ptr(dP), 2 * n, L, heads,
                                ctx.p, ctx.seed, ctx.off, st)
@@ -773,15 +804,14 @@ class _PairedCrossAttnFn(torch.autograd.Function):
         C.uniter_gemm_dgrad_ld(d1 + H * es, 3 * H, wkv2, dx_l, dx_l, T2, 2 * H, H, st)
         C.uniter_gemm_dgrad_ld(d1, 3 * H, wq2, None, dx_r, T2, H, H, st)
         C.uniter_gemm_dgrad_ld(d0 + H * es, 3 * H, wkv1, dx_r, dx_r, T2, 2 * H, H, st)
+        # the four in_proj weight gradients (q and k|v blocks of both modules) and their bias gradients in one launch
         g1, g2 = grad_of(w1), grad_of(w2)
-        C.uniter_gemm_wgrad_ld(d0, 3 * H, x_l, H, g1.data_ptr(), None, T2, H, H, 1, ptr(ws), wsb, st)
-        C.uniter_gemm_wgrad_ld(d0 + H * es, 3 * H, x_r, H, g1.data_ptr() + H * H * es, None, T2, 2 * H, H, 1, ptr(ws), wsb, st)
-        C.uniter_gemm_wgrad_ld(d1, 3 * H, x_r, H, g2.data_ptr(), None, T2, H, H, 1, ptr(ws), wsb, st)
-        C.uniter_gemm_wgrad_ld(d1 + H * es, 3 * H, x_l, H, g2.data_ptr() + H * H * es, None, T2, 2 * H, H, 1, ptr(ws), wsb, st)
-        if attn1.in_proj_bias is not None:
-            C.uniter_colsum(d0, ptr(grad_of(attn1.in_proj_bias)), T2, 3 * H, 1, ptr(ws), wsb, st)
-        if attn2.in_proj_bias is not None:
-            C.uniter_colsum(d1, ptr(grad_of(attn2.in_proj_bias)), T2, 3 * H, 1, ptr(ws), wsb, st)
+        gb1, gb2 = grad_of(attn1.in_proj_bias), grad_of(attn2.in_proj_bias)
+        bq1, bkv1 = (gb1.data_ptr(), gb1.data_ptr() + H * es) if gb1 is not None else (None, None)
+        bq2, bkv2 = (gb2.data_ptr(), gb2.data_ptr() + H * es) if gb2 is not None else (None, None)
+        wgrad_group([d0, d0 + H * es, d1, d1 + H * es], [3 * H] * 4, [x_l, x_r, x_r, x_l], [H] * 4,
+                    [g1.data_ptr(), g1.data_ptr() + H * H * es, g2.data_ptr(), g2.data_ptr() + H * H * es],
+                    [bq1, bkv1, bq2, bkv2], T2, [H, 2 * H, H, 2 * H], [H, H, H, H])
         return (dxs if ctx.needs_input_grad[0] else None, None, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 6)
 
 
