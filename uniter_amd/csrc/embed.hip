@@ -65,25 +65,56 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const int64_t* __rest
     float acc[NC][4];
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0.f;
-    for (int q0 = p; q0 < n_keys; q0 += 64) {            // the key list is scanned once; positions are summed in order
+    // Sum, in position order (deterministic), the dz rows of every position that holds this key.  Rows are fetched eight
+    // at a time before they are added: a frequent token ([CLS], [SEP], [MASK]: tens to hundreds of positions per batch)
+    // would otherwise cost its owner wave one dependent memory round trip per occurrence.
+    constexpr int RB = 8;                                // rows in flight per batch
+    auto add4 = [&](const int64_t (&rows)[RB]) {
+        u32x2 raw[RB][NC];
+#pragma unroll
+        for (int k = 0; k < RB; ++k)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int ch = ch0 + 64 * c;
+                raw[k][c] = u32x2{0u, 0u};
+                if (rows[k] >= 0 && ch < nch) raw[k][c] = *reinterpret_cast<const u32x2*>(dz + rows[k] * H + ch * 4);
+            }
+#pragma unroll
+        for (int k = 0; k < RB; ++k)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float v[4];
+                unpack4(raw[k][c], v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[c][e] += v[e];
+            }
+    };
+    for (int q0 = p; q0 < n_keys; q0 += 64) {            // the key list is scanned once
         const int q = q0 + lane;
         const bool hit = (q < n_keys) && (keys[q] == key);
         unsigned long long mask = __ballot(hit);
-        while (mask) {
-            const int b = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const int pos = q0 + b;
-            for (int r = 0; r < reps; ++r) {
-                const bf16_t* src = dz + ((int64_t)pos + (int64_t)r * row_stride) * H;
+        if (reps == 1) {
+            while (mask) {
+                int64_t rows[RB];
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const int ch = ch0 + 64 * c;
-                    if (ch < nch) {
-                        float v[4];
-                        unpack4(*reinterpret_cast<const u32x2*>(src + ch * 4), v);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[c][e] += v[e];
+                for (int k = 0; k < RB; ++k) {
+                    rows[k] = -1;
+                    if (mask) {
+                        rows[k] = q0 + (__ffsll((long long)mask) - 1);
+                        mask &= mask - 1;
                     }
+                }
+                add4(rows);
+            }
+        } else {
+            while (mask) {
+                const int pos = q0 + (__ffsll((long long)mask) - 1);
+                mask &= mask - 1;
+                for (int r = 0; r < reps; r += RB) {
+                    int64_t rows[RB];
+#pragma unroll
+                    for (int k = 0; k < RB; ++k) rows[k] = (r + k < reps) ? (int64_t)pos + (int64_t)(r + k) * row_stride : -1;
+                    add4(rows);
                 }
             }
         }
