@@ -38,18 +38,9 @@ __global__ __launch_bounds__(256) void embed_txt_fwd_kernel(const int64_t* __res
 // keys: n_keys entries; the dz rows of key position k are rows {k + r*row_stride, r < reps} (reps > 1 for the
 // position table whose ids are shared by the whole batch).
 template <int NC>
-__global__ __launch_bounds__(256) void scatter_rows_kernel(const int64_t* __restrict__ keys_g, int n_keys, int reps, int row_stride,
-                                                           const bf16_t* __restrict__ dz, bf16_t* __restrict__ table,
-                                                           int H, int64_t padding_idx, int use_lds) {
-    // grid (ceil(n_keys / 4), column groups): a wave covers NC chunks of 256 columns starting at blockIdx.y * NC * 256
-    // The key list is staged in LDS first (one burst of coalesced loads): the two scans below would otherwise be a chain
-    // of ~n_keys/64 dependent global loads per wave (46 us for the 1920 word ids of a 32 x 60 batch).
-    extern __shared__ int64_t skeys[];
-    if (use_lds) {
-        for (int q = threadIdx.x; q < n_keys; q += 256) skeys[q] = keys_g[q];
-        __syncthreads();
-    }
-    const int64_t* keys = use_lds ? skeys : keys_g;
+__device__ __forceinline__ void scatter_rows_body(const int64_t* keys, int n_keys, int reps, int row_stride,
+                                                  const bf16_t* __restrict__ dz, bf16_t* __restrict__ table,
+                                                  int H, int64_t padding_idx) {
     const int lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= n_keys) return;
@@ -129,6 +120,24 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const int64_t* __rest
             for (int e = 0; e < 4; ++e) o[e] += acc[c][e];
             *reinterpret_cast<u32x2*>(trow + ch * 4) = pack4(o);
         }
+    }
+}
+
+// grid (ceil(n_keys / 4), column groups): a wave covers NC chunks of 256 columns starting at blockIdx.y * NC * 256.
+// The key list is staged in LDS first (one burst of coalesced loads) and the body is instantiated on the LDS pointer
+// itself: its two scans are ~n_keys/64 dependent reads per wave, which through global (or generic "flat") addressing cost
+// 46 us for the 1920 word ids of a 32 x 60 batch.
+template <int NC>
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const int64_t* __restrict__ keys_g, int n_keys, int reps, int row_stride,
+                                                           const bf16_t* __restrict__ dz, bf16_t* __restrict__ table,
+                                                           int H, int64_t padding_idx, int use_lds) {
+    extern __shared__ int64_t skeys[];
+    if (use_lds) {
+        for (int q = threadIdx.x; q < n_keys; q += 256) skeys[q] = keys_g[q];
+        __syncthreads();
+        scatter_rows_body<NC>(skeys, n_keys, reps, row_stride, dz, table, H, padding_idx);
+    } else {
+        scatter_rows_body<NC>(keys_g, n_keys, reps, row_stride, dz, table, H, padding_idx);
     }
 }
 
