@@ -838,6 +838,22 @@ static void bench(int B, int L, int H, int heads, int I, int layers) {
             double one = tm.run([&] { UHCHK(uniter_encoder_forward(&sh2, lp.data(), 0, layers, dX, dMask, actsA, scratch, 1, 0, 0)); }, 2, 10);
             printf("  (experiment: forward of two B=%d halves on two streams: %.1f us; one half alone: %.1f us; full batch: %.1f us)\n", B / 2, us2, one, tf);
         }
+        {   // word-embedding scatter-add of a 32 x 60 batch (uniter_embed_txt_bwd, word table only)
+            const int Bq = 32, Lt = 60, V = 28996;
+            std::vector<int64_t> ids((size_t)Bq * Lt), pos(Lt);
+            for (auto& v : ids) v = 1000 + (int64_t)(rndu() * 0.5f * 27000 + 13500) % 27000;
+            for (int b2 = 0; b2 < Bq; ++b2) { ids[(size_t)b2 * Lt] = 101; ids[(size_t)b2 * Lt + Lt - 1] = 102; }
+            for (int t2 = 0; t2 < Lt; ++t2) pos[t2] = t2;
+            int64_t* dIds = dalloc<int64_t>(ids.size()); int64_t* dPos = dalloc<int64_t>(Lt);
+            HIPCHK(hipMemcpy(dIds, ids.data(), ids.size() * 8, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(dPos, pos.data(), Lt * 8, hipMemcpyHostToDevice));
+            uint16_t* dzq = dalloc<uint16_t>((size_t)Bq * Lt * H);
+            HIPCHK(hipMemset(dzq, 0x3c, (size_t)Bq * Lt * H * 2));
+            uint16_t* gword = dalloc<uint16_t>((size_t)V * H);
+            HIPCHK(hipMemset(gword, 0, (size_t)V * H * 2));
+            double ts = tm.run([&] { UHCHK(uniter_embed_txt_bwd(dIds, dPos, nullptr, dzq, gword, nullptr, nullptr, Bq, Lt, H, V, 512, 2, 0)); }, 3, 20);
+            printf("  embedding scatter-add (32 x 60 ids -> [28996, %d] gradient): %.1f us\n", H, ts);
+        }
         {   // grouped weight gradients of one layer vs the four separate launches
             const int64_t Ng[4] = {H, I, H, 3 * (int64_t)H}, Kg[4] = {I, H, H, H};
             HostBf big; big.fill((size_t)T * I, 1.f);

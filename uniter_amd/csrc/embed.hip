@@ -47,8 +47,15 @@ __device__ __forceinline__ void scatter_rows_body(const int64_t* keys, int n_key
     const int64_t key = keys[p];
     if (key == padding_idx) return;
     // first-occurrence test
+    // first-occurrence test; four keys per lane and step so that the LDS latency is paid once per 256 keys
     bool dup = false;
-    for (int q = lane; q < p; q += 64) dup |= (keys[q] == key);
+    for (int q0 = 0; q0 < p; q0 += 256) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + 64 * j + lane;
+            dup |= (q < p) && (keys[q] == key);
+        }
+    }
     if (__any(dup)) return;
     bf16_t* trow = table + key * H;
     const int nch = H >> 2;
@@ -60,56 +67,70 @@ __device__ __forceinline__ void scatter_rows_body(const int64_t* keys, int n_key
     // at a time before they are added: a frequent token ([CLS], [SEP], [MASK]: tens to hundreds of positions per batch)
     // would otherwise cost its owner wave one dependent memory round trip per occurrence.
     constexpr int RB = 8;                                // rows in flight per batch
+    // The loads are unconditional (absent rows / columns are clamped to a valid address and discarded afterwards): with
+    // predicated loads the compiler keeps a wait between them and the batch degenerates into RB dependent round trips.
     auto add4 = [&](const int64_t (&rows)[RB]) {
         u32x2 raw[RB][NC];
 #pragma unroll
-        for (int k = 0; k < RB; ++k)
+        for (int k = 0; k < RB; ++k) {
+            const int64_t r = rows[k] >= 0 ? rows[k] : 0;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int ch = ch0 + 64 * c;
-                raw[k][c] = u32x2{0u, 0u};
-                if (rows[k] >= 0 && ch < nch) raw[k][c] = *reinterpret_cast<const u32x2*>(dz + rows[k] * H + ch * 4);
+                raw[k][c] = *reinterpret_cast<const u32x2*>(dz + r * H + (ch < nch ? ch : nch - 1) * 4);
             }
+        }
 #pragma unroll
-        for (int k = 0; k < RB; ++k)
+        for (int k = 0; k < RB; ++k) {
+            const bool live = rows[k] >= 0;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
+                const int ch = ch0 + 64 * c;
                 float v[4];
                 unpack4(raw[k][c], v);
+                if (live && ch < nch) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[c][e] += v[e];
-            }
-    };
-    for (int q0 = p; q0 < n_keys; q0 += 64) {            // the key list is scanned once
-        const int q = q0 + lane;
-        const bool hit = (q < n_keys) && (keys[q] == key);
-        unsigned long long mask = __ballot(hit);
-        if (reps == 1) {
-            while (mask) {
-                int64_t rows[RB];
-#pragma unroll
-                for (int k = 0; k < RB; ++k) {
-                    rows[k] = -1;
-                    if (mask) {
-                        rows[k] = q0 + (__ffsll((long long)mask) - 1);
-                        mask &= mask - 1;
-                    }
-                }
-                add4(rows);
-            }
-        } else {
-            while (mask) {
-                const int pos = q0 + (__ffsll((long long)mask) - 1);
-                mask &= mask - 1;
-                for (int r = 0; r < reps; r += RB) {
-                    int64_t rows[RB];
-#pragma unroll
-                    for (int k = 0; k < RB; ++k) rows[k] = (r + k < reps) ? (int64_t)pos + (int64_t)(r + k) * row_stride : -1;
-                    add4(rows);
+                    for (int e = 0; e < 4; ++e) acc[c][e] += v[e];
                 }
             }
         }
+    };
+    // matching rows are queued (in position order) and fetched RB at a time, across scan steps: the occurrences of a
+    // frequent token are spread over the whole key list, a flush per 64-key mask would again be one round trip each
+    int64_t pend[RB];
+#pragma unroll
+    for (int k = 0; k < RB; ++k) pend[k] = -1;
+    int npend = 0;
+    auto push = [&](int64_t row) {
+#pragma unroll
+        for (int k = 0; k < RB; ++k)
+            if (k == npend) pend[k] = row;
+        if (++npend == RB) {
+            add4(pend);
+#pragma unroll
+            for (int k = 0; k < RB; ++k) pend[k] = -1;
+            npend = 0;
+        }
+    };
+    for (int q0 = p; q0 < n_keys; q0 += 256) {           // the key list is scanned once, 256 keys per step
+        bool hit[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + 64 * j + lane;
+            hit[j] = (q < n_keys) && (keys[q] == key);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned long long mask = __ballot(hit[j]);
+            const int base = q0 + 64 * j;
+            while (mask) {
+                const int pos = base + (__ffsll((long long)mask) - 1);
+                mask &= mask - 1;
+                for (int r = 0; r < reps; ++r) push((int64_t)pos + (int64_t)r * row_stride);
+            }
+        }
     }
+    if (npend > 0) add4(pend);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int ch = ch0 + 64 * c;
