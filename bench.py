@@ -332,6 +332,15 @@ def main():
     final_loss = float(loss.item())
     assert final_loss == final_loss, "loss is NaN"
 
+    # In-situ per-launch timing for the roofline object: extra optimizer steps AFTER the timed region.  With several
+    # ranks these steps contain the gradient collectives, so EVERY rank runs them (only rank 0 reports).
+    kernels = None
+    if not args.no_kernel_timing and mode == "eager":
+        tsteps = max(1, min(args.steps, 5))
+        kernels = timed_pass(train_step, tsteps)
+        if world > 1:
+            torch.distributed.barrier()
+
     if rank == 0:
         B, L = TRAIN['batch'], TRAIN['max_txt_len'] + TRAIN['num_bb']
         ms = elapsed / args.steps * 1e3
@@ -339,10 +348,7 @@ def main():
         flop_step = 3.0 * encoder_flops(B, L, BASE_CFG['hidden_size'], BASE_CFG['intermediate_size'], BASE_CFG['num_hidden_layers'])
         step_tf = flop_step / (ms * 1e-3) * 1e-12
         roofline = None
-        kernels = None
-        if not args.no_kernel_timing and mode == "eager":
-            tsteps = max(1, min(args.steps, 5))
-            kernels = timed_pass(train_step, tsteps)
+        if kernels is not None:
             mfma = [k for k in kernels if k["tflops"] is not None]
             dom = max(mfma, key=lambda k: k["us_per_step"])
             M, N, K = dom["shape"]
