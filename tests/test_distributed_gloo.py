@@ -110,7 +110,58 @@ def _case_gradient_reducer(rank, world, D):
     assert torch.equal(arena.grad, before)
 
 
-@pytest.mark.parametrize("case", ["_case_allreduce", "_case_broadcast_and_objects", "_case_gradient_reducer"])
+def _case_task_mix_and_retrieval_gather(rank, world, D):
+    """MetaLoader: every rank trains the task rank 0 drew.  itm_eval.evaluate: ranks own different numbers of texts, the
+    score rows are gathered in rank order and only rank 0 reports (reference utils/itm_eval.py:68-90)."""
+    import random
+    from uniter_amd.data import MetaLoader
+    from uniter_amd.utils import itm_eval as IE
+
+    class Listy(list):
+        pass
+    loaders = {"mlm": (Listy([{"t": "mlm"}] * 2), 1), "itm": (Listy([{"t": "itm"}] * 2), 1), "mrfr": (Listy([{"t": "mrfr"}]), 1)}
+    meta = MetaLoader(loaders, accum_steps=1, distributed=True, rng=random.Random(1234 + 17 * rank))   # different local draws
+    it = iter(meta)
+    mine = [next(it)[0] for _ in range(24)]
+    both = D.all_gather_list(mine)
+    assert both[0] == both[1] and len(set(both[0])) > 1
+
+    n_img = 9
+    img_ids = ["i%d" % j for j in range(n_img)]
+    all_txt = ["t%d" % k for k in range(13)]
+    txt2img = {t: img_ids[k % n_img] for k, t in enumerate(all_txt)}
+    img2txts = {i: [t for t in all_txt if txt2img[t] == i] for i in img_ids}
+    g = torch.Generator().manual_seed(3)
+    full = torch.randn(len(all_txt), n_img, generator=g)
+    own = all_txt[:8] if rank == 0 else all_txt[8:]                     # 8 + 5 rows
+    rows = [all_txt.index(t) for t in own]
+
+    class Dset:
+        ids, all_img_ids = own, img_ids
+
+        def __len__(self):
+            return len(own)
+    Dset.txt2img, Dset.img2txts = txt2img, img2txts
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, batch, compute_loss=False):
+            return full[batch['row'], batch['cols']].unsqueeze(1)
+    loader = Listy([[{'row': r, 'cols': torch.arange(0, 4)}, {'row': r, 'cols': torch.arange(4, n_img)}] for r in rows])
+    loader.dataset = Dset()
+    log = IE.evaluate(Model(), loader)
+    if rank == 0:
+        ref = IE.itm_eval(full.to(torch.bfloat16).float(), all_txt, img_ids, txt2img, img2txts)
+        assert all(abs(log[k] - ref[k]) < 1e-12 for k in ref)
+    else:
+        assert log == {}
+
+
+@pytest.mark.parametrize("case", ["_case_allreduce", "_case_broadcast_and_objects", "_case_gradient_reducer",
+                                  "_case_task_mix_and_retrieval_gather"])
 def test_world_size_2(case, tmp_path):
     _spawn(case, tmp_path)
 
