@@ -79,10 +79,18 @@ def bf16_bits(t):
     return t.detach().to(torch.bfloat16).view(torch.int16).numpy().copy()
 
 
-def main():
+def store_batch(out, prefix, batch):
+    """Only the tensor entries of a batch are fixture data: `seq_lens` (a host-side python list, a hint for the packed
+    encoder path) and `ot_inputs` (None / a dict, covered by make_golden_ot.py) are derived from them and skipped."""
+    for k, v in batch.items():
+        if isinstance(v, torch.Tensor):
+            out["%s/%s" % (prefix, k)] = v.numpy()
+
+
+def main(out_path=None):
     torch.manual_seed(1234)
     gen = torch.Generator().manual_seed(4321)
-    cfg_path = os.path.join(HERE, "uniter_tiny_config.json")
+    cfg_path = os.path.join(os.path.dirname(os.path.abspath(out_path)) if out_path else HERE, "uniter_tiny_config.json")
     with open(cfg_path, "w") as f:
         json.dump(CFG, f, indent=2, sort_keys=True)
     out = {"config_json": np.array(json.dumps(CFG))}
@@ -99,8 +107,7 @@ def main():
     tasks = [('mlm', 11), ('mrfr', 12), ('mrckl', 13), ('mrc', 14), ('itm', 15)]
     for task, seed in tasks:
         batch = make_batch(task, seed=seed, **BATCH)
-        for k, v in batch.items():
-            out["batch_%s/%s" % (task, k)] = v.numpy()
+        store_batch(out, "batch_%s" % task, batch)
         pre.zero_grad()
         rb = dict(batch)
         if 'img_masks' in rb:
@@ -156,8 +163,7 @@ def main():
         if k.startswith('vqa_output.'):
             out["vqa/" + k] = bf16_bits(v)
     batch = make_batch('vqa', seed=21, **BATCH)
-    for k, v in batch.items():
-        out["batch_vqa/%s" % k] = v.numpy()
+    store_batch(out, "batch_vqa", batch)
     loss = vqa(batch, compute_loss=True)
     out["out_vqa/loss"] = loss.detach().numpy()
     (loss.mean() * N_ANS).backward()
@@ -183,8 +189,7 @@ def main():
         if not k.startswith('uniter.') or 'token_type_embeddings' in k:
             out["nlvr2/" + k] = bf16_bits(v)
     batch = make_batch('nlvr2', seed=31, **BATCH)
-    for k, v in batch.items():
-        out["batch_nlvr2/%s" % k] = v.numpy()
+    store_batch(out, "batch_nlvr2", batch)
     loss = nl(batch, compute_loss=True)
     out["out_nlvr2/loss"] = loss.detach().numpy()
     loss.mean().backward()
@@ -195,10 +200,10 @@ def main():
     out["grad_nlvr2/uniter.encoder.layer.1.intermediate.dense.weight"] = \
         nl.uniter.encoder.layer[1].intermediate.dense.weight.grad.numpy().copy()
 
-    path = os.path.join(HERE, "uniter_tiny.npz")
+    path = out_path or os.path.join(HERE, "uniter_tiny.npz")
     np.savez_compressed(path, **out)
     print("wrote %s (%.2f MB, %d arrays)" % (path, os.path.getsize(path) / 1e6, len(out)))
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else None)

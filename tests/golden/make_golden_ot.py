@@ -26,7 +26,7 @@ def bf16_bits(t):
     return t.to(torch.bfloat16).view(torch.int16).numpy().astype(np.uint16)
 
 
-def main():
+def main(out_path=None):
     sys.path.insert(0, REF)
     ot = importlib.import_module("model.ot")
     out = {}
@@ -62,10 +62,10 @@ def main():
         out[name + "/dx"] = x.grad.numpy()
         out[name + "/dy"] = y.grad.numpy()
         print(name, "dist", dist.detach().numpy())
-    path = os.path.join(HERE, "ot_golden.npz")
+    path = out_path or os.path.join(HERE, "ot_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else None)

@@ -1,7 +1,9 @@
 """Pins the CPU oracle (oracle/uniter_oracle.py) against vectors produced by the REAL reference
 (tests/golden/make_golden.py -> tests/golden/uniter_tiny.npz).  fp32, no GPU needed."""
 import math
+import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -156,3 +158,21 @@ def test_optimal_transport_matches_reference(name):
     # transport plan: rows of padded slots are exactly zero, the rest is a non-negative coupling
     assert float(T.min()) >= 0.0
     assert float(T[c["img_pad"]].abs().max() if c["img_pad"].any() else 0.0) == 0.0
+
+
+# ---- the committed fixtures regenerate bit-exactly from the committed recipes (needs /root/reference: this container) ----
+@pytest.mark.skipif(not os.path.isdir("/root/reference/model"), reason="the reference checkout only exists in the build container")
+@pytest.mark.parametrize("script,fixture", [("make_golden.py", "uniter_tiny.npz"), ("make_golden_ot.py", "ot_golden.npz")])
+def test_golden_recipe_regenerates_committed_fixture(tmp_path, script, fixture):
+    import subprocess
+    import sys
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    out = str(tmp_path / fixture)
+    r = subprocess.run([sys.executable, os.path.join(here, script), out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    new, old = np.load(out), np.load(os.path.join(here, fixture))
+    assert sorted(new.files) == sorted(old.files)
+    for k in old.files:
+        a, b = new[k], old[k]
+        assert a.dtype == b.dtype and a.shape == b.shape, k
+        assert a.tobytes() == b.tobytes(), "array %s differs from the committed fixture" % k
