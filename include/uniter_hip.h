@@ -68,6 +68,9 @@ int uniter_hip_timing_end(UniterTimingRecord* out, int32_t cap, int32_t* n_out);
 /* Test / tuning hook: force the GEMM tile (0=128x128, 1=128x64, 2=64x128, 3=64x64; -1 = heuristic)
  * and the wgrad split-K factor (-1 = heuristic). */
 int uniter_gemm_debug_force(int cfg, int splits);
+/* Tuning hook: workgroups of a grouped weight-gradient launch (0 = one per tile; 256 = one persistent workgroup per CU,
+ * each walking its share of the tiles, so that the launch never occupies more than one LDS ring per CU). */
+int uniter_gemm_debug_group_persist(int workgroups);
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM family — bf16 operands, fp32 MFMA accumulation, fused epilogues.

@@ -883,6 +883,95 @@ static void bench(int B, int L, int H, int heads, int I, int layers) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// --enc: the 12-layer encoder alone with the shipped tile table (uniter_amd/tuned/gfx950.json), no sweeps: the quick
+// A/B harness for scheduling experiments (UNITER_AMD_GROUP_PERSIST, UNITER_AMD_WGRAD_DEFER, ...)
+// ---------------------------------------------------------------------------------------------
+static int load_tuned_json(const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return 0;
+    std::string txt;
+    char buf[4096];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof(buf), f)) > 0) txt.append(buf, n);
+    fclose(f);
+    int cnt = 0;
+    size_t pos = 0;
+    while ((pos = txt.find("{\"kind\"", pos)) != std::string::npos) {
+        int kind = 0, cfg = 0, sp = 1;
+        long long M = 0, N = 0, K = 0;
+        if (sscanf(txt.c_str() + pos, "{\"kind\": %d, \"M\": %lld, \"N\": %lld, \"K\": %lld, \"cfg\": %d, \"splits\": %d", &kind, &M, &N, &K, &cfg, &sp) == 6) {
+            if (uniter_gemm_set_tuned(kind, M, N, K, cfg, sp) == 0) ++cnt;
+        }
+        ++pos;
+    }
+    return cnt;
+}
+
+static void bench_encoder(int B, int L, int H, int heads, int I, int layers) {
+    printf("== encoder B%d L%d H%d I%d layers%d ==\n", B, L, H, I, layers);
+    const int64_t T = (int64_t)B * L;
+    Timer tm;
+    HostBf X;
+    X.fill((size_t)T * H, 1.f);
+    uint16_t* dX = upload(X);
+    uint16_t* dY = upload(X);
+    const float pdrop = getenv("UNITER_BENCH_NODROP") ? 0.f : 0.1f;
+    UniterEncoderShape sh{B, L, H, heads, I, pdrop, pdrop, 1e-12f, 1};
+    const size_t act = uniter_encoder_layer_act_bytes(&sh), scr = uniter_encoder_scratch_bytes(&sh);
+    char* acts = dalloc<char>(act * layers);
+    char* scratch = dalloc<char>(scr);
+    const size_t per = (size_t)3 * H * H + 3 * H + (size_t)H * H + H + 2 * H + (size_t)I * H + I + (size_t)H * I + H + 2 * H;
+    HostBf P;
+    P.fill(per, 0.03f);
+    std::vector<UniterLayerParams> lp(layers);
+    const bool share_w = getenv("UNITER_BENCH_SHARE_WEIGHTS") != nullptr;   // experiment: every layer reads the same (cache-hot) weights
+    uint16_t* p_shared = share_w ? upload(P) : nullptr;
+    for (int l = 0; l < layers; ++l) {
+        uint16_t* p = share_w ? p_shared : upload(P);
+        uint16_t* g = dalloc<uint16_t>(per);
+        HIPCHK(hipMemset(g, 0, per * 2));
+        size_t o = 0;
+        auto nxt = [&](size_t n) { size_t r = o; o += n; return r; };
+        size_t o_wqkv = nxt((size_t)3 * H * H), o_bqkv = nxt(3 * H), o_wo = nxt((size_t)H * H), o_bo = nxt(H), o_g1 = nxt(H), o_b1n = nxt(H);
+        size_t o_w1 = nxt((size_t)I * H), o_b1 = nxt(I), o_w2 = nxt((size_t)H * I), o_b2 = nxt(H), o_g2 = nxt(H), o_b2n = nxt(H);
+        lp[l] = UniterLayerParams{p + o_wqkv, p + o_bqkv, p + o_wo, p + o_bo, p + o_g1, p + o_b1n, p + o_w1, p + o_b1, p + o_w2, p + o_b2, p + o_g2, p + o_b2n,
+                                  g + o_wqkv, g + o_bqkv, g + o_wo, g + o_bo, g + o_g1, g + o_b1n, g + o_w1, g + o_b1, g + o_w2, g + o_b2, g + o_g2, g + o_b2n};
+    }
+    float* dMask = dalloc<float>((size_t)B * L);
+    HIPCHK(hipMemset(dMask, 0, (size_t)B * L * 4));
+    uint16_t* dDx = dalloc<uint16_t>((size_t)T * H);
+    const char* tj = getenv("UNITER_TUNED_JSON");
+    const int nt = load_tuned_json(tj ? tj : "uniter_amd/tuned/gfx950.json");
+    printf("  tile table: %d entries\n", nt);
+    if (nt == 0) { UHCHK(uniter_encoder_autotune(&sh, 0)); }
+    double tf = 1e30, tb = 1e30;
+    for (int rep = 0; rep < 5; ++rep) {
+        tf = std::min(tf, tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 20));
+        tb = std::min(tb, tm.run([&] { UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0)); }, 2, 20));
+    }
+    {
+        static const char* kinds[] = {"gemm fwd +bias", "gemm fwd +gelu", "gemm fwd +drop+res", "gemm dgrad", "gemm dgrad gelu'", "gemm wgrad",
+                                      "attn fwd", "attn bwd", "ln fwd", "ln bwd rows", "colsum", "adamw", "ln bwd cols", "gemm wgrad group"};
+        const int nkinds = (int)(sizeof(kinds) / sizeof(kinds[0]));
+        UniterTimingRecord rec[64];
+        int32_t nrec = 0;
+        HIPCHK(hipDeviceSynchronize());
+        UHCHK(uniter_hip_timing_begin());
+        UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0));
+        UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0));
+        UHCHK(uniter_hip_timing_end(rec, 64, &nrec));
+        for (int i = 0; i < nrec && i < 64; ++i)
+            printf("  in-situ %-18s M%-5lld N%-5lld K%-5lld x%-3d avg %7.2f us\n", rec[i].kind >= 0 && rec[i].kind < nkinds ? kinds[rec[i].kind] : "?", (long long)rec[i].M,
+                   (long long)rec[i].N, (long long)rec[i].K, rec[i].calls, rec[i].total_us / rec[i].calls);
+    }
+    const double flf = (double)layers * (24.0 * T * H * H + 4.0 * T * L * H);
+    printf("  ENCODER fwd %.1f us (%.1f TF) | bwd %.1f us (%.1f TF) | fwd+bwd %.1f us = %.1f TF = %.1f%% of 2.5 PF ; %.0f ex/s\n", tf,
+           flf / tf * 1e-6, tb, 2 * flf / tb * 1e-6, tf + tb, 3 * flf / (tf + tb) * 1e-6, 3 * flf / (tf + tb) * 1e-6 / 2500 * 100,
+           B / ((tf + tb) * 1e-6));
+}
+
 #ifdef UNITER_GEMM_PROBE
 extern "C" int uniter_gemm_debug_probe(unsigned long long* dev);
 #endif
@@ -911,14 +1000,15 @@ static int run_one(int argc, char** argv, int at) {
 #ifdef UNITER_GEMM_PROBE
     {
         const int nblk = 4096;
-        unsigned long long* dpr = dalloc<unsigned long long>((size_t)nblk * 64 * 5 + (size_t)nblk * 2);
+        const size_t pr_total = (size_t)nblk * 64 * 5 + (size_t)nblk * 2 + (size_t)nblk * 64 * 4;
+        unsigned long long* dpr = dalloc<unsigned long long>(pr_total);
         for (int i = 0; i < 3; ++i) fn();
-        HIPCHK(hipMemset(dpr, 0, ((size_t)nblk * 64 * 5 + (size_t)nblk * 2) * 8));
+        HIPCHK(hipMemset(dpr, 0, pr_total * 8));
         uniter_gemm_debug_probe(dpr);
         fn();
         HIPCHK(hipDeviceSynchronize());
         uniter_gemm_debug_probe(nullptr);
-        std::vector<unsigned long long> h((size_t)nblk * 64 * 5 + (size_t)nblk * 2);
+        std::vector<unsigned long long> h(pr_total);
         HIPCHK(hipMemcpy(h.data(), dpr, h.size() * 8, hipMemcpyDeviceToHost));
         const int nkt = (int)std::min<int64_t>((kind == "wgrad" ? M : (kind == "dgrad" ? N : K)) / 64, 63);
         double ph[4] = {0, 0, 0, 0}, tot = 0, gap = 0; long cnt = 0, gcnt = 0;
@@ -934,8 +1024,22 @@ static int run_one(int argc, char** argv, int at) {
                 tmin = std::min(tmin, r[0]); tmax = std::max(tmax, r[4]);
             }
         }
-        printf("   probe: %ld iterations; cycles/iter: dma-wait %.0f | barrier %.0f | dma-issue %.0f | lds+mfma %.0f | total %.0f (+%.0f between) ; kernel span %.0f kcycles\n",
-               cnt, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, tot / cnt, gcnt ? gap / gcnt : 0.0, (double)(tmax - tmin) / 1e3);
+        printf("   probe: %ld compute-wave iterations; cycles/iter: mma step 0 (+ issue of step-1 reads) %.0f | lgkm + barrier wait %.0f | mma step 1 (+ next tile reads) %.0f | total %.0f (+%.0f between)\n",
+               cnt, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, tot / cnt, gcnt ? gap / gcnt : 0.0);
+        {   // loader wave 0
+            const unsigned long long* L = &h[(size_t)nblk * 64 * 5 + (size_t)nblk * 2];
+            double lw[3] = {0, 0, 0}, ltot = 0; long lc = 0;
+            for (int b = 0; b < nblk; ++b)
+                for (int k = 1; k + 1 < nkt; ++k) {          // steady state: skip the first and last tile
+                    const unsigned long long* r = &L[((size_t)b * 64 + k) * 4];
+                    const unsigned long long* rn = &L[((size_t)b * 64 + k + 1) * 4];
+                    if (!r[0] || !r[3] || !rn[0]) continue;
+                    lw[0] += (double)(r[1] - r[0]); lw[1] += (double)(r[2] - r[1]); lw[2] += (double)(r[3] - r[2]);
+                    ltot += (double)(rn[0] - r[0]); ++lc;
+                }
+            if (lc) printf("   probe: %ld loader-wave iterations; cycles/iter: wait for DMA %.0f | wait at barrier %.0f | issue next tile %.0f | total %.0f\n",
+                           lc, lw[0] / lc, lw[1] / lc, lw[2] / lc, ltot / lc);
+        }
         // per-block span distribution
         std::vector<double> spans;
         for (int b = 0; b < nblk; ++b) {
@@ -987,6 +1091,18 @@ int main(int argc, char** argv) {
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--bench")) do_bench = true;
         if (!strcmp(argv[i], "--quick")) quick = true;
+        if (!strcmp(argv[i], "--enc")) {
+            int32_t inf[4];
+            UHCHK(uniter_hip_device_info(inf));
+            printf("== grouped weight gradients ==\n");
+            test_wgrad_group(320);
+            test_wgrad_group(300);
+            if (i + 1 < argc && !strcmp(argv[i + 1], "large")) bench_encoder(32, 96, 1024, 16, 4096, 24);
+            else if (i + 1 < argc && !strcmp(argv[i + 1], "large178")) bench_encoder(32, 178, 1024, 16, 4096, 24);
+            else bench_encoder(32, 96, 768, 12, 3072, 12);
+            printf("== %d check(s) failed ==\n", g_fail);
+            return g_fail;
+        }
         if (!strcmp(argv[i], "--one")) {
             int32_t inf[4];
             UHCHK(uniter_hip_device_info(inf));
