@@ -68,9 +68,6 @@ int uniter_hip_timing_end(UniterTimingRecord* out, int32_t cap, int32_t* n_out);
 /* Test / tuning hook: force the GEMM tile (0=128x128, 1=128x64, 2=64x128, 3=64x64; -1 = heuristic)
  * and the wgrad split-K factor (-1 = heuristic). */
 int uniter_gemm_debug_force(int cfg, int splits);
-/* Tuning hook: workgroups of a grouped weight-gradient launch (0 = one per tile; 256 = one persistent workgroup per CU,
- * each walking its share of the tiles, so that the launch never occupies more than one LDS ring per CU). */
-int uniter_gemm_debug_group_persist(int workgroups);
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM family — bf16 operands, fp32 MFMA accumulation, fused epilogues.
@@ -425,6 +422,25 @@ int uniter_adamw_grad_norm(void* plan, float grad_scale, float max_norm, float* 
  * multiplies every gradient element on the fly (fused clipping). */
 int uniter_adamw_step(void* plan, const UniterAdamGroup* groups, int32_t n_groups,
                       const float* clip_coef, void* stream);
+
+/* uniter_adamw_step that also zeroes every gradient element once it has been read: optimizer.zero_grad()
+ * (pretrain.py:334) folded into the update — one pass over the gradients and one launch fewer. */
+int uniter_adamw_step_zero(void* plan, const UniterAdamGroup* groups, int32_t n_groups,
+                           const float* clip_coef, void* stream);
+
+/* The same update, asynchronous and segmented, so that the next forward pass overlaps it: the work is cut at the given
+ * parameter addresses (ascending, e.g. the first parameter of every BertLayer of a flat arena) and the segments run in
+ * ascending address order on an internal stream that first waits for everything enqueued on `stream`.  With zero_grads
+ * != 0 each gradient element is zeroed once read (optimizer.zero_grad(), pretrain.py:334, folded in).  Afterwards
+ *   uniter_params_wait(addr, s)   makes stream s wait until the segment holding parameter address `addr` is updated
+ *                                 (no-op for other addresses / when nothing is pending); uniter_encoder_forward calls it
+ *                                 for every layer, the embedding entry points for their tables;
+ *   uniter_params_wait_all(s)     makes s wait for the whole step (call before gradients are written again or any
+ *                                 parameter is read by code that does not use the per-address form). */
+int uniter_adamw_step_async(void* plan, const UniterAdamGroup* groups, int32_t n_groups, const float* clip_coef,
+                            const void* const* bounds, int32_t n_bounds, int32_t zero_grads, void* stream);
+int uniter_params_wait(const void* addr, void* stream);
+int uniter_params_wait_all(void* stream);
 
 /* Same update with the per-group hyper-parameters read from DEVICE memory: dev_hyper = n_groups x 6 floats
  * {lr, beta1, beta2, eps, weight_decay, step_size}, step_size = lr*sqrt(1-b2^t)/(1-b1^t) (or lr without bias

@@ -445,6 +445,95 @@ def test_arena_training_step_matches_unflattened(golden):
         assert rel_l2(results[1][n], results[0][n]) < 1e-3, n
 
 
+def test_overlapped_adamw_step_is_bit_identical_and_skips_untouched_params(golden):
+    """AdamW.enable_overlap (segmented update on the optimizer stream, forward of the next step overlapping it, zero_grad
+    folded into the kernel) must produce exactly the parameters of the synchronous step; parameters the loss never
+    reaches keep grad None and are neither decayed nor stepped (optim/adamw.py:52-53)."""
+    from uniter_amd.model.nlvr2 import UniterForNlvr2PairedAttn
+    from uniter_amd.optim import build_optimizer, clip_grad_norm_, overlap_boundaries
+    from uniter_amd.utils.arena import flatten_model
+    from uniter_amd.utils.misc import Struct
+    batch = _to_dev(golden.batch('nlvr2'))
+    opts = Struct(dict(optim='adamw', learning_rate=1e-3, betas=(0.9, 0.98), weight_decay=0.01))
+    results = []
+    for mode in ('plain', 'fused_zero', 'overlap'):
+        overlap = mode == 'overlap'
+        w = golden.weights('pre')
+        nl = golden.weights('nlvr2')
+        table3 = nl.pop('uniter.embeddings.token_type_embeddings.weight')
+        model = UniterForNlvr2PairedAttn.from_pretrained(TINY_CONFIG, {**w, **nl}, img_dim=IMG_DIM)
+        model.init_type_embedding()
+        model.uniter.embeddings.token_type_embeddings.weight.data.copy_(table3)
+        _prep(model)
+        arena = flatten_model(model)
+        opt = build_optimizer(model, opts)
+        pool0 = model.uniter.pooler.dense.weight.detach().clone()
+        if overlap:
+            b = overlap_boundaries(model)
+            assert len(b) == len(model.uniter.encoder.layer) + 1 and b == sorted(b)
+            opt.enable_overlap(b)
+        opt.fuse_zero_grad = mode == 'fused_zero'       # zero_grad folded into the synchronous update kernel
+        for step in range(3):
+            model(batch, compute_loss=True).mean().backward()
+            clip_grad_norm_(opt, 1.0)
+            opt.step()
+            opt.zero_grad()
+        opt.synchronize()
+        torch.cuda.synchronize()
+        assert arena.check()
+        # the pooler is unused by the paired-attention head: no gradient, no update, no optimizer state
+        assert model.uniter.pooler.dense.weight.grad is None
+        assert torch.equal(model.uniter.pooler.dense.weight, pool0)
+        assert len(opt.state[model.uniter.pooler.dense.weight]) == 0
+        assert float(arena.grad.float().abs().max()) == 0.0            # zero_grad happened (fused or memset)
+        results.append({n: p.detach().clone() for n, p in model.named_parameters()})
+    for n in results[0]:
+        assert torch.equal(results[0][n], results[1][n]), n
+        assert torch.equal(results[0][n], results[2][n]), n
+
+
+def test_adamw_state_dict_roundtrip_keeps_fp32_state(golden):
+    """save -> load -> step for bf16 parameters: torch would cast the fp32 moments / master weights to bf16 on load."""
+    from uniter_amd.model.pretrain import UniterForPretraining
+    from uniter_amd.optim import build_optimizer, clip_grad_norm_
+    from uniter_amd.utils.arena import flatten_model
+    from uniter_amd.utils.misc import Struct
+    batch = _to_dev(golden.batch('itm'))
+    opts = Struct(dict(optim='adamw', learning_rate=1e-3, betas=(0.9, 0.98), weight_decay=0.01))
+
+    def fresh():
+        m = _prep(UniterForPretraining.from_pretrained(TINY_CONFIG, golden.pretrain_sd(), img_dim=IMG_DIM, img_label_dim=LABEL_DIM))
+        flatten_model(m)
+        return m, build_optimizer(m, opts)
+
+    def one_step(m, o):
+        m(batch, task='itm', compute_loss=True)[0].mean().backward()
+        clip_grad_norm_(o, 1.0)
+        o.step()
+        o.zero_grad()
+
+    m1, o1 = fresh()
+    one_step(m1, o1)
+    ckpt_model = {k: v.detach().clone() for k, v in m1.state_dict().items()}
+    import copy
+    ckpt_opt = copy.deepcopy(o1.state_dict())      # state_dict() returns the live tensors; a saver serialises them at once
+    one_step(m1, o1)
+    m2, o2 = fresh()
+    m2.load_state_dict(ckpt_model)
+    one_step(m2, o2)                                     # builds a plan that load_state_dict must invalidate
+    m2.load_state_dict(ckpt_model)
+    o2.load_state_dict(ckpt_opt)
+    for p in m2.parameters():
+        st = o2.state.get(p, {})
+        for k in ('exp_avg', 'exp_avg_sq', 'master'):
+            if k in st:
+                assert st[k].dtype == torch.float32 and st[k].is_contiguous()
+    one_step(m2, o2)
+    torch.cuda.synchronize()
+    for (n, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.equal(a, b), n
+
+
 # --------------------------------------------------------------------------------------------------------------
 # whole-step hipGraph capture
 # --------------------------------------------------------------------------------------------------------------

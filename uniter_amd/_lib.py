@@ -64,7 +64,6 @@ SIGNATURES = {
     "uniter_hip_timing_begin": (c_int, []),
     "uniter_hip_timing_end": (c_int, [POINTER(UniterTimingRecord), c_int32, POINTER(c_int32)]),
     "uniter_gemm_debug_force": (c_int, [c_int, c_int]),
-    "uniter_gemm_debug_group_persist": (c_int, [c_int]),
     "uniter_gemm_autotune": (c_int, [c_int, _I, _I, _I, _P]),
     "uniter_gemm_set_tuned": (c_int, [c_int, _I, _I, _I, c_int32, c_int32]),
     "uniter_gemm_tuned_choice": (c_int, [c_int, _I, _I, _I, POINTER(c_int32)]),
@@ -129,6 +128,10 @@ SIGNATURES = {
     "uniter_adamw_grad_norm": (c_int, [_P, c_float, c_float, _P, _P]),
     "uniter_adamw_step": (c_int, [_P, POINTER(UniterAdamGroup), c_int32, _P, _P]),
     "uniter_adamw_step_dev": (c_int, [_P, _P, c_int32, _P, _P]),
+    "uniter_adamw_step_zero": (c_int, [_P, POINTER(UniterAdamGroup), c_int32, _P, _P]),
+    "uniter_adamw_step_async": (c_int, [_P, POINTER(UniterAdamGroup), c_int32, _P, POINTER(c_void_p), c_int32, c_int32, _P]),
+    "uniter_params_wait": (c_int, [_P, _P]),
+    "uniter_params_wait_all": (c_int, [_P]),
     "uniter_attn_pool_workspace_bytes": (c_size_t, [_I, _I]),
     "uniter_attn_pool_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
     "uniter_attn_pool_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
@@ -201,6 +204,19 @@ def ptr(t):
     if t is None:
         return None
     return t.data_ptr()
+
+
+_async_pending = False
+
+
+def async_pending():
+    """True while an asynchronous optimizer step (AdamW.enable_overlap) may still be writing parameters."""
+    return _async_pending
+
+
+def set_async_pending(flag):
+    global _async_pending
+    _async_pending = bool(flag)
 
 
 def stream_ptr():

@@ -12,6 +12,8 @@
 #include "kernels.h"
 #include "../../include/uniter_hip.h"
 
+#include <algorithm>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -21,7 +23,7 @@ constexpr int MAX_GROUPS = 16;
 
 struct DevTensor {
     void* param;
-    const void* grad;
+    void* grad;
     float* master;
     float* m;
     float* v;
@@ -41,6 +43,7 @@ struct HyperTable {
 };
 
 struct Plan {
+    std::vector<uintptr_t> chunk_addr;   // host copy: parameter address of every chunk, ascending (chunks are sorted by it)
     DevTensor* d_tensors = nullptr;
     ChunkRef* d_chunks = nullptr;
     float* d_partial = nullptr;      // per-block partial sums for the norm
@@ -49,12 +52,14 @@ struct Plan {
     int norm_blocks = 0;
 };
 
+// `zero_grads`: the gradient element is overwritten with zero once it has been read — optimizer.zero_grad() folded into
+// the update (same bytes written as the separate memset, one pass and one launch fewer).
 __global__ __launch_bounds__(256) void adamw_kernel(const DevTensor* __restrict__ tensors,
-                                                    const ChunkRef* __restrict__ chunks, int64_t n_chunks,
+                                                    const ChunkRef* __restrict__ chunks, int64_t chunk_begin, int64_t n_chunks,
                                                     const HyperTable hyp, const GroupHyper* __restrict__ hyp_dev,
-                                                    const float* __restrict__ clip_coef) {
+                                                    const float* __restrict__ clip_coef, const int zero_grads) {
     const float coef = clip_coef ? *clip_coef : 1.0f;
-    for (int64_t ci = blockIdx.x; ci < n_chunks; ci += gridDim.x) {
+    for (int64_t ci = chunk_begin + blockIdx.x; ci < n_chunks; ci += gridDim.x) {
         const ChunkRef cr = chunks[ci];
         const DevTensor t = tensors[cr.tensor];
         const GroupHyper h = hyp_dev ? hyp_dev[t.group] : hyp.g[t.group];
@@ -98,10 +103,18 @@ __global__ __launch_bounds__(256) void adamw_kernel(const DevTensor* __restrict_
                 *reinterpret_cast<f32x4*>(t.m + idx) = f32x4{m[0], m[1], m[2], m[3]};
                 *reinterpret_cast<f32x4*>(t.v + idx) = f32x4{v[0], v[1], v[2], v[3]};
                 if (t.is_bf16) *reinterpret_cast<u32x2*>((bf16_t*)t.param + idx) = pack4(p);
+                if (zero_grads) {
+                    if (t.is_bf16) *reinterpret_cast<u32x2*>((bf16_t*)t.grad + idx) = u32x2{0u, 0u};
+                    else *reinterpret_cast<f32x4*>((float*)t.grad + idx) = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             } else {
                 for (int e = 0; e < n; ++e) {
                     pm[idx + e] = p[e]; t.m[idx + e] = m[e]; t.v[idx + e] = v[e];
                     if (t.is_bf16) ((bf16_t*)t.param)[idx + e] = f2bf(p[e]);
+                    if (zero_grads) {
+                        if (t.is_bf16) ((bf16_t*)t.grad)[idx + e] = f2bf(0.f);
+                        else ((float*)t.grad)[idx + e] = 0.f;
+                    }
                 }
             }
         }
@@ -206,11 +219,27 @@ int uniter_adamw_plan_create(const UniterAdamTensor* tensors, int64_t n_tensors,
         UH_CHECK_ARG(((uintptr_t)t.param % (t.param_is_bf16 ? 8 : 16) == 0) && ((uintptr_t)t.grad % (t.param_is_bf16 ? 8 : 16) == 0),
                      "param / grad pointers must be 8-byte (bf16) / 16-byte (fp32) aligned");
         UH_CHECK_ARG(!t.param_is_bf16 || ((uintptr_t)t.master % 16 == 0), "master copy must be 16-byte aligned");
-        dt[(size_t)i] = DevTensor{t.param, t.grad, t.master, t.exp_avg, t.exp_avg_sq, t.numel, t.group, t.param_is_bf16};
+        dt[(size_t)i] = DevTensor{t.param, (void*)t.grad, t.master, t.exp_avg, t.exp_avg_sq, t.numel, t.group, t.param_is_bf16};
+    }
+    // chunks in ascending parameter-address order: with the parameters in one arena laid out in module order
+    // (utils/arena.py) that is the order the next forward pass needs them in, which is what the segmented asynchronous
+    // step (uniter_adamw_step_async) relies on; for a single launch the order is irrelevant
+    std::vector<int64_t> order((size_t)n_tensors);
+    for (int64_t i = 0; i < n_tensors; ++i) order[(size_t)i] = i;
+    std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return (uintptr_t)tensors[a].param < (uintptr_t)tensors[b].param; });
+    std::vector<uintptr_t> chunk_addr;
+    for (int64_t oi = 0; oi < n_tensors; ++oi) {
+        const int64_t i = order[(size_t)oi];
+        const UniterAdamTensor& t = tensors[i];
         const int64_t nc = (t.numel + CHUNK - 1) / CHUNK;
-        for (int64_t c = 0; c < nc; ++c) ch.push_back(ChunkRef{(int32_t)i, (int32_t)c});
+        const size_t esz = t.param_is_bf16 ? 2 : 4;
+        for (int64_t c = 0; c < nc; ++c) {
+            ch.push_back(ChunkRef{(int32_t)i, (int32_t)c});
+            chunk_addr.push_back((uintptr_t)t.param + (size_t)c * CHUNK * esz);
+        }
     }
     Plan* p = new Plan();
+    p->chunk_addr = chunk_addr;
     p->n_tensors = n_tensors;
     p->n_chunks = (int64_t)ch.size();
     p->norm_blocks = (int)(p->n_chunks < 1024 ? p->n_chunks : 1024);
@@ -254,12 +283,7 @@ int uniter_adamw_grad_norm(void* plan, float grad_scale, float max_norm, float* 
     return 0;
 }
 
-int uniter_adamw_step(void* plan, const UniterAdamGroup* groups, int32_t n_groups,
-                      const float* clip_coef, void* stream) {
-    UH_CHECK_ARG(plan != nullptr && groups != nullptr, "null pointer");
-    UH_CHECK_ARG(n_groups > 0 && n_groups <= MAX_GROUPS, "1..16 parameter groups supported");
-    Plan* p = (Plan*)plan;
-    HyperTable ht{};
+static int fill_hyper(const UniterAdamGroup* groups, int32_t n_groups, HyperTable* ht) {
     for (int i = 0; i < n_groups; ++i) {
         const UniterAdamGroup& g = groups[i];
         UH_CHECK_ARG(g.step >= 1, "step must be >= 1");
@@ -269,14 +293,37 @@ int uniter_adamw_step(void* plan, const UniterAdamGroup* groups, int32_t n_group
             const double bc2 = 1.0 - pow((double)g.beta2, (double)g.step);
             step_size = step_size * sqrt(bc2) / bc1;
         }
-        ht.g[i] = GroupHyper{g.lr, g.beta1, g.beta2, g.eps, g.weight_decay, (float)step_size};
+        ht->g[i] = GroupHyper{g.lr, g.beta1, g.beta2, g.eps, g.weight_decay, (float)step_size};
     }
+    return 0;
+}
+
+static int adamw_step_impl(void* plan, const UniterAdamGroup* groups, int32_t n_groups, const float* clip_coef, int zero_grads,
+                           void* stream);
+
+int uniter_adamw_step(void* plan, const UniterAdamGroup* groups, int32_t n_groups,
+                      const float* clip_coef, void* stream) {
+    return adamw_step_impl(plan, groups, n_groups, clip_coef, 0, stream);
+}
+
+int uniter_adamw_step_zero(void* plan, const UniterAdamGroup* groups, int32_t n_groups,
+                           const float* clip_coef, void* stream) {
+    return adamw_step_impl(plan, groups, n_groups, clip_coef, 1, stream);
+}
+
+static int adamw_step_impl(void* plan, const UniterAdamGroup* groups, int32_t n_groups, const float* clip_coef, int zero_grads,
+                           void* stream) {
+    UH_CHECK_ARG(plan != nullptr && groups != nullptr, "null pointer");
+    UH_CHECK_ARG(n_groups > 0 && n_groups <= MAX_GROUPS, "1..16 parameter groups supported");
+    Plan* p = (Plan*)plan;
+    HyperTable ht{};
+    { int rc = fill_hyper(groups, n_groups, &ht); if (rc) return rc; }
     // enough blocks to fill the chip several times over; chunks are grid-strided
     int64_t blocks = p->n_chunks < 8192 ? p->n_chunks : 8192;
     uh::LaunchTimer lt(uh::TIME_ADAMW, p->n_chunks, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const DevTensor*)p->d_tensors, (const ChunkRef*)p->d_chunks, p->n_chunks, ht, (const GroupHyper*)nullptr,
-                       clip_coef);
+                       (const DevTensor*)p->d_tensors, (const ChunkRef*)p->d_chunks, (int64_t)0, p->n_chunks, ht, (const GroupHyper*)nullptr,
+                       clip_coef, zero_grads);
     UH_LAUNCH_CHECK();
     return 0;
 }
@@ -289,9 +336,112 @@ int uniter_adamw_step_dev(void* plan, const float* dev_hyper, int32_t n_groups, 
     int64_t blocks = p->n_chunks < 8192 ? p->n_chunks : 8192;
     uh::LaunchTimer lt(uh::TIME_ADAMW, p->n_chunks, 0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const DevTensor*)p->d_tensors, (const ChunkRef*)p->d_chunks, p->n_chunks, ht,
-                       (const GroupHyper*)dev_hyper, clip_coef);
+                       (const DevTensor*)p->d_tensors, (const ChunkRef*)p->d_chunks, (int64_t)0, p->n_chunks, ht,
+                       (const GroupHyper*)dev_hyper, clip_coef, 0);
     UH_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- asynchronous, segmented step -------------------------------------------------------------------------------------
+// The update is HBM-bound (28 B per parameter) while the forward pass that follows it is MFMA / LDS bound, so the two
+// overlap almost for free — but only if the forward pass can start before the last parameter is written.  The step is
+// therefore cut at caller-given parameter addresses (ascending; typically the first parameter of every BertLayer) into
+// segments that run back to back on an internal stream, each followed by an event; consumers call
+// uniter_params_wait(address, stream) before they read a parameter (the encoder does it per layer) and
+// uniter_params_wait_all(stream) before they write gradients again (the fused zero_grad also runs on that stream).
+namespace {
+struct ParamSegment { uintptr_t lo, hi; hipEvent_t ev; };
+struct ParamTracker {
+    hipStream_t stream = nullptr;
+    hipEvent_t start = nullptr;
+    std::vector<hipEvent_t> pool;
+    std::vector<ParamSegment> pending;   // in issue order
+    int device = -1;
+};
+ParamTracker g_pt;                  // process-wide: the step is issued by the training thread, waits may come from
+std::mutex g_pt_mu;                 // autograd worker threads
+
+int tracker_init() {
+    int dev = 0;
+    UH_CHECK_HIP(hipGetDevice(&dev));
+    if (g_pt.stream != nullptr && g_pt.device == dev) return 0;
+    UH_CHECK_HIP(hipStreamCreateWithFlags(&g_pt.stream, hipStreamNonBlocking));
+    UH_CHECK_HIP(hipEventCreateWithFlags(&g_pt.start, hipEventDisableTiming));
+    g_pt.device = dev;
+    return 0;
+}
+}  // namespace
+
+int uniter_adamw_step_async(void* plan, const UniterAdamGroup* groups, int32_t n_groups, const float* clip_coef,
+                            const void* const* bounds, int32_t n_bounds, int32_t zero_grads, void* stream) {
+    UH_CHECK_ARG(plan != nullptr && groups != nullptr, "null pointer");
+    UH_CHECK_ARG(n_groups > 0 && n_groups <= MAX_GROUPS, "1..16 parameter groups supported");
+    UH_CHECK_ARG(n_bounds >= 0 && n_bounds <= 255 && (n_bounds == 0 || bounds != nullptr), "0..255 segment boundaries");
+    Plan* p = (Plan*)plan;
+    HyperTable ht{};
+    { int rc = fill_hyper(groups, n_groups, &ht); if (rc) return rc; }
+    std::lock_guard<std::mutex> lk(g_pt_mu);
+    { int rc = tracker_init(); if (rc) return rc; }
+    hipStream_t main = (hipStream_t)stream, side = g_pt.stream;
+    // an earlier asynchronous step may still be pending on the side stream: it is ordered before this one there
+    UH_CHECK_HIP(hipEventRecord(g_pt.start, main));              // gradients + clip coefficient are final here
+    UH_CHECK_HIP(hipStreamWaitEvent(side, g_pt.start, 0));
+    g_pt.pending.clear();
+    int64_t begin = 0;
+    for (int sgm = 0; sgm <= n_bounds; ++sgm) {
+        int64_t end = p->n_chunks;
+        if (sgm < n_bounds) {
+            const uintptr_t b = (uintptr_t)bounds[sgm];
+            end = (int64_t)(std::lower_bound(p->chunk_addr.begin(), p->chunk_addr.end(), b) - p->chunk_addr.begin());
+            if (end < begin) { uh_set_error("uniter_adamw_step_async: boundaries must ascend"); return -1; }
+        }
+        if (end == begin) continue;
+        const int64_t n = end - begin;
+        // the first segments gate the start of the forward pass and run flat out; later ones only have to stay ahead of
+        // a forward pass that takes ~100 us per layer, and a throttled grid leaves the memory system to that pass
+        static const int throttle = [] { const char* e = getenv("UNITER_AMD_ADAMW_BLOCKS"); return e ? atoi(e) : 0; }();
+        static const int full_segs = [] { const char* e = getenv("UNITER_AMD_ADAMW_FULL_SEGS"); return e ? atoi(e) : 2; }();
+        int64_t blocks = n < 8192 ? n : 8192;
+        if (throttle > 0 && sgm >= full_segs && blocks > throttle) blocks = throttle;
+        {
+            uh::LaunchTimer lt(uh::TIME_ADAMW, n, 0, 0, side);
+            hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, side, (const DevTensor*)p->d_tensors,
+                               (const ChunkRef*)p->d_chunks, begin, end, ht, (const GroupHyper*)nullptr, clip_coef, (int)zero_grads);
+            UH_LAUNCH_CHECK();
+        }
+        if ((size_t)g_pt.pending.size() >= g_pt.pool.size()) {
+            hipEvent_t e;
+            UH_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            g_pt.pool.push_back(e);
+        }
+        hipEvent_t ev = g_pt.pool[g_pt.pending.size()];
+        UH_CHECK_HIP(hipEventRecord(ev, side));
+        const uintptr_t lo = p->chunk_addr[(size_t)begin];
+        const uintptr_t hi = end < p->n_chunks ? p->chunk_addr[(size_t)end] : ~(uintptr_t)0;
+        g_pt.pending.push_back(ParamSegment{lo, hi, ev});
+        begin = end;
+    }
+    return 0;
+}
+
+int uniter_params_wait(const void* addr, void* stream) {
+    std::lock_guard<std::mutex> lk(g_pt_mu);
+    if (g_pt.pending.empty()) return 0;
+    const uintptr_t a = (uintptr_t)addr;
+    for (const ParamSegment& sgm : g_pt.pending) {
+        if (a >= sgm.lo && a < sgm.hi) {
+            UH_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, sgm.ev, 0));   // segments complete in order
+            return 0;
+        }
+    }
+    return 0;          // not a parameter of the pending step
+}
+
+int uniter_params_wait_all(void* stream) {
+    std::lock_guard<std::mutex> lk(g_pt_mu);
+    if (g_pt.pending.empty()) return 0;
+    UH_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, g_pt.pending.back().ev, 0));
+    g_pt.pending.clear();
     return 0;
 }
 

@@ -146,11 +146,6 @@ int uniter_gemm_debug_force(int cfg, int splits) {
     return 0;
 }
 
-int uniter_gemm_debug_group_persist(int workgroups) {
-    uh::gemm_debug_group_persist(workgroups);
-    return 0;
-}
-
 int uniter_gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, void* stream) {
     return uh::gemm_autotune(kind, M, N, K, (hipStream_t)stream);
 }

@@ -167,6 +167,7 @@ int uniter_encoder_forward(const UniterEncoderShape* s, const UniterLayerParams*
         const DropoutCfg d_attn = tr ? make_dropout(s->p_attn, seed, off + 0) : nodrop;
         const DropoutCfg d_h1 = tr ? make_dropout(s->p_hidden, seed, off + 1) : nodrop;
         const DropoutCfg d_h2 = tr ? make_dropout(s->p_hidden, seed, off + 2) : nodrop;
+        RC(uniter_params_wait(P.wqkv, stream));        // an asynchronous optimizer step may still be writing this layer
         // model/layer.py:76-78  (three Linear(H,H) fused into one [3H,H] GEMM)
         RC(uh::gemm_fwd(uh::GEMM_EPI_BIAS, x, P.wqkv, P.bqkv, nullptr, A + al.qkv, nullptr, T, 3 * H, H, nodrop, st));
         // model/layer.py:80-100
@@ -184,6 +185,8 @@ int uniter_encoder_forward(const UniterEncoderShape* s, const UniterLayerParams*
                              T, H, s->ln_eps, nodrop, st));
         x = A + al.y;
     }
+    // everything after the stack (task heads, the backward pass that accumulates into .grad) sees a finished update
+    RC(uniter_params_wait_all(stream));
     return 0;
 }
 

@@ -45,8 +45,6 @@ struct GemmArgs {
     int k_per_split;      // multiple of 64
     int accumulate;       // EPI_WGRAD, splits == 1: C += result
     int xr;               // 2-D XCD blocking: rows of the XCD grid (0 = 1-D contiguous ranges)
-    int dbg;              // experiment switches (UNITER_AMD_GEMM_DBG): 1 = compute waves skip LDS reads + MFMAs, 2 = loaders skip the DMA
-    int pf;               // L2 prefetch distance in K tiles ahead of the tile being multiplied (0 = off), see l2_touch
 #ifdef UNITER_GEMM_PROBE
     unsigned long long* probe;   // cycle stamps of wave 0 of every workgroup: [block][kt][5] (profiling builds only)
 #endif
@@ -171,91 +169,39 @@ __device__ __forceinline__ void glds16(const bf16_t* src, bf16_t* lds_wave_base)
     __builtin_amdgcn_global_load_lds((global_void_t*)src, (lds_void_t*)lds_wave_base, 16, 0, 0);
 }
 
-// The per-lane part of every source address (row, swizzled chunk) does not depend on the K tile, so it is computed ONCE
-// per output tile as a 32-bit byte offset from the tile's origin; per K tile an instruction then is
-// "global_load_lds_dwordx4 v_off, s[base:base+1]" with a uniform base the scalar unit advances — one VMEM issue slot
-// instead of ~20 VALU instructions (two 64-bit multiplies) per piece, which made the loader waves issue-bound
-// (cycle stamps: 506 cycles to issue the six pieces of a 96x96 K tile, i.e. the whole K step).
 // K-contiguous tile [ROWS][64]: instruction j covers rows 8j..8j+7.
 template <int ROWS>
-struct GldsKC {
-    static constexpr int NP = ROWS / 32;         // pieces per loader wave and K tile
-    uint32_t off[NP];
-    __device__ __forceinline__ void init(int64_t ld, int row0, int rows_total, int wid, int lane) {
+__device__ __forceinline__ void glds_kc(bf16_t* tile, const bf16_t* base, int64_t ld, int row0, int rows_total,
+                                        int k0, int wid, int lane) {
 #pragma unroll
-        for (int it = 0; it < NP; ++it) {
-            const int j = it * 4 + wid;
-            const int r = 8 * j + (lane >> 3);
-            const int c = (lane & 7) ^ ((r >> 1) & 7);
-            int gr = row0 + r;
-            gr = gr < rows_total ? gr : rows_total - 1;
-            off[it] = (uint32_t)(((int64_t)(gr - row0) * ld + c * 8) * 2);
-        }
+    for (int it = 0; it < ROWS / 32; ++it) {
+        const int j = it * 4 + wid;
+        const int r = 8 * j + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int gr = row0 + r;
+        gr = gr < rows_total ? gr : rows_total - 1;
+        glds16(base + (int64_t)gr * ld + k0 + c * 8, tile + j * 512);
     }
-    // origin = &base[row0 * ld + k0]  (uniform)
-    __device__ __forceinline__ void issue(bf16_t* tile, const bf16_t* origin, int wid) const {
-#pragma unroll
-        for (int it = 0; it < NP; ++it)
-            glds16(reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(origin) + off[it]), tile + (it * 4 + wid) * 512);
-    }
-};
-// K-strided tile [64][W]: W = 128 -> 4 rows per instruction, W = 64 -> 8 rows per instruction; W = 192 = [64][128] + [64][64].
+}
+// K-strided tile [64][W]: W = 128 -> 4 rows per instruction, W = 64 -> 8 rows per instruction.
 template <int W>
-struct GldsKS {
-    static constexpr int RPI = 1024 / (2 * W);   // rows per instruction
-    static constexpr int NI = 64 / RPI;          // instructions per tile
-    static constexpr int CPR = W / 8;            // 16-byte chunks per row
-    static constexpr int NP = NI / 4;
-    uint32_t off[NP];
-    __device__ __forceinline__ void init(int64_t ld, int wid, int lane) {
+__device__ __forceinline__ void glds_ks(bf16_t* tile, const bf16_t* base, int64_t ld, int col0, int k0, int wid, int lane) {
+    if constexpr (W == 192) {
+        glds_ks<128>(tile, base, ld, col0, k0, wid, lane);
+        glds_ks<64>(tile + 64 * 128, base, ld, col0 + 128, k0, wid, lane);
+        return;
+    }
+    constexpr int RPI = 1024 / (2 * W);          // rows per instruction
+    constexpr int NI = 64 / RPI;                 // instructions per tile
+    constexpr int CPR = W / 8;                   // 16-byte chunks per row
 #pragma unroll
-        for (int it = 0; it < NP; ++it) {
-            const int j = it * 4 + wid;
-            const int r = RPI * j + lane / CPR;
-            const int c = (lane % CPR) ^ (ks_swz<W>(r) << 1);
-            off[it] = (uint32_t)(((int64_t)r * ld + c * 8) * 2);
-        }
+    for (int it = 0; it < NI / 4; ++it) {
+        const int j = it * 4 + wid;
+        const int r = RPI * j + lane / CPR;
+        const int c = (lane % CPR) ^ (ks_swz<W>(r) << 1);
+        glds16(base + (int64_t)(k0 + r) * ld + col0 + c * 8, tile + j * 512);
     }
-    // origin = &base[k0 * ld + col0]  (uniform)
-    __device__ __forceinline__ void issue(bf16_t* tile, const bf16_t* origin, int wid) const {
-#pragma unroll
-        for (int it = 0; it < NP; ++it)
-            glds16(reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(origin) + off[it]), tile + (it * 4 + wid) * 512);
-    }
-};
-template <>
-struct GldsKS<192> {
-    GldsKS<128> a;
-    GldsKS<64> b;
-    __device__ __forceinline__ void init(int64_t ld, int wid, int lane) { a.init(ld, wid, lane); b.init(ld, wid, lane); }
-    __device__ __forceinline__ void issue(bf16_t* tile, const bf16_t* origin, int wid) const {
-        a.issue(tile, origin, wid);
-        b.issue(tile + 64 * 128, origin + 128, wid);
-    }
-};
-// one operand's loader state, K-contiguous or K-strided
-template <int ROWS, bool TR>
-struct Glds;
-template <int ROWS>
-struct Glds<ROWS, false> {
-    GldsKC<ROWS> g;
-    const bf16_t* origin;                        // &base[row0 * ld]
-    __device__ __forceinline__ void init(const bf16_t* base, int64_t ld, int row0, int rows_total, int wid, int lane) {
-        g.init(ld, row0, rows_total, wid, lane);
-        origin = base + (int64_t)row0 * ld;
-    }
-    __device__ __forceinline__ void issue(bf16_t* tile, int64_t ld, int k0, int wid) const { (void)ld; g.issue(tile, origin + k0, wid); }
-};
-template <int ROWS>
-struct Glds<ROWS, true> {
-    GldsKS<ROWS> g;
-    const bf16_t* origin;                        // &base[col0]
-    __device__ __forceinline__ void init(const bf16_t* base, int64_t ld, int col0, int, int wid, int lane) {
-        g.init(ld, wid, lane);
-        origin = base + col0;
-    }
-    __device__ __forceinline__ void issue(bf16_t* tile, int64_t ld, int k0, int wid) const { g.issue(tile, origin + (int64_t)k0 * ld, wid); }
-};
+}
 
 template <int ROWS, bool TR>
 struct Stage;
@@ -276,47 +222,6 @@ struct Stage<192, true> {                       // [64][128] + [64][64] sub-tile
         b.store(tile + 64 * 128, t);
     }
 };
-
-// ---- L2 prefetch ------------------------------------------------------------------------------------------------------
-// In a training step every GEMM meets operands no L2 has seen (activations written by the previous kernel, weights last
-// touched an optimizer step ago): a quarter of the ring's DMA requests miss to the fabric, ~2000 cycles under load, and
-// the two or three tiles an LDS ring can keep in flight do not cover that — the main loop runs at the fabric's latency,
-// not at the MFMA or LDS rate (the same kernel on L2-resident operands is 1.3-1.9x faster).  The compute waves never
-// wait on vmcnt inside the main loop, so they can carry fire-and-forget loads: each K step they touch the 64-byte
-// granules of the tile `pf` steps ahead, which is then L2-resident when the loader waves' DMA asks for it.  The loaded
-// dword is discarded (inline asm: the compiler's wait-count pass never sees the load, nothing ever waits for it).
-// `sink` is the one VGPR every such load returns into: it is threaded through all touches as a read-write operand and
-// consumed by l2_touch_drain (behind a vmcnt(0)) after the main loop, so the register stays reserved for as long as a
-// load can still land in it — a plain output operand would be reused by the compiler while loads are in flight.
-__device__ __forceinline__ void l2_touch(const void* addr, uint32_t& sink) {
-    asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(addr) : "memory");
-}
-__device__ __forceinline__ void l2_touch_drain(uint32_t& sink) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
-}
-// K-contiguous operand: rows [row0, row0+ROWS) x 128 bytes at element column k0; `slot` indexes 64-byte granules.
-template <int ROWS, int NLANES>
-__device__ __forceinline__ void l2_touch_kc(const bf16_t* base, int64_t ld, int row0, int rows_total, int k0, int slot, uint32_t& sink) {
-#pragma unroll
-    for (int j = 0; j < (2 * ROWS + NLANES - 1) / NLANES; ++j) {
-        int idx = j * NLANES + slot;
-        idx = idx < 2 * ROWS ? idx : 2 * ROWS - 1;
-        int gr = row0 + (idx >> 1);
-        gr = gr < rows_total ? gr : rows_total - 1;
-        l2_touch(base + (int64_t)gr * ld + k0 + (idx & 1) * 32, sink);
-    }
-}
-// K-strided operand: 64 rows (k0 ..) x W columns starting at col0.
-template <int W, int NLANES>
-__device__ __forceinline__ void l2_touch_ks(const bf16_t* base, int64_t ld, int col0, int k0, int slot, uint32_t& sink) {
-    constexpr int GPR = W / 32;                  // 64-byte granules per row
-#pragma unroll
-    for (int j = 0; j < (64 * GPR + NLANES - 1) / NLANES; ++j) {
-        int idx = j * NLANES + slot;
-        idx = idx < 64 * GPR ? idx : 64 * GPR - 1;
-        l2_touch(base + (int64_t)(k0 + idx / GPR) * ld + col0 + (idx % GPR) * 32, sink);
-    }
-}
 
 // bijective XCD-aware block remap (cdna_hip_programming.md T1): consecutive hardware block ids go to
 // different XCDs; give each XCD a contiguous range of logical tiles so neighbours share an L2.
@@ -353,10 +258,7 @@ struct WaveGrid {
 
 // One output tile (bx = tile slot of the launch, by = split-K slice).  Shared by the plain kernel (one problem per
 // launch) and the grouped kernel (several problems of one layout in one launch).
-// LOOP: the caller runs several tiles per workgroup (persistent grouped launch).  The loader waves then stay alive after
-// their last DMA and take part in the epilogue's barriers (a raw s_barrier counts every live wave), and one more barrier
-// closes the tile so that the next tile's DMA cannot overwrite the LDS block the epilogue is still reading.
-template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, int WS, bool LOOP = false>
+template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, int WS>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const int by, char* smem_raw) {
     using WG = WaveGrid<BM, BN, WS>;
     constexpr int WM = BM / WG::GM, WN = BN / WG::GN, MI = WM / 16, NI = WN / 16;
@@ -413,20 +315,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         sr.store(smem + buf * STAGE, t);
         sc.store(smem + buf * STAGE + TILE_R, t);
     };
-    // direct-to-LDS path (full K tiles): per-lane offsets once, then one instruction per piece.  The waves that issue DMA
-    // are waves 0-3 of a plain workgroup and the four loader waves (wid - NCW) of a wave-specialised one.
-    const int dw = __builtin_amdgcn_readfirstlane((WS != 0) ? (wid - WG::NCW) & 3 : wid);   // wave-uniform: LDS destinations stay scalar
-    Glds<BM, TRA> gl_r;
-    Glds<BN, TRB> gl_c;
-    if (WS == 0 || wid >= WG::NCW) {
-        gl_r.init(p.R, p.ldr, m0, p.M, dw, lane);
-        gl_c.init(p.Cc, p.ldcc, n0, p.N, dw, lane);
-    }
-    auto do_glds = [&](int kt, int buf) {
+    auto do_glds = [&](int kt, int buf) {       // direct-to-LDS path (full K tiles)
         const int k0 = k_begin + kt * 64;
         bf16_t* tr_ = smem + buf * STAGE;
-        gl_r.issue(tr_, p.ldr, k0, dw);
-        gl_c.issue(tr_ + TILE_R, p.ldcc, k0, dw);
+        bf16_t* tc_ = tr_ + TILE_R;
+        if constexpr (TRA) glds_ks<BM>(tr_, p.R, p.ldr, m0, k0, wid, lane);
+        else               glds_kc<BM>(tr_, p.R, p.ldr, m0, p.M, k0, wid, lane);
+        if constexpr (TRB) glds_ks<BN>(tc_, p.Cc, p.ldcc, n0, k0, wid, lane);
+        else               glds_kc<BN>(tc_, p.Cc, p.ldcc, n0, p.N, k0, wid, lane);
     };
 
     f32x4 acc[NI][MI];
@@ -446,53 +342,34 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 #pragma unroll
     for (int b = 0; b < MI; ++b) bacc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // One K tile = two 32-deep MFMA steps.  The fragments of a step live in registers (fr / fc); load_frags issues the
-    // LDS reads of one step, mma consumes one step.  A compute wave is alone on its SIMD (or shares it with one partner),
-    // so nothing but its own instruction stream hides LDS latency: the main loops below keep the reads of the NEXT step
-    // in flight under the MFMAs of the current one (two register sets, software-pipelined across the tile barrier).
-    auto load_frags = [&](int buf, int ks, bf16x8 (&fr)[MI], bf16x8 (&fc)[NI]) {
+    auto compute = [&](int buf) {
         const bf16_t* tr = smem + buf * STAGE;
         const bf16_t* tc = tr + TILE_R;
 #pragma unroll
-        for (int b = 0; b < MI; ++b) {
-            if constexpr (TRA) fr[b] = frag_ks<BM>(tr, wm * WM + b * 16, ks, g, i);
-            else               fr[b] = frag_kc(tr, wm * WM + b * 16 + i, ks, g);
-        }
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fr[MI], fc[NI];
 #pragma unroll
-        for (int a = 0; a < NI; ++a) {
-            if constexpr (TRB) fc[a] = frag_ks<BN>(tc, wn * WN + a * 16, ks, g, i);
-            else               fc[a] = frag_kc(tc, wn * WN + a * 16 + i, ks, g);
-        }
-    };
-    // One step's MFMAs.  `after_first` runs behind the first MFMA and issues the LDS reads of a LATER step: at the first
-    // MFMA the only reads outstanding are this step's own (issued a whole step earlier), so the wait the compiler puts in
-    // front of it is exact, and the new reads then have the remaining MFMAs to land under.
-    auto mma = [&](const bf16x8 (&fr)[MI], const bf16x8 (&fc)[NI], auto&& after_first) {
-        __builtin_amdgcn_sched_barrier(0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[0], fr[0], acc[0][0], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        after_first();
-        __builtin_amdgcn_sched_barrier(0);
+            for (int b = 0; b < MI; ++b) {
+                if constexpr (TRA) fr[b] = frag_ks<BM>(tr, wm * WM + b * 16, ks, g, i);
+                else               fr[b] = frag_kc(tr, wm * WM + b * 16 + i, ks, g);
+            }
+            if constexpr (EPI == EPI_WGRAD) {
+                if (rowsum) {
 #pragma unroll
-        for (int a = 0; a < NI; ++a)
+                    for (int b = 0; b < MI; ++b)
+                        bacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fr[b], bacc[b], 0, 0, 0);
+                }
+            }
 #pragma unroll
-            for (int b = 0; b < MI; ++b)
-                if (a != 0 || b != 0) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[a], fr[b], acc[a][b], 0, 0, 0);
-        if constexpr (EPI == EPI_WGRAD) {
-            if (rowsum) {
+            for (int a = 0; a < NI; ++a) {
+                if constexpr (TRB) fc[a] = frag_ks<BN>(tc, wn * WN + a * 16, ks, g, i);
+                else               fc[a] = frag_kc(tc, wn * WN + a * 16 + i, ks, g);
+            }
+#pragma unroll
+            for (int a = 0; a < NI; ++a)
 #pragma unroll
                 for (int b = 0; b < MI; ++b)
-                    bacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fr[b], bacc[b], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    bf16x8 fr0[MI], fc0[NI], fr1[MI], fc1[NI];
-    auto compute = [&](int buf) {               // un-pipelined form (the zero-filled partial K tile)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            load_frags(buf, ks, fr0, fc0);
-            mma(fr0, fc0, [] {});
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[a], fr[b], acc[a][b], 0, 0, 0);
         }
     };
 
@@ -506,126 +383,74 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         if (wid >= WG::NCW) {
             // ---- loader waves: one barrier per tile, shared with the compute waves ----
             const int lw = wid - WG::NCW;
-            auto ws_glds = [&](int kt, int b) { do_glds(kt, b); };
+            auto ws_glds = [&](int kt, int b) {
+                const int k0 = k_begin + kt * 64;
+                bf16_t* tr_ = smem + b * STAGE;
+                bf16_t* tc_ = tr_ + TILE_R;
+                if constexpr (TRA) glds_ks<BM>(tr_, p.R, p.ldr, m0, k0, lw, lane);
+                else               glds_kc<BM>(tr_, p.R, p.ldr, m0, p.M, k0, lw, lane);
+                if constexpr (TRB) glds_ks<BN>(tc_, p.Cc, p.ldcc, n0, k0, lw, lane);
+                else               glds_kc<BN>(tc_, p.Cc, p.ldcc, n0, p.N, k0, lw, lane);
+            };
 #pragma unroll
             for (int d = 0; d < NSTAGE - 1; ++d)
                 if (d < nfull) ws_glds(d, d);
             int pre = NSTAGE - 1;
             for (int kt = 0; kt < nfull; ++kt) {
-#ifdef UNITER_GEMM_PROBE
-                // loader wave 0: [wait for its DMA share | wait at the barrier | issue the next tile's DMA]
-                unsigned long long* lp = (p.probe && lw == 0 && lane == 0 && bx < 4096)
-                    ? p.probe + (size_t)4096 * 64 * 5 + (size_t)4096 * 2 + ((size_t)bx * 64 + (kt < 63 ? kt : 63)) * 4 : nullptr;
-                if (lp) lp[0] = __builtin_readcyclecounter();
-#endif
                 wait_tile<NSTAGE, G>(nfull - 1 - kt);
-#ifdef UNITER_GEMM_PROBE
-                if (lp) lp[1] = __builtin_readcyclecounter();
-#endif
                 __builtin_amdgcn_s_barrier();
-#ifdef UNITER_GEMM_PROBE
-                if (lp) lp[2] = __builtin_readcyclecounter();
-#endif
-                if (kt + NSTAGE - 1 < nfull && !(p.dbg & 2)) ws_glds(kt + NSTAGE - 1, pre);
-#ifdef UNITER_GEMM_PROBE
-                if (lp) lp[3] = __builtin_readcyclecounter();
-#endif
+                if (kt + NSTAGE - 1 < nfull) ws_glds(kt + NSTAGE - 1, pre);
                 pre = (pre + 1 == NSTAGE) ? 0 : pre + 1;
             }
-            if constexpr (!LOOP) return;
+            return;
         }
-        // ---- compute waves ----
-        // barrier kt = "tile kt has landed AND every wave has finished reading tile kt-1" (the loaders refill that buffer
-        // right after it).  The reads of tile kt are issued right behind barrier kt and are complete (lgkmcnt(0)) before
-        // this wave arrives at barrier kt+1, which it does half-way through the MFMAs of tile kt: the second half then
-        // runs over the first reads of tile kt+1.
-        if (wid < WG::NCW && nfull > 0) {
-            constexpr int NL = WG::NCW * 64;
-            uint32_t sink = 0;
-            auto touch = [&](int kt) {            // L2 prefetch of K tile kt (see l2_touch)
-                const int k0 = k_begin + kt * 64;
-                if constexpr (TRA) l2_touch_ks<BM, NL>(p.R, p.ldr, m0, k0, t, sink);
-                else               l2_touch_kc<BM, NL>(p.R, p.ldr, m0, p.M, k0, t, sink);
-                if constexpr (TRB) l2_touch_ks<BN, NL>(p.Cc, p.ldcc, n0, k0, t, sink);
-                else               l2_touch_kc<BN, NL>(p.Cc, p.ldcc, n0, p.N, k0, t, sink);
-            };
-            const int pf = p.pf;
-            if (pf > 0)
-                for (int d = NSTAGE - 1; d < pf && d < nfull; ++d) touch(d);
+        int buf = 0;
+        for (int kt = 0; kt < nfull; ++kt) {
+#ifdef UNITER_GEMM_PROBE
+            unsigned long long* pr = p.probe ? p.probe + ((size_t)bx * 64 + (kt < 63 ? kt : 63)) * 5 : nullptr;
+            const bool rec = pr != nullptr && t == 0;
+            if (rec) pr[0] = __builtin_readcyclecounter();
+#endif
             __builtin_amdgcn_s_barrier();
-            if (p.dbg & 1) {
-                for (int kt = 1; kt < nfull; ++kt) __builtin_amdgcn_s_barrier();
-            } else if constexpr (WS == 2) {
-                // eight compute waves = two per SIMD: the partner wave's MFMAs cover this wave's LDS latency, and two
-                // fragment sets on top of a 96x48 accumulator would not fit three waves per SIMD — plain loop
-                int buf = 0;
-                for (int kt = 0; kt < nfull; ++kt) {
-                    if (kt > 0) __builtin_amdgcn_s_barrier();
-                    if (pf > 0 && kt + pf < nfull) touch(kt + pf);
-                    compute(buf);
-                    buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
-                }
-            } else {
-            load_frags(0, 0, fr0, fc0);
-            int buf = 0;
-            for (int kt = 0; kt < nfull; ++kt) {
-                const int nb = (buf + 1 == NSTAGE) ? 0 : buf + 1;
-                const bool more = kt + 1 < nfull;
 #ifdef UNITER_GEMM_PROBE
-                unsigned long long* pr = (p.probe && t == 0 && bx < 4096) ? p.probe + ((size_t)bx * 64 + (kt < 63 ? kt : 63)) * 5 : nullptr;
-                if (pr) pr[0] = __builtin_readcyclecounter();
+            if (rec) pr[1] = pr[2] = pr[3] = __builtin_readcyclecounter();   // phases: [0,1] wait for the loaders' barrier
 #endif
-                mma(fr0, fc0, [&] {                                             // second step of this tile
-                    load_frags(buf, 1, fr1, fc1);
-                    if (pf > 0 && kt + pf < nfull) touch(kt + pf);
-                });
+            compute(buf);
 #ifdef UNITER_GEMM_PROBE
-                if (pr) pr[1] = __builtin_readcyclecounter();
+            if (rec) { asm volatile("s_nop 0" ::: "memory"); pr[4] = __builtin_readcyclecounter(); }   // [3,4] lds + mfma
 #endif
-                if (more) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // every read of tile kt is complete
-                    __builtin_amdgcn_s_barrier();
-                }
-#ifdef UNITER_GEMM_PROBE
-                if (pr) pr[2] = __builtin_readcyclecounter();
-#endif
-                mma(fr1, fc1, [&] { load_frags(nb, 0, fr0, fc0); });   // first step of the next tile (unconditional: after the
-                                                                         // last tile it reads a stale buffer and is never used;
-                                                                         // a branch here would merge wait states conservatively)
-#ifdef UNITER_GEMM_PROBE
-                if (pr) { pr[3] = __builtin_readcyclecounter(); pr[4] = pr[3]; }
-#endif
-                buf = nb;
-            }
-            }
-            if (pf > 0) l2_touch_drain(sink);
+            buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
         }
     } else {
-        // every wave loads and computes.  Same pipelining: tile kt's fragments are in registers by the time the wave
-        // reaches barrier kt+1, so that barrier also frees tile kt's buffer and the ring holds NSTAGE tiles beyond the
-        // one in registers.
-        if (nfull > 0) {
 #pragma unroll
-            for (int d = 0; d < NSTAGE - 1; ++d)
-                if (d < nfull) do_glds(d, d);
-            wait_tile<NSTAGE, G>(nfull - 1);
+        for (int d = 0; d < NSTAGE - 1; ++d)
+            if (d < nfull) do_glds(d, d);
+        int buf = 0;                  // kt % NSTAGE
+        int pre = NSTAGE - 1;         // (kt + NSTAGE - 1) % NSTAGE
+        for (int kt = 0; kt < nfull; ++kt) {
+#ifdef UNITER_GEMM_PROBE
+            unsigned long long* pr = p.probe ? p.probe + ((size_t)bx * 64 + (kt < 63 ? kt : 63)) * 5 : nullptr;
+            const bool rec = pr != nullptr && t == 0;
+            if (rec) pr[0] = __builtin_readcyclecounter();
+#endif
+            wait_tile<NSTAGE, G>(nfull - 1 - kt);
+#ifdef UNITER_GEMM_PROBE
+            if (rec) pr[1] = __builtin_readcyclecounter();
+#endif
             __builtin_amdgcn_s_barrier();
-            if (NSTAGE - 1 < nfull) do_glds(NSTAGE - 1, NSTAGE - 1);
-            load_frags(0, 0, fr0, fc0);
-            int buf = 0;                  // kt % NSTAGE
-            for (int kt = 0; kt < nfull; ++kt) {
-                const int nb = (buf + 1 == NSTAGE) ? 0 : buf + 1;
-                const bool more = kt + 1 < nfull;
-                mma(fr0, fc0, [&] { load_frags(buf, 1, fr1, fc1); });
-                if (more) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of tile kt are complete
-                    wait_tile<NSTAGE, G>(nfull - 2 - kt);                // tile kt+1 landed; tiles kt+2.. stay in flight
-                    __builtin_amdgcn_s_barrier();
-                    if (kt + NSTAGE < nfull) do_glds(kt + NSTAGE, buf);  // tile kt's buffer is free now
-                }
-                mma(fr1, fc1, [&] { load_frags(nb, 0, fr0, fc0); });
-                buf = nb;
-            }
+#ifdef UNITER_GEMM_PROBE
+            if (rec) pr[2] = __builtin_readcyclecounter();
+#endif
+            if (kt + NSTAGE - 1 < nfull) do_glds(kt + NSTAGE - 1, pre);
+#ifdef UNITER_GEMM_PROBE
+            if (rec) pr[3] = __builtin_readcyclecounter();
+#endif
+            compute(buf);
+#ifdef UNITER_GEMM_PROBE
+            if (rec) { asm volatile("s_nop 0" ::: "memory"); pr[4] = __builtin_readcyclecounter(); }
+#endif
+            buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+            pre = (pre + 1 == NSTAGE) ? 0 : pre + 1;
         }
     }
     // ---- partial K tile (contraction length not a multiple of 64): zero-filled register staging --------------------
@@ -643,9 +468,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     // a 9-25 us kernel).  Instead every 16-row MFMA block is staged through the (now idle) LDS ring as fp32 and read
     // back row-contiguously, so all global traffic of the epilogue — output, residual / pre-activation reads, the
     // accumulate read of wgrad — is 16 bytes per lane over full tile rows.  The arithmetic per element is unchanged.
-    const bool cw = !(WS != 0 && LOOP) || wid < WG::NCW;     // this wave holds accumulators (always true unless LOOP keeps the loaders)
     if constexpr (EPI == EPI_WGRAD) {
-        if (cw && rowsum && g == 0) {                       // lane i of the first lane group holds the sum of row m
+        if (rowsum && g == 0) {                             // lane i of the first lane group holds the sum of row m
 #pragma unroll
             for (int b = 0; b < MI; ++b) {
                 const int m = m0 + wm * WM + b * 16 + i;
@@ -661,7 +485,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 #pragma unroll
         for (int b = 0; b < MI; ++b) {
             const int m = m0 + wm * WM + b * 16 + i;
-            if (m >= p.M || !cw) continue;
+            if (m >= p.M) continue;
 #pragma unroll
             for (int a = 0; a < NI; ++a) {
                 const int n = n0 + wn * WN + a * 16 + 4 * g;
@@ -669,7 +493,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 *reinterpret_cast<f32x4*>(dst) = acc[a][b];
             }
         }
-    } else if (!(p.dbg & 4)) {
+    } else {
         constexpr int NT = WG::NCW * 64;                    // the compute waves (loader waves have exited)
         constexpr int SROW = BN + 4;                        // fp32 row stride of the staging block (+4 spreads banks)
         constexpr int PASS_ROWS = WG::GM * 16;              // one 16-row MFMA block of every wave row per pass
@@ -681,14 +505,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 #pragma unroll
         for (int b = 0; b < MI; ++b) {
             float* sb = stage + (b & 1) * PASS_ROWS * SROW;
-            if (cw) {
 #pragma unroll
-                for (int a = 0; a < NI; ++a)
-                    *reinterpret_cast<f32x4*>(sb + (wm * 16 + i) * SROW + wn * WN + a * 16 + 4 * g) = acc[a][b];
-            }
+            for (int a = 0; a < NI; ++a)
+                *reinterpret_cast<f32x4*>(sb + (wm * 16 + i) * SROW + wn * WN + a * 16 + 4 * g) = acc[a][b];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                   // (also orders the reads of pass b-1 before the writes of b+1)
-            for (int c = cw ? t : PASS_ROWS * CPR; c < PASS_ROWS * CPR; c += NT) {
+            for (int c = t; c < PASS_ROWS * CPR; c += NT) {
                 const int r = c / CPR, c8 = c - r * CPR;
                 const int m = m0 + (r >> 4) * WM + b * 16 + (r & 15);
                 if (m >= p.M) continue;
@@ -748,34 +570,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
             }
         }
     }
-    if constexpr (LOOP) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                       // the staging block is free: the next tile may fill the ring
-    }
 #ifdef UNITER_GEMM_PROBE
     if (life != nullptr && t == 0 && bx < 4096) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); life[1] = __builtin_readcyclecounter(); }
 #endif
 }
 
-// Register budget.  A compute wave holds its accumulator tile plus one (WS == 2) or two (software-pipelined) fragment
-// sets; the kernel may ask for two workgroups per CU only when both the LDS ring and that register need allow it.
-template <int BM, int BN, int NSTAGE, int WS>
-constexpr int gemm_min_waves() {
-    using WG = WaveGrid<BM, BN, WS>;
-    constexpr int MI = BM / WG::GM / 16, NI = BN / WG::GN / 16;
-    constexpr int need = MI * NI * 4 + (WS == 2 ? 1 : 2) * (MI + NI) * 4 + 56;      // + addressing, epilogue temporaries
-    constexpr int alloc = (need + 7) / 8 * 8;
-    constexpr int cap = 512 / alloc < 1 ? 1 : 512 / alloc;                            // waves per SIMD the registers allow
-    constexpr int wpw = (WG::THREADS + 255) / 256;                                    // waves one workgroup puts on a SIMD
-    constexpr int lds = NSTAGE * (BM + BN) * 128;
-    constexpr int wgs = (2 * lds <= 160 * 1024 && 2 * wpw <= cap) ? 2 : 1;
-    return wgs * wpw;
-}
 template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, int WS>
-__global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), (gemm_min_waves<BM, BN, NSTAGE, WS>())) void gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS == 2 ? 3 : 1)) void gemm_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     gemm_tile<BM, BN, TRA, TRB, EPI, NSTAGE, WS>(p, (int)blockIdx.x, (int)blockIdx.y, smem_raw);
 }
+
 // Grouped launch: up to 4 problems of the same operand layout (the four weight gradients of a BertLayer) share one
 // grid — one set of launch / ramp / drain costs instead of four, and the tiles of small problems fill the CUs the big
 // ones leave idle.  Problem q owns grid slots [start[q], start[q+1]); starts are multiples of 8 so that the slot -> XCD
@@ -786,21 +591,17 @@ struct GemmGroupArgs {
     int n;
 };
 template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, int WS>
-__global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), (gemm_min_waves<BM, BN, NSTAGE, WS>())) void gemm_group_kernel(const GemmGroupArgs ga) {
+__global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS == 2 ? 3 : 1)) void gemm_group_kernel(const GemmGroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    // persistent form: the grid may be smaller than the slot count (a multiple of 8, so slot % 8 = XCD still holds); each
-    // workgroup then walks its slots.  With one workgroup per CU the launch is "polite": it never holds more than its
-    // one LDS ring and wave set per CU, so a critical-path kernel on another stream always finds room beside it.
-    for (int b = (int)blockIdx.x; b < ga.start[ga.n]; b += (int)gridDim.x) {
-        int q = 0;
+    const int b = (int)blockIdx.x;
+    int q = 0;
 #pragma unroll
-        for (int k = 1; k < 4; ++k)
-            if (k < ga.n && b >= ga.start[k]) q = k;
-        const GemmArgs& p = ga.g[q];
-        const int bx = b - ga.start[q];
-        if (bx >= ((p.M + BM - 1) / BM) * (p.N / BN)) continue;      // padding slot
-        gemm_tile<BM, BN, TRA, TRB, EPI, NSTAGE, WS, true>(p, bx, 0, smem_raw);
-    }
+    for (int k = 1; k < 4; ++k)
+        if (k < ga.n && b >= ga.start[k]) q = k;
+    const GemmArgs& p = ga.g[q];
+    const int bx = b - ga.start[q];
+    if (bx >= ((p.M + BM - 1) / BM) * (p.N / BN)) return;        // padding slot
+    gemm_tile<BM, BN, TRA, TRB, EPI, NSTAGE, WS>(p, bx, 0, smem_raw);
 }
 
 // out[M*N] bf16 (+)= sum_s partial[s][M*N]
@@ -826,9 +627,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #ifdef UNITER_GEMM_PROBE
 unsigned long long* g_probe = nullptr;
 #endif
-// L2 prefetch distance of the wave-specialised kernels, in K tiles (0 = off).  UNITER_AMD_PF_DIST overrides it.
-int g_gemm_dbg = [] { const char* e = getenv("UNITER_AMD_GEMM_DBG"); return e ? atoi(e) : 0; }();
-int g_pf_dist = [] { const char* e = getenv("UNITER_AMD_PF_DIST"); return e ? atoi(e) : 0; }();
 
 // XCD grid for the 2-D mapping: the factorisation xr x xc = 8 that divides the tile grid and minimises the operand
 // bytes one XCD touches (sub_m*BM + sub_n*BN rows of K elements); 0 if none divides.
@@ -853,8 +651,6 @@ int launch_cfg(const GemmArgs& a_in, int splits, hipStream_t st) {
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
     a.xr = pick_xr(tiles_m, tiles_n, BM, BN);
-    a.pf = g_pf_dist;
-    a.dbg = g_gemm_dbg;
 #ifdef UNITER_GEMM_PROBE
     a.probe = g_probe;
 #endif
@@ -981,8 +777,6 @@ int launch_gemm(const GemmArgs& a, int cfg, int splits, hipStream_t st) {
 }
 
 // ---- grouped weight-gradient launch ------------------------------------------------------------------------------
-// Workgroups of a grouped launch (0 = one per tile).  UNITER_AMD_GROUP_PERSIST / uniter_gemm_debug_group_persist.
-int g_group_persist = [] { const char* e = getenv("UNITER_AMD_GROUP_PERSIST"); return e ? atoi(e) : 0; }();
 template <int IDX>
 int launch_group_idx(GemmGroupArgs& ga, hipStream_t st) {
     if constexpr (tile_ok<true, true>(IDX)) {
@@ -996,8 +790,6 @@ int launch_group_idx(GemmGroupArgs& ga, hipStream_t st) {
             }
             const int tiles_m = a.M / BM, tiles_n = a.N / BN;
             a.xr = pick_xr(tiles_m, tiles_n, BM, BN);
-            a.pf = g_pf_dist;
-            a.dbg = g_gemm_dbg;
             a.k_per_split = (a.K + 63) / 64 * 64;
             a.partial = nullptr;
             ga.start[q] = total;
@@ -1011,9 +803,7 @@ int launch_group_idx(GemmGroupArgs& ga, hipStream_t st) {
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_done = true;
         }
-        int grid = total;
-        if (g_group_persist > 0 && g_group_persist < total) grid = (g_group_persist + 7) / 8 * 8;
-        hipLaunchKernelGGL((gemm_group_kernel<BM, BN, true, true, EPI_WGRAD, NSTAGE, WS>), dim3(grid), dim3(WaveGrid<BM, BN, WS>::THREADS),
+        hipLaunchKernelGGL((gemm_group_kernel<BM, BN, true, true, EPI_WGRAD, NSTAGE, WS>), dim3(total), dim3(WaveGrid<BM, BN, WS>::THREADS),
                            lds, st, ga);
         UH_LAUNCH_CHECK();
         return 0;
@@ -1104,7 +894,6 @@ int pick_cfg(int M, int N, bool trm, bool trn, bool k_mult64 = false) {
 namespace uh {
 
 void gemm_debug_force(int cfg, int splits) { g_force_cfg = cfg; g_force_splits = splits; }
-void gemm_debug_group_persist(int wgs) { g_group_persist = wgs; }
 #ifdef UNITER_GEMM_PROBE
 extern "C" int uniter_gemm_debug_probe(unsigned long long* dev) { g_probe = dev; return 0; }
 #endif

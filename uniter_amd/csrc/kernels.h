@@ -41,7 +41,6 @@ int gemm_wgrad_group(int n, const void* const* dy, const void* const* x, void* c
                      const int64_t* lddy = nullptr, const int64_t* ldx = nullptr);
 int gemm_group_autotune(int n, int64_t M, const int64_t* N, const int64_t* K, hipStream_t st);
 void gemm_debug_force(int cfg, int splits);
-void gemm_debug_group_persist(int wgs);
 int gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, hipStream_t st);
 int gemm_tuned_choice(int kind, int64_t M, int64_t N, int64_t K, int* cfg, int* splits);
 int gemm_set_tuned(int kind, int64_t M, int64_t N, int64_t K, int cfg, int splits);

@@ -84,10 +84,22 @@ def _check_dev(t, name, dtype=_BF16):
     return t
 
 
+def params_ready(*tensors):
+    """Order the current stream behind the segments of a pending asynchronous optimizer step that hold these parameters
+    (AdamW.enable_overlap).  Free when no such step is pending."""
+    if not _lib.async_pending():
+        return
+    st = _lib.stream_ptr()
+    for t in tensors:
+        if t is not None:
+            C.uniter_params_wait(t.data_ptr(), st)
+
+
 def ensure_grad(p):
     """param.grad as a zero-initialised contiguous tensor the kernels can accumulate into."""
     if p.grad is None:
-        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        slot = getattr(p, '_uniter_grad_slot', None)          # flat gradient arena (utils.arena): zero until first used
+        p.grad = slot if slot is not None else torch.zeros_like(p, memory_format=torch.contiguous_format)
     elif not p.grad.is_contiguous() or p.grad.dtype != p.dtype:
         raise _lib.UniterHipError("param.grad must be contiguous and of the parameter's dtype")
     return p.grad
@@ -350,6 +362,7 @@ class _EncoderFn(torch.autograd.Function):
         xc = x.contiguous()
         C.uniter_encoder_forward(ctypes.byref(s), table, 0, n, ptr(xc), None if packed is not None else ptr(mask_bias),
                                  ptr(acts), None, seed, off, _lib.stream_ptr())
+        _lib.set_async_pending(False)          # the call ends with uniter_params_wait_all on this stream
 
         n_rows = out_shape[0] if packed is not None else B * L
 
@@ -577,6 +590,8 @@ class _TxtEmbedFn(torch.autograd.Function):
 
 
 def txt_embeddings(mod, input_ids, position_ids, token_type_ids):
+    params_ready(mod.word_embeddings.weight, mod.position_embeddings.weight, mod.token_type_embeddings.weight,
+                 mod.LayerNorm.weight, mod.LayerNorm.bias)
     p = float(mod.dropout.p) if (mod.training and torch.is_grad_enabled()) else 0.0
     args = (input_ids, position_ids, token_type_ids, mod, p, mod.word_embeddings.weight, mod.position_embeddings.weight,
             mod.token_type_embeddings.weight, mod.LayerNorm.weight, mod.LayerNorm.bias)
@@ -672,6 +687,7 @@ def img_embeddings(mod, img_feat, img_pos_feat, type_table, type_ids, img_masks)
     params = (mod.img_linear.weight, mod.img_linear.bias, mod.img_layer_norm.weight, mod.img_layer_norm.bias,
               mod.pos_layer_norm.weight, mod.pos_layer_norm.bias, mod.pos_linear.weight, mod.pos_linear.bias,
               mod.mask_embedding.weight, mod.LayerNorm.weight, mod.LayerNorm.bias)
+    params_ready(type_table, *params)
     return _ImgEmbedFn.apply(img_feat, img_pos_feat, type_ids, img_masks, mod, type_table, p, *params)
 
 

@@ -13,7 +13,12 @@ MI355X specifics:
     in `state[p]['master']`; fp32 parameters are updated directly;
   * gradient clipping is fused: `clip_grad_norm_(optimizer, max_norm)` computes the global norm on the
     device (no host sync) and leaves a device-side coefficient that the next `step()` applies while it
-    reads the gradients — identical to scaling the gradients in place first.
+    reads the gradients — identical to scaling the gradients in place first;
+  * `enable_overlap(boundaries)`: the update (HBM-bound, 28 B per parameter) runs on a side stream in
+    address-ordered segments and the next forward pass (MFMA-bound) overlaps it; every consumer of a
+    parameter waits for that parameter's segment only (`uniter_params_wait`, called by the encoder per layer
+    and by the embedding ops), `zero_grad()` is folded into the kernel.  `synchronize()` joins the side
+    stream for code that reads parameters / optimizer state some other way.
 """
 import ctypes
 import math
@@ -54,6 +59,10 @@ class AdamW(Optimizer):
         self._clip = None             # device tensor [norm, coef] left by clip_grad_norm_
         self._norm_buf = None
         self._graph = None            # (pinned host hyper table, device hyper table) in hipGraph mode
+        self._overlap = None          # ctypes array of segment boundaries (parameter addresses) or None
+        self._grads_zeroed = False    # the last step zeroed the gradients itself (fused), zero_grad() has nothing to do
+        self.fuse_zero_grad = False   # True: step() zeroes every gradient once read and the next zero_grad() is a no-op —
+                                      # for loops that call zero_grad() right after step() (pretrain.py:332-334)
 
     # ---- plan management ------------------------------------------------------------------------------
     def _active(self):
@@ -114,6 +123,11 @@ class AdamW(Optimizer):
             groups.append((gi, plist))
             for p in plist:
                 st = self.state[p]
+                for name in ('exp_avg', 'exp_avg_sq') + (('master',) if p.dtype == torch.bfloat16 else ()):
+                    buf = st[name]
+                    if buf.dtype != torch.float32 or not buf.is_contiguous() or buf.device != p.device:
+                        raise _lib.UniterHipError("AdamW state '%s' must be a contiguous fp32 tensor on the parameter's device "
+                                                  "(got %s); load checkpoints through AdamW.load_state_dict" % (name, buf.dtype))
                 t = table[i]
                 t.param, t.grad = p.data.data_ptr(), p.grad.data_ptr()
                 t.master = st['master'].data_ptr() if p.dtype == torch.bfloat16 else None
@@ -165,13 +179,72 @@ class AdamW(Optimizer):
         active = self._active()
         if not active:
             return False
-        key = tuple((gi, p.data.data_ptr(), p.grad.data_ptr(), p.numel()) for gi, p in active)
+        key = tuple((gi, p.data.data_ptr(), p.grad.data_ptr(), p.numel(),
+                     self.state[p]['exp_avg'].data_ptr() if 'exp_avg' in self.state[p] else 0) for gi, p in active)
         if self._plan is None or key != self._plan_key:
             self._build_plan(active)
             self._plan_key = key
         self._plan_refs = [(p, p.grad) for _, p in active]
         self._flat_grads = None
         return True
+
+    # ---- asynchronous step ------------------------------------------------------------------------------
+    def enable_overlap(self, boundaries, fuse_zero_grad=True):
+        """Run every later step() asynchronously on the library's optimizer stream, cut into segments at the given
+        parameter addresses (any iterable of ints / tensors; see `overlap_boundaries(model)`), so that the next forward
+        pass overlaps the update.  Contract: between step() and the next backward the parameters are only read through
+        uniter_amd modules (they wait per segment) or after `synchronize()`; with `fuse_zero_grad` the following
+        `zero_grad()` is a no-op because the step zeroes each gradient right after reading it."""
+        addrs = sorted(set(int(b.data_ptr()) if isinstance(b, torch.Tensor) else int(b) for b in boundaries))
+        self._overlap = ((ctypes.c_void_p * len(addrs))(*addrs), len(addrs), bool(fuse_zero_grad))
+
+    def disable_overlap(self):
+        self.synchronize()
+        self._overlap = None
+
+    def synchronize(self):
+        """Make the current stream wait for a pending asynchronous step (no host synchronisation)."""
+        if _lib.async_pending():
+            C.uniter_params_wait_all(_lib.stream_ptr())
+            _lib.set_async_pending(False)
+
+    def state_dict(self):
+        self.synchronize()
+        return super(AdamW, self).state_dict()
+
+    def load_state_dict(self, state_dict):
+        """torch's Optimizer.load_state_dict casts floating-point state to the PARAMETER dtype: for bf16 parameters the
+        fp32 moments and master weights of the checkpoint would come back as bf16 while the kernel reads them as fp32.
+        Restore them in fp32 (contiguous, 16-byte aligned) and drop the device plan, which points at the old buffers."""
+        self.synchronize()
+        import copy
+        sd = copy.deepcopy(state_dict) if isinstance(state_dict, dict) else state_dict
+        # keep fp32 copies of the saved state before torch casts them
+        saved = {k: {n: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for n, v in st.items()}
+                 for k, st in sd['state'].items()}
+        super(AdamW, self).load_state_dict(sd)
+        id_map = {}
+        for g_saved, g_live in zip(sd['param_groups'], self.param_groups):
+            for pid, p in zip(g_saved['params'], g_live['params']):
+                id_map[pid] = p
+        for pid, st in saved.items():
+            p = id_map.get(pid)
+            if p is None:
+                continue
+            live = self.state[p]
+            for name in ('exp_avg', 'exp_avg_sq', 'master'):
+                if name in st and isinstance(st[name], torch.Tensor):
+                    live[name] = st[name].to(device=p.device, dtype=torch.float32).contiguous().view_as(p).clone()
+            if 'step' in st:
+                live['step'] = int(st['step']) if not isinstance(st['step'], torch.Tensor) else int(st['step'].item())
+            if p.dtype == torch.bfloat16:
+                if 'master' not in live:
+                    live['master'] = p.detach().float().clone()
+                else:
+                    p.data.copy_(live['master'])          # the model restarts from the fp32 weights of the checkpoint
+        self._destroy_plan()
+        self._plan_key = None
+        self._flat_grads = None
 
     # ---- public API -----------------------------------------------------------------------------------
     def grad_norm(self, max_norm=0.0, grad_scale=1.0):
@@ -240,6 +313,18 @@ class AdamW(Optimizer):
             h.step = int(self.state[plist[0]]['step'])
         clip = self._clip
         self._clip = None
+        if self._overlap is not None and not torch.cuda.is_current_stream_capturing():
+            arr, n, fuse = self._overlap
+            C.uniter_adamw_step_async(self._plan, hyper, len(self._plan_groups), ptr(clip[1:]) if clip is not None else None,
+                                      arr, n, 1 if fuse else 0, _lib.stream_ptr())
+            self._grads_zeroed = fuse
+            _lib.set_async_pending(True)
+            return loss
+        if self.fuse_zero_grad:
+            C.uniter_adamw_step_zero(self._plan, hyper, len(self._plan_groups), ptr(clip[1:]) if clip is not None else None,
+                                     _lib.stream_ptr())
+            self._grads_zeroed = True
+            return loss
         C.uniter_adamw_step(self._plan, hyper, len(self._plan_groups), ptr(clip[1:]) if clip is not None else None,
                             _lib.stream_ptr())
         return loss
@@ -248,8 +333,13 @@ class AdamW(Optimizer):
         """Zero the gradients IN PLACE by default: the kernels accumulate into `.grad` storages that may be views of
         one flat arena (utils.arena), which must survive the step."""
         if set_to_none:
+            self.synchronize()
+            self._grads_zeroed = False
             self._flat_grads = None
             return super(AdamW, self).zero_grad(set_to_none=True)
+        if self._grads_zeroed:                   # the asynchronous step zeroes every gradient it has consumed
+            self._grads_zeroed = False
+            return
         flats = getattr(self, '_flat_grads', None)
         if flats is not None and self._plan is not None:
             for f in flats:                      # fast path: everything lives in flat arenas found earlier
@@ -272,6 +362,26 @@ class AdamW(Optimizer):
                         all_flat = False
                         p.grad.zero_()
         self._flat_grads = bases if (all_flat and bases) else None
+
+
+def overlap_boundaries(model):
+    """Segment boundaries for `AdamW.enable_overlap`: the first parameter of every BertLayer and of whatever follows the
+    last layer in module order.  With the parameters in a flat arena (utils.arena.flatten_model) these addresses ascend in
+    the order the forward pass consumes them; without an arena the result is still correct, only less overlapped."""
+    from ..model.layer import BertLayer
+    layers = [m for m in model.modules() if isinstance(m, BertLayer)]
+    out = []
+    for lay in layers:
+        ps = [p.data_ptr() for p in lay.parameters()]
+        if ps:
+            out.append(min(ps))
+    if layers:
+        last = list(layers[-1].parameters())
+        end = max(p.data_ptr() + p.numel() * p.element_size() for p in last)
+        after = [p.data_ptr() for p in model.parameters() if p.data_ptr() >= end]
+        if after:
+            out.append(min(after))
+    return out
 
 
 def clip_grad_norm_(parameters_or_optimizer, max_norm, grad_scale=1.0):

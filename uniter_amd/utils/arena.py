@@ -8,6 +8,14 @@ of the same layout; every nn.Parameter and its `.grad` become views.  This gives
     flatten/unflatten copies (the reference copies 228 tensors in and out, utils/distributed.py:24-43);
   * `optimizer.zero_grad()` is one memset; the fused AdamW walks aligned 16-byte streams.
 Tensors are aligned to 128 elements (256 B in bf16).
+
+Gradients are attached lazily: a parameter's `.grad` stays None until a backward pass first produces a gradient for
+it, exactly like the reference (optim/adamw.py:52-53 skips `p.grad is None`; `zero_grad()` keeps existing gradients
+as zeros).  Parameters the loss never reaches — the pooler under the NLVR2 paired-attention head, `mask_embedding`
+in fine-tuning, a pre-training head before its task is first drawn — are therefore neither decayed nor stepped, and
+a head's bias correction starts at its own first update.  The arena slot is handed out by `ops.ensure_grad` (kernels
+that write gradients themselves) or by a post-accumulate hook that moves autograd's freshly allocated gradient into
+the slot (PyTorch modules).
 """
 import torch
 
@@ -40,6 +48,18 @@ def _ordered_parameters(model):
 
     visit(model, "")
     return out
+
+
+def _adopt_grad(param):
+    """post-accumulate hook: autograd allocated a gradient of its own for a parameter whose `.grad` was None — move it
+    into the arena slot (which is all zeros until then) and make the slot the gradient."""
+    slot = getattr(param, '_uniter_grad_slot', None)
+    g = param.grad
+    if slot is None or g is None or g.data_ptr() == slot.data_ptr():
+        return
+    with torch.no_grad():
+        slot.copy_(g)
+    param.grad = slot
 
 
 class ParamArena(object):
@@ -85,9 +105,13 @@ class ParamArena(object):
                 p.data = view
                 if self.grad is not None:
                     g = self.grad[off:off + p.numel()].view(p.shape)
-                    if p.grad is not None:
+                    p._uniter_grad_slot = g
+                    if p.grad is not None:              # an existing gradient moves in; otherwise it stays None
                         g.copy_(p.grad)
-                    p.grad = g
+                        p.grad = g
+                    if not getattr(p, '_uniter_grad_hook', False):
+                        p.register_post_accumulate_grad_hook(_adopt_grad)
+                        p._uniter_grad_hook = True
         for m in model.modules():                      # parameter storages moved: drop cached device pointers
             if hasattr(m, "_ptr_cache"):
                 m._ptr_cache = None
@@ -110,7 +134,7 @@ class ParamArena(object):
         for p, off in zip(self.params, self.offsets):
             if p.data.data_ptr() != self.data.data_ptr() + off * esz:
                 return False
-            if self.grad is not None and (p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + off * esz):
+            if self.grad is not None and p.grad is not None and p.grad.data_ptr() != self.grad.data_ptr() + off * esz:
                 return False
         return True
 
