@@ -449,6 +449,22 @@ int uniter_params_wait_all(void* stream);
 int uniter_adamw_step_dev(void* plan, const float* dev_hyper, int32_t n_groups, const float* clip_coef, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Dense pieces of the NLVR2 paired-attention head — model/nlvr2.py:150-153,196-204.
+ *   uniter_gemm_bias_relu_dropout_fwd   y = dropout(relu(x w^T + b))  (self.fc = Linear(2H,H) + ReLU + Dropout), one GEMM
+ *   uniter_relu_dropout_bwd             dpre = dy * scale where y > 0 else 0  (y is the saved output: it is positive
+ *                                       exactly where the unit is active and kept)
+ *   uniter_cls_ce_fwd / _bwd            Linear(D, C <= 8) + F.cross_entropy(reduction='none') over n rows; logits are
+ *                                       rounded to bf16 like the module's; probs [n,C] fp32 saved for backward; bwd writes
+ *                                       dx [n,D] and ACCUMULATES into gw [C,D] / gb [C] (bf16).  targets int64 [n]. */
+int uniter_gemm_bias_relu_dropout_fwd(const void* x, const void* w, const void* bias, void* y, int64_t M, int64_t N, int64_t K,
+                                      float p_drop, uint64_t seed, uint64_t offset, void* stream);
+int uniter_relu_dropout_bwd(const void* dy, const void* out, void* dpre, int64_t numel, float p_drop, void* stream);
+int uniter_cls_ce_fwd(const void* x, const void* w, const void* b, const int64_t* target, float* loss, float* probs, float* logits,
+                      int64_t n, int64_t D, int64_t C, void* stream);
+int uniter_cls_ce_bwd(const void* x, const void* w, const float* probs, const int64_t* target, const float* gloss, void* dx,
+                      void* gw, void* gb, int64_t n, int64_t D, int64_t C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Attention pooling of the NLVR2 paired-attention head — model/nlvr2.py:110-125 (AttentionPool):
  *   score_t = relu(x_t . w + b) - 1e4 * pad_t ; p = dropout(softmax_t(score)) ; out[B,H] = sum_t p_t x_t
  * x [B,L,H] bf16, pad [B,L] uint8/bool (1 = padded, may be NULL), w [H] bf16 (= fc.0.weight[0]), b [1] bf16.

@@ -123,6 +123,10 @@ SIGNATURES = {
     "uniter_encoder_autotune": (c_int, [POINTER(UniterEncoderShape), _P]),
     "uniter_encoder_debug_side_stream": (c_int, [c_int]),
     "uniter_encoder_debug_tune_in_situ": (c_int, [c_int]),
+    "uniter_gemm_bias_relu_dropout_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
+    "uniter_relu_dropout_bwd": (c_int, [_P, _P, _P, _I, c_float, _P]),
+    "uniter_cls_ce_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "uniter_cls_ce_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "uniter_adamw_plan_create": (c_int, [POINTER(UniterAdamTensor), _I, POINTER(c_void_p)]),
     "uniter_adamw_plan_destroy": (c_int, [_P]),
     "uniter_adamw_grad_norm": (c_int, [_P, c_float, c_float, _P, _P]),

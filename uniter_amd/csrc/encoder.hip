@@ -113,6 +113,10 @@ int g_group_wgrad = 1;      // 1: the four weight gradients of a layer go out as
 // (0 = immediately, 1 = after the layer's last dgrad, 2 = after the next layer's first LayerNorm row kernel, ...).
 // The grouped kernel shares the CUs with whatever the main stream runs meanwhile; which neighbours it slows least is
 // an empirical question.  UNITER_AMD_WGRAD_DEFER overrides it.
+// 1: LayerNorm backward as ONE kernel on the caller's stream (rows + per-block column partials in the same pass over dy / z)
+// with only the tiny finalize on the side stream; 0: row kernel on the caller's stream + column kernel (re-reads dy, z) on
+// the side stream.  UNITER_AMD_LN_FUSED overrides.
+int g_ln_fused = [] { const char* e = getenv("UNITER_AMD_LN_FUSED"); return e ? atoi(e) : 0; }();
 int g_group_defer = [] { const char* e = getenv("UNITER_AMD_WGRAD_DEFER"); return e ? atoi(e) : 0; }();
 
 int check_shape(const UniterEncoderShape* s) {
@@ -290,6 +294,17 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         // (dgamma, dbeta and the dense bias gradient) go to the side stream.  dd is always materialised (a copy of dz
         // when there is no dropout) so that the weight-gradient work can read it after bufA has moved on.
         RC(before_overwrite(par));                 // weight gradients of layer l+2 used this buffer set
+        const bool lnf = g_ln_fused != 0 && grouped;
+        if (lnf) {
+            int nbp = 0;
+            RC(before_overwrite(4));               // the finalize of the previous LayerNorm still reads `red`
+            RC(uh::layernorm_bwd_fused_rows(dyl, A + al.z2, (const float*)(A + al.mean2), (const float*)(A + al.rstd2), P.ln2_g, bufA,
+                                            ddb2, T, H, d_h2, red, sl.red_bytes, &nbp, st));
+            RC(tick());
+            RC(fork(4));
+            RC(uh::layernorm_bwd_fused_finalize(red, nbp, P.g_ln2_g, P.g_ln2_b, H, 1, ss));
+            RC(joined(4));
+        } else {
         RC(uh::layernorm_bwd_rows(dyl, nullptr, A + al.z2, (const float*)(A + al.mean2), (const float*)(A + al.rstd2),
                                   P.ln2_g, bufA, ddb2, T, H, d_h2, 0, st));
         RC(tick());
@@ -298,6 +313,7 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
                                   bufA, ddb2, P.g_ln2_g, P.g_ln2_b, grouped ? nullptr : P.g_b2, T, H, 1, d_h2, 0,
                                   side ? red2 : red, sl.red_bytes, ss));
         RC(joined(4));                         // dyl (bufB below the top layer) has been read
+        }
         if (!grouped) {
             RC(uh::gemm_wgrad(ddb2, A + al.g, P.g_w2, T, H, I, 1, wg, sl.wg_bytes, ss));
             RC(joined(par));
@@ -315,6 +331,16 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dpre, P.w1, bufA, bufB, T, I, H, st));          // da = dpre*W1 + dz2
         RC(tick());
         // ---- BertSelfOutput backward (model/layer.py:111-115) ----
+        if (lnf) {
+            int nbp = 0;
+            RC(before_overwrite(5));               // the finalize of the previous LayerNorm still reads `red2`
+            RC(uh::layernorm_bwd_fused_rows(bufB, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1), P.ln1_g, bufA,
+                                            ddb1, T, H, d_h1, red2, sl.red_bytes, &nbp, st));
+            RC(tick());
+            RC(fork(5));
+            RC(uh::layernorm_bwd_fused_finalize(red2, nbp, P.g_ln1_g, P.g_ln1_b, H, 1, ss));
+            RC(joined(5));
+        } else {
         RC(uh::layernorm_bwd_rows(bufB, nullptr, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1),
                                   P.ln1_g, bufA, ddb1, T, H, d_h1, 0, st));
         RC(tick());
@@ -323,6 +349,7 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
                                   bufA, ddb1, P.g_ln1_g, P.g_ln1_b, grouped ? nullptr : P.g_bo, T, H, 1, d_h1, 0,
                                   side ? red2 : red, sl.red_bytes, ss));
         RC(joined(5));                         // bufB (da) has been read
+        }
         if (!grouped) {
             RC(uh::gemm_wgrad(ddb1, A + al.ctx, P.g_wo, T, H, H, 1, wg, sl.wg_bytes, ss));
             RC(joined(par));

@@ -45,6 +45,7 @@ struct GemmArgs {
     int k_per_split;      // multiple of 64
     int accumulate;       // EPI_WGRAD, splits == 1: C += result
     int xr;               // 2-D XCD blocking: rows of the XCD grid (0 = 1-D contiguous ranges)
+    int relu;             // EPI_BIAS_DROP_RES: clamp at zero after the bias, before the dropout (Linear + ReLU + Dropout heads)
 #ifdef UNITER_GEMM_PROBE
     unsigned long long* probe;   // cycle stamps of wave 0 of every workgroup: [block][kt][5] (profiling builds only)
 #endif
@@ -539,6 +540,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                     continue;
                 }
                 if (EPI == EPI_BIAS_DROP_RES) {
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
                     if (p.drop.p > 0.f) {
                         float mv[8];
                         dropout_mult8(p.drop, ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 3, mv);   // N % 8 == 0
@@ -906,7 +911,7 @@ static int check_common(int64_t M, int64_t N, int64_t K) {
 }
 
 int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void* resid, void* y, void* y2,
-             int64_t M, int64_t N, int64_t K, const DropoutCfg& drop, hipStream_t st, int64_t ldx, int64_t ldy) {
+             int64_t M, int64_t N, int64_t K, const DropoutCfg& drop, hipStream_t st, int64_t ldx, int64_t ldy, int relu) {
     if (check_common(M, N, K)) return -1;
     if (ldx == 0) ldx = K;
     if (ldy == 0) ldy = N;
@@ -923,6 +928,7 @@ int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.k_per_split = (int)((K + 63) / 64 * 64);
     a.accumulate = 0;
+    a.relu = relu;
     a.drop = drop;
     int cfg = pick_cfg((int)M, (int)N, false, false, K % 64 == 0);
     Tuned tn;

@@ -27,7 +27,8 @@ struct LaunchTimer {
 // ---- gemm.hip ----
 enum { GEMM_EPI_BIAS = 0, GEMM_EPI_BIAS_GELU = 1, GEMM_EPI_BIAS_DROP_RES = 2, GEMM_EPI_RES = 3, GEMM_EPI_GELU_BWD = 4 };
 int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void* resid, void* y, void* y2,
-             int64_t M, int64_t N, int64_t K, const DropoutCfg& drop, hipStream_t st, int64_t ldx = 0, int64_t ldy = 0);
+             int64_t M, int64_t N, int64_t K, const DropoutCfg& drop, hipStream_t st, int64_t ldx = 0, int64_t ldy = 0,
+             int relu = 0);
 int gemm_dgrad(int epi, const void* dy, const void* w, const void* aux, void* dx,
                int64_t M, int64_t N, int64_t K, hipStream_t st, int64_t lddy = 0);
 size_t gemm_dgrad_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
@@ -64,6 +65,10 @@ int layernorm_bwd(const void* dy, const void* dy_extra, const void* z, const flo
                   const void* gamma, void* dz, void* dd, void* dgamma, void* dbeta, void* dbias,
                   int64_t rows, int64_t H, int accumulate, const DropoutCfg& drop, int post_drop,
                   void* workspace, size_t ws_bytes, hipStream_t st);
+int layernorm_bwd_fused_rows(const void* dy, const void* z, const float* mean, const float* rstd, const void* gamma, void* dz,
+                             void* dd, int64_t rows, int64_t H, const DropoutCfg& drop, void* workspace, size_t ws_bytes,
+                             int* nb_out, hipStream_t st);
+int layernorm_bwd_fused_finalize(const void* workspace, int nb, void* dgamma, void* dbeta, int64_t H, int accumulate, hipStream_t st);
 int layernorm_bwd_rows(const void* dy, const void* dy_extra, const void* z, const float* mean, const float* rstd,
                        const void* gamma, void* dz, void* dd, int64_t rows, int64_t H, const DropoutCfg& drop,
                        int post_drop, hipStream_t st);

@@ -132,9 +132,18 @@ class UniterForNlvr2PairedAttn(_Nlvr2Base):
             r2l, _ = self.attn2(right, left, left, key_padding_mask=pad[:n], need_weights=False)
             att = torch.stack([l2r.transpose(0, 1), r2l.transpose(0, 1)], dim=0)
         # both sides at once: fc(cat([attended, self])) -> masked attention pooling -> cat(left, right) -> classifier
-        hidden = self.fc(torch.cat([att, xs], dim=-1)).view(bs, tl, d)
+        fused = self._fused_pair_attention(seq) and d % 64 == 0 and self.fc[0].weight.dtype == torch.bfloat16
+        cat = torch.cat([att, xs], dim=-1)
+        if fused:
+            from .. import ops
+            # Linear(2H, H) + ReLU + Dropout as one GEMM with a fused epilogue
+            hidden = ops.linear_relu_dropout(cat.view(bs * tl, 2 * d), self.fc[0], self.fc[2].p, self.training).view(bs, tl, d)
+        else:
+            hidden = self.fc(cat).view(bs, tl, d)
         pooled = self.attn_pool(hidden, pad)                                            # [2n, H]
         pooled = pooled.view(2, n, d).transpose(0, 1).reshape(n, 2 * d)
+        if fused and compute_loss and self.nlvr2_output.weight.dtype == torch.bfloat16:
+            return ops.linear_cross_entropy(pooled, self.nlvr2_output, batch['targets'])  # classifier + loss, one kernel
         return self._finish(self.nlvr2_output(pooled), batch, compute_loss)
 
     def _fused_pair_attention(self, seq):

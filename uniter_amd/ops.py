@@ -1039,3 +1039,99 @@ def attention_pool(x, pad, lin, p_drop, training):
     anchor = next((p for p in lin.parameters() if p.requires_grad), None)
     extra = () if anchor is None else (anchor,)
     return _AttnPoolFn.apply(x, pad_u8, lin, p_drop, training, *extra)
+
+
+# ----------------------------------------------------------------------------------------------------
+# dense pieces of the NLVR2 paired-attention head (model/nlvr2.py:150-153, 196-204)
+# ----------------------------------------------------------------------------------------------------
+class _LinearReluDropoutFn(torch.autograd.Function):
+    """y = dropout(relu(x W^T + b)) as ONE GEMM with a fused epilogue; backward = mask kernel + dgrad + grouped wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, lin, p, *anchor):
+        T, K = x.shape
+        N = lin.weight.size(0)
+        y = torch.empty(T, N, dtype=_BF16, device=x.device)
+        seed, off = _next_offsets(1) if p > 0.0 else (0, 0)
+        C.uniter_gemm_bias_relu_dropout_fwd(ptr(x), ptr(lin.weight), ptr(lin.bias), ptr(y), T, N, K, p, seed, off,
+                                            _lib.stream_ptr())
+        ctx.lin, ctx.p = lin, p
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        lin = ctx.lin
+        T, K = x.shape
+        N = lin.weight.size(0)
+        st = _lib.stream_ptr()
+        dy = dy.contiguous()
+        dpre = torch.empty_like(y)
+        C.uniter_relu_dropout_bwd(ptr(dy), ptr(y), ptr(dpre), y.numel(), ctx.p, st)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            C.uniter_gemm_dgrad(ptr(dpre), ptr(lin.weight), None, ptr(dx), T, N, K, st)
+        pool = {}
+        gw = ensure_grad(lin.weight) if lin.weight.requires_grad else _dummy_grad_like(lin.weight, pool)
+        gb = None
+        if lin.bias is not None:
+            gb = ensure_grad(lin.bias) if lin.bias.requires_grad else _dummy_grad_like(lin.bias, pool)
+        wgrad_group([dpre.data_ptr()], [0], [x.data_ptr()], [0], [gw.data_ptr()], [ptr(gb)], T, [N], [K])
+        return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+def linear_relu_dropout(x, lin, p_drop, training):
+    """x [T, K] bf16, lin = nn.Linear(K, N) (bf16, N % 64 == 0, K % 64 == 0) -> dropout(relu(lin(x))) [T, N]."""
+    _check_dev(x, "fc input")
+    _check_dev(lin.weight, "fc weight")
+    if x.dim() != 2 or lin.weight.size(1) != x.size(1) or x.size(1) % 64 or lin.weight.size(0) % 64:
+        raise _lib.UniterHipError("linear_relu_dropout: x must be [T, K] with K and N multiples of 64")
+    p = float(p_drop) if training else 0.0
+    x = x.contiguous()
+    anchor = next((q for q in lin.parameters() if q.requires_grad), None) if torch.is_grad_enabled() else None
+    return _LinearReluDropoutFn.apply(x, lin, p, *(() if anchor is None else (anchor,)))
+
+
+class _LinearCrossEntropyFn(torch.autograd.Function):
+    """F.cross_entropy(lin(x).float(), targets, reduction='none') for a handful of classes: one small kernel each way."""
+
+    @staticmethod
+    def forward(ctx, x, lin, targets, *anchor):
+        n, D = x.shape
+        Cn = lin.weight.size(0)
+        loss = torch.empty(n, dtype=torch.float32, device=x.device)
+        probs = torch.empty(n, Cn, dtype=torch.float32, device=x.device)
+        C.uniter_cls_ce_fwd(ptr(x), ptr(lin.weight), ptr(lin.bias), ptr(targets), ptr(loss), ptr(probs), None, n, D, Cn,
+                            _lib.stream_ptr())
+        ctx.lin = lin
+        ctx.save_for_backward(x, targets, probs)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        x, targets, probs = ctx.saved_tensors
+        lin = ctx.lin
+        n, D = x.shape
+        Cn = lin.weight.size(0)
+        pool = {}
+        gw = ensure_grad(lin.weight) if lin.weight.requires_grad else _dummy_grad_like(lin.weight, pool)
+        gb = None
+        if lin.bias is not None:
+            gb = ensure_grad(lin.bias) if lin.bias.requires_grad else _dummy_grad_like(lin.bias, pool)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        C.uniter_cls_ce_bwd(ptr(x), ptr(lin.weight), ptr(probs), ptr(targets), ptr(gloss.to(torch.float32).contiguous()), ptr(dx),
+                            ptr(gw), ptr(gb), n, D, Cn, _lib.stream_ptr())
+        return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+def linear_cross_entropy(x, lin, targets):
+    """x [n, D] bf16, lin = nn.Linear(D, C <= 8) bf16, targets [n] int64 -> per-row cross entropy [n] fp32."""
+    _check_dev(x, "classifier input")
+    _check_dev(lin.weight, "classifier weight")
+    if x.dim() != 2 or lin.weight.size(1) != x.size(1) or x.size(1) % 8 or lin.weight.size(0) > 8 or x.size(0) > 4096:
+        raise _lib.UniterHipError("linear_cross_entropy: x must be [n <= 4096, D % 8 == 0] and the classifier at most 8-way")
+    t = targets.to(device=x.device, dtype=torch.int64).contiguous()
+    anchor = next((q for q in lin.parameters() if q.requires_grad), None) if torch.is_grad_enabled() else None
+    return _LinearCrossEntropyFn.apply(x.contiguous(), lin, t, *(() if anchor is None else (anchor,)))
