@@ -34,18 +34,10 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-BASE_CFG = dict(vocab_size=28996, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
-                hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
-                max_position_embeddings=512, type_vocab_size=2, initializer_range=0.02)
-TRAIN = dict(batch=32, max_txt_len=60, num_bb=36, learning_rate=3e-5, betas=(0.9, 0.98), weight_decay=0.01,
-             grad_norm=2.0, warmup_steps=800, num_train_steps=8000, dropout=0.1, optim='adamw')
+from uniter_amd.train import BASE as BASE_CFG, WORKLOADS, StepRunner, encoder_flops  # noqa: E402
+
+TRAIN = WORKLOADS['c2']
 MFMA_PEAK_TFLOPS = 2500.0
-
-
-def encoder_flops(B, L, H, I, n_layers):
-    """Algorithmic FLOP of one encoder forward: n_layers * (24*T*H^2 + 4*T*L*H); I = 4H."""
-    T = B * L
-    return n_layers * (2.0 * T * H * (3 * H + H + 2 * I) + 4.0 * T * L * H)
 
 
 def write_cfg(path):
@@ -54,12 +46,10 @@ def write_cfg(path):
 
 
 def build_model(device, cfg_path, seed):
-    from uniter_amd.model.nlvr2 import UniterForNlvr2PairedAttn
-    from uniter_amd.utils.misc import set_dropout, set_random_seed
-    set_random_seed(seed)
-    model = UniterForNlvr2PairedAttn.from_pretrained(cfg_path, {}, img_dim=2048)      # no checkpoint: random init
-    model.init_type_embedding()                                                       # use_img_type (train_nlvr2.py:117)
-    model.to(device).bfloat16()
+    """UNITER-base NLVR2 paired-attention model, random init (kept for scripts/host_profile.py and friends)."""
+    from uniter_amd.train import build_model as _build
+    from uniter_amd.utils.misc import set_dropout
+    model = _build('nlvr2', BASE_CFG, device, seed, cfg_path)
     set_dropout(model, TRAIN['dropout'])
     model.train()
     return model
@@ -143,31 +133,75 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(seed=77, budget_s=20.0):
-    """The oracle (CPU port of the reference path) on the same workload: fwd + bwd + clip + AdamW, fp32.
-    Runs in this process; main() calls it through a subprocess with a hard timeout."""
-    from oracle import uniter_oracle as O
+def _oracle_setup(seed):
+    """Weights (as autograd leaves) and the batch of the headline workload on the CPU: the same seeded construction the
+    GPU side uses, so both sides start from identical bf16-representable-or-not fp32 values (the GPU casts to bf16)."""
     from uniter_amd.model.nlvr2 import UniterForNlvr2PairedAttn
+    from uniter_amd.utils.misc import set_random_seed
     from uniter_amd.utils.synthetic import make_batch
-    cores = min(usable_cores(), 64)
-    torch.set_num_threads(cores)
     cfg_path = os.path.join("/tmp", "uniter_base_cpu_%d.json" % os.getpid())
     write_cfg(cfg_path)
-    torch.manual_seed(seed)
+    set_random_seed(seed)
     ref_model = UniterForNlvr2PairedAttn.from_pretrained(cfg_path, {}, img_dim=2048)   # only a weight container
     ref_model.init_type_embedding()
-    sd = {k: v.detach().clone().requires_grad_(True) for k, v in ref_model.state_dict().items()}
-    del ref_model
     os.remove(cfg_path)
-    B = TRAIN['batch']
-    batch = make_batch('nlvr2', B, TRAIN['max_txt_len'], TRAIN['num_bb'], seed=seed)
-    state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in sd.items()}
+    # the GPU model holds bf16 weights: the oracle starts from exactly those values
+    sd = {k: v.detach().to(torch.bfloat16).float().clone().requires_grad_(True) for k, v in ref_model.state_dict().items()}
+    del ref_model
+    batch = make_batch('nlvr2', TRAIN['batch'], TRAIN['max_txt_len'], TRAIN['num_bb'], seed=1000)
+    return sd, batch
 
-    def step(i):
+
+def cpu_baseline(seed=77, budget_s=20.0, parity_file=None):
+    """The oracle (CPU port of the reference path) on the same workload: fwd + bwd + clip + AdamW, fp32.
+    Runs in this process; main() calls it through a subprocess with a hard timeout.  With `parity_file` (loss and
+    gradients of one dropout-free GPU step on the same weights and batch, written by main()) the same oracle forward /
+    backward is also the parity check of the headline workload."""
+    from oracle import uniter_oracle as O
+    cores = min(usable_cores(), 64)
+    torch.set_num_threads(cores)
+    sd, batch = _oracle_setup(seed)
+    B = TRAIN['batch']
+    state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in sd.items()}
+    parity = None
+
+    def fwd_bwd():
         for v in sd.values():
             v.grad = None
         loss, _ = O.nlvr2_paired_attn_loss(sd, BASE_CFG, batch)
         loss.mean().backward()
+        return loss
+
+    if parity_file and os.path.exists(parity_file):
+        gpu = torch.load(parity_file)
+        loss = fwd_bwd().detach()
+        lrel = float((gpu['loss'].float() - loss).abs().max() / loss.abs().max())
+        worst, worst_name, n_cmp, cos_min, zero_abs = 0.0, None, 0, 1.0, 0.0
+        for k, g in gpu['grads'].items():
+            ref = sd[k].grad
+            if ref is None:
+                continue
+            g = g.float()
+            den = float(ref.norm())
+            # gradients that are mathematically zero (the key bias: softmax is invariant to a per-query shift of all
+            # scores) are rounding noise on both sides — compare them absolutely against the layer's query-bias scale
+            if den < 1e-6 * max(float(ref.numel()) ** 0.5, 1.0) or k.endswith('attention.self.key.bias'):
+                zero_abs = max(zero_abs, float(g.abs().max()))
+                continue
+            rel = float((g - ref).norm()) / den
+            cos = float((g * ref).sum() / (g.norm() * ref.norm() + 1e-30))
+            n_cmp += 1
+            cos_min = min(cos_min, cos)
+            if rel > worst:
+                worst, worst_name = rel, k
+        parity = {"loss_rel_err": round(lrel, 6), "grad_rel_l2_max": round(worst, 5), "grad_rel_l2_max_tensor": worst_name,
+                  "grad_cosine_min": round(cos_min, 6), "gradients_compared": n_cmp,
+                  "zero_gradients_max_abs": float("%.3e" % zero_abs),
+                  "what": "one dropout-free step of the headline workload (UNITER-base NLVR2 paired-attn, B=32, L=96, 12 layers) on "
+                          "the GPU vs oracle/uniter_oracle.py in fp32 on the CPU, identical bf16-representable weights and batch"}
+
+    def step(i):
+        fwd_bwd()
         grads = [v.grad for v in sd.values() if v.grad is not None]
         _, coef = O.clip_coef(grads, TRAIN['grad_norm'])
         lr = O.get_lr_sched(i + 1, TRAIN['learning_rate'], TRAIN['warmup_steps'], TRAIN['num_train_steps'])
@@ -192,16 +226,23 @@ def cpu_baseline(seed=77, budget_s=20.0):
         times.append(time.time() - t0)
         i += 1
     best = min(times) if times else warm
-    return {"value": round(B / best, 2), "unit": "examples/s", "cores": cores, "kind": "port",
-            "sample": "oracle/uniter_oracle.py (fp32 torch-CPU port of the reference NLVR2 paired-attn step: fwd+bwd+clip+AdamW) "
-                      "on the same UNITER-base workload, B=%d x (60+36), 1 warm-up + %d timed step(s), best %.2f s/step, "
-                      "%d torch threads" % (B, len(times), best, cores)}
+    out = {"value": round(B / best, 2), "unit": "examples/s", "cores": cores, "kind": "port",
+           "sample": "oracle/uniter_oracle.py (fp32 torch-CPU port of the reference NLVR2 paired-attn step: fwd+bwd+clip+AdamW; "
+                     "the GPU box has no /root/reference, the oracle is pinned to the reference by tests/golden) "
+                     "on the same UNITER-base workload, B=%d x (60+36), 1 warm-up + %d timed step(s), best %.2f s/step, "
+                     "%d torch threads" % (B, len(times), best, cores)}
+    if parity is not None:
+        out["parity"] = parity
+    return out
 
 
-def cpu_baseline_subprocess(timeout_s=150):
+def cpu_baseline_subprocess(timeout_s=240, parity_file=None):
     import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"]
+    if parity_file:
+        cmd += ["--parity-file", parity_file]
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True, text=True,
+        r = subprocess.run(cmd, capture_output=True, text=True,
                            timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
         for line in reversed(r.stdout.strip().splitlines()):
             if line.startswith("{"):
@@ -213,33 +254,55 @@ def cpu_baseline_subprocess(timeout_s=150):
                 "sample": "cpu baseline did not finish within %d s" % timeout_s}
 
 
+def gpu_parity_probe(runner, path):
+    """One dropout-free forward + backward of the headline workload on the freshly initialised GPU model; loss and every
+    gradient except the word-embedding table go to `path` for the oracle leg (cpu_baseline) to compare against."""
+    from uniter_amd.utils.misc import set_dropout
+    from uniter_amd.utils.synthetic import make_batch, to_device
+    model = runner.model
+    set_dropout(model, 0.0)
+    batch = to_device(make_batch('nlvr2', TRAIN['batch'], TRAIN['max_txt_len'], TRAIN['num_bb'], seed=1000), runner.device)
+    batch['img_feat'] = batch['img_feat'].to(torch.bfloat16)
+    batch['img_pos_feat'] = batch['img_pos_feat'].to(torch.bfloat16)
+    loss = model(batch, compute_loss=True)
+    loss.mean().backward()
+    grads = {n: p.grad.detach().to('cpu') for n, p in model.named_parameters()
+             if p.grad is not None and 'word_embeddings' not in n}
+    torch.save({'loss': loss.detach().float().cpu(), 'grads': grads}, path)
+    for p in model.parameters():
+        if p.grad is not None:
+            p.grad.zero_()
+    set_dropout(model, runner.w['dropout'])
+    torch.cuda.synchronize()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=sorted(WORKLOADS),
+                    help="c2 = the headline workload (BASELINE.json metric); c3 / c4 / c5 = the other north-star "
+                         "configurations as one GPU's share of the job (uniter_amd/train.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--overlap", action="store_true",
                     help="run the optimizer update asynchronously under the next forward pass (AdamW.enable_overlap)")
     ap.add_argument("--graph", action="store_true",
-                    help="capture the whole optimizer step into a hipGraph and replay it (N=1 only); measured slower than "
-                         "eager issue on ROCm 7.2 (8.65 vs 8.27 ms), so it is opt-in")
+                    help="capture the whole optimizer step into a hipGraph and replay it (N=1, c2 only); measured slower than "
+                         "eager issue on ROCm 7.2, so it is opt-in")
     ap.add_argument("--ragged", action="store_true",
                     help="NOT the headline config: ragged synthetic batch (10-60 text tokens, 10-36 regions per sequence) "
                          "to measure padding-free execution (SURVEY.md section 8 f-3)")
     ap.add_argument("--pack", action="store_true", help="run the encoder on real tokens only (UniterModel.pack_padding)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--parity-file", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline()), flush=True)
+        print(json.dumps(cpu_baseline(parity_file=args.parity_file)), flush=True)
         return
 
-    from uniter_amd.optim import build_optimizer, clip_grad_norm_, get_lr_sched
     from uniter_amd.utils import distributed as D
-    from uniter_amd.utils.arena import flatten_model
-    from uniter_amd.utils.misc import Struct
-    from uniter_amd.utils.synthetic import make_batch, to_device
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
@@ -255,75 +318,48 @@ def main():
     D.init("nccl")
     rank = D.rank()
 
-    cfg_path = os.path.join("/tmp", "uniter_base_bench_%d.json" % os.getpid())
-    write_cfg(cfg_path)
-    opts = Struct(TRAIN)
-    model = build_model(device, cfg_path, seed=77)                      # same seed -> same init on every rank
-    arena = flatten_model(model)
-    D.broadcast_tensors([p.data for p in model.parameters()], 0)        # train_nlvr2.py:118
-    optimizer = build_optimizer(model, opts)
-    overlap = bool(args.overlap and not args.graph)
-    if overlap:
-        # opt-in: the AdamW update runs on the optimizer stream in per-layer segments under the next step's forward.
-        # Measured neutral on one MI355X (the forward pass is itself bound by the memory system the update saturates:
-        # 5.51 vs 5.46 ms/step), so the default is the synchronous step with zero_grad folded into the update kernel.
-        from uniter_amd.optim import overlap_boundaries
-        optimizer.enable_overlap(overlap_boundaries(model))
-    elif not args.graph:
-        optimizer.fuse_zero_grad = True
+    cfg_path = os.path.join("/tmp", "uniter_bench_%d.json" % os.getpid())
     lpb = int(os.environ.get("UNITER_BENCH_LAYERS_PER_BUCKET", "4"))
-    reducer = D.GradientReducer(arena, model.uniter.encoder, layers_per_bucket=lpb) if (world > 1 or D._on()) else None
-    # each rank trains on its own shard (data/data.py:222): different synthetic batch per rank, resident in HBM
-    batch = to_device(make_batch('nlvr2', TRAIN['batch'], TRAIN['max_txt_len'], TRAIN['num_bb'], seed=1000 + rank,
-                                 ragged=args.ragged), device)
-    model.uniter.pack_padding = bool(args.pack)
-    real_tokens = int(batch['attn_masks'].sum().item())
-    batch['img_feat'] = batch['img_feat'].to(torch.bfloat16)            # fp16 features under amp O2 in the reference
-    batch['img_pos_feat'] = batch['img_pos_feat'].to(torch.bfloat16)
+    overlap = bool(args.overlap and not args.graph)
+    runner = StepRunner(args.config, device, rank=rank, world=world, seed=77, ragged=args.ragged, pack=args.pack,
+                        overlap=overlap, cfg_path=cfg_path, reducer_layers_per_bucket=lpb)
+    first_batch = next(iter(runner.batches.values()))
+    real_tokens = int(first_batch['attn_masks'].sum().item())
 
-    optimizer.zero_grad()
-    optimizer.step()                                                     # train_nlvr2.py:150-151 dummy step (no-op)
-    global_step = 0
+    # parity of the headline workload, checked in this very run: one dropout-free GPU step now, the oracle later in the
+    # cpu_baseline subprocess (same weights: same seed; same batch: same seed)
+    parity_file = None
+    if rank == 0 and world == 1 and args.config == 'c2' and not args.no_cpu_baseline and not args.ragged:
+        parity_file = os.path.join("/tmp", "uniter_bench_parity_%d.pt" % os.getpid())
+        gpu_parity_probe(runner, parity_file)
 
-    def schedule_lr():                        # train_nlvr2.py:174-178 (host side, before the update)
-        nonlocal global_step
-        global_step += 1
-        lr_this_step = get_lr_sched(global_step, opts)
-        for group in optimizer.param_groups:
-            group['lr'] = lr_this_step
-
-    def device_step():                        # everything that runs on the GPU for one optimizer step
-        if reducer is not None:
-            reducer.begin()
-        loss = model(batch, compute_loss=True)
-        loss = loss.mean()
-        loss.backward()
-        scale = reducer.finish() if reducer is not None else 1.0
-        clip_grad_norm_(optimizer, opts.grad_norm, grad_scale=scale)
-        optimizer.step()
-        optimizer.zero_grad()
-        return loss
-
-    # --graph (N == 1): the whole step is captured once into a hipGraph and replayed (one launch per step instead of
-    # ~550).  Default is eager issue: the step is GPU-bound and graph replay measured slower on this ROCm.
+    # --graph (N == 1): the whole step is captured once into a hipGraph and replayed.  Default is eager issue.
     mode = "eager"
-    train_step = None
-    if world == 1 and args.graph:
+    train_step = runner.train_step
+    if world == 1 and args.graph and args.config == 'c2':
+        from uniter_amd.optim import clip_grad_norm_
         from uniter_amd.utils.graph import GraphedStep
+        runner.optimizer.fuse_zero_grad = False
+
+        def device_step():
+            loss = runner.model(first_batch, compute_loss=True).mean()
+            loss.backward()
+            clip_grad_norm_(runner.optimizer, runner.opts.grad_norm)
+            runner.optimizer.step()
+            runner.optimizer.zero_grad()
+            return loss
         try:
-            graphed = GraphedStep(device_step, optimizer, device, warmup=3, pre_step=schedule_lr).capture()
-            train_step = graphed
+            train_step = GraphedStep(device_step, runner.optimizer, device, warmup=3, pre_step=runner._schedule_lr).capture()
             mode = "hipgraph"
         except Exception as e:                                  # pragma: no cover - depends on the runtime
             sys.stderr.write("hipGraph capture failed (%s: %s); falling back to eager steps\n" % (type(e).__name__, e))
             from uniter_amd import ops as _ops
             _ops.disable_graph_rng()
-            optimizer._graph = None
-    if train_step is None:
-        def train_step():
-            schedule_lr()
-            return device_step()
+            runner.optimizer._graph = None
+            train_step = runner.train_step
 
+    if len(runner.batches) > 1:
+        runner.warm_up_tasks()                # every task of the mix once, untimed (on top of the W warm-up steps)
     for _ in range(args.warmup):
         train_step()
     if world > 1:
@@ -353,10 +389,11 @@ def main():
             torch.distributed.barrier()
 
     if rank == 0:
-        B, L = TRAIN['batch'], TRAIN['max_txt_len'] + TRAIN['num_bb']
+        w = runner.w
+        B, L = runner.examples_per_step, runner.seq_len
         ms = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
-        flop_step = 3.0 * encoder_flops(B, L, BASE_CFG['hidden_size'], BASE_CFG['intermediate_size'], BASE_CFG['num_hidden_layers'])
+        flop_step = runner.flop_per_step()
         step_tf = flop_step / (ms * 1e-3) * 1e-12
         roofline = None
         if kernels is not None:
@@ -364,7 +401,6 @@ def main():
             dom = max(mfma, key=lambda k: k["us_per_step"])
             M, N, K = dom["shape"]
             traffic = pmc_traffic(dom["kind_id"], dom["shape"])
-            # algorithmic HBM bytes of the dominant kernel for reference (bf16 operands + output [+ aux read])
             roofline = {"bound": "mfma", "kernel": "%s M%d N%d K%d" % (dom["kernel"], M, N, K), "achieved": dom["tflops"],
                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4),
                         "traffic": None if traffic is None else traffic["hbm_bytes"],
@@ -376,25 +412,36 @@ def main():
                         "step": {"algorithmic_tflop_per_step": round(flop_step * 1e-12, 4), "achieved": round(step_tf, 1),
                                  "frac": round(step_tf / MFMA_PEAK_TFLOPS, 4),
                                  "note": "encoder fwd+bwd algorithmic FLOP (heads, embeddings, optimizer excluded) / whole step time"}}
+        metric = "train examples/sec UNITER-base seq=60txt+36img bs32/GPU"
+        if args.config != 'c2':
+            metric = "train examples/sec (%s: %s seq=%dtxt+%dimg bs%dx%d/GPU)" % (
+                args.config, "UNITER-large" if w['cfg']['hidden_size'] == 1024 else "UNITER-base", w['max_txt_len'], w['num_bb'],
+                w['batch'], w['accum'])
         result = {
-            "metric": "train examples/sec UNITER-base seq=60txt+36img bs32/GPU", "value": round(value, 1), "unit": "examples/s",
+            "metric": metric, "value": round(value, 1), "unit": "examples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "UNITER-base NLVR2 paired-attn finetune step (config/train-nlvr2-base-1gpu.json shapes): "
-                                   "fwd+bwd+clip+fused AdamW, dropout 0.1, random-init weights",
-                       "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world, "launch": mode, "optimizer_overlap": overlap,
+            "config": {"workload": "%s: %s" % (args.config, w['desc']),
+                       "global_batch": B * world, "micro_batch": w['batch'], "grad_accumulation": w['accum'], "seq_len": L,
+                       "parallelism": "dp%d" % world, "launch": mode, "optimizer_overlap": overlap,
                        "ragged": bool(args.ragged), "pack_padding": bool(args.pack),
-                       "real_token_fraction": round(real_tokens / float(B * batch['attn_masks'].size(1)), 3),
-                       "examples": "encoder sequences (32/GPU = 16 NLVR2 pairs)"},
+                       "real_token_fraction": round(real_tokens / float(w['batch'] * first_batch['attn_masks'].size(1)), 3),
+                       "examples": "encoder sequences per optimizer step" + (" (32/GPU = 16 NLVR2 pairs)" if args.config == 'c2' else ""),
+                       "task_draws": runner.task_counts},
             "final_loss": round(final_loss, 4),
             "roofline": roofline,
         }
         if kernels is not None:
             result["kernels"] = kernels
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline_subprocess()
+        if world == 1 and not args.no_cpu_baseline and args.config == 'c2':
+            cb = cpu_baseline_subprocess(parity_file=parity_file)
+            if isinstance(cb, dict) and "parity" in cb:
+                result["parity"] = cb.pop("parity")
+            result["cpu_baseline"] = cb
         else:
             result["cpu_baseline"] = None
+        if parity_file and os.path.exists(parity_file):
+            os.remove(parity_file)
         # RCCL prints its banner through C stdio, which sits in libc's buffer until exit when stdout is a pipe: flush
         # it now so that the JSON line is the LAST line this process writes
         try:
