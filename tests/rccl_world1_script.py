@@ -1,0 +1,79 @@
+"""Helper of tests/test_rccl_gpu.py, run as a subprocess on the GPU box with UNITER_DIST_FORCE=1 (a one-rank RCCL group):
+two optimizer steps of a tiny NLVR2 model through GradientReducer with the REAL backward hook (the encoder backward hands
+control back at bucket boundaries, the bucket's in-place allreduce runs on the reducer's side stream while the library's
+internal wgrad stream is still busy) against the same two steps without any collective.  Prints one JSON line."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    from tests.common import IMG_DIM, TINY_CONFIG, load_golden
+    from uniter_amd.model.nlvr2 import UniterForNlvr2PairedAttn
+    from uniter_amd.optim import build_optimizer, clip_grad_norm_
+    from uniter_amd.utils import distributed as D
+    from uniter_amd.utils.arena import flatten_model
+    from uniter_amd.utils.misc import Struct, set_dropout
+    from uniter_amd.utils.synthetic import to_device
+    assert os.environ.get("UNITER_DIST_FORCE") == "1"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    D.init("nccl")
+    assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1 and D._on()
+    calls = {"n": 0, "elems": 0}
+    real_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(t, *a, **k):
+        calls["n"] += 1
+        calls["elems"] += t.numel()
+        return real_all_reduce(t, *a, **k)
+    dist.all_reduce = counting_all_reduce
+
+    g = load_golden()
+    batch = to_device(g.batch('nlvr2'), dev)
+    opts = Struct(dict(optim='adamw', learning_rate=1e-3, betas=(0.9, 0.98), weight_decay=0.01))
+    results = []
+    for use_reducer in (False, True):
+        w, nl = g.weights('pre'), g.weights('nlvr2')
+        table3 = nl.pop('uniter.embeddings.token_type_embeddings.weight')
+        model = UniterForNlvr2PairedAttn.from_pretrained(TINY_CONFIG, {**w, **nl}, img_dim=IMG_DIM)
+        model.init_type_embedding()
+        model.uniter.embeddings.token_type_embeddings.weight.data.copy_(table3)
+        model.to(dev).bfloat16()
+        set_dropout(model, 0.0)
+        for m in model.modules():
+            if hasattr(m, 'dropout') and isinstance(m.dropout, float):
+                m.dropout = 0.0
+        model.train()
+        arena = flatten_model(model)
+        D.broadcast_tensors([p.data for p in model.parameters()], 0)
+        opt = build_optimizer(model, opts)
+        reducer = D.GradientReducer(arena, model.uniter.encoder, layers_per_bucket=1) if use_reducer else None
+        before = calls["n"]
+        for step in range(2):
+            if reducer is not None:
+                reducer.begin()
+            model(batch, compute_loss=True).mean().backward()
+            scale = reducer.finish() if reducer is not None else 1.0
+            clip_grad_norm_(opt, 1.0, grad_scale=scale)
+            opt.step()
+            opt.zero_grad()
+        torch.cuda.synchronize()
+        results.append(({n: p.detach().clone() for n, p in model.named_parameters()}, calls["n"] - before, arena.numel))
+    (plain, _, _), (reduced, n_calls, numel) = results
+    same = all(torch.equal(plain[n], reduced[n]) for n in plain)
+    n_layers = len(model.uniter.encoder.layer)
+    print(json.dumps({"identical": bool(same), "allreduce_calls": n_calls, "encoder_layers": n_layers,
+                      "elements_reduced_per_step": calls["elems"] // 2 if n_calls else 0, "arena_elements": numel,
+                      "backend": dist.get_backend()}))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
