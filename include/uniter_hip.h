@@ -155,7 +155,10 @@ int uniter_gemm_wgrad_ld(const void* dy, int64_t lddy, const void* x, int64_t ld
 
 /* ------------------------------------------------------------------------------------------------
  * Fused self-attention (scale + additive key mask + softmax + dropout + P·V), head_dim fixed at 64,
- * L <= 256.  qkv is the fused projection output [B*L, 3H] = [Q | K | V], head h owns columns
+ * L <= 512 (max_position_embeddings of the shipped configs; pretrain.py:637-640).  Up to L = 256 one workgroup per
+ * (example, head) keeps Q, K, V, dO in LDS for the backward pass; beyond, the backward pass is two launches (dQ, then
+ * dK / dV) and needs the small workspace of uniter_attention_bwd_workspace_bytes — use uniter_attention_bwd_ws.
+ * qkv is the fused projection output [B*L, 3H] = [Q | K | V], head h owns columns
  * h*64..h*64+63 of each third.  mask_bias[B,L] fp32 is the reference's extended_attention_mask
  * (1-m)*-10000 (model/model.py:342-345) without the two singleton dims.   model/layer.py:75-101
  * ---------------------------------------------------------------------------------------------- */
@@ -169,8 +172,15 @@ int uniter_attention_bwd(const void* qkv, const float* mask_bias, const void* ct
                          int64_t B, int64_t L, int64_t heads,
                          float p_drop, uint64_t seed, uint64_t offset, void* stream);
 
+/* Backward with a caller workspace (required for 256 < L <= 512, 0 bytes otherwise).  Dense: mask_bias != NULL,
+ * cu_seqlens == NULL; packed: cu_seqlens != NULL (mask_bias ignored) and L = the longest example. */
+size_t uniter_attention_bwd_workspace_bytes(int64_t B, int64_t L, int64_t heads);
+int uniter_attention_bwd_ws(const void* qkv, const float* mask_bias, const int32_t* cu_seqlens, const void* ctx, const float* lse,
+                            const void* dctx, void* dqkv, int64_t B, int64_t L, int64_t heads,
+                            float p_drop, uint64_t seed, uint64_t offset, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Packed ("varlen") forms: qkv [total, 3H], ctx / dctx [total, H], dqkv [total, 3H]; example b owns rows
- * cu_seqlens[b] .. cu_seqlens[b+1]-1 (device int32 [B+1]); max_len = longest example (<= 256); lse [B, heads, max_len].
+ * cu_seqlens[b] .. cu_seqlens[b+1]-1 (device int32 [B+1]); max_len = longest example (<= 256 for the backward entry below, <= 512 through uniter_attention_bwd_ws); lse [B, heads, max_len].
  * No key mask: only real tokens exist. */
 int uniter_attention_fwd_packed(const void* qkv, const int32_t* cu_seqlens, void* ctx, float* lse,
                                 int64_t B, int64_t max_len, int64_t heads,
@@ -351,6 +361,7 @@ typedef struct UniterEncoderShape {
      * compact order; data/sampler.py:31-57 batches by token count). */
     int64_t total_tokens;
     const int32_t* cu_seqlens;
+    int32_t hidden_act;  /* config.hidden_act (model/layer.py:44 ACT2FN): 0 = gelu (exact erf form), 1 = relu, 2 = swish */
 } UniterEncoderShape;
 
 /* Bytes of saved activations per layer / of shared scratch, for the caller to allocate. */

@@ -63,12 +63,20 @@ def self_attention(x, ext_mask, sd, prefix, num_heads):
     return ctx.permute(0, 2, 1, 3).contiguous().view(B, L, H)       # :98-100
 
 
-def bert_layer(x, ext_mask, sd, prefix, num_heads):
+def swish(x):
+    """model/layer.py:40-41."""
+    return x * torch.sigmoid(x)
+
+
+ACT2FN = {"gelu": gelu, "relu": F.relu, "swish": swish}           # model/layer.py:44
+
+
+def bert_layer(x, ext_mask, sd, prefix, num_heads, act="gelu"):
     """model/layer.py:166-170 BertLayer.forward = attention (:124-127) -> intermediate (:139-142) -> output (:152-156)."""
     ctx = self_attention(x, ext_mask, sd, prefix + 'attention.self.', num_heads)
     a = linear(ctx, sd[prefix + 'attention.output.dense.weight'], sd[prefix + 'attention.output.dense.bias'])
     a = layer_norm(a + x, sd[prefix + 'attention.output.LayerNorm.weight'], sd[prefix + 'attention.output.LayerNorm.bias'])
-    i = gelu(linear(a, sd[prefix + 'intermediate.dense.weight'], sd[prefix + 'intermediate.dense.bias']))
+    i = ACT2FN[act](linear(a, sd[prefix + 'intermediate.dense.weight'], sd[prefix + 'intermediate.dense.bias']))   # :134-142
     o = linear(i, sd[prefix + 'output.dense.weight'], sd[prefix + 'output.dense.bias'])
     return layer_norm(o + a, sd[prefix + 'output.LayerNorm.weight'], sd[prefix + 'output.LayerNorm.bias'])
 
@@ -121,7 +129,8 @@ def uniter_model(sd, cfg, input_ids, position_ids, img_feat, img_pos_feat, atten
         h = torch.gather(torch.cat([txt, img], dim=1), dim=1, index=idx)
     outs = []
     for l in range(cfg['num_hidden_layers']):                                       # :282-292
-        h = bert_layer(h, ext_mask, sd, '%sencoder.layer.%d.' % (prefix, l), cfg['num_attention_heads'])
+        h = bert_layer(h, ext_mask, sd, '%sencoder.layer.%d.' % (prefix, l), cfg['num_attention_heads'],
+                       act=cfg.get('hidden_act', 'gelu'))
         outs.append(h)
     return outs if all_layers else h
 
@@ -148,7 +157,8 @@ def mlm_loss(sd, cfg, batch):
     picked = batch['txt_labels'] != -1
     h = txt_part[picked]
     t = 'cls.predictions.transform.'
-    h = layer_norm(gelu(linear(h, sd[t + 'dense.weight'], sd[t + 'dense.bias'])),
+    act = ACT2FN[cfg.get('hidden_act', 'gelu')]                                     # model/layer.py:192-195
+    h = layer_norm(act(linear(h, sd[t + 'dense.weight'], sd[t + 'dense.bias'])),
                    sd[t + 'LayerNorm.weight'], sd[t + 'LayerNorm.bias'])
     scores = linear(h, sd['uniter.embeddings.word_embeddings.weight']) + sd['cls.predictions.bias']
     return F.cross_entropy(scores, batch['txt_labels'][picked], reduction='none'), seq

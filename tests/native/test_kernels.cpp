@@ -139,9 +139,10 @@ static float drop_mult(float p, uint64_t seed, uint64_t offset, uint64_t elem) {
 }
 // element index of attention probability (row = (b,h,query), key j) in the dropout stream: one 8-element group holds the
 // 4 keys 4g..4g+3 of both tiles of a key-tile pair (attention.hip)
-static uint64_t attn_drop_elem(uint64_t row, int j) {
+static uint64_t attn_drop_elem(uint64_t row, int j, int L) {
     const int u = j >> 5, hf = (j >> 4) & 1, g = (j & 15) >> 2, r = j & 3;
-    return ((row * 8 + (uint64_t)u) * 4 + (uint64_t)g) * 8 + (uint64_t)(4 * hf + r);
+    const uint64_t pairs = L > 256 ? 16 : 8;      // element groups per query row (attention.hip pair_stride)
+    return ((row * pairs + (uint64_t)u) * 4 + (uint64_t)g) * 8 + (uint64_t)(4 * hf + r);
 }
 static float gelu_h(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
 static float gelu_grad_h(float x) {
@@ -404,7 +405,9 @@ static void test_attention(int B, int L, int heads, float p) {
     HIPCHK(hipMemset(dDQKV, 0xff, T * 3 * H * 2));
     const uint64_t seed = 99, off = 5;
     UHCHK(uniter_attention_fwd(dQKV, dMask, dCtx, dLse, B, L, heads, p, seed, off, 0));
-    UHCHK(uniter_attention_bwd(dQKV, dMask, dCtx, dLse, dDO, dDQKV, B, L, heads, p, seed, off, 0));
+    const size_t awsb = uniter_attention_bwd_workspace_bytes(B, L, heads);
+    void* aws = dalloc<char>(awsb + 16);
+    UHCHK(uniter_attention_bwd_ws(dQKV, dMask, nullptr, dCtx, dLse, dDO, dDQKV, B, L, heads, p, seed, off, aws, awsb, 0));
     HIPCHK(hipDeviceSynchronize());
 
     std::vector<float> ctx_ref(T * H, 0.f), lse_ref((size_t)B * heads * L), dqkv_ref(T * 3 * H, 0.f);
@@ -429,7 +432,7 @@ static void test_attention(int B, int L, int heads, float p) {
                 lse_ref[(size_t)bh * L + i] = mx + logf(sum);
                 for (int j = 0; j < L; ++j) {
                     P[(size_t)i * L + j] /= sum;
-                    const uint64_t elem = attn_drop_elem((uint64_t)bh * L + i, j);
+                    const uint64_t elem = attn_drop_elem((uint64_t)bh * L + i, j, L);
                     Pd[(size_t)i * L + j] = P[(size_t)i * L + j] * drop_mult(p, seed, off, elem);
                 }
                 for (int d = 0; d < 64; ++d) {
@@ -445,7 +448,7 @@ static void test_attention(int B, int L, int heads, float p) {
                 for (int j = 0; j < L; ++j) {
                     float dp = 0;
                     for (int d = 0; d < 64; ++d) dp += DO.v[((size_t)b * L + i) * H + h * 64 + d] * v(j, d);
-                    const uint64_t elem = attn_drop_elem((uint64_t)bh * L + i, j);
+                    const uint64_t elem = attn_drop_elem((uint64_t)bh * L + i, j, L);
                     const float mult = drop_mult(p, seed, off, elem);
                     dPd[(size_t)i * L + j] = P[(size_t)i * L + j] * (dp * mult - Di) * 0.125f;   // dS * scale
                 }
@@ -1128,6 +1131,9 @@ int main(int argc, char** argv) {
     test_attention(2, 178, 2, 0.1f);
     test_attention(1, 250, 1, 0.f);
     test_attention(2, 17, 1, 0.1f);
+    test_attention(2, 260, 2, 0.1f);          // 60 text + 2 x 100 regions (the NLVR2 triplet format): the split backward
+    test_attention(1, 384, 1, 0.f);
+    test_attention(1, 512, 2, 0.1f);
     printf("== layernorm ==\n");
     printf("== grouped weight gradients ==\n");
     test_wgrad_group(320);

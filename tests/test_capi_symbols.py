@@ -38,9 +38,9 @@ def test_argument_errors_are_reported_not_thrown():
     assert rc < 0
     assert b"null pointer" in lib.uniter_hip_last_error()
     s = _lib.UniterEncoderShape()
-    s.B, s.L, s.H, s.heads, s.I = 2, 300, 128, 2, 128
-    assert lib.uniter_encoder_layer_act_bytes(ctypes.byref(s)) == 0          # L > 256 is rejected
-    assert b"256" in lib.uniter_hip_last_error()
+    s.B, s.L, s.H, s.heads, s.I = 2, 600, 128, 2, 128
+    assert lib.uniter_encoder_layer_act_bytes(ctypes.byref(s)) == 0          # L > 512 (max_position_embeddings) is rejected
+    assert b"512" in lib.uniter_hip_last_error()
     s.L = 96
     assert lib.uniter_encoder_layer_act_bytes(ctypes.byref(s)) > 0
     assert lib.uniter_encoder_scratch_bytes(ctypes.byref(s)) > 0

@@ -1281,3 +1281,92 @@ def test_large_full_depth_vqa_vs_oracle(tmp_path):
         p.grad = None
     (model(d, compute_loss=True).float().mean() * N_ANS).backward()
     _check_all_grads(dict(model.named_parameters()), leaf, ygrads, scale=1.0 / N_ANS, min_checked=390)
+
+
+def test_long_sequences_up_to_512_dense_and_packed_vs_oracle(tmp_path):
+    """L = 284 text + 100 regions = 384 (max_position_embeddings is 512, pretrain.py:637-640; the NLVR2 triplet format of
+    60 + 2 x 100 tokens already exceeds 256): the forward kernel keeps a 512-key score row in registers and the backward pass
+    is the two-launch form.  Dense and packed execution against the oracle and against each other."""
+    import json
+    from uniter_amd.model.pretrain import UniterForPretraining
+    from uniter_amd.utils.synthetic import make_batch
+    cfg = dict(BASE_CFG, num_hidden_layers=2, hidden_size=256, num_attention_heads=4, intermediate_size=512)
+    path = tmp_path / "long.json"
+    path.write_text(json.dumps(cfg))
+    torch.manual_seed(5)
+    model = UniterForPretraining.from_pretrained(str(path), {}, img_dim=2048, img_label_dim=1601)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(6)
+        for n, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn(p.shape, generator=g) * 0.02)
+            p.copy_(p.to(torch.bfloat16).float())
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    batch = make_batch('mlm', 3, max_txt_len=284, num_bb=100, seed=4, ragged=True, min_txt_len=200, min_bb=60)
+    assert 256 < batch['attn_masks'].shape[1] <= 384           # longest example of the ragged batch: beyond the one-launch limit
+    valid = batch['attn_masks'].bool()
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != 'cls.predictions.decoder.weight'}
+    leaf['cls.predictions.decoder.weight'] = leaf['uniter.embeddings.word_embeddings.weight']
+    ref_loss, ref_seq = O.mlm_loss(leaf, cfg, batch)
+    ref_loss.mean().backward()
+    _prep(model)
+    d = _to_dev(batch)
+    _, yseq, ygrads = _yardstick(O.mlm_loss, sd, cfg, batch)
+    outs = {}
+    for pack in (False, True):
+        model.uniter.pack_padding = pack
+        for p in model.parameters():
+            p.grad = None
+        seq = model.uniter(d['input_ids'], d['position_ids'], d['img_feat'], d['img_pos_feat'], d['attn_masks'],
+                           d['gather_index'], output_all_encoded_layers=False)
+        _check_hidden(seq.detach()[valid.to(seq.device)], ref_seq.detach()[valid], "L=384 hidden (pack=%s)" % pack, yseq[valid])
+        loss = model(d, task='mlm', compute_loss=True)
+        _check_loss(loss, ref_loss.detach(), atol=3e-2)
+        loss.float().mean().backward()
+        _check_all_grads(dict(model.named_parameters()), leaf, ygrads, min_checked=40)
+        outs[pack] = seq.detach().float().cpu()
+    model.uniter.pack_padding = False
+    torch.testing.assert_close(outs[True][valid], outs[False][valid], rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("act", ["relu", "swish"])
+def test_hidden_act_relu_and_swish_vs_oracle(tmp_path, act):
+    """config.hidden_act other than gelu (model/layer.py:44 ACT2FN): the FFN epilogues switch activation, the MLM head's
+    transform falls back to the module path."""
+    import json
+    from uniter_amd.model.pretrain import UniterForPretraining
+    from uniter_amd.utils.synthetic import make_batch
+    cfg = dict(BASE_CFG, num_hidden_layers=2, hidden_size=256, num_attention_heads=4, intermediate_size=512, hidden_act=act)
+    path = tmp_path / "act.json"
+    path.write_text(json.dumps(cfg))
+    torch.manual_seed(15)
+    model = UniterForPretraining.from_pretrained(str(path), {}, img_dim=2048, img_label_dim=1601)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(16)
+        for n, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn(p.shape, generator=g) * 0.02)
+            elif 'intermediate' in n:
+                p.mul_(4.0)                                    # larger pre-activations so that the non-linearity matters
+            p.copy_(p.to(torch.bfloat16).float())
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    batch = make_batch('mlm', 4, seed=17, ragged=True)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != 'cls.predictions.decoder.weight'}
+    leaf['cls.predictions.decoder.weight'] = leaf['uniter.embeddings.word_embeddings.weight']
+    ref_loss, ref_seq = O.mlm_loss(leaf, cfg, batch)
+    ref_loss.mean().backward()
+    gelu_seq = O.mlm_loss({k: v.detach() for k, v in leaf.items()}, dict(cfg, hidden_act='gelu'), batch)[1]
+    valid = batch['attn_masks'].bool()
+    assert float((gelu_seq - ref_seq.detach())[valid].abs().max()) > 0.1      # the activation really changes the result
+    _prep(model)
+    d = _to_dev(batch)
+    seq = model.uniter(d['input_ids'], d['position_ids'], d['img_feat'], d['img_pos_feat'], d['attn_masks'],
+                       d['gather_index'], output_all_encoded_layers=False)
+    _, yseq, ygrads = _yardstick(O.mlm_loss, sd, cfg, batch)
+    _check_hidden(seq.detach()[valid.to(seq.device)], ref_seq.detach()[valid], "hidden_act=%s" % act, yseq[valid])
+    loss = model(d, task='mlm', compute_loss=True)
+    _check_loss(loss, ref_loss.detach(), atol=3e-2)
+    for p in model.parameters():
+        p.grad = None
+    model(d, task='mlm', compute_loss=True).mean().backward()
+    _check_all_grads(dict(model.named_parameters()), leaf, ygrads, min_checked=40)

@@ -34,7 +34,7 @@ class UniterHeadParams(Structure):
 class UniterEncoderShape(Structure):
     _fields_ = [("B", c_int64), ("L", c_int64), ("H", c_int64), ("heads", c_int64), ("I", c_int64),
                 ("p_hidden", c_float), ("p_attn", c_float), ("ln_eps", c_float), ("training", c_int32),
-                ("total_tokens", c_int64), ("cu_seqlens", c_void_p)]
+                ("total_tokens", c_int64), ("cu_seqlens", c_void_p), ("hidden_act", c_int32)]
 
 
 class UniterAdamTensor(Structure):
@@ -93,6 +93,8 @@ SIGNATURES = {
     "uniter_gemm_wgrad_group_autotune": (c_int, [c_int32, _I, _P, _P, _P]),
     "uniter_attention_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
     "uniter_attention_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
+    "uniter_attention_bwd_workspace_bytes": (c_size_t, [_I, _I, _I]),
+    "uniter_attention_bwd_ws": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P, c_size_t, _P]),
     "uniter_attention_fwd_packed": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
     "uniter_attention_bwd_packed": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
     "uniter_layernorm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, c_float, c_float, c_uint64, c_uint64, _P]),

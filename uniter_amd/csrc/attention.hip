@@ -19,7 +19,8 @@
 namespace {
 
 constexpr int DH = 64;
-constexpr int LMAX = 256;
+constexpr int LMAX = 256;      // one workgroup holds Q, K, V, dO of a head in LDS up to here (backward); dropout group stride
+constexpr int LLONG = 512;     // forward and the split backward (attn_bwd_dq_kernel / attn_bwd_dkv_kernel) reach this
 
 __device__ __forceinline__ int at_off8(int r, int ch8) { return r * 64 + ((ch8 ^ (((r >> 1) & 3) << 2)) << 2); }
 
@@ -65,28 +66,35 @@ __device__ __forceinline__ void load_tile(bf16_t* tile, const bf16_t* src, int64
 // a load -> wait -> write loop would pay one full memory round trip per iteration and tile (measured: 10 serialized
 // round trips were most of the backward kernel's 20 us).
 constexpr int TILE_IT = 4;
-__device__ __forceinline__ void tile_fetch(u32x4 (&r)[TILE_IT], const bf16_t* src, int64_t ld, int L, int Lp) {
+template <int NIT>
+__device__ __forceinline__ void tile_fetch(u32x4 (&r)[NIT], const bf16_t* src, int64_t ld, int L, int Lp) {
 #pragma unroll
-    for (int it = 0; it < TILE_IT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int idx = threadIdx.x + it * blockDim.x;
         const int row = idx >> 3, c = idx & 7;
         r[it] = u32x4{0u, 0u, 0u, 0u};
         if (idx < Lp * 8 && row < L) r[it] = *reinterpret_cast<const u32x4*>(src + (int64_t)row * ld + c * 8);
     }
 }
-__device__ __forceinline__ void tile_commit(bf16_t* tile, const u32x4 (&r)[TILE_IT], int Lp) {
+template <int NIT>
+__device__ __forceinline__ void tile_commit(bf16_t* tile, const u32x4 (&r)[NIT], int Lp) {
 #pragma unroll
-    for (int it = 0; it < TILE_IT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int idx = threadIdx.x + it * blockDim.x;
         if (idx < Lp * 8) *reinterpret_cast<u32x4*>(tile + at_off8(idx >> 3, 2 * (idx & 7))) = r[it];
     }
 }
+
+// dropout element groups per query row: one per pair of 16-key tiles, 8 up to L = 256 (the layout every shorter sequence
+// has always used), 16 beyond
+__host__ __device__ __forceinline__ int pair_stride(int Lm) { return Lm > LMAX ? LLONG / 32 : LMAX / 32; }
 
 struct AttnArgs {
     const bf16_t* qkv;
     const float* mask_bias;
     bf16_t* ctx;        // fwd: out ; bwd: forward output (for D = rowsum(dO*O))
     float* lse;
+    float* dsum;        // long backward: D[q] = sum_d dO*O, written by the dQ kernel for the dK/dV kernel  [B*heads, L]
     const bf16_t* dctx;
     bf16_t* dqkv;
     int B, L, heads, Lp;   // L = rows per example (dense) or the longest example (packed); Lp = L rounded up to 32
@@ -131,7 +139,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
     bf16x8 qf[2] = {};
     if (wid < nqt) fetch_q(wid, qf);
     {
-        u32x4 rk[TILE_IT], rv[TILE_IT];
+        constexpr int NIT = MAXKT > 16 ? 2 * TILE_IT : TILE_IT;
+        u32x4 rk[NIT], rv[NIT];
         tile_fetch(rk, base + H, ld, L, Lp);
         tile_fetch(rv, base + 2 * H, ld, L, Lp);
         float mbv[2];
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
         // dropout: one Philox call covers this lane's 4 keys in BOTH tiles of a key-tile pair (element group
         // ((b,h,q) * 8 + pair) * 4 + g; fields 0-3 = tile 2u, 4-7 = tile 2u+1) — the backward pass indexes the same way
         const bool drop = p.drop.p > 0.f;
-        const uint64_t drow = ((uint64_t)bh * (uint64_t)Lm + (uint64_t)q) * (LMAX / 32);
+        const uint64_t drow = ((uint64_t)bh * (uint64_t)Lm + (uint64_t)q) * (uint64_t)pair_stride(Lm);
 #pragma unroll
         for (int u = 0; u < MAXKT / 2; ++u) {
             if (2 * u < nkt) {
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
         const bf16x8 qf0 = at_frag(Qs, q, 0, g), qf1 = at_frag(Qs, q, 1, g);
         const bf16x8 of0 = at_frag(Os, q, 0, g), of1 = at_frag(Os, q, 1, g);
         const float lse_q = lse_s[q], D_q = D_s[q];
-        const uint64_t drow = ((uint64_t)bh * (uint64_t)Lm + (uint64_t)q) * (LMAX / 32);
+        const uint64_t drow = ((uint64_t)bh * (uint64_t)Lm + (uint64_t)q) * (uint64_t)pair_stride(Lm);
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -419,6 +428,220 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward for 256 < L <= 512: Q, K, V and dO of a head no longer fit one CU's LDS together, so the two sweeps of
+// attn_bwd_kernel become two launches that each keep only the operands they re-read in LDS (K, V / Q, dO: 128 KiB at
+// L = 512) and take their own 16-row tile straight from global memory as MFMA fragments.  The dropout keep bits are
+// regenerated from Philox in both (the L x L/4 nibble cache would not fit either).  Same arithmetic per element as the
+// one-launch kernel.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void frag_global(const bf16_t* base, int64_t ld, int row, int L, int g, bf16x8 (&f)[2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < L) v = *reinterpret_cast<const u32x4*>(base + (int64_t)row * ld + ks * 32 + g * 8);
+        f[ks] = __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+// query-tile owners -> dQ (and D[q] for the second launch)
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int Lp = p.Lp, Lm = p.L;
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* Vs = Ks + Lp * 64;
+    float* mb = reinterpret_cast<float*>(Vs + Lp * 64);
+    const int bh = blockIdx.x;
+    const int b = bh / p.heads, h = bh % p.heads;
+    const int H = p.heads * DH;
+    const int64_t ld = 3 * (int64_t)H;
+    const int64_t row0 = p.cu ? (int64_t)p.cu[b] : (int64_t)b * Lm;
+    const int L = p.cu ? (p.cu[b + 1] - p.cu[b]) : Lm;
+    const bf16_t* base = p.qkv + row0 * ld + h * DH;
+    const bf16_t* dO = p.dctx + row0 * H + h * DH;
+    const bf16_t* O = p.ctx + row0 * H + h * DH;
+    {
+        u32x4 rk[2 * TILE_IT], rv[2 * TILE_IT];
+        tile_fetch(rk, base + H, ld, L, Lp);
+        tile_fetch(rv, base + 2 * H, ld, L, Lp);
+        float mbv[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int k = threadIdx.x + it * blockDim.x;
+            mbv[it] = (k < L) ? (p.mask_bias ? p.mask_bias[(int64_t)b * Lm + k] : 0.f) : -INFINITY;
+        }
+        tile_commit(Ks, rk, Lp);
+        tile_commit(Vs, rv, Lp);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int k = threadIdx.x + it * blockDim.x;
+            if (k < Lp) mb[k] = mbv[it];
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int npair = Lp >> 5;
+    const int nt = (L + 15) >> 4;
+    const bool drop = p.drop.p > 0.f;
+    for (int qt = wid; qt < nt; qt += nw) {
+        const int q = qt * 16 + i;
+        bf16x8 qf[2], of[2], oo[2];
+        frag_global(base, ld, q, L, g, qf);
+        frag_global(dO, H, q, L, g, of);
+        frag_global(O, H, q, L, g, oo);
+        // D[q] = sum_d dO*O: this lane holds 16 of the 64 columns of row q, the other three lane groups the rest
+        float D_q = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) D_q += (float)of[ks][e] * (float)oo[ks][e];
+        D_q += __shfl_xor(D_q, 16, WAVE);
+        D_q += __shfl_xor(D_q, 32, WAVE);
+        if (g == 0 && q < L) p.dsum[(int64_t)bh * Lm + q] = D_q;
+        const float lse_q = (q < L) ? p.lse[(int64_t)bh * Lm + q] : INFINITY;
+        const uint64_t drow = ((uint64_t)bh * (uint64_t)Lm + (uint64_t)q) * (uint64_t)pair_stride(Lm);
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < npair; ++u) {
+            float ds[2][4];
+            const uint32_t keep8 = drop ? dropout_keep8(p.drop, (drow + (uint64_t)u) * 4 + (uint64_t)g) : 0xffu;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int kt = 2 * u + hf;
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Ks, kt * 16 + i, 0, g), qf[0], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Ks, kt * 16 + i, 1, g), qf[1], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Vs, kt * 16 + i, 0, g), of[0], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Vs, kt * 16 + i, 1, g), of[1], dp, 0, 0, 0);
+                const f32x4 mv = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
+                const uint32_t keep = (keep8 >> (4 * hf)) & 0xfu;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float mult = drop ? (((keep >> r) & 1u) ? p.drop.scale : 0.f) : 1.f;
+                    const float pr = __expf(s[r] * 0.125f + mv[r] - lse_q);
+                    ds[hf][r] = pr * (dp[r] * mult - D_q) * 0.125f;
+                }
+            }
+            const bf16x8 dsf = pack_frag(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Ks, u, dt, g, i), dsf, dq[dt], 0, 0, 0);
+        }
+        if (q < L) {
+            bf16_t* dst = p.dqkv + (row0 + q) * ld + h * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const float v[4] = {dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]};
+                __builtin_nontemporal_store(pack4(v), reinterpret_cast<u32x2*>(dst + dt * 16));
+            }
+        }
+    }
+}
+
+// key-tile owners -> dK, dV
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int Lp = p.Lp, Lm = p.L;
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* Os = Qs + Lp * 64;            // dO
+    float* lse_s = reinterpret_cast<float*>(Os + Lp * 64);
+    float* D_s = lse_s + Lp;
+    const int bh = blockIdx.x;
+    const int b = bh / p.heads, h = bh % p.heads;
+    const int H = p.heads * DH;
+    const int64_t ld = 3 * (int64_t)H;
+    const int64_t row0 = p.cu ? (int64_t)p.cu[b] : (int64_t)b * Lm;
+    const int L = p.cu ? (p.cu[b + 1] - p.cu[b]) : Lm;
+    const bf16_t* base = p.qkv + row0 * ld + h * DH;
+    const bf16_t* dO = p.dctx + row0 * H + h * DH;
+    {
+        u32x4 rq[2 * TILE_IT], rdo[2 * TILE_IT];
+        tile_fetch(rq, base, ld, L, Lp);
+        tile_fetch(rdo, dO, H, L, Lp);
+        float lsv[2], dv2[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int k = threadIdx.x + it * blockDim.x;
+            lsv[it] = (k < L) ? p.lse[(int64_t)bh * Lm + k] : INFINITY;
+            dv2[it] = (k < L) ? p.dsum[(int64_t)bh * Lm + k] : 0.f;
+        }
+        tile_commit(Qs, rq, Lp);
+        tile_commit(Os, rdo, Lp);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int k = threadIdx.x + it * blockDim.x;
+            if (k < Lp) { lse_s[k] = lsv[it]; D_s[k] = dv2[it]; }
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int npair = Lp >> 5;
+    const int nt = (L + 15) >> 4;
+    const bool drop = p.drop.p > 0.f;
+    const int pstride = pair_stride(Lm);
+    for (int kt = wid; kt < nt; kt += nw) {
+        const int key = kt * 16 + i;
+        bf16x8 kf[2], vf[2];
+        frag_global(base + H, ld, key, L, g, kf);
+        frag_global(base + 2 * H, ld, key, L, g, vf);
+        const float mb_k = (key < L) ? (p.mask_bias ? p.mask_bias[(int64_t)b * Lm + key] : 0.f) : -INFINITY;
+        // position of this lane's key inside the forward's dropout groups: pair kt/2, lane group (key%16)/4, field
+        const uint64_t kgrp = (uint64_t)(kt >> 1);
+        const uint32_t kg = (uint32_t)((key & 15) >> 2);
+        const int kfield = (kt & 1) * 4 + (key & 3);
+        f32x4 dk[4], dv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int u = 0; u < npair; ++u) {
+            float ds[2][4], pd[2][4];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int qt = 2 * u + hf;
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Qs, qt * 16 + i, 0, g), kf[0], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Qs, qt * 16 + i, 1, g), kf[1], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Os, qt * 16 + i, 0, g), vf[0], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Os, qt * 16 + i, 1, g), vf[1], dp, 0, 0, 0);
+                const int qb = qt * 16 + 4 * g;
+                const f32x4 lv = *reinterpret_cast<const f32x4*>(lse_s + qb);
+                const f32x4 Dv = *reinterpret_cast<const f32x4*>(D_s + qb);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float mult = 1.f;
+                    if (drop) {
+                        const uint64_t drow = ((uint64_t)bh * (uint64_t)Lm + (uint64_t)(qb + r)) * (uint64_t)pstride;
+                        const u32x4 bits = dropout_bits8(p.drop, (drow + kgrp) * 4 + (uint64_t)kg);
+                        mult = dropout_keep_field(p.drop, bits, kfield) ? p.drop.scale : 0.f;
+                    }
+                    const float pr = __expf(s[r] * 0.125f + mb_k - lv[r]);
+                    pd[hf][r] = pr * mult;
+                    ds[hf][r] = pr * (dp[r] * mult - Dv[r]) * 0.125f;
+                }
+            }
+            const bf16x8 pdf = pack_frag(pd[0], pd[1]);
+            const bf16x8 dsf = pack_frag(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Os, u, dt, g, i), pdf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Qs, u, dt, g, i), dsf, dk[dt], 0, 0, 0);
+            }
+        }
+        if (key < L) {
+            bf16_t* dst = p.dqkv + (row0 + key) * ld + h * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const float kv[4] = {dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]};
+                const float vv[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
+                __builtin_nontemporal_store(pack4(kv), reinterpret_cast<u32x2*>(dst + H + dt * 16));
+                __builtin_nontemporal_store(pack4(vv), reinterpret_cast<u32x2*>(dst + 2 * H + dt * 16));
+            }
+        }
+    }
+}
+
 int pick_waves(int nt) {
     const int rounds = (nt + 7) / 8;
     for (int w = 1; w <= 8; ++w)
@@ -442,7 +665,7 @@ namespace uh {
 
 static int check(int64_t B, int64_t L, int64_t heads) {
     if (B <= 0 || L <= 0 || heads <= 0) { uh_set_error("attention: non-positive dimension"); return -1; }
-    if (L > LMAX) { uh_set_error("attention: L=%lld exceeds the supported maximum %d", (long long)L, LMAX); return -1; }
+    if (L > LLONG) { uh_set_error("attention: L=%lld exceeds the supported maximum %d", (long long)L, LLONG); return -1; }
     if (B * heads > INT32_MAX) { uh_set_error("attention: grid too large"); return -1; }
     return 0;
 }
@@ -459,12 +682,16 @@ int attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse
     a.cu = cu;
     if (cu == nullptr && mask_bias == nullptr) { uh_set_error("attention: dense mode needs mask_bias"); return -1; }
     const int nkt = a.Lp / 16;
-    const int nw = pick_waves((int)((L + 15) / 16));
-    if (a.Lp * 8 > TILE_IT * nw * 64 || a.Lp > 2 * nw * 64) { uh_set_error("attention: prologue staging does not cover L=%lld with %d waves", (long long)L, nw); return -1; }
+    const int nw = L > LMAX ? 8 : pick_waves((int)((L + 15) / 16));
+    const int nit = L > LMAX ? 2 * TILE_IT : TILE_IT;
+    if (a.Lp * 8 > nit * nw * 64 || a.Lp > 2 * nw * 64) { uh_set_error("attention: prologue staging does not cover L=%lld with %d waves", (long long)L, nw); return -1; }
     const size_t lds = (size_t)a.Lp * 64 * 2 * 2 + (size_t)a.Lp * 4;
     dim3 grid((unsigned)(B * heads)), block(nw * 64);
     int rc;
-    if (nkt <= 6) {
+    if (nkt > 16) {            // 256 < L <= 512: the whole score row of a query tile in registers (128 accumulators)
+        if ((rc = set_lds(attn_fwd_kernel<32>, lds))) return rc;
+        hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, lds, st, a);
+    } else if (nkt <= 6) {
         if ((rc = set_lds(attn_fwd_kernel<6>, lds))) return rc;
         hipLaunchKernelGGL(attn_fwd_kernel<6>, grid, block, lds, st, a);
     } else if (nkt <= 8) {
@@ -481,9 +708,13 @@ int attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse
     return 0;
 }
 
+size_t attention_bwd_workspace_bytes(int64_t B, int64_t L, int64_t heads) {
+    return L > LMAX ? (size_t)B * (size_t)heads * (size_t)L * sizeof(float) : 0;
+}
+
 int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, const float* lse,
                   const void* dctx, void* dqkv, int64_t B, int64_t L, int64_t heads,
-                  const DropoutCfg& drop, hipStream_t st, const int32_t* cu) {
+                  const DropoutCfg& drop, hipStream_t st, const int32_t* cu, void* workspace) {
     if (check(B, L, heads)) return -1;
     LaunchTimer lt(TIME_ATTN_BWD, B, L, heads, st);
     AttnArgs a{};
@@ -493,6 +724,20 @@ int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, cons
     a.drop = drop;
     a.cu = cu;
     if (cu == nullptr && mask_bias == nullptr) { uh_set_error("attention: dense mode needs mask_bias"); return -1; }
+    if (L > LMAX) {            // two launches: dQ (+ D) with K, V in LDS, then dK / dV with Q, dO in LDS
+        if (workspace == nullptr) { uh_set_error("attention_bwd: L > %d needs the workspace of uniter_attention_bwd_workspace_bytes", LMAX); return -1; }
+        a.dsum = (float*)workspace;
+        const size_t lds1 = (size_t)a.Lp * 64 * 2 * 2 + (size_t)a.Lp * 4;
+        const size_t lds2 = (size_t)a.Lp * 64 * 2 * 2 + (size_t)a.Lp * 4 * 2;
+        int rc2;
+        if ((rc2 = set_lds(attn_bwd_dq_kernel, lds1))) return rc2;
+        if ((rc2 = set_lds(attn_bwd_dkv_kernel, lds2))) return rc2;
+        hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(B * heads)), dim3(512), lds1, st, a);
+        UH_LAUNCH_CHECK();
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(B * heads)), dim3(512), lds2, st, a);
+        UH_LAUNCH_CHECK();
+        return 0;
+    }
     const int nw = pick_waves((int)((L + 15) / 16));
     if (a.Lp * 8 > TILE_IT * nw * 64 || a.Lp > 2 * nw * 64) { uh_set_error("attention: prologue staging does not cover L=%lld with %d waves", (long long)L, nw); return -1; }
     const size_t lds = (size_t)a.Lp * 64 * 2 * 4 + (size_t)a.Lp * 4 * 3 + (size_t)a.Lp * (a.Lp / 4);

@@ -272,6 +272,20 @@ int uniter_attention_bwd(const void* qkv, const float* mask_bias, const void* ct
                              (hipStream_t)stream);
 }
 
+size_t uniter_attention_bwd_workspace_bytes(int64_t B, int64_t L, int64_t heads) {
+    return uh::attention_bwd_workspace_bytes(B, L, heads);
+}
+
+int uniter_attention_bwd_ws(const void* qkv, const float* mask_bias, const int32_t* cu_seqlens, const void* ctx, const float* lse,
+                            const void* dctx, void* dqkv, int64_t B, int64_t L, int64_t heads,
+                            float p_drop, uint64_t seed, uint64_t offset, void* workspace, size_t workspace_bytes, void* stream) {
+    UH_CHECK_ARG(qkv && (mask_bias || cu_seqlens) && ctx && lse && dctx && dqkv, "null pointer");
+    UH_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "dropout probability must be in [0,1)");
+    UH_CHECK_ARG(workspace_bytes >= uh::attention_bwd_workspace_bytes(B, L, heads), "workspace too small");
+    return uh::attention_bwd(qkv, cu_seqlens ? nullptr : mask_bias, ctx, lse, dctx, dqkv, B, L, heads, make_dropout(p_drop, seed, offset),
+                             (hipStream_t)stream, cu_seqlens, workspace_bytes ? workspace : nullptr);
+}
+
 int uniter_attention_fwd_packed(const void* qkv, const int32_t* cu_seqlens, void* ctx, float* lse,
                                 int64_t B, int64_t max_len, int64_t heads,
                                 float p_drop, uint64_t seed, uint64_t offset, void* stream) {

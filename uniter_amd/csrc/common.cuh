@@ -206,6 +206,19 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return cdf + x * pdf;
 }
 
+// hidden_act of the config (model/layer.py:44 ACT2FN): 0 = gelu (erf form), 1 = relu, 2 = swish (x * sigmoid(x))
+enum { UH_ACT_GELU = 0, UH_ACT_RELU = 1, UH_ACT_SWISH = 2 };
+__device__ __forceinline__ float act_fwd(int act, float x) {
+    if (act == UH_ACT_RELU) return fmaxf(x, 0.f);
+    if (act == UH_ACT_SWISH) return x * __frcp_rn(1.0f + __expf(-x));
+    return gelu_erf(x);
+}
+__device__ __forceinline__ float act_grad(int act, float x) {
+    if (act == UH_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+    if (act == UH_ACT_SWISH) { const float s = __frcp_rn(1.0f + __expf(-x)); return s * (1.0f + x * (1.0f - s)); }
+    return gelu_erf_grad(x);
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side status plumbing for the C ABI
 // ---------------------------------------------------------------------------------------------

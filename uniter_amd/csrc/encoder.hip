@@ -44,7 +44,7 @@ ActLayout act_layout(const UniterEncoderShape& s) {
 }
 
 struct ScratchLayout {
-    size_t bufA, bufB, dd[2], dd1[2], dctx, dqkv[2], dpre[2], red, red2, red_bytes, wg, wg_bytes, total;
+    size_t bufA, bufB, dd[2], dd1[2], dctx, dqkv[2], dpre[2], red, red2, red_bytes, wg, wg_bytes, attn_ws, total;
 };
 ScratchLayout scratch_layout(const UniterEncoderShape& s) {
     const size_t T = tokens(s), H = s.H, I = s.I;
@@ -75,6 +75,7 @@ ScratchLayout scratch_layout(const UniterEncoderShape& s) {
     if (I * H > big) big = I * H;
     l.wg_bytes = big * 8 * sizeof(float);
     l.wg = take(l.wg_bytes);
+    l.attn_ws = take(uh::attention_bwd_workspace_bytes(s.B, s.L, s.heads) + 16);      // D = rowsum(dO*O) of the split backward (L > 256)
     l.total = o;
     return l;
 }
@@ -124,9 +125,10 @@ int check_shape(const UniterEncoderShape* s) {
     if (s->B <= 0 || s->L <= 0 || s->H <= 0 || s->heads <= 0 || s->I <= 0) { uh_set_error("encoder: non-positive dimension"); return -1; }
     if (s->H != s->heads * 64) { uh_set_error("encoder: hidden_size must be heads*64 (H=%lld heads=%lld)", (long long)s->H, (long long)s->heads); return -1; }
     if (s->H % 64 != 0 || s->I % 64 != 0) { uh_set_error("encoder: H and I must be multiples of 64"); return -1; }
-    if (s->L > 256) { uh_set_error("encoder: L=%lld > 256 unsupported", (long long)s->L); return -1; }
+    if (s->L > 512) { uh_set_error("encoder: L=%lld > 512 unsupported", (long long)s->L); return -1; }
     if (s->total_tokens < 0 || s->total_tokens > s->B * s->L) { uh_set_error("encoder: total_tokens must be in [0, B*L]"); return -1; }
     if (s->total_tokens > 0 && s->cu_seqlens == nullptr) { uh_set_error("encoder: packed mode needs cu_seqlens"); return -1; }
+    if (s->hidden_act < 0 || s->hidden_act > 2) { uh_set_error("encoder: hidden_act must be 0 (gelu), 1 (relu) or 2 (swish)"); return -1; }
     return 0;
 }
 
@@ -182,7 +184,7 @@ int uniter_encoder_forward(const UniterEncoderShape* s, const UniterLayerParams*
         RC(uh::layernorm_fwd(A + al.z1, P.ln1_g, P.ln1_b, A + al.a, (float*)(A + al.mean1), (float*)(A + al.rstd1),
                              T, H, s->ln_eps, nodrop, st));
         // model/layer.py:140-141  dense + erf-GELU
-        RC(uh::gemm_fwd(uh::GEMM_EPI_BIAS_GELU, A + al.a, P.w1, P.b1, nullptr, A + al.u, A + al.g, T, I, H, nodrop, st));
+        RC(uh::gemm_fwd(uh::GEMM_EPI_BIAS_GELU, A + al.a, P.w1, P.b1, nullptr, A + al.u, A + al.g, T, I, H, nodrop, st, 0, 0, s->hidden_act));
         // model/layer.py:153-155
         RC(uh::gemm_fwd(uh::GEMM_EPI_BIAS_DROP_RES, A + al.g, P.w2, P.b2, A + al.a, A + al.z2, nullptr, T, H, I, d_h2, st));
         RC(uh::layernorm_fwd(A + al.z2, P.ln2_g, P.ln2_b, A + al.y, (float*)(A + al.mean2), (float*)(A + al.rstd2),
@@ -318,7 +320,7 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
             RC(uh::gemm_wgrad(ddb2, A + al.g, P.g_w2, T, H, I, 1, wg, sl.wg_bytes, ss));
             RC(joined(par));
         }
-        RC(uh::gemm_dgrad(uh::GEMM_EPI_GELU_BWD, ddb2, P.w2, A + al.u, dpre, T, H, I, st));
+        RC(uh::gemm_dgrad(uh::GEMM_EPI_GELU_BWD, ddb2, P.w2, A + al.u, dpre, T, H, I, st, 0, s->hidden_act));
         RC(tick());
         // ---- BertIntermediate backward (model/layer.py:139-142) ----
         if (!grouped) {
@@ -358,7 +360,7 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         RC(tick());
         // ---- BertSelfAttention backward (model/layer.py:75-101) ----
         RC(uh::attention_bwd(A + al.qkv, s->total_tokens > 0 ? nullptr : mask_bias, A + al.ctx, (const float*)(A + al.lse), dctx, dqkv,
-                             s->B, s->L, s->heads, d_attn, st, s->total_tokens > 0 ? s->cu_seqlens : nullptr));
+                             s->B, s->L, s->heads, d_attn, st, s->total_tokens > 0 ? s->cu_seqlens : nullptr, S + sl.attn_ws));
         if (grouped) {
             RC(tick());                        // (a still-pending earlier layer goes first)
             if (pending >= 0) RC(group_launch(pending));

@@ -45,7 +45,8 @@ struct GemmArgs {
     int k_per_split;      // multiple of 64
     int accumulate;       // EPI_WGRAD, splits == 1: C += result
     int xr;               // 2-D XCD blocking: rows of the XCD grid (0 = 1-D contiguous ranges)
-    int relu;             // EPI_BIAS_DROP_RES: clamp at zero after the bias, before the dropout (Linear + ReLU + Dropout heads)
+    int relu;             // EPI_BIAS_DROP_RES: 1 = clamp at zero after the bias, before the dropout (Linear + ReLU + Dropout heads);
+                          // EPI_BIAS_GELU / EPI_GELU_BWD: the activation (UH_ACT_*: 0 = erf GELU, 1 = ReLU, 2 = swish)
 #ifdef UNITER_GEMM_PROBE
     unsigned long long* probe;   // cycle stamps of wave 0 of every workgroup: [block][kt][5] (profiling builds only)
 #endif
@@ -535,7 +536,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                     float uq[8], gq[8];
                     unpack8(uq_bits, uq);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) gq[e] = gelu_erf(uq[e]);
+                    for (int e = 0; e < 8; ++e) gq[e] = act_fwd(p.relu, uq[e]);
                     __builtin_nontemporal_store(pack8(gq), reinterpret_cast<u32x4*>(p.C2 + (int64_t)m * p.ldc + n));
                     continue;
                 }
@@ -563,7 +564,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                     float uv[8];
                     unpack8(*reinterpret_cast<const u32x4*>(p.aux + (int64_t)m * p.ldaux + n), uv);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(uv[e]);
+                    for (int e = 0; e < 8; ++e) v[e] *= act_grad(p.relu, uv[e]);
                 }
                 if (EPI == EPI_WGRAD && p.accumulate) {
                     float ov[8];
@@ -943,7 +944,7 @@ int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void
 
 // dx[M,K] = dy[M,N] * w[N,K]  -> output dims (M, K), contraction N
 int gemm_dgrad(int epi, const void* dy, const void* w, const void* aux, void* dx,
-               int64_t M, int64_t N, int64_t K, hipStream_t st, int64_t lddy) {
+               int64_t M, int64_t N, int64_t K, hipStream_t st, int64_t lddy, int act) {
     if (check_common(M, N, K)) return -1;
     if (K % 64 != 0 || N % 8 != 0) { uh_set_error("gemm_dgrad: need K %% 64 == 0 and N %% 8 == 0"); return -1; }
     if (lddy == 0) lddy = N;
@@ -958,6 +959,7 @@ int gemm_dgrad(int epi, const void* dy, const void* w, const void* aux, void* dx
     a.partial = nullptr;
     a.M = (int)M; a.N = (int)K; a.K = (int)N;
     a.k_per_split = (int)((N + 63) / 64 * 64);
+    a.relu = act;
     a.accumulate = 0;
     a.drop = make_dropout(0.f, 0, 0);
     int cfg = pick_cfg((int)M, (int)K, false, true, N % 64 == 0);

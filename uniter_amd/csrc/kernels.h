@@ -30,7 +30,7 @@ int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void
              int64_t M, int64_t N, int64_t K, const DropoutCfg& drop, hipStream_t st, int64_t ldx = 0, int64_t ldy = 0,
              int relu = 0);
 int gemm_dgrad(int epi, const void* dy, const void* w, const void* aux, void* dx,
-               int64_t M, int64_t N, int64_t K, hipStream_t st, int64_t lddy = 0);
+               int64_t M, int64_t N, int64_t K, hipStream_t st, int64_t lddy = 0, int act = 0);
 size_t gemm_dgrad_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int gemm_dgrad_splitk(const void* dy, const void* w, void* dx, int64_t M, int64_t N, int64_t K, void* workspace,
                       size_t ws_bytes, hipStream_t st, int64_t lddy = 0);
@@ -53,9 +53,10 @@ int gemm_tile_count();
 int attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse,
                   int64_t B, int64_t L, int64_t heads, const DropoutCfg& drop, hipStream_t st,
                   const int32_t* cu = nullptr);
+size_t attention_bwd_workspace_bytes(int64_t B, int64_t L, int64_t heads);
 int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, const float* lse,
                   const void* dctx, void* dqkv, int64_t B, int64_t L, int64_t heads,
-                  const DropoutCfg& drop, hipStream_t st, const int32_t* cu = nullptr);
+                  const DropoutCfg& drop, hipStream_t st, const int32_t* cu = nullptr, void* workspace = nullptr);
 
 // ---- layernorm.hip ----
 int layernorm_fwd(const void* z, const void* gamma, const void* beta, void* y, float* mean, float* rstd,

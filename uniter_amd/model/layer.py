@@ -40,10 +40,11 @@ class GELU(nn.Module):
 
 def _encoder_cfg(config):
     act = config.hidden_act
-    if act != "gelu":
-        raise UniterHipError("the HIP encoder implements hidden_act='gelu' (both shipped configs use it), got %r" % (act,))
+    codes = {"gelu": 0, "relu": 1, "swish": 2}                    # model/layer.py:44 ACT2FN
+    if act not in codes:
+        raise UniterHipError("hidden_act must be one of %s (model/layer.py:44), got %r" % (sorted(codes), act))
     return {"H": int(config.hidden_size), "heads": int(config.num_attention_heads),
-            "I": int(config.intermediate_size), "ln_eps": 1e-12}
+            "I": int(config.intermediate_size), "ln_eps": 1e-12, "act": codes[act]}
 
 
 class BertSelfAttention(nn.Module):

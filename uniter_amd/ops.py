@@ -229,6 +229,7 @@ def _shape(cfg_like, B, L, training):
     s.p_hidden = float(cfg_like["p_hidden"]) if training else 0.0
     s.p_attn = float(cfg_like["p_attn"]) if training else 0.0
     s.ln_eps = float(cfg_like["ln_eps"])
+    s.hidden_act = int(cfg_like.get("act", 0))
     s.training = 1 if training else 0
     return s
 
