@@ -3,7 +3,7 @@
 # (FETCH_SIZE, WRITE_SIZE — never combined with other trace domains) for the HBM-traffic figure of bench.py's
 # roofline object.  Output under gpurun_out/<tag>/ ; scripts/summarize_profile.py turns it into profiles/<tag>_*.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"

@@ -225,8 +225,18 @@ def set_async_pending(flag):
     _async_pending = bool(flag)
 
 
+_raw_stream = None
+
+
 def stream_ptr():
+    """hipStream_t of torch's current stream on the current device.  torch.cuda.current_stream() builds a Stream object
+    through several Python layers (~12 us, a few hundred calls per step); the raw getter is one C call."""
+    global _raw_stream
     import torch
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _raw_stream:
+        return _raw_stream(torch._C._cuda_getDevice())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -283,7 +283,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     const int tiles_n = p.N / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     int tm, tn;
-    if (p.xr > 0) {
+    if (p.xr < 0) {                 // the caller chose the tile (grouped launch, compact per-XCD mapping)
+        tm = bx / tiles_n;
+        tn = bx % tiles_n;
+    } else if (p.xr > 0) {
         // 2-D XCD blocking: hardware block b runs on XCD b % 8; XCD (xi, xj) of an xr x xc grid owns a
         // (tiles_m/xr) x (tiles_n/xc) sub-block of tiles, so its private L2 holds only that sub-block's operand rows
         const int xcd = bx & 7, loc = bx >> 3;
@@ -591,22 +594,41 @@ __global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS 
 // grid — one set of launch / ramp / drain costs instead of four, and the tiles of small problems fill the CUs the big
 // ones leave idle.  Problem q owns grid slots [start[q], start[q+1]); starts are multiples of 8 so that the slot -> XCD
 // relation of the 2-D tile mapping is preserved.
+// Compact mapping (default): all tiles of the group form ONE linear order — problem after problem, each walked with its
+// longer tile dimension outermost — and XCD x (hardware blocks b with b % 8 == x) runs the contiguous segment
+// [x*per, (x+1)*per).  A segment is then one compact rectangle of one problem (or the tail of one plus the head of the
+// next), so the K slabs an XCD's L2 has to hold are rows + columns of that rectangle: 132 slabs chip-wide for the four
+// weight gradients of a UNITER-base layer against 248 when every problem is spread over all eight XCDs (HBM-side
+// traffic of the launch 239 MB -> see profiles/).
 struct GemmGroupArgs {
     GemmArgs g[4];
-    int start[5];
+    int start[5];         // spread mapping: first grid slot of each problem (multiples of 8); compact: cumulative tile counts
     int n;
+    int compact;          // 1: compact per-XCD segments of `per` tiles
+    int per;
 };
 template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, int WS>
 __global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS == 2 ? 3 : 1)) void gemm_group_kernel(const GemmGroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int b = (int)blockIdx.x;
+    int b = (int)blockIdx.x;
+    if (ga.compact) {
+        const int loc = b >> 3;
+        b = (b & 7) * ga.per + loc;                               // position in the linear tile order
+        if (b >= ga.start[ga.n]) return;                          // the last segment may be short
+    }
     int q = 0;
 #pragma unroll
     for (int k = 1; k < 4; ++k)
         if (k < ga.n && b >= ga.start[k]) q = k;
     const GemmArgs& p = ga.g[q];
-    const int bx = b - ga.start[q];
-    if (bx >= ((p.M + BM - 1) / BM) * (p.N / BN)) return;        // padding slot
+    int bx = b - ga.start[q];
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
+    if (bx >= tiles_m * tiles_n) return;                          // padding slot
+    if (ga.compact) {                                             // longer tile dimension outermost
+        const int tm = tiles_n >= tiles_m ? bx % tiles_m : bx / tiles_n;
+        const int tn = tiles_n >= tiles_m ? bx / tiles_m : bx % tiles_n;
+        bx = tm * tiles_n + tn;
+    }
     gemm_tile<BM, BN, TRA, TRB, EPI, NSTAGE, WS>(p, bx, 0, smem_raw);
 }
 
@@ -783,6 +805,9 @@ int launch_gemm(const GemmArgs& a, int cfg, int splits, hipStream_t st) {
 }
 
 // ---- grouped weight-gradient launch ------------------------------------------------------------------------------
+// 1 (default): compact per-XCD tile segments (GemmGroupArgs); 0: every problem spread over all XCDs with its own 2-D
+// blocking.  UNITER_AMD_GROUP_COMPACT overrides.
+int g_group_compact = [] { const char* e = getenv("UNITER_AMD_GROUP_COMPACT"); return e ? atoi(e) : 1; }();
 template <int IDX>
 int launch_group_idx(GemmGroupArgs& ga, hipStream_t st) {
     if constexpr (tile_ok<true, true>(IDX)) {
@@ -795,13 +820,16 @@ int launch_group_idx(GemmGroupArgs& ga, hipStream_t st) {
                 return -1;
             }
             const int tiles_m = a.M / BM, tiles_n = a.N / BN;
-            a.xr = pick_xr(tiles_m, tiles_n, BM, BN);
+            a.xr = g_group_compact ? -1 : pick_xr(tiles_m, tiles_n, BM, BN);
             a.k_per_split = (a.K + 63) / 64 * 64;
             a.partial = nullptr;
             ga.start[q] = total;
-            total += (tiles_m * tiles_n + 7) / 8 * 8;
+            total += g_group_compact ? tiles_m * tiles_n : (tiles_m * tiles_n + 7) / 8 * 8;
         }
         ga.start[ga.n] = total;
+        ga.compact = g_group_compact;
+        ga.per = (total + 7) / 8;
+        if (g_group_compact) total = ga.per * 8;
         constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * 64 * sizeof(bf16_t);
         static bool attr_done = false;
         if (lds > 64 * 1024 && !attr_done) {

@@ -205,14 +205,25 @@ def _layer_row(lay, with_grads, pool):
     return pptrs, gptrs, (ps, gs)
 
 
+_table_cache = {}
+
+
 def _layer_table(layers, with_grads):
+    """ctypes array of UniterLayerParams for a list of BertLayers.  Filling it costs ~25 ctypes attribute stores per layer,
+    which sat on the critical path at the start of every backward pass (the GPU idles until the first launch), so the filled
+    array is kept and reused while every row's device pointers are unchanged."""
     n = len(layers)
+    pool = {}
+    rows = [_layer_row(lay, with_grads, pool) for lay in layers]
+    sig = tuple(id(r[0]) for r in rows) + tuple(id(r[1]) for r in rows)          # the cached pointer lists themselves
+    key = (id(layers[0]) if n else 0, n, with_grads)
+    hit = _table_cache.get(key)
+    if hit is not None and hit[0] == sig:
+        return hit[1], hit[2]
     table = (UniterLayerParams * n)()
     keep = []
-    pool = {}
     names = LayerView.NAMES
-    for i, lay in enumerate(layers):
-        pptrs, gptrs, alive = _layer_row(lay, with_grads, pool)
+    for i, (pptrs, gptrs, alive) in enumerate(rows):
         keep.append(alive)
         row = table[i]
         for name, v in zip(names, pptrs):
@@ -220,6 +231,7 @@ def _layer_table(layers, with_grads):
         if with_grads:
             for name, v in zip(names, gptrs):
                 setattr(row, "g_" + name, v)
+    _table_cache[key] = (sig, table, keep, [r[0] for r in rows], [r[1] for r in rows])   # (keeps the id()s alive)
     return table, keep
 
 

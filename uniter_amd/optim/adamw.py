@@ -152,13 +152,18 @@ class AdamW(Optimizer):
         except Exception:
             pass
 
-    def _ensure_plan(self):
+    def _ensure_plan(self, in_step=False):
         """(Re)build the device-side tensor table when the set of (parameter, gradient) storages changed.
 
         Full validation (two data_ptr() calls per tensor, ~0.5 ms for 230 tensors) runs every 32nd call; in between a
         cheap check catches the two things that happen in practice: a gradient tensor was replaced (set_to_none,
         first backward) -> identity test per parameter, or the parameter groups were edited."""
         self._calls = getattr(self, '_calls', 0) + 1
+        if in_step and self._plan is not None and getattr(self, '_checked_for_step', False):
+            # grad_norm() validated the plan a moment ago in this same optimizer step (clip_grad_norm_ -> step())
+            self._checked_for_step = False
+            return True
+        self._checked_for_step = False
         if self._plan is not None and (self._calls & 31):
             refs = self._plan_refs
             n = 0
@@ -257,6 +262,7 @@ class AdamW(Optimizer):
             self._norm_buf = torch.zeros(2, dtype=torch.float32, device=dev)
         C.uniter_adamw_grad_norm(self._plan, float(grad_scale), float(max_norm), ptr(self._norm_buf), _lib.stream_ptr())
         self._clip = self._norm_buf
+        self._checked_for_step = True
         return self._norm_buf[0]
 
     # ---- hipGraph mode ----------------------------------------------------------------------------------
@@ -291,7 +297,7 @@ class AdamW(Optimizer):
         loss = None
         if closure is not None:
             loss = closure()
-        if not self._ensure_plan():
+        if not self._ensure_plan(in_step=True):
             return loss           # nothing has a gradient: no-op, like the reference's dummy first step (pretrain.py:261-263)
         if self._graph is not None:
             host, dev = self._graph
