@@ -395,6 +395,13 @@ int uniter_encoder_autotune(const UniterEncoderShape* s, void* stream);
 /* Test / tuning hook: backward runs the weight-gradient GEMMs and bias column sums on an internal side stream
  * (ordered against `stream` purely by events) unless disabled with 0. */
 int uniter_encoder_debug_side_stream(int enable);
+/* The forward of an eligible shape (H = 768, L <= 128, B >= 8, training or not) runs as ONE persistent launch with one team of
+ * workgroups per XCD (csrc/xcd_forward.hip) — bit-identical to the kernel-per-operation path, which 0 selects for every shape
+ * (default 0 while it is the slower of the two; the environment variable UNITER_AMD_XCD_FWD=1 switches it on). */
+int uniter_encoder_debug_xcd_forward(int enable);
+/* Profiling hook of that launch: dev = device buffer of 256*32*8*2 uint64 that receives 100 MHz wall-clock stamps per
+ * workgroup / layer / phase (work done, barrier passed); NULL (default) switches it off. */
+int uniter_encoder_debug_xcd_probe(void* dev);
 /* 0 = uniter_encoder_autotune keeps the isolated per-GEMM winners; 1 (default) = it then re-picks every GEMM's tile among
  * its fastest candidates by timing a short forward+backward stack (cold weights, wgrad side stream running). */
 int uniter_encoder_debug_tune_in_situ(int enable);

@@ -901,10 +901,10 @@ static int load_tuned_json(const char* path) {
     fclose(f);
     int cnt = 0;
     size_t pos = 0;
-    while ((pos = txt.find("{\"kind\"", pos)) != std::string::npos) {
+    while ((pos = txt.find("\"kind\"", pos)) != std::string::npos) {        // scanf's blanks match any run of white space (either json.dump layout)
         int kind = 0, cfg = 0, sp = 1;
         long long M = 0, N = 0, K = 0;
-        if (sscanf(txt.c_str() + pos, "{\"kind\": %d, \"M\": %lld, \"N\": %lld, \"K\": %lld, \"cfg\": %d, \"splits\": %d", &kind, &M, &N, &K, &cfg, &sp) == 6) {
+        if (sscanf(txt.c_str() + pos, "\"kind\" : %d , \"M\" : %lld , \"N\" : %lld , \"K\" : %lld , \"cfg\" : %d , \"splits\" : %d", &kind, &M, &N, &K, &cfg, &sp) == 6) {
             if (uniter_gemm_set_tuned(kind, M, N, K, cfg, sp) == 0) ++cnt;
         }
         ++pos;
@@ -949,6 +949,87 @@ static void bench_encoder(int B, int L, int H, int heads, int I, int layers) {
     const int nt = load_tuned_json(tj ? tj : "uniter_amd/tuned/gfx950.json");
     printf("  tile table: %d entries\n", nt);
     if (nt == 0) { UHCHK(uniter_encoder_autotune(&sh, 0)); }
+    if (!getenv("UNITER_BENCH_SKIP_XCD_CHECK")) {
+        // the persistent per-XCD forward against the kernel-per-operation forward: every saved activation, bit for bit
+        std::vector<unsigned char> ref(act * layers), got(act * layers);
+        UHCHK(uniter_encoder_debug_xcd_forward(0));
+        HIPCHK(hipMemset(acts, 0, act * layers));
+        UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0));
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(ref.data(), acts, ref.size(), hipMemcpyDeviceToHost));
+        UHCHK(uniter_encoder_debug_xcd_forward(1));
+        HIPCHK(hipMemset(acts, 0, act * layers));
+        UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0));
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(got.data(), acts, got.size(), hipMemcpyDeviceToHost));
+        size_t bad = 0, first = 0;
+        for (size_t k = 0; k < ref.size(); ++k) if (ref[k] != got[k]) { if (!bad) first = k; ++bad; }
+        printf("[%s] persistent per-XCD forward == per-operation forward: %zu of %zu bytes differ", bad ? "FAIL" : " OK ", bad, ref.size());
+        if (bad) { printf(" (first at layer %zu, offset %zu of %zu)", first / act, first % act, act); ++g_fail; }
+        printf("\n");
+        if (bad) {          // which saved tensor of which layer (the block layout of encoder.hip: 256-byte aligned fields in this order)
+            static const char* names[] = {"qkv", "lse", "ctx", "z1", "mean1", "rstd1", "a", "u", "g", "z2", "mean2", "rstd2", "y"};
+            const size_t sizes[] = {(size_t)T * 3 * H * 2, (size_t)B * heads * L * 4, (size_t)T * H * 2, (size_t)T * H * 2, (size_t)T * 4, (size_t)T * 4, (size_t)T * H * 2,
+                                    (size_t)T * I * 2, (size_t)T * I * 2, (size_t)T * H * 2, (size_t)T * 4, (size_t)T * 4, (size_t)T * H * 2};
+            for (int l = 0; l < layers && l < 2; ++l) {
+                size_t o = 0;
+                for (int f = 0; f < 13; ++f) {
+                    size_t nb = 0, fb = 0;
+                    for (size_t k = 0; k < sizes[f]; ++k) if (ref[l * act + o + k] != got[l * act + o + k]) { if (!nb) fb = k; ++nb; }
+                    if (nb) printf("      layer %d %-6s %zu of %zu bytes differ, first at byte %zu\n", l, names[f], nb, sizes[f], fb);
+                    o += (sizes[f] + 255) & ~(size_t)255;
+                }
+            }
+        }
+        double t0 = 1e30, t1 = 1e30;
+        for (int rep = 0; rep < 3; ++rep) {
+            UHCHK(uniter_encoder_debug_xcd_forward(0));
+            t0 = std::min(t0, tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 20));
+            UHCHK(uniter_encoder_debug_xcd_forward(1));
+            t1 = std::min(t1, tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 20));
+        }
+        printf("  forward: per-operation kernels %.1f us | one persistent launch %.1f us\n", t0, t1);
+        {   // where the persistent launch spends its time: per phase, work (previous barrier -> done) and wait at the barrier
+            const size_t nst = (size_t)256 * 32 * 8 * 2 + (size_t)256 * 4 * 8;
+            unsigned long long* dpr = dalloc<unsigned long long>(nst);
+            HIPCHK(hipMemset(dpr, 0, nst * 8));
+            UHCHK(uniter_encoder_debug_xcd_probe(dpr));
+            UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0));
+            HIPCHK(hipDeviceSynchronize());
+            UHCHK(uniter_encoder_debug_xcd_probe(nullptr));
+            std::vector<unsigned long long> h(nst);
+            HIPCHK(hipMemcpy(h.data(), dpr, nst * 8, hipMemcpyDeviceToHost));
+            static const char* ph[] = {"qkv gemm", "attention", "out-proj", "layernorm 1", "ffn1 + act", "ffn2", "layernorm 2"};
+            auto at = [&](int wg, int l, int p, int w) { return h[(((size_t)wg * 32 + l) * 8 + p) * 2 + w]; };
+            for (int p = 0; p < 7; ++p) {
+                double work = 0, wait = 0, wmax = 0; long n = 0;
+                for (int wg = 0; wg < 256; ++wg)
+                    for (int l = 1; l + 1 < layers; ++l) {
+                        const unsigned long long start = p == 0 ? at(wg, l - 1, 6, 1) : at(wg, l, p - 1, 1);
+                        const unsigned long long done = at(wg, l, p, 0), passed = at(wg, l, p, 1);
+                        if (!start || !done || !passed) continue;
+                        work += (double)(done - start); wait += (double)(passed - done); wmax = std::max(wmax, (double)(done - start)); ++n;
+                    }
+                if (n) printf("    phase %-12s work avg %6.2f us (max %6.2f) | barrier wait avg %5.2f us\n", ph[p], work / n * 0.01, wmax * 0.01, wait / n * 0.01);
+            }
+            static const char* gn[] = {"qkv gemm", "out-proj", "ffn1 + act", "ffn2"};
+            static const int gphase[] = {0, 2, 4, 5};
+            for (int k = 0; k < 4; ++k) {          // inside the GEMM phases of layer 5 (wave 0 = MFMA wave, wave 4 = loader wave)
+                double c[4] = {0, 0, 0, 0}, ld[4] = {0, 0, 0, 0}; long n = 0;
+                for (int wg = 0; wg < 256; ++wg) {
+                    const unsigned long long* r = &h[(size_t)256 * 32 * 8 * 2 + ((size_t)wg * 4 + k) * 8];
+                    const unsigned long long start = gphase[k] == 0 ? at(wg, 4, 6, 1) : at(wg, 5, gphase[k] - 1, 1);
+                    if (!r[0] || !r[3] || !r[4] || !r[7] || !start) continue;
+                    c[0] += (double)(r[0] - start); c[1] += (double)(r[1] - r[0]); c[2] += (double)(r[2] - r[1]); c[3] += (double)(r[3] - r[2]);
+                    ld[0] += (double)(r[4] - start); ld[1] += (double)(r[5] - r[4]); ld[2] += (double)(r[6] - r[5]); ld[3] += (double)(r[7] - r[6]);
+                    ++n;
+                }
+                if (n) printf("    %-10s MFMA wave: call %.2f | first tile ready %.2f | main loop %.2f | last epilogue %.2f us   loader: call %.2f | first issues %.2f | first step landed %.2f | rest %.2f us\n",
+                              gn[k], c[0] / n * 0.01, c[1] / n * 0.01, c[2] / n * 0.01, c[3] / n * 0.01, ld[0] / n * 0.01, ld[1] / n * 0.01, ld[2] / n * 0.01, ld[3] / n * 0.01);
+            }
+        }
+    }
+    if (getenv("UNITER_BENCH_XCD_ONLY")) return;
     double tf = 1e30, tb = 1e30;
     for (int rep = 0; rep < 5; ++rep) {
         tf = std::min(tf, tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 20));
@@ -1098,8 +1179,10 @@ int main(int argc, char** argv) {
             int32_t inf[4];
             UHCHK(uniter_hip_device_info(inf));
             printf("== grouped weight gradients ==\n");
-            test_wgrad_group(320);
-            test_wgrad_group(300);
+            if (!getenv("UNITER_BENCH_XCD_ONLY")) {
+                test_wgrad_group(320);
+                test_wgrad_group(300);
+            }
             if (i + 1 < argc && !strcmp(argv[i + 1], "large")) bench_encoder(32, 96, 1024, 16, 4096, 24);
             else if (i + 1 < argc && !strcmp(argv[i + 1], "large178")) bench_encoder(32, 178, 1024, 16, 4096, 24);
             else bench_encoder(32, 96, 768, 12, 3072, 12);

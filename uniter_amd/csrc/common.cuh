@@ -54,6 +54,30 @@ __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Global loads of data another CU of the same launch may have just written (persistent per-XCD forward): COH = true
+// turns the load into an `nt` load, which the vector L1 never serves (measured, tests/native/xcd_probe.cpp: 0 stale words
+// of 2e7 with the L1 holding the previous contents; a plain load was stale 43 % of the time); the XCD's L2 still does.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) u32x4 gmem_u32x4;      // the global address space, named at the access: pointers that
+typedef __attribute__((address_space(1))) u32x2 gmem_u32x2;      // went through a function call are generic (flat) otherwise
+template <bool COH>
+__device__ __forceinline__ u32x4 ldg16(const void* p) {
+    if constexpr (COH) return __builtin_nontemporal_load((const gmem_u32x4*)p);
+    else return *(const gmem_u32x4*)p;
+}
+template <bool COH>
+__device__ __forceinline__ u32x2 ldg8(const void* p) {
+    if constexpr (COH) return __builtin_nontemporal_load((const gmem_u32x2*)p);
+    else return *(const gmem_u32x2*)p;
+}
+// store for a consumer in this launch (COH: default policy, the line stays in the XCD's L2) or in a later one (nt)
+template <bool COH>
+__device__ __forceinline__ void stg8(void* p, const u32x2 v) {
+    if constexpr (COH) *(gmem_u32x2*)p = v;
+    else __builtin_nontemporal_store(v, (gmem_u32x2*)p);
+}
+
+// ---------------------------------------------------------------------------------------------
 // wave64 reductions
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
@@ -187,10 +211,16 @@ __device__ __forceinline__ float dropout_mult1(const DropoutCfg& d, uint64_t idx
 // erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1/(1 + p z)  (Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7,
 // far below the bf16 resolution of the stored result) with z = |x|/sqrt2, so exp(-z^2) = exp(-x^2/2) serves both.
 __device__ __forceinline__ void normal_cdf_pdf(float x, float& cdf, float& pdf) {
+    // every multiply-add is spelled out (and nothing else may be contracted): the same bits wherever this is inlined
+#pragma clang fp contract(off)
     const float ax = fabsf(x);
     const float e = __expf(-0.5f * ax * ax);
-    const float t = __frcp_rn(1.0f + 0.23164189f * ax);          // p / sqrt2 = 0.3275911 / 1.41421356
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float t = __frcp_rn(__fmaf_rn(0.23164189f, ax, 1.0f));          // p / sqrt2 = 0.3275911 / 1.41421356
+    float poly = __fmaf_rn(t, 1.061405429f, -1.453152027f);
+    poly = __fmaf_rn(t, poly, 1.421413741f);
+    poly = __fmaf_rn(t, poly, -0.284496736f);
+    poly = __fmaf_rn(t, poly, 0.254829592f);
+    poly = t * poly;
     const float tail = 0.5f * poly * e;                            // = 0.5 * erfc(|x| / sqrt2)
     cdf = x >= 0.f ? 1.0f - tail : tail;
     pdf = 0.39894228040143267794f * e;
@@ -203,12 +233,13 @@ __device__ __forceinline__ float gelu_erf(float x) {
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     float cdf, pdf;
     normal_cdf_pdf(x, cdf, pdf);
-    return cdf + x * pdf;
+    return __fmaf_rn(x, pdf, cdf);
 }
 
 // hidden_act of the config (model/layer.py:44 ACT2FN): 0 = gelu (erf form), 1 = relu, 2 = swish (x * sigmoid(x))
 enum { UH_ACT_GELU = 0, UH_ACT_RELU = 1, UH_ACT_SWISH = 2 };
 __device__ __forceinline__ float act_fwd(int act, float x) {
+#pragma clang fp contract(off)
     if (act == UH_ACT_RELU) return fmaxf(x, 0.f);
     if (act == UH_ACT_SWISH) return x * __frcp_rn(1.0f + __expf(-x));
     return gelu_erf(x);

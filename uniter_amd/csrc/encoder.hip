@@ -165,6 +165,12 @@ int uniter_encoder_forward(const UniterEncoderShape* s, const UniterLayerParams*
     const int64_t T = (int64_t)tokens(*s), H = s->H, I = s->I;
     const bool tr = s->training != 0;
     const DropoutCfg nodrop = make_dropout(0.f, 0, 0);
+    if (layer_end > layer_begin && uh::xcd_forward_eligible(*s, layer_end)) {
+        // one persistent launch, one team of workgroups per XCD (xcd_forward.hip); same results as the loop below
+        RC(uniter_params_wait_all(stream));
+        const uh::XcdActOffsets xo{al.qkv, al.lse, al.ctx, al.z1, al.mean1, al.rstd1, al.a, al.u, al.g, al.z2, al.mean2, al.rstd2, al.y};
+        return uh::xcd_forward(s, layers, layer_begin, layer_end, x_in, mask_bias, acts, al.total, xo, seed, offset, st);
+    }
     const char* x = (const char*)x_in;
     for (int l = layer_begin; l < layer_end; ++l) {
         const UniterLayerParams& P = layers[l];
@@ -506,6 +512,8 @@ int uniter_encoder_debug_tune_in_situ(int enable) {
 }
 
 // test / tuning hook: 0 = run the weight-gradient GEMMs on the caller's stream, 1 = on the library's side stream
+int uniter_encoder_debug_xcd_forward(int enable) { uh::xcd_forward_enable(enable); return 0; }
+int uniter_encoder_debug_xcd_probe(void* dev) { uh::xcd_forward_probe(dev); return 0; }
 int uniter_encoder_debug_side_stream(int enable) {
     g_use_side_stream = enable;
     return 0;

@@ -18,6 +18,10 @@
 // with ds_read_b64_tr_b16, with a 32-byte-block XOR swizzle that makes those reads conflict free.
 #include "common.cuh"
 #include "kernels.h"
+#include "gemm_lds.cuh"
+#ifndef UNITER_AUX_EARLY
+#define UNITER_AUX_EARLY 1
+#endif
 
 #include <algorithm>
 #include <map>
@@ -27,6 +31,7 @@
 
 namespace {
 
+constexpr bool g_aux_early_dev = UNITER_AUX_EARLY;
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_DROP_RES = 2, EPI_RES = 3, EPI_GELU_BWD = 4, EPI_WGRAD = 5 };
 
 struct GemmArgs {
@@ -53,11 +58,7 @@ struct GemmArgs {
     DropoutCfg drop;
 };
 
-// ---- LDS layouts -------------------------------------------------------------------------------
-// K-contiguous tile: [rows][64] bf16, 8 chunks of 16 B per row, chunk c stored at c ^ ((row>>1)&7).
-__device__ __forceinline__ int kc_off(int row, int chunk) {
-    return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3);
-}
+// ---- LDS layouts (K-contiguous tile: gemm_lds.cuh) ---------------------------------------------
 // K-strided tile: [64][W] bf16 (W = 64 or 128).  8-byte chunk ch of row r stored at ch ^ (h(r) << 2).
 // A 192-wide K-strided tile is a [64][128] sub-tile followed by a [64][64] sub-tile (columns 128..191), each in its
 // own swizzle; only the N-side operand may be 192 wide (dgrad with 192x192 / 128x192 / 96x192 tiles).
@@ -71,18 +72,11 @@ __device__ __forceinline__ int ks_off8(int r, int ch8) {   // element offset of 
     return r * W + ((ch8 ^ (ks_swz<W>(r) << 2)) << 2);
 }
 
-__device__ __forceinline__ bf16x8 lds_read_b128(const bf16_t* p) {
-    return *reinterpret_cast<const bf16x8*>(p);
-}
 __device__ __forceinline__ s16x4 lds_read_tr(const bf16_t* p) {
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
 }
 
-// fragment (8 k-values for row/col `i` of a 16-wide sub-tile) from a K-contiguous tile
-__device__ __forceinline__ bf16x8 frag_kc(const bf16_t* tile, int row, int ks, int g) {
-    return lds_read_b128(tile + kc_off(row, ks * 4 + g));
-}
 // same from a K-strided tile: lane (g, i = 4j+q) supplies row ks*32+8g+j (+4), cols cb+4q..
 template <int W>
 __device__ __forceinline__ bf16x8 frag_ks(const bf16_t* tile, int cb, int ks, int g, int i) {
@@ -157,34 +151,7 @@ struct StageKS {
     }
 };
 
-// ---- direct global -> LDS staging (global_load_lds_dwordx4) ---------------------------------------
-// One wave instruction moves 64 lanes x 16 B = 1 KiB to LDS base + lane*16 (the destination is lane-linear by
-// hardware), so the XOR swizzle is applied on the SOURCE address: lane l, which lands in physical 16-byte
-// chunk c' of row r, fetches the logical chunk c = c' ^ swz(r).  Lanes of one row still read one contiguous
-// 128/256-byte row segment, so HBM/L2 coalescing is unchanged.  Rows beyond the matrix are clamped to the last
-// valid row (their products land in output rows the epilogue never stores); partial K tiles do not use this
-// path (they need zero fill).
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void global_void_t;
-
-__device__ __forceinline__ void glds16(const bf16_t* src, bf16_t* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((global_void_t*)src, (lds_void_t*)lds_wave_base, 16, 0, 0);
-}
-
-// K-contiguous tile [ROWS][64]: instruction j covers rows 8j..8j+7.
-template <int ROWS>
-__device__ __forceinline__ void glds_kc(bf16_t* tile, const bf16_t* base, int64_t ld, int row0, int rows_total,
-                                        int k0, int wid, int lane) {
-#pragma unroll
-    for (int it = 0; it < ROWS / 32; ++it) {
-        const int j = it * 4 + wid;
-        const int r = 8 * j + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        int gr = row0 + r;
-        gr = gr < rows_total ? gr : rows_total - 1;
-        glds16(base + (int64_t)gr * ld + k0 + c * 8, tile + j * 512);
-    }
-}
+// ---- direct global -> LDS staging: glds16 / glds_kc live in gemm_lds.cuh --------------------------
 // K-strided tile [64][W]: W = 128 -> 4 rows per instruction, W = 64 -> 8 rows per instruction.
 template <int W>
 __device__ __forceinline__ void glds_ks(bf16_t* tile, const bf16_t* base, int64_t ld, int col0, int k0, int wid, int lane) {
@@ -232,16 +199,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int xcd = bid & 7, loc = bid >> 3;
     const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return start + loc;
-}
-
-// Wait until this wave's DMA share of the current tile has landed while the younger tiles of the ring (at most
-// NSTAGE-2 of them, `later` = tiles still to come after this one) stay in flight: vmcnt counts outstanding VMEM
-// instructions in issue order and every tile is G instructions per wave.
-template <int NSTAGE, int G>
-__device__ __forceinline__ void wait_tile(int later) {
-    if (NSTAGE >= 4 && later >= 2)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
-    else if (NSTAGE >= 3 && later >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-    else                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // WS ("wave specialised"): 8 waves per workgroup — waves 0-3 only read LDS and issue MFMAs, waves 4-7 only issue
@@ -378,6 +335,40 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         }
     };
 
+    // ---- epilogue geometry, and the global operands the epilogue combines with the accumulators --------------------------
+    constexpr int NT = WG::NCW * 64;                        // the compute waves (loader waves have exited by then)
+    constexpr int SROW = BN + 4;                            // fp32 row stride of the staging block (+4 spreads banks)
+    constexpr int PASS_ROWS = WG::GM * 16;                  // one 16-row MFMA block of every wave row per pass
+    constexpr int CPR = BN / 8;                             // 16-byte output chunks per tile row
+    constexpr int ITERS = (PASS_ROWS * CPR + NT - 1) / NT;
+    constexpr bool HAS_AUX = (EPI == EPI_BIAS_DROP_RES || EPI == EPI_RES || EPI == EPI_GELU_BWD || EPI == EPI_WGRAD);
+    // Residual, pre-activation, the gradient a weight gradient accumulates into: written by an earlier kernel, so every
+    // one of these loads misses this XCD's L2 (a fabric round trip, ~2000 cycles under load).  They are requested for ALL
+    // passes of the epilogue at once, before the last K step's MFMAs, instead of one exposed round trip per 16-row pass.
+    // (early only where accumulators + fragments + these registers stay inside the wave's register budget: the 128x128 tiles
+    //  would spill ~100 registers otherwise; they fetch at the start of the epilogue, where the fragments are dead)
+    constexpr bool AUX_EARLY = g_aux_early_dev && HAS_AUX && (MI * NI * 4 + (MI + NI) * 4 + MI * ITERS * 4 + 24 <= (WS == 2 ? 168 : 128));
+    u32x4 auxr[HAS_AUX ? MI : 1][ITERS];
+    bool aux_fetched = false;
+    auto aux_fetch = [&]() {
+        aux_fetched = true;
+        if constexpr (HAS_AUX) {
+            const bf16_t* abase = (EPI == EPI_WGRAD) ? (p.accumulate && p.partial == nullptr ? p.C : nullptr) : (p.partial == nullptr ? p.aux : nullptr);
+            const int64_t ald = (EPI == EPI_WGRAD) ? p.ldc : p.ldaux;
+#pragma unroll
+            for (int b = 0; b < MI; ++b)
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int c = t + it * NT;
+                    const int r = c / CPR, c8 = c - r * CPR;
+                    const int m = m0 + (r >> 4) * WM + b * 16 + (r & 15);
+                    auxr[b][it] = u32x4{0u, 0u, 0u, 0u};
+                    if (abase != nullptr && c < PASS_ROWS * CPR && m < p.M)
+                        auxr[b][it] = *reinterpret_cast<const u32x4*>(abase + (int64_t)m * ald + n0 + c8 * 8);
+                }
+        }
+    };
+
     // ---- main loop over the full K tiles: NSTAGE-deep ring of LDS buffers filled by LDS-DMA -----------------------
     // Up to NSTAGE-1 tiles are in flight.  vmcnt counts this wave's DMA instructions in issue order, so
     // "vmcnt(G * tiles_allowed_in_flight)" means "my share of tile kt has landed"; the raw s_barrier then makes
@@ -416,6 +407,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
             const bool rec = pr != nullptr && t == 0;
             if (rec) pr[0] = __builtin_readcyclecounter();
 #endif
+            if (AUX_EARLY && kt == nfull - 1) aux_fetch();
             __builtin_amdgcn_s_barrier();
 #ifdef UNITER_GEMM_PROBE
             if (rec) pr[1] = pr[2] = pr[3] = __builtin_readcyclecounter();   // phases: [0,1] wait for the loaders' barrier
@@ -450,6 +442,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 #ifdef UNITER_GEMM_PROBE
             if (rec) pr[3] = __builtin_readcyclecounter();
 #endif
+            if (AUX_EARLY && kt == nfull - 1) aux_fetch();
             compute(buf);
 #ifdef UNITER_GEMM_PROBE
             if (rec) { asm volatile("s_nop 0" ::: "memory"); pr[4] = __builtin_readcyclecounter(); }
@@ -499,12 +492,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
             }
         }
     } else {
-        constexpr int NT = WG::NCW * 64;                    // the compute waves (loader waves have exited)
-        constexpr int SROW = BN + 4;                        // fp32 row stride of the staging block (+4 spreads banks)
-        constexpr int PASS_ROWS = WG::GM * 16;              // one 16-row MFMA block of every wave row per pass
-        constexpr int CPR = BN / 8;                         // 16-byte output chunks per tile row
+#pragma clang fp contract(off)                              // bias, dropout, residual: three roundings, the same in every kernel that has this epilogue (xcd_forward.hip)
         static_assert(2 * PASS_ROWS * SROW * 4 <= NSTAGE * STAGE * 2, "staging blocks must fit the LDS ring");
         float* stage = reinterpret_cast<float*>(smem_raw);
+        if (!aux_fetched) aux_fetch();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                       // every wave is done reading the ring
 #pragma unroll
@@ -515,7 +506,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 *reinterpret_cast<f32x4*>(sb + (wm * 16 + i) * SROW + wn * WN + a * 16 + 4 * g) = acc[a][b];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                   // (also orders the reads of pass b-1 before the writes of b+1)
-            for (int c = t; c < PASS_ROWS * CPR; c += NT) {
+#pragma unroll HAS_AUX ? ITERS : 1                          // unrolled only where the prefetched registers need static indices (the GELU body is big)
+            for (int it = 0; it < ITERS; ++it) {
+                const int c = t + it * NT;
+                if (c >= PASS_ROWS * CPR) continue;
                 const int r = c / CPR, c8 = c - r * CPR;
                 const int m = m0 + (r >> 4) * WM + b * 16 + (r & 15);
                 if (m >= p.M) continue;
@@ -558,20 +552,20 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 if (EPI == EPI_BIAS_DROP_RES || EPI == EPI_RES) {
                     if (p.aux != nullptr) {
                         float rv[8];
-                        unpack8(*reinterpret_cast<const u32x4*>(p.aux + (int64_t)m * p.ldaux + n), rv);
+                        unpack8(auxr[b][it], rv);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += rv[e];
                     }
                 }
                 if (EPI == EPI_GELU_BWD) {
                     float uv[8];
-                    unpack8(*reinterpret_cast<const u32x4*>(p.aux + (int64_t)m * p.ldaux + n), uv);
+                    unpack8(auxr[b][it], uv);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= act_grad(p.relu, uv[e]);
                 }
                 if (EPI == EPI_WGRAD && p.accumulate) {
                     float ov[8];
-                    unpack8(*reinterpret_cast<const u32x4*>(cptr), ov);
+                    unpack8(auxr[b][it], ov);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += ov[e];
                 }

@@ -6,6 +6,8 @@
 #include <stdint.h>
 
 struct DropoutCfg;
+struct UniterEncoderShape;
+struct UniterLayerParams;
 
 namespace uh {
 
@@ -48,6 +50,15 @@ int gemm_set_tuned(int kind, int64_t M, int64_t N, int64_t K, int cfg, int split
 int gemm_autotune_candidates(int kind, int64_t M, int64_t N, int64_t K, int* cfgs, int* splits, int cap);
 void gemm_set_num_cus(int n);
 int gemm_tile_count();
+
+// ---- xcd_forward.hip: the forward pass of a layer range as one persistent launch, one team of workgroups per XCD ----
+struct XcdActOffsets { size_t qkv, lse, ctx, z1, mean1, rstd1, a, u, g, z2, mean2, rstd2, y; };   // byte offsets inside a layer's block
+bool xcd_forward_eligible(const UniterEncoderShape& s, int n_layers);
+int xcd_forward(const UniterEncoderShape* s, const UniterLayerParams* layers, int layer_begin, int layer_end, const void* x_in,
+                const float* mask_bias, void* acts, size_t act_stride, const XcdActOffsets& o, uint64_t seed, uint64_t offset,
+                hipStream_t st);
+void xcd_forward_enable(int on);
+void xcd_forward_probe(void* dev);   // debug: 256 x 32 x 8 x 2 wall-clock stamps (100 MHz) per launch, null = off
 
 // ---- attention.hip ----
 int attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse,

@@ -6,6 +6,7 @@
 // row fully coalesced), statistics by wave-level reductions, no LDS on the forward path.
 #include "common.cuh"
 #include "kernels.h"
+#include "layernorm_fwd.cuh"
 
 namespace {
 
@@ -20,56 +21,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int row = blockIdx.x * ROWS_PER_BLOCK + wid;
     if (row >= rows) return;
-    const int nch = H >> 2;
-    const bf16_t* zr = z + (int64_t)row * H;
-    float x[NC][4];
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int ch = lane + 64 * c;
-        if (ch < nch) {
-            unpack4(*reinterpret_cast<const u32x2*>(zr + ch * 4), x[c]);
-            s += (x[c][0] + x[c][1]) + (x[c][2] + x[c][3]);
-        } else {
-            x[c][0] = x[c][1] = x[c][2] = x[c][3] = 0.f;
-        }
-    }
-    const float mean = wave_sum(s) / (float)H;
-    float v = 0.f;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int ch = lane + 64 * c;
-        if (ch < nch) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = x[c][e] - mean; v += d * d; }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(v) / (float)H + eps);
-    if (lane == 0) {
-        if (mean_out) mean_out[row] = mean;
-        if (rstd_out) rstd_out[row] = rstd;
-    }
-    bf16_t* yr = y + (int64_t)row * H;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int ch = lane + 64 * c;
-        if (ch < nch) {
-            float gv[4], bv[4], o[4];
-            unpack4(*reinterpret_cast<const u32x2*>(gamma + ch * 4), gv);
-            unpack4(*reinterpret_cast<const u32x2*>(beta + ch * 4), bv);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (x[c][e] - mean) * rstd * gv[e] + bv[e];
-            if (drop.p > 0.f) {
-                // the dropped value is the bf16-rounded LN output (what a separate dropout kernel would see)
-                float mult[4], oq[4];
-                unpack4(pack4(o), oq);
-                dropout_mult4(drop, ((uint64_t)row * (uint64_t)H + (uint64_t)ch * 4) >> 2, mult);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = oq[e] * mult[e];
-            }
-            __builtin_nontemporal_store(pack4(o), reinterpret_cast<u32x2*>(yr + ch * 4));
-        }
-    }
+    ln_fwd_row<NC, false>(z, gamma, beta, y, mean_out, rstd_out, row, H, eps, drop, lane);
 }
 
 // Backward.  partial layout: [gridDim.x][3][H] fp32 = per-block column sums of (dgamma, dbeta, dbias).
