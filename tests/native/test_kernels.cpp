@@ -999,26 +999,26 @@ static void bench_encoder(int B, int L, int H, int heads, int I, int layers) {
             UHCHK(uniter_encoder_debug_xcd_probe(nullptr));
             std::vector<unsigned long long> h(nst);
             HIPCHK(hipMemcpy(h.data(), dpr, nst * 8, hipMemcpyDeviceToHost));
-            static const char* ph[] = {"qkv gemm", "attention", "out-proj", "layernorm 1", "ffn1 + act", "ffn2", "layernorm 2"};
+            static const char* ph[] = {"qkv gemm", "attention", "out-proj", "layernorm 1", "ffn1", "activation", "ffn2", "layernorm 2"};
             auto at = [&](int wg, int l, int p, int w) { return h[(((size_t)wg * 32 + l) * 8 + p) * 2 + w]; };
-            for (int p = 0; p < 7; ++p) {
+            for (int p = 0; p < 8; ++p) {
                 double work = 0, wait = 0, wmax = 0; long n = 0;
                 for (int wg = 0; wg < 256; ++wg)
                     for (int l = 1; l + 1 < layers; ++l) {
-                        const unsigned long long start = p == 0 ? at(wg, l - 1, 6, 1) : at(wg, l, p - 1, 1);
+                        const unsigned long long start = p == 0 ? at(wg, l - 1, 7, 1) : at(wg, l, p - 1, 1);
                         const unsigned long long done = at(wg, l, p, 0), passed = at(wg, l, p, 1);
                         if (!start || !done || !passed) continue;
                         work += (double)(done - start); wait += (double)(passed - done); wmax = std::max(wmax, (double)(done - start)); ++n;
                     }
                 if (n) printf("    phase %-12s work avg %6.2f us (max %6.2f) | barrier wait avg %5.2f us\n", ph[p], work / n * 0.01, wmax * 0.01, wait / n * 0.01);
             }
-            static const char* gn[] = {"qkv gemm", "out-proj", "ffn1 + act", "ffn2"};
-            static const int gphase[] = {0, 2, 4, 5};
+            static const char* gn[] = {"qkv gemm", "out-proj", "ffn1", "ffn2"};
+            static const int gphase[] = {0, 2, 4, 6};
             for (int k = 0; k < 4; ++k) {          // inside the GEMM phases of layer 5 (wave 0 = MFMA wave, wave 4 = loader wave)
                 double c[4] = {0, 0, 0, 0}, ld[4] = {0, 0, 0, 0}; long n = 0;
                 for (int wg = 0; wg < 256; ++wg) {
                     const unsigned long long* r = &h[(size_t)256 * 32 * 8 * 2 + ((size_t)wg * 4 + k) * 8];
-                    const unsigned long long start = gphase[k] == 0 ? at(wg, 4, 6, 1) : at(wg, 5, gphase[k] - 1, 1);
+                    const unsigned long long start = gphase[k] == 0 ? at(wg, 4, 7, 1) : at(wg, 5, gphase[k] - 1, 1);
                     if (!r[0] || !r[3] || !r[4] || !r[7] || !start) continue;
                     c[0] += (double)(r[0] - start); c[1] += (double)(r[1] - r[0]); c[2] += (double)(r[2] - r[1]); c[3] += (double)(r[3] - r[2]);
                     ld[0] += (double)(r[4] - start); ld[1] += (double)(r[5] - r[4]); ld[2] += (double)(r[6] - r[5]); ld[3] += (double)(r[7] - r[6]);

@@ -310,6 +310,42 @@ def test_full_size_determinism_and_eval_equals_p0(full_model):
     assert torch.isfinite(y1.float()).all()
 
 
+def test_persistent_per_xcd_forward_is_bit_identical(full_model):
+    """csrc/xcd_forward.hip (one launch, one team of workgroups per XCD, L2-local barriers; opt-in) against the
+    kernel-per-operation forward at the benchmark shape: every layer's output with dropout on and a ragged batch, and the
+    gradients of a backward pass that runs off the activations each path saved."""
+    from uniter_amd import _lib, ops
+    from uniter_amd.utils.misc import set_dropout
+    lib = _lib.load()
+    b = _full_batch(seed=11, ragged=True)
+    params = [p for p in full_model.uniter.parameters()]
+    set_dropout(full_model, 0.1)
+
+    def run(enable):
+        lib.uniter_encoder_debug_xcd_forward(enable)
+        ops.manual_seed(1234)
+        for p in params:
+            p.grad = None
+        ys = full_model.uniter(b['input_ids'], b['position_ids'], b['img_feat'], b['img_pos_feat'], b['attn_masks'],
+                               b['gather_index'], output_all_encoded_layers=True)
+        (ys[-1].float() * b['attn_masks'].unsqueeze(-1)).square().mean().backward()
+        return [y.detach().clone() for y in ys], [None if p.grad is None else p.grad.detach().clone() for p in params]
+
+    try:
+        y0, g0 = run(0)
+        y1, g1 = run(1)
+    finally:
+        lib.uniter_encoder_debug_xcd_forward(0)
+        set_dropout(full_model, 0.0)
+    assert len(y0) == len(y1) == 12
+    for a, c in zip(y0, y1):
+        assert torch.equal(a, c)
+    for a, c in zip(g0, g1):
+        assert (a is None) == (c is None)
+        if a is not None:
+            assert torch.equal(a, c)
+
+
 def test_full_size_padding_invariance(full_model):
     """Valid positions must not depend on what sits in padded slots (key mask -10000, model/model.py:342-345)."""
     b = _full_batch(seed=4, ragged=True)

@@ -349,9 +349,20 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     //  would spill ~100 registers otherwise; they fetch at the start of the epilogue, where the fragments are dead)
     constexpr bool AUX_EARLY = g_aux_early_dev && HAS_AUX && (MI * NI * 4 + (MI + NI) * 4 + MI * ITERS * 4 + 24 <= (WS == 2 ? 168 : 128));
     u32x4 auxr[HAS_AUX ? MI : 1][ITERS];
+    constexpr bool HAS_BIAS = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RES);
+    u32x4 biasr[ITERS];                                     // the bias chunk of a thread's column does not depend on the pass
     bool aux_fetched = false;
     auto aux_fetch = [&]() {
         aux_fetched = true;
+        if constexpr (HAS_BIAS) {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int c = t + it * NT;
+                const int c8 = c % CPR;
+                biasr[it] = u32x4{0u, 0u, 0u, 0u};
+                if (p.bias != nullptr && c < PASS_ROWS * CPR) biasr[it] = *reinterpret_cast<const u32x4*>(p.bias + n0 + c8 * 8);
+            }
+        }
         if constexpr (HAS_AUX) {
             const bf16_t* abase = (EPI == EPI_WGRAD) ? (p.accumulate && p.partial == nullptr ? p.C : nullptr) : (p.partial == nullptr ? p.aux : nullptr);
             const int64_t ald = (EPI == EPI_WGRAD) ? p.ldc : p.ldaux;
@@ -506,7 +517,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 *reinterpret_cast<f32x4*>(sb + (wm * 16 + i) * SROW + wn * WN + a * 16 + 4 * g) = acc[a][b];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                   // (also orders the reads of pass b-1 before the writes of b+1)
-#pragma unroll HAS_AUX ? ITERS : 1                          // unrolled only where the prefetched registers need static indices (the GELU body is big)
+#pragma unroll HAS_AUX ? ITERS : 1                          // unrolled only where the prefetched aux registers need static indices (the GELU body is big)
             for (int it = 0; it < ITERS; ++it) {
                 const int c = t + it * NT;
                 if (c >= PASS_ROWS * CPR) continue;
@@ -520,7 +531,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RES) {
                     if (p.bias != nullptr) {
                         float bv[8];
-                        unpack8(*reinterpret_cast<const u32x4*>(p.bias + n), bv);
+                        u32x4 bq = biasr[0];                 // select chain instead of a dynamic register index (the loop may stay rolled)
+#pragma unroll
+                        for (int k = 1; k < ITERS; ++k) bq = (it == k) ? biasr[k] : bq;
+                        unpack8(bq, bv);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += bv[e];
                     }

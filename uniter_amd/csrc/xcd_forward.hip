@@ -115,105 +115,114 @@ __device__ __forceinline__ bool xbar(Team& tm) {
 }
 
 // ---- GEMM phase ------------------------------------------------------------------------------------------------------
-enum { XEPI_BIAS = 0, XEPI_BIAS_ACT = 1, XEPI_BIAS_DROP_RES = 2 };
+// One tile shape for every GEMM of a layer (96 x 96 x 64, six-stage ring = 147 KB of LDS) and ONE inlined instance of the
+// code: the phases differ only in run-time arguments.  The activation of the FFN is its own element-wise phase so that
+// all eight waves of a workgroup share its transcendental work instead of the four MFMA waves alone.
+constexpr int XBM = 96, XBN = 96, XNS = 6;
+constexpr int XSTAGE = (XBM + XBN) * 64;           // bf16 elements per ring slot
+static_assert(XNS * XSTAGE * 2 <= X_SMEM, "ring must fit the launch's LDS");
 
-struct XGemm {                             // dense operands: A [M][K], W [N][K], res / C / C2 [M][N]
+struct XGemm {                             // dense operands: A [M][K], W [N][K], res / C [M][N]
     const bf16_t* A;                       // activations of this group (written earlier in this launch)
     const bf16_t* W;                       // weights
     const bf16_t* bias;                    // [N]
-    const bf16_t* res;                     // residual (XEPI_BIAS_DROP_RES)
-    bf16_t* C; bf16_t* C2;                 // C2: activation output (XEPI_BIAS_ACT)
+    const bf16_t* res;                     // residual: non-null selects bias + dropout + residual, null bias only
+    bf16_t* C;
     int M, N, K;
-    int act;
-    int dbg;                               // experiment switches (UNITER_AMD_XCD_DBG)
-    unsigned long long* pr;                // debug stamps of this workgroup for this phase (8 words) or null
     int row_base;                          // row of the whole batch that row 0 of the group is (dropout element index)
+    int dbg;                               // experiment switches (UNITER_AMD_XCD_DBG): 4 = no MFMA, 8 = no DMA
+    unsigned long long* pr;                // debug stamps of this workgroup for this phase (8 words) or null
     DropoutCfg drop;
 };
 
-// The phases are real (non-inlined) functions so that each gets its own register allocation; their arguments arrive in
-// VGPRs although they are wave-uniform: pass them through readfirstlane so that addresses and loop control stay scalar.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-template <typename T>
-__device__ __forceinline__ T* uni(T* p) {
-    const uint64_t v = (uint64_t)p;
-    const uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)(v >> 32));
-    return (T*)(((uint64_t)hi << 32) | (uint64_t)lo);
-}
-__device__ __forceinline__ DropoutCfg uni(const DropoutCfg& d) {
-    DropoutCfg r;
-    r.p = uni(d.p); r.scale = uni(d.scale); r.thresh = uni(d.thresh);
-    r.seed_lo = uni(d.seed_lo); r.seed_hi = uni(d.seed_hi); r.off_lo = uni(d.off_lo); r.off_hi = uni(d.off_hi);
-    r.off_ptr = uni(d.off_ptr);
-    return r;
-}
-// pointers that went through a call are generic: name the global address space at the access
-typedef __attribute__((address_space(1))) u32x2 g_u32x2;
-__device__ __forceinline__ u32x2 gload8(const void* p) { return *(const g_u32x2*)p; }
-__device__ __forceinline__ u32x2 gload8_nt(const void* p) { return __builtin_nontemporal_load((const g_u32x2*)p); }
-__device__ __forceinline__ void gstore8(void* p, const u32x2 v) { *(g_u32x2*)p = v; }
 
-template <int NSTAGE, int G>
+template <int G>
 __device__ __forceinline__ void xwait(int younger) {       // this wave's share of a step has landed; `younger` steps stay in flight
     static_assert(4 * G <= 63, "vmcnt is a 6-bit counter");
-    if (NSTAGE >= 6 && younger >= 4)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * G) : "memory");
-    else if (NSTAGE >= 5 && younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * G) : "memory");
-    else if (NSTAGE >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
-    else if (NSTAGE >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-    else                                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (younger >= 4)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * G) : "memory");
+    else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * G) : "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+    else                   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // C[M,N] = epilogue(A[M,K] * W[N,K]^T): tiles role, role+nx, ... of the group's tile list (M fastest), as one stream of K steps.
-template <int BM, int BN, int NSTAGE, int EPI>
-__device__ __noinline__ void xgemm(const XGemm q_in, const int role_in, const int nx_in, bf16_t* smem_in) {
+__device__ __forceinline__ void xgemm(const XGemm& q, const int role, const int nx, bf16_t* smem) {
 #pragma clang fp contract(off)          // the epilogue arithmetic of gemm.hip, rounding for rounding
-    XGemm q;
-    q.A = uni(q_in.A); q.W = uni(q_in.W); q.bias = uni(q_in.bias); q.res = uni(q_in.res); q.C = uni(q_in.C); q.C2 = uni(q_in.C2);
-    q.M = uni(q_in.M); q.N = uni(q_in.N); q.K = uni(q_in.K); q.act = uni(q_in.act); q.dbg = uni(q_in.dbg); q.pr = uni(q_in.pr); q.row_base = uni(q_in.row_base);
-    q.drop = uni(q_in.drop);
-    const int role = uni(role_in), nx = uni(nx_in);
-    bf16_t* smem = uni(smem_in);
-    constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
-    static_assert(WM % 16 == 0 && WN % 16 == 0 && BM % 32 == 0 && BN % 32 == 0, "tile shape");
-    constexpr int TILE_R = BM * 64, TILE_C = BN * 64, STAGE = TILE_R + TILE_C;
-    constexpr int G = BM / 32 + BN / 32;
-    static_assert(NSTAGE * STAGE * 2 <= X_SMEM, "ring must fit the launch's LDS");
+    constexpr int WM = XBM / 2, WN = XBN / 2, MI = WM / 16, NI = WN / 16;
+    constexpr int TILE_R = XBM * 64;
+    constexpr int NP = XBM / 32;                         // LDS-DMA pieces per loader wave, operand and K step
+    constexpr int G = 2 * NP;
+    static_assert(XBM == XBN, "one piece table serves both operands");
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    const int tiles_m = (q.M + BM - 1) / BM, tiles_n = q.N / BN, ntiles = tiles_m * tiles_n;
+    const int tiles_m = (q.M + XBM - 1) / XBM, tiles_n = q.N / XBN, ntiles = tiles_m * tiles_n;
     const int ntl = role < ntiles ? (ntiles - role + nx - 1) / nx : 0;
     const int nk = q.K >> 6;
     const int nsteps = ntl * nk;
 
     if (wid >= 4) {
-        // ---- loader waves: step s goes to ring slot s % NSTAGE; one s_barrier per step, shared with the MFMA waves ----
+        // ---- loader waves: step s goes to ring slot s % XNS; one s_barrier per step, shared with the MFMA waves ----
+        // The per-lane part of a source address (row, swizzled 16-byte chunk) is a 32-bit byte offset computed once per
+        // tile; per K step a piece is "uniform origin + that offset" — the scalar unit advances the origin.
         const int lw = wid - 4;
         const bool rec = q.pr != nullptr && t == 256;
         if (rec) q.pr[4] = wall_clock64();
+        uint32_t offw[NP], offa[NP];
+        int prow[NP];
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const int j = it * 4 + lw;
+            const int r = 8 * j + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            prow[it] = r;
+            offw[it] = (uint32_t)((r * q.K + c * 8) * 2);
+            offa[it] = offw[it];
+        }
         int lt = role, lkt = 0, slot = 0, issued = 0;
-        auto issue = [&]() {
+        const char* oa = nullptr;
+        const char* ow = nullptr;
+        auto new_tile = [&]() {
             const int tm = lt % tiles_m, tn = lt / tiles_m;
-            bf16_t* tr_ = smem + slot * STAGE;
-            if (!(q.dbg & 8)) {
-                if ((q.dbg & 3) == 0)      glds_kc<BM, 16>(tr_, q.A, q.K, tm * BM, q.M, lkt * 64, lw, lane);
-                else if ((q.dbg & 3) == 1) glds_kc<BM, 0>(tr_, q.A, q.K, tm * BM, q.M, lkt * 64, lw, lane);
-                else                       glds_kc<BM, 2>(tr_, q.A, q.K, tm * BM, q.M, lkt * 64, lw, lane);
-                if (q.dbg & 16) glds_kc<BN, 2>(tr_ + TILE_R, q.W, q.K, tn * BN, q.N, lkt * 64, lw, lane);
-                else            glds_kc<BN, 0>(tr_ + TILE_R, q.W, q.K, tn * BN, q.N, lkt * 64, lw, lane);
+            const int m0 = tm * XBM;
+            oa = reinterpret_cast<const char*>(q.A) + (int64_t)m0 * q.K * 2;
+            ow = reinterpret_cast<const char*>(q.W) + (int64_t)tn * XBN * q.K * 2;
+            if (m0 + XBM > q.M) {                         // rows beyond the group: clamp to its last row (never stored)
+#pragma unroll
+                for (int it = 0; it < NP; ++it) {
+                    const int r = prow[it] < q.M - m0 ? prow[it] : q.M - m0 - 1;
+                    offa[it] = offw[it] - (uint32_t)((prow[it] - r) * q.K * 2);
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < NP; ++it) offa[it] = offw[it];
             }
-            slot = (slot + 1 == NSTAGE) ? 0 : slot + 1;
+        };
+        auto issue = [&]() {
+            if (lkt == 0) new_tile();
+            bf16_t* tr_ = smem + slot * XSTAGE;
+            if (!(q.dbg & 8)) {
+#pragma unroll
+                for (int it = 0; it < NP; ++it)
+                    glds16<16>(reinterpret_cast<const bf16_t*>(oa + offa[it]), tr_ + (it * 4 + lw) * 512);
+#pragma unroll
+                for (int it = 0; it < NP; ++it)
+                    glds16<0>(reinterpret_cast<const bf16_t*>(ow + offw[it]), tr_ + TILE_R + (it * 4 + lw) * 512);
+            }
+            oa += 128; ow += 128;
+            slot = (slot + 1 == XNS) ? 0 : slot + 1;
             if (++lkt == nk) { lkt = 0; lt += nx; }
             ++issued;
         };
-#pragma unroll
-        for (int d = 0; d < NSTAGE - 1; ++d)
+#pragma unroll 1
+        for (int d = 0; d < XNS - 1; ++d)
             if (issued < nsteps) issue();
         if (rec) q.pr[5] = wall_clock64();
+#pragma unroll 1
         for (int j = 0; j < nsteps; ++j) {
             if (j == 1 && rec) q.pr[6] = wall_clock64();
             if (q.dbg & 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else xwait<NSTAGE, G>(issued - 1 - j);
+            else xwait<G>(issued - 1 - j);
             __builtin_amdgcn_s_barrier();      // step j is complete in LDS; every MFMA wave is done with step j-1's slot
             if (issued < nsteps) issue();
         }
@@ -224,29 +233,27 @@ __device__ __noinline__ void xgemm(const XGemm q_in, const int role_in, const in
     // ---- MFMA waves (2 x 2) ----
     const int g = lane >> 4, i = lane & 15;
     const int wm = wid >> 1, wn = wid & 1;
+    const bool with_res = q.res != nullptr;
     f32x4 acc[NI][MI];
 #pragma unroll
     for (int a = 0; a < NI; ++a)
 #pragma unroll
         for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // bias and residual of a tile are fetched at the tile's FIRST K step: their latency hides under the main loop instead of
-    // being paid once per 16x16 block in the epilogue (measured: 10-30 us per phase when loaded where they are used)
+    // bias and residual of a tile are fetched at the tile's FIRST K step: their latency hides under the main loop
     u32x2 bias_r[NI];
     u32x2 res_r[NI][MI];
     auto prefetch = [&](const int tile) {
-        const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+        const int m0 = (tile % tiles_m) * XBM, n0 = (tile / tiles_m) * XBN;
 #pragma unroll
         for (int a = 0; a < NI; ++a) {
             const int n = n0 + wn * WN + a * 16 + 4 * g;
-            bias_r[a] = q.bias != nullptr ? gload8(q.bias + n) : u32x2{0u, 0u};
-            if constexpr (EPI == XEPI_BIAS_DROP_RES) {
+            bias_r[a] = ldg8<false>(q.bias + n);
 #pragma unroll
-                for (int b = 0; b < MI; ++b) {
-                    int m = m0 + wm * WM + b * 16 + i;
-                    m = m < q.M ? m : q.M - 1;
-                    res_r[a][b] = gload8_nt(q.res + (int64_t)m * q.N + n);
-                }
+            for (int b = 0; b < MI; ++b) {
+                int m = m0 + wm * WM + b * 16 + i;
+                m = m < q.M ? m : q.M - 1;
+                res_r[a][b] = with_res ? ldg8<true>(q.res + (int64_t)m * q.N + n) : u32x2{0u, 0u};
             }
         }
     };
@@ -254,32 +261,34 @@ __device__ __noinline__ void xgemm(const XGemm q_in, const int role_in, const in
     const bool rec = q.pr != nullptr && t == 0;
     if (rec) q.pr[0] = wall_clock64();
     int slot = 0, kt = 0, ct = role;
+#pragma unroll 1
     for (int j = 0; j < nsteps; ++j) {
         if (kt == 0) prefetch(ct);
         __builtin_amdgcn_s_barrier();
         if (j == 0 && rec) q.pr[1] = wall_clock64();
-        const bf16_t* tr = smem + slot * STAGE;
+        const bf16_t* tr = smem + slot * XSTAGE;
         const bf16_t* tc = tr + TILE_R;
-        if (!(q.dbg & 4))
+        if (!(q.dbg & 4)) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fr[MI], fc[NI];
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fr[MI], fc[NI];
 #pragma unroll
-            for (int b = 0; b < MI; ++b) fr[b] = frag_kc(tr, wm * WM + b * 16 + i, ks, g);
+                for (int b = 0; b < MI; ++b) fr[b] = frag_kc(tr, wm * WM + b * 16 + i, ks, g);
 #pragma unroll
-            for (int a = 0; a < NI; ++a) fc[a] = frag_kc(tc, wn * WN + a * 16 + i, ks, g);
+                for (int a = 0; a < NI; ++a) fc[a] = frag_kc(tc, wn * WN + a * 16 + i, ks, g);
 #pragma unroll
-            for (int a = 0; a < NI; ++a)
+                for (int a = 0; a < NI; ++a)
 #pragma unroll
-                for (int b = 0; b < MI; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[a], fr[b], acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < MI; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[a], fr[b], acc[a][b], 0, 0, 0);
+            }
         }
-        slot = (slot + 1 == NSTAGE) ? 0 : slot + 1;
+        slot = (slot + 1 == XNS) ? 0 : slot + 1;
         if (++kt < nk) continue;
         if (j == nsteps - 1 && rec) q.pr[2] = wall_clock64();
         // ---- epilogue of tile ct, straight from the accumulators: lane (g, i) holds C[m][n .. n+3] ----
         kt = 0;
-        const int m0 = (ct % tiles_m) * BM, n0 = (ct / tiles_m) * BN;
+        const int m0 = (ct % tiles_m) * XBM, n0 = (ct / tiles_m) * XBN;
         ct += nx;
 #pragma unroll
         for (int a = 0; a < NI; ++a) {
@@ -293,31 +302,20 @@ __device__ __noinline__ void xgemm(const XGemm q_in, const int role_in, const in
                 acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (m >= q.M) continue;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += bv[e];              // (a null bias was fetched as zeros: + 0.0f changes nothing but -0.0f, which bf16 GEMM outputs never keep apart)
-                bf16_t* cptr = q.C + (int64_t)m * q.N + n;
-                if constexpr (EPI == XEPI_BIAS_ACT) {
-                    const u32x2 ub = pack4(v);
-                    gstore8(cptr, ub);                                            // u (pre-activation)
-                    float uq[4], gq[4];
-                    unpack4(ub, uq);                                              // the activation sees the bf16-rounded u, as backward will
+                for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                if (with_res) {
+                    if (q.drop.p > 0.f) {
+                        float mv[4];
+                        dropout_mult4(q.drop, ((uint64_t)(q.row_base + m) * (uint64_t)q.N + (uint64_t)n) >> 2, mv);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) gq[e] = act_fwd(q.act, uq[e]);
-                    gstore8(q.C2 + (int64_t)m * q.N + n, pack4(gq));
-                } else {
-                    if constexpr (EPI == XEPI_BIAS_DROP_RES) {
-                        if (q.drop.p > 0.f) {
-                            float mv[4];
-                            dropout_mult4(q.drop, ((uint64_t)(q.row_base + m) * (uint64_t)q.N + (uint64_t)n) >> 2, mv);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] *= mv[e];
-                        }
-                        float rv[4];
-                        unpack4(res_r[a][b], rv);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                        for (int e = 0; e < 4; ++e) v[e] *= mv[e];
                     }
-                    gstore8(cptr, pack4(v));
+                    float rv[4];
+                    unpack4(res_r[a][b], rv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rv[e];
                 }
+                stg8<true>(q.C + (int64_t)m * q.N + n, pack4(v));
             }
         }
     }
@@ -330,19 +328,6 @@ __device__ __forceinline__ DropoutCfg site_dropout(const DropoutCfg& base, int l
     d.off_lo = (uint32_t)o;
     d.off_hi = (uint32_t)(o >> 32);
     return d;
-}
-
-template <int NC>
-__device__ __noinline__ void xlayernorm(const bf16_t* z_in, const bf16_t* gamma_in, const bf16_t* beta_in, bf16_t* y_in, float* mean_in, float* rstd_in,
-                                        int r0_in, int r1_in, int H_in, float eps_in, int role_in, int nx_in) {
-    const bf16_t* z = uni(z_in); const bf16_t* gamma = uni(gamma_in); const bf16_t* beta = uni(beta_in);
-    bf16_t* y = uni(y_in); float* mean = uni(mean_in); float* rstd = uni(rstd_in);
-    const int r0 = uni(r0_in), r1 = uni(r1_in), H = uni(H_in), role = uni(role_in), nx = uni(nx_in);
-    const float eps = uni(eps_in);
-    DropoutCfg nodrop{};
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    for (int row = r0 + role * 8 + wid; row < r1; row += nx * 8)
-        ln_fwd_row<NC, true>(z, gamma, beta, y, mean, rstd, row, H, eps, nodrop, lane);
 }
 
 __global__ __launch_bounds__(XT) void xcd_forward_kernel(const XArgs a) {
@@ -375,11 +360,12 @@ __global__ __launch_bounds__(XT) void xcd_forward_kernel(const XArgs a) {
     }
     __syncthreads();
     if (s_ok == 0u) return;
-    Team tm{a.ctl, a.host_flag, &a.ctl->bar[xcc * 32], 0u, s_nx, s_role, &s_ok};
+    Team tm{a.ctl, a.host_flag, &a.ctl->bar[xcc * 32], 0u, (unsigned)uni((int)s_nx), (unsigned)uni((int)s_role), &s_ok};
     const int role = (int)tm.role, nx = (int)tm.nx;
+    const int gi = uni((int)s_gi), ng = uni((int)s_ng);
 
     // this team's group of consecutive examples and its rows
-    const int b0 = (int)(((int64_t)a.B * s_gi) / s_ng), b1 = (int)(((int64_t)a.B * (s_gi + 1)) / s_ng);
+    const int b0 = (int)(((int64_t)a.B * gi) / ng), b1 = (int)(((int64_t)a.B * (gi + 1)) / ng);
     const int r0 = a.cu ? a.cu[b0] : b0 * a.L, r1 = a.cu ? a.cu[b1] : b1 * a.L;
     const int R = r1 - r0;
     if (R <= 0) return;                                        // the whole team leaves: nobody waits for it
@@ -387,16 +373,17 @@ __global__ __launch_bounds__(XT) void xcd_forward_kernel(const XArgs a) {
     const int H = a.H, I = a.I;
     DropoutCfg nodrop = a.d_hidden;
     nodrop.p = 0.f;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 
     auto stamp = [&](int l, int phase, int which) {
         if (a.probe != nullptr && threadIdx.x == 0)
             a.probe[(((size_t)blockIdx.x * X_MAX_LAYERS + l) * 8 + phase) * 2 + which] = wall_clock64();
     };
-    stamp(a.layer_begin, 7, 1);                                // start of the walk
     auto gpr = [&](int l, int k) -> unsigned long long* {      // GEMM-internal stamps of layer 5: behind the phase stamps
         if (a.probe == nullptr || l != 5) return nullptr;
         return a.probe + (size_t)256 * X_MAX_LAYERS * 8 * 2 + ((size_t)blockIdx.x * 4 + k) * 8;
     };
+
     const bf16_t* x = a.x_in;
     for (int l = a.layer_begin; l < a.layer_end; ++l) {
         const XLayer& P = a.layer[l];
@@ -409,66 +396,71 @@ __global__ __launch_bounds__(XT) void xcd_forward_kernel(const XArgs a) {
         bf16_t* gq = reinterpret_cast<bf16_t*>(A + a.o.g);
         bf16_t* z2 = reinterpret_cast<bf16_t*>(A + a.o.z2);
         bf16_t* y = reinterpret_cast<bf16_t*>(A + a.o.y);
-
-        // ---- model/layer.py:76-78: Q, K, V projections as one [3H, H] GEMM ----
-        {
-            const XGemm q{x + (int64_t)r0 * H, P.wqkv, P.bqkv, nullptr, qkv + (int64_t)r0 * 3 * H, nullptr, R, 3 * H, H, 0, a.dbg, gpr(l, 0), r0, nodrop};
-            xgemm<96, 288, 3, XEPI_BIAS>(q, role, nx, smem);
-        }
-        stamp(l, 0, 0);
-        if (!xbar(tm)) return;
-        stamp(l, 0, 1);
-        // ---- model/layer.py:80-100: attention, one (example, head) unit at a time ----
-        {
-            AttnArgs p{};
-            p.qkv = qkv; p.mask_bias = a.cu ? nullptr : a.mask_bias; p.ctx = ctx; p.lse = reinterpret_cast<float*>(A + a.o.lse);
-            p.B = a.B; p.L = a.L; p.heads = a.heads; p.Lp = a.Lp; p.cu = a.cu;
-            p.drop = site_dropout(a.d_attn, l, 0);
-            const int units = (b1 - b0) * a.heads;
-            for (int un = role; un < units; un += nx) {
-                attn_fwd_unit<8, true>(p, (b0 + un / a.heads) * a.heads + un % a.heads, smem_raw);
-                __syncthreads();
+#pragma unroll 1
+        for (int ph = 0; ph < 8; ++ph) {
+            if (ph == 0 || ph == 2 || ph == 4 || ph == 6) {
+                XGemm q;
+                q.dbg = a.dbg; q.row_base = r0; q.M = R; q.drop = nodrop; q.res = nullptr;
+                q.pr = gpr(l, ph >> 1);
+                if (ph == 0) {            // model/layer.py:76-78: Q, K, V projections as one [3H, H] GEMM
+                    q.A = x + (int64_t)r0 * H; q.W = P.wqkv; q.bias = P.bqkv; q.C = qkv + (int64_t)r0 * 3 * H; q.N = 3 * H; q.K = H;
+                } else if (ph == 2) {     // model/layer.py:112-114: dense + dropout + residual
+                    q.A = ctx + (int64_t)r0 * H; q.W = P.wo; q.bias = P.bo; q.res = x + (int64_t)r0 * H; q.C = z1 + (int64_t)r0 * H; q.N = H; q.K = H;
+                    q.drop = site_dropout(a.d_hidden, l, 1);
+                } else if (ph == 4) {     // model/layer.py:140: dense (its activation is phase 5)
+                    q.A = av + (int64_t)r0 * H; q.W = P.w1; q.bias = P.b1; q.C = u + (int64_t)r0 * I; q.N = I; q.K = H;
+                } else {                  // model/layer.py:153-155: dense + dropout + residual
+                    q.A = gq + (int64_t)r0 * I; q.W = P.w2; q.bias = P.b2; q.res = av + (int64_t)r0 * H; q.C = z2 + (int64_t)r0 * H; q.N = H; q.K = I;
+                    q.drop = site_dropout(a.d_hidden, l, 2);
+                }
+                xgemm(q, role, nx, smem);
+            } else if (ph == 1) {         // model/layer.py:80-100: attention, one (example, head) unit at a time
+                AttnArgs p{};
+                p.qkv = qkv; p.mask_bias = a.cu ? nullptr : a.mask_bias; p.ctx = ctx; p.lse = reinterpret_cast<float*>(A + a.o.lse);
+                p.B = a.B; p.L = a.L; p.heads = a.heads; p.Lp = a.Lp; p.cu = a.cu;
+                p.drop = site_dropout(a.d_attn, l, 0);
+                const int units = (b1 - b0) * a.heads;
+                for (int un = role; un < units; un += nx) {
+                    attn_fwd_unit<8, true>(p, (b0 + un / a.heads) * a.heads + un % a.heads, smem_raw);
+                    __syncthreads();
+                }
+            } else if (ph == 5) {         // model/layer.py:141: activation, on the bf16-rounded pre-activation as backward will see it
+                const int64_t nchunk = (int64_t)R * I / 8;
+                const bf16_t* ub = u + (int64_t)r0 * I;
+                bf16_t* gb = gq + (int64_t)r0 * I;
+                const int64_t stride = (int64_t)nx * XT;
+                for (int64_t c = (int64_t)role * XT + threadIdx.x; c < nchunk; c += 3 * stride) {
+                    u32x4 v[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        if (c + k * stride < nchunk) v[k] = ldg16<true>(ub + (c + k * stride) * 8);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        if (c + k * stride >= nchunk) continue;
+                        float f[8];
+                        unpack8(v[k], f);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = act_fwd(a.act, f[e]);
+                        *(gmem_u32x4*)(gb + (c + k * stride) * 8) = pack8(f);
+                    }
+                }
+            } else {                      // LayerNorm of the attention block (3) / of the layer (7)
+                const bf16_t* z = ph == 3 ? z1 : z2;
+                const bf16_t* gam = ph == 3 ? P.ln1_g : P.ln2_g;
+                const bf16_t* bet = ph == 3 ? P.ln1_b : P.ln2_b;
+                bf16_t* out = ph == 3 ? av : y;
+                float* mean = reinterpret_cast<float*>(A + (ph == 3 ? a.o.mean1 : a.o.mean2));
+                float* rstd = reinterpret_cast<float*>(A + (ph == 3 ? a.o.rstd1 : a.o.rstd2));
+                for (int row = r0 + role * 8 + wid; row < r1; row += nx * 8) {
+                    if (H == 768) ln_fwd_row<3, true>(z, gam, bet, out, mean, rstd, row, H, a.eps, nodrop, lane);
+                    else          ln_fwd_row<4, true>(z, gam, bet, out, mean, rstd, row, H, a.eps, nodrop, lane);
+                }
             }
+            stamp(l, ph, 0);
+            if (ph == 7 && l + 1 == a.layer_end) break;
+            if (!xbar(tm)) return;
+            stamp(l, ph, 1);
         }
-        stamp(l, 1, 0);
-        if (!xbar(tm)) return;
-        stamp(l, 1, 1);
-        // ---- model/layer.py:112-114: dense + dropout + residual ----
-        {
-            const XGemm q{ctx + (int64_t)r0 * H, P.wo, P.bo, x + (int64_t)r0 * H, z1 + (int64_t)r0 * H, nullptr, R, H, H, 0, a.dbg, gpr(l, 1), r0,
-                          site_dropout(a.d_hidden, l, 1)};
-            xgemm<96, 96, 6, XEPI_BIAS_DROP_RES>(q, role, nx, smem);
-        }
-        stamp(l, 2, 0);
-        if (!xbar(tm)) return;
-        stamp(l, 2, 1);
-        if (H == 768) xlayernorm<3>(z1, P.ln1_g, P.ln1_b, av, reinterpret_cast<float*>(A + a.o.mean1), reinterpret_cast<float*>(A + a.o.rstd1), r0, r1, H, a.eps, role, nx);
-        else          xlayernorm<4>(z1, P.ln1_g, P.ln1_b, av, reinterpret_cast<float*>(A + a.o.mean1), reinterpret_cast<float*>(A + a.o.rstd1), r0, r1, H, a.eps, role, nx);
-        stamp(l, 3, 0);
-        if (!xbar(tm)) return;
-        stamp(l, 3, 1);
-        // ---- model/layer.py:140-141: dense + activation ----
-        {
-            const XGemm q{av + (int64_t)r0 * H, P.w1, P.b1, nullptr, u + (int64_t)r0 * I, gq + (int64_t)r0 * I, R, I, H, a.act, a.dbg, gpr(l, 2), r0, nodrop};
-            xgemm<96, 192, 4, XEPI_BIAS_ACT>(q, role, nx, smem);
-        }
-        stamp(l, 4, 0);
-        if (!xbar(tm)) return;
-        stamp(l, 4, 1);
-        // ---- model/layer.py:153-155: dense + dropout + residual ----
-        {
-            const XGemm q{gq + (int64_t)r0 * I, P.w2, P.b2, av + (int64_t)r0 * H, z2 + (int64_t)r0 * H, nullptr, R, H, I, 0, a.dbg, gpr(l, 3), r0,
-                          site_dropout(a.d_hidden, l, 2)};
-            xgemm<96, 96, 6, XEPI_BIAS_DROP_RES>(q, role, nx, smem);
-        }
-        stamp(l, 5, 0);
-        if (!xbar(tm)) return;
-        stamp(l, 5, 1);
-        if (H == 768) xlayernorm<3>(z2, P.ln2_g, P.ln2_b, y, reinterpret_cast<float*>(A + a.o.mean2), reinterpret_cast<float*>(A + a.o.rstd2), r0, r1, H, a.eps, role, nx);
-        else          xlayernorm<4>(z2, P.ln2_g, P.ln2_b, y, reinterpret_cast<float*>(A + a.o.mean2), reinterpret_cast<float*>(A + a.o.rstd2), r0, r1, H, a.eps, role, nx);
-        stamp(l, 6, 0);
-        if (l + 1 < a.layer_end && !xbar(tm)) return;
-        stamp(l, 6, 1);
         x = y;
     }
 }
