@@ -860,7 +860,7 @@ int launch_group(GemmGroupArgs& ga, int cfg, hipStream_t st) {
 #define UH_GROUP_CASE(I) case I: return launch_group_idx<I>(ga, st);
         UH_GROUP_CASE(0) UH_GROUP_CASE(1) UH_GROUP_CASE(2) UH_GROUP_CASE(3) UH_GROUP_CASE(13) UH_GROUP_CASE(14) UH_GROUP_CASE(15)
         UH_GROUP_CASE(20) UH_GROUP_CASE(23) UH_GROUP_CASE(24) UH_GROUP_CASE(26) UH_GROUP_CASE(27) UH_GROUP_CASE(29) UH_GROUP_CASE(33)
-        UH_GROUP_CASE(34) UH_GROUP_CASE(36) UH_GROUP_CASE(37) UH_GROUP_CASE(43) UH_GROUP_CASE(44) UH_GROUP_CASE(45) UH_GROUP_CASE(51)
+        UH_GROUP_CASE(34) UH_GROUP_CASE(36) UH_GROUP_CASE(37) UH_GROUP_CASE(43) UH_GROUP_CASE(44) UH_GROUP_CASE(45) UH_GROUP_CASE(49) UH_GROUP_CASE(51)
         UH_GROUP_CASE(52)
 #undef UH_GROUP_CASE
         default: uh_set_error("gemm group: tile index %d is not a wgrad tile", cfg); return -1;
@@ -1106,7 +1106,7 @@ int gemm_wgrad(const void* dy, const void* x, void* dw, int64_t M, int64_t N, in
 }
 
 // Up to four weight gradients dw_q[N_q,K_q] (+)= dy_q[M,N_q]^T x_q[M,K_q] over the same M tokens in ONE launch.
-static const int kGroupCfgs[] = {0, 1, 2, 3, 13, 14, 15, 20, 23, 24, 26, 27, 29, 33, 34, 36, 37, 43, 44, 45, 51, 52};
+static const int kGroupCfgs[] = {0, 1, 2, 3, 13, 14, 15, 20, 23, 24, 26, 27, 29, 33, 34, 36, 37, 43, 44, 45, 49, 51, 52};
 static bool group_cfg_ok(int cfg, int n, int64_t M, const int64_t* N, const int64_t* K) {
     const int bm = kTiles[cfg].bm, bn = kTiles[cfg].bn;
     if (kTiles[cfg].ws && M % 64 != 0) return false;
@@ -1141,7 +1141,9 @@ int gemm_wgrad_group(int n, const void* const* dy, const void* const* x, void* c
     int cfg = cfg_override;
     if (cfg < 0) {
         Tuned tn;
-        if (tuned_lookup(3, M, group_sum(n, N), group_sum(n, K), &tn) && group_cfg_ok(tn.cfg, n, M, N, K)) cfg = tn.cfg;
+        static const int env_cfg = [] { const char* e = getenv("UNITER_AMD_GROUP_CFG"); return e ? atoi(e) : -1; }();   // experiment hook
+        if (env_cfg >= 0 && env_cfg < kNumTiles && group_cfg_ok(env_cfg, n, M, N, K)) cfg = env_cfg;
+        else if (tuned_lookup(3, M, group_sum(n, N), group_sum(n, K), &tn) && group_cfg_ok(tn.cfg, n, M, N, K)) cfg = tn.cfg;
         else {
             const int prefer[] = {33, 29, 0, 3};                      // 128x128 ws, 64x64 ws, then the plain tiles
             for (int c : prefer)
