@@ -9,10 +9,8 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --no-cpu-baseline --no-kernel-timing"
-# pin the GEMM tile choices: the first (unprofiled) run sweeps and saves them, the profiled runs reuse them, so the
-# traces contain the step's kernels only and all passes measure the same kernels
-export UNITER_AMD_TUNE_CACHE=$OUT/tune_cache.json
-rm -f "$UNITER_AMD_TUNE_CACHE"
+# the GEMM tile choices are the shipped ones (uniter_amd/tuned/gfx950.json): every pass measures the same kernels and no
+# pass contains tuning sweeps
 timeout 300 python $ROOT/bench.py --no-cpu-baseline --steps 30 --warmup 5 > "$OUT/bench.json.log" 2> "$OUT/bench.err.log"
 echo "bench rc=$?"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python $ROOT/bench.py --no-cpu-baseline --steps 10 --warmup 3 > "$OUT/trace.log" 2>&1
