@@ -319,7 +319,7 @@ def main():
     rank = D.rank()
 
     cfg_path = os.path.join("/tmp", "uniter_bench_%d.json" % os.getpid())
-    lpb = int(os.environ.get("UNITER_BENCH_LAYERS_PER_BUCKET", "4"))
+    lpb = int(os.environ.get("UNITER_BENCH_LAYERS_PER_BUCKET", "3"))
     overlap = bool(args.overlap and not args.graph)
     runner = StepRunner(args.config, device, rank=rank, world=world, seed=77, ragged=args.ragged, pack=args.pack,
                         overlap=overlap, cfg_path=cfg_path, reducer_layers_per_bucket=lpb)

@@ -388,6 +388,16 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
                             const void* x_in, const float* mask_bias, const void* dy, void* dx,
                             void* acts, void* scratch, uint64_t seed, uint64_t offset, void* stream);
 
+/* Backward keeps the weight-gradient work on an internal side stream and, at the end of every call, makes `stream` wait for
+ * it.  A caller that runs the stack as several layer ranges (one per gradient bucket of a data-parallel reducer) can avoid
+ * serialising the two streams at every range boundary: uniter_encoder_defer_side_join(1) makes the following calls of THIS
+ * thread return without that wait — the parameter gradients of those ranges are then only complete on a stream that has
+ * called uniter_encoder_side_join(stream) after them (typically the communication stream of the bucket) — and
+ * uniter_encoder_defer_side_join(0) before the last range restores the default, whose end-of-call wait covers everything.
+ * (model/model.py:282-292 has no counterpart: the reference's autograd runs layer by layer on one stream.) */
+int uniter_encoder_defer_side_join(int enable);
+int uniter_encoder_side_join(void* stream);
+
 /* Autotune the 12 GEMM shapes (4 forward, 4 dgrad, 4 wgrad) of one BertLayer for this (B, L, H, I): synchronous,
  * call once per shape at set-up time (the Python side does it on the first forward of a new shape). */
 int uniter_encoder_autotune(const UniterEncoderShape* s, void* stream);

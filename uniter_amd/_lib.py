@@ -124,6 +124,8 @@ SIGNATURES = {
                                         _P, _P, _P, _P, _P, _P, c_uint64, c_uint64, _P]),
     "uniter_encoder_autotune": (c_int, [POINTER(UniterEncoderShape), _P]),
     "uniter_encoder_debug_side_stream": (c_int, [c_int]),
+    "uniter_encoder_defer_side_join": (c_int, [c_int]),
+    "uniter_encoder_side_join": (c_int, [c_void_p]),
     "uniter_encoder_debug_xcd_forward": (c_int, [c_int]),
     "uniter_encoder_debug_xcd_probe": (c_int, [c_void_p]),
     "uniter_encoder_debug_tune_in_situ": (c_int, [c_int]),

@@ -77,6 +77,32 @@ __device__ __forceinline__ void stg8(void* p, const u32x2 v) {
     else __builtin_nontemporal_store(v, (gmem_u32x2*)p);
 }
 
+// Store of a kernel's OUTPUT (read next by a later kernel, possibly on another XCD).  UNITER_STORE_POLICY: 0 = `nt`
+// (the line stays dirty in this XCD's L2 until it is evicted or the end-of-kernel write-back flushes it), 1 = `sc1`
+// (write-through: the bytes leave the L2 while the kernel is still running), 2 = default policy.
+#ifndef UNITER_STORE_POLICY
+#define UNITER_STORE_POLICY 0
+#endif
+__device__ __forceinline__ void out_store16(void* p, const u32x4 v) {
+#if UNITER_STORE_POLICY == 1
+    // (inline asm: the builtin stores have no cache-policy operand; the s_nop covers the data-register hazard of a 128-bit store)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"((gmem_u32x4*)p), "v"(v) : "memory");
+#elif UNITER_STORE_POLICY == 2
+    *(gmem_u32x4*)p = v;
+#else
+    __builtin_nontemporal_store(v, (gmem_u32x4*)p);
+#endif
+}
+__device__ __forceinline__ void out_store8(void* p, const u32x2 v) {
+#if UNITER_STORE_POLICY == 1
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 0" ::"v"((gmem_u32x2*)p), "v"(v) : "memory");
+#elif UNITER_STORE_POLICY == 2
+    *(gmem_u32x2*)p = v;
+#else
+    __builtin_nontemporal_store(v, (gmem_u32x2*)p);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave64 reductions
 // ---------------------------------------------------------------------------------------------

@@ -90,6 +90,11 @@ struct SideStream {
     hipEvent_t side_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // recorded on the side stream
     hipEvent_t done = nullptr;
     int device = -1;
+    // state that outlives one uniter_encoder_backward call when the caller defers the end-of-call join (see
+    // uniter_encoder_defer_side_join): which side jobs may still be reading their input buffers
+    bool pending[6] = {false, false, false, false, false, false};
+    bool deferred = false;        // the previous call ended without making the caller's stream wait for the side stream
+    bool defer_request = false;   // the next call shall end that way
 };
 thread_local SideStream g_side;
 
@@ -235,7 +240,10 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
     //   0 / 1  the weight-gradient work of even / odd layers (reads dd2, dpre, dd1, dqkv of that parity's buffer set)
     //   2 / 3  the early column sums of the current layer (bias gradients of FFN1 / QKV read dpre / dqkv)   [ungrouped: wgrads too]
     //   4 / 5  the LayerNorm column sums of BertOutput / BertSelfOutput (read bufB)
-    bool side_pending[6] = {false, false, false, false, false, false};
+    bool local_pending[6] = {false, false, false, false, false, false};
+    bool* side_pending = side ? g_side.pending : local_pending;
+    if (side && !g_side.deferred)
+        for (int k = 0; k < 6; ++k) side_pending[k] = false;       // a fresh sequence: nothing of an earlier call is in flight
     auto fork = [&](int k) -> int {            // side stream may start job k once the main stream reaches this point
         if (!side) return 0;
         UH_CHECK_HIP(hipEventRecord(g_side.main_ev[k], st));
@@ -387,10 +395,29 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
     }
     if (pending >= 0) RC(group_launch(pending));
     if (side) {
-        // every weight gradient is complete (and the scratch buffers are free) once the caller's stream passes this point
-        UH_CHECK_HIP(hipEventRecord(g_side.done, ss));
-        UH_CHECK_HIP(hipStreamWaitEvent(st, g_side.done, 0));
+        if (g_side.defer_request) {
+            // the caller continues with the next range of layers right away and joins later (uniter_encoder_side_join):
+            // the buffer-reuse protection above carries over through g_side.pending
+            g_side.deferred = true;
+        } else {
+            // every weight gradient is complete (and the scratch buffers are free) once the caller's stream passes this point
+            UH_CHECK_HIP(hipEventRecord(g_side.done, ss));
+            UH_CHECK_HIP(hipStreamWaitEvent(st, g_side.done, 0));
+            g_side.deferred = false;
+        }
     }
+    return 0;
+}
+
+int uniter_encoder_defer_side_join(int enable) {
+    g_side.defer_request = enable != 0;
+    return 0;
+}
+
+int uniter_encoder_side_join(void* stream) {
+    if (g_side.stream == nullptr) return 0;                         // nothing was ever put on a side stream by this thread
+    UH_CHECK_HIP(hipEventRecord(g_side.done, g_side.stream));
+    UH_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, g_side.done, 0));
     return 0;
 }
 

@@ -542,13 +542,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 bf16_t* cptr = p.C + (int64_t)m * p.ldc + n;
                 if (EPI == EPI_BIAS_GELU) {
                     const u32x4 uq_bits = pack8(v);
-                    __builtin_nontemporal_store(uq_bits, reinterpret_cast<u32x4*>(cptr));   // u (pre-activation)
+                    out_store16(cptr, uq_bits);   // u (pre-activation)
                     // activation is applied to the bf16-rounded u so that backward (which only has u) is consistent
                     float uq[8], gq[8];
                     unpack8(uq_bits, uq);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) gq[e] = act_fwd(p.relu, uq[e]);
-                    __builtin_nontemporal_store(pack8(gq), reinterpret_cast<u32x4*>(p.C2 + (int64_t)m * p.ldc + n));
+                    out_store16(p.C2 + (int64_t)m * p.ldc + n, pack8(gq));
                     continue;
                 }
                 if (EPI == EPI_BIAS_DROP_RES) {
@@ -583,7 +583,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += ov[e];
                 }
-                __builtin_nontemporal_store(pack8(v), reinterpret_cast<u32x4*>(cptr));    // consumed by a later kernel from MALL/HBM, never from this L2
+                out_store16(cptr, pack8(v));    // consumed by a later kernel from MALL/HBM, never from this L2
             }
         }
     }

@@ -420,6 +420,9 @@ class _EncoderFn(torch.autograd.Function):
         dx = torch.empty(out_shape, dtype=_BF16, device=xc.device)
         cuts = set(l for l in range(n - 1) if extra[l] is not None)
         hook = ctx.hook
+        # a hook that joins the library's weight-gradient stream itself (uniter_encoder_side_join on its own stream) lets
+        # the ranges below follow each other without serialising the two streams at every range boundary
+        defer = hook is not None and getattr(hook, "joins_side_stream", False)
         while end > 0:
             inner = [c for c in cuts if c + 1 < end]
             begin = (max(inner) + 1) if inner else 0
@@ -436,6 +439,8 @@ class _EncoderFn(torch.autograd.Function):
                 x_in = ptr(xc)
             else:
                 x_in = ctx.acts.data_ptr() + (begin - 1) * act_bytes + out_off
+            if defer:
+                C.uniter_encoder_defer_side_join(1 if begin > 0 else 0)
             C.uniter_encoder_backward(ctypes.byref(s), table, begin, end, x_in,
                                       None if ctx.packed is not None else ptr(mask_bias), ptr(dy), ptr(dx),
                                       ptr(ctx.acts), ptr(scratch), ctx.seed, ctx.off, st)

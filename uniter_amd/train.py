@@ -92,7 +92,7 @@ class StepRunner(object):
     """Model + optimizer + resident synthetic batches of one workload; `train_step()` runs one optimizer step."""
 
     def __init__(self, name, device, rank=0, world=1, seed=77, ragged=False, pack=False, overlap=False, cfg_path=None,
-                 reducer_layers_per_bucket=4):
+                 reducer_layers_per_bucket=3):
         from .optim import build_optimizer, build_vqa_optimizer, overlap_boundaries
         from .utils import distributed as D
         from .utils.arena import flatten_model

@@ -18,6 +18,7 @@ MI355X design notes (xGMI is point-to-point, 7 links x ~153 GB/s per GPU; SURVEY
     gradient-norm / AdamW kernels instead of a separate pass over the gradients.
 The CPU tests run the same code over gloo with world_size 2.
 """
+import ctypes
 import math
 import os
 
@@ -212,9 +213,10 @@ def any_broadcast(data, root_rank):
 class _LayerHook(object):
     """callable(layer_index) + the set of layers at which it actually has work to do."""
 
-    def __init__(self, fn, ready_layers):
+    def __init__(self, fn, ready_layers, joins_side_stream=False):
         self.fn = fn
         self.ready_layers = ready_layers
+        self.joins_side_stream = joins_side_stream      # ops._EncoderFn.backward: see uniter_encoder_defer_side_join
 
     def __call__(self, layer_index):
         return self.fn(layer_index)
@@ -236,7 +238,7 @@ class GradientReducer(object):
     (heads finish first in backward, embeddings last: both are small next to the encoder).
     """
 
-    def __init__(self, arena, encoder=None, layers_per_bucket=4):
+    def __init__(self, arena, encoder=None, layers_per_bucket=3):
         self.arena = arena
         self.encoder = encoder
         self.buckets = []          # (lo, hi) element ranges
@@ -258,7 +260,8 @@ class GradientReducer(object):
                 covered.append(span)
             # backward only has to hand control back at the layers that complete a bucket (ops._EncoderFn.backward cuts
             # the stack there instead of after every layer)
-            encoder.grad_ready_hook = _LayerHook(self._on_layer, set(self.layer_bucket.keys()))
+            encoder.grad_ready_hook = _LayerHook(self._on_layer, set(self.layer_bucket.keys()),
+                                                 joins_side_stream=bool(arena.grad.is_cuda) and os.environ.get("UNITER_AMD_DEFER_JOIN", "1") != "0")
         covered.sort()
         pos = 0
         for lo, hi in covered:
@@ -282,6 +285,10 @@ class GradientReducer(object):
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self._stream.wait_event(ev)
+            # the weight gradients of the bucket come from the library's side stream, which the current stream has not
+            # been made to wait for between layer ranges (uniter_encoder_defer_side_join)
+            from .. import _lib
+            _lib.load().uniter_encoder_side_join(ctypes.c_void_p(self._stream.cuda_stream))
             with torch.cuda.stream(self._stream):
                 self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
         else:
