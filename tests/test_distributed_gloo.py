@@ -88,7 +88,7 @@ def _case_gradient_reducer(rank, world, D):
     model = UniterForPretraining.from_pretrained(TINY_CONFIG, {}, img_dim=IMG_DIM, img_label_dim=LABEL_DIM)
     arena = flatten_model(model)
     reducer = D.GradientReducer(arena, model.uniter.encoder, layers_per_bucket=1)
-    covered = sorted(reducer.buckets + reducer.rest)
+    covered = sorted(reducer.buckets + reducer.rest + reducer.rest_early)
     assert covered[0][0] == 0 and covered[-1][1] == arena.numel
     for (a, b), (c, d) in zip(covered, covered[1:]):
         assert b == c                                         # buckets tile the arena exactly once

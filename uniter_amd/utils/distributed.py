@@ -270,10 +270,18 @@ class GradientReducer(object):
             pos = max(pos, hi)
         if pos < arena.numel:
             self.rest.append((pos, arena.numel))
+        # Parameters that sit behind the encoder in the arena (pooler, task heads) are downstream of it in the model: their
+        # gradients are final before the encoder's backward starts, so their ranges go out with the first bucket instead
+        # of at finish(), where only the embeddings (final last) are left.
+        enc_hi = covered[-1][1] if covered else 0
+        self.rest_early = [r for r in self.rest if covered and r[0] >= enc_hi]
+        self.rest = [r for r in self.rest if r not in self.rest_early]
+        self._early_done = False
 
     def begin(self):
         self._armed = True
         self._pending = []
+        self._early_done = False
         if _on() and self.arena.grad.is_cuda and self._stream is None:
             self._stream = torch.cuda.Stream()
 
@@ -299,6 +307,10 @@ class GradientReducer(object):
             return
         b = self.layer_bucket.get(layer_index)
         if b is not None:
+            if not self._early_done:
+                self._early_done = True
+                for lo, hi in self.rest_early:
+                    self._reduce_range(lo, hi)
             self._reduce_range(*self.buckets[b])
 
     def finish(self):
@@ -307,6 +319,9 @@ class GradientReducer(object):
             if self.encoder is None:
                 self._reduce_range(0, self.arena.numel)
             else:
+                if not self._early_done:
+                    for lo, hi in self.rest_early:
+                        self._reduce_range(lo, hi)
                 for lo, hi in self.rest:
                     self._reduce_range(lo, hi)
         for w in self._pending:
