@@ -310,7 +310,8 @@ def test_full_size_determinism_and_eval_equals_p0(full_model):
     assert torch.isfinite(y1.float()).all()
 
 
-def test_persistent_per_xcd_forward_is_bit_identical(full_model):
+@pytest.mark.parametrize("pack", [False, True])
+def test_persistent_per_xcd_forward_is_bit_identical(full_model, pack):
     """csrc/xcd_forward.hip (one launch, one team of workgroups per XCD, L2-local barriers; opt-in) against the
     kernel-per-operation forward at the benchmark shape: every layer's output with dropout on and a ragged batch, and the
     gradients of a backward pass that runs off the activations each path saved."""
@@ -320,6 +321,7 @@ def test_persistent_per_xcd_forward_is_bit_identical(full_model):
     b = _full_batch(seed=11, ragged=True)
     params = [p for p in full_model.uniter.parameters()]
     set_dropout(full_model, 0.1)
+    full_model.uniter.pack_padding = pack            # padding-free rows (cu_seqlens): team boundaries fall on ragged row counts
 
     def run(enable):
         lib.uniter_encoder_debug_xcd_forward(enable)
@@ -337,6 +339,7 @@ def test_persistent_per_xcd_forward_is_bit_identical(full_model):
     finally:
         lib.uniter_encoder_debug_xcd_forward(0)
         set_dropout(full_model, 0.0)
+        full_model.uniter.pack_padding = False
     assert len(y0) == len(y1) == 12
     for a, c in zip(y0, y1):
         assert torch.equal(a, c)
