@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UNITER_HIP_ABI_VERSION 4
+#define UNITER_HIP_ABI_VERSION 5
 
 /* ------------------------------------------------------------------------------------------------
  * Library

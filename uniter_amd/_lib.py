@@ -11,7 +11,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "build", "libuniter_hip.so")
-ABI_VERSION = 4          # UNITER_HIP_ABI_VERSION of include/uniter_hip.h (struct layouts below must match it)
+ABI_VERSION = 5          # UNITER_HIP_ABI_VERSION of include/uniter_hip.h (struct layouts below must match it)
 
 
 class UniterHipError(RuntimeError):
