@@ -519,7 +519,10 @@ int layernorm_bwd(const void* dy, const void* dy_extra, const void* z, const flo
                   void* workspace, size_t ws_bytes, hipStream_t st) {
     if (ln_bwd_check(rows, H)) return -1;
     if (ws_bytes < layernorm_bwd_workspace_bytes(rows, H)) { uh_set_error("layernorm_bwd: workspace too small"); return -1; }
-    if (H % 8 == 0) {
+    // Large row counts (the encoder's LayerNorms go through layernorm_bwd_rows / _cols directly): row kernel + column kernel.
+    // The embedding LayerNorms (a few hundred to ~2000 rows, all on one stream) take the one-pass kernel below: two launches
+    // instead of three, and dy / z are read once.
+    if (H % 8 == 0 && rows > 2048) {
         int rc = layernorm_bwd_rows(dy, dy_extra, z, mean, rstd, gamma, dz, dd, rows, H, drop, post_drop, st);
         if (rc) return rc;
         return layernorm_bwd_cols(dy, dy_extra, z, mean, rstd, dz, dd, dgamma, dbeta, dbias, rows, H, accumulate, drop,
