@@ -19,6 +19,44 @@ __device__ __forceinline__ bf16x8 frag_kc(const bf16_t* tile, int row, int ks, i
     return lds_read_b128(tile + kc_off(row, ks * 4 + g));
 }
 
+// ---- K-strided tiles ---------------------------------------------------------------------------
+// K-strided tile: [64][W] bf16 (W = 64 or 128).  8-byte chunk ch of row r stored at ch ^ (h(r) << 2).
+// A 192-wide K-strided tile is a [64][128] sub-tile followed by a [64][64] sub-tile (columns 128..191), each in its
+// own swizzle; only the N-side operand may be 192 wide (dgrad with 192x192 / 128x192 / 96x192 tiles).
+template <int W>
+__device__ __forceinline__ int ks_swz(int r) {
+    if (W == 128) return (r & 3) | (((r >> 3) & 1) << 2);
+    return ((r >> 1) & 1) | (((r >> 3) & 1) << 1);
+}
+template <int W>
+__device__ __forceinline__ int ks_off8(int r, int ch8) {   // element offset of 8-byte chunk ch8 of row r
+    return r * W + ((ch8 ^ (ks_swz<W>(r) << 2)) << 2);
+}
+
+__device__ __forceinline__ s16x4 lds_read_tr(const bf16_t* p) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+}
+
+// same from a K-strided tile: lane (g, i = 4j+q) supplies row ks*32+8g+j (+4), cols cb+4q..
+template <int W>
+__device__ __forceinline__ bf16x8 frag_ks(const bf16_t* tile, int cb, int ks, int g, int i) {
+    if constexpr (W == 192) {
+        if (cb < 128) return frag_ks<128>(tile, cb, ks, g, i);
+        return frag_ks<64>(tile + 64 * 128, cb - 128, ks, g, i);
+    }
+    const int j = i >> 2, q = i & 3;
+    const int r0 = ks * 32 + 8 * g + j;
+    const int ch = (cb >> 2) + q;
+    const s16x4 lo = lds_read_tr(tile + ks_off8<W>(r0, ch));
+    const s16x4 hi = lds_read_tr(tile + ks_off8<W>(r0 + 4, ch));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 // ---- direct global -> LDS staging (global_load_lds_dwordx4) ---------------------------------------
 // One wave instruction moves 64 lanes x 16 B = 1 KiB to LDS base + lane*16 (the destination is lane-linear by
 // hardware), so the XOR swizzle is applied on the SOURCE address: lane l, which lands in physical 16-byte
