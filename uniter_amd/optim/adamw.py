@@ -58,7 +58,7 @@ class AdamW(Optimizer):
         self._keep = None
         self._clip = None             # device tensor [norm, coef] left by clip_grad_norm_
         self._norm_buf = None
-        self._graph = None            # (pinned host hyper table, device hyper table) in hipGraph mode
+        self._graph = None            # (ring of pinned hyper tables, device hyper table) in hipGraph mode
         self._overlap = None          # ctypes array of segment boundaries (parameter addresses) or None
         self._grads_zeroed = False    # the last step zeroed the gradients itself (fused), zero_grad() has nothing to do
         self.fuse_zero_grad = False   # True: step() zeroes every gradient once read and the next zero_grad() is a no-op —
@@ -267,18 +267,29 @@ class AdamW(Optimizer):
 
     # ---- hipGraph mode ----------------------------------------------------------------------------------
     def enable_graph_mode(self):
-        """Make step() capturable: hyper-parameters travel through a pinned host table + captured H2D copy instead of
-        kernel arguments.  Protocol per training step: `graph_prepare()` on the host (advances state['step'], folds the
-        current param_groups' lr / betas / ... into the pinned table), then step() — eagerly, under capture, or as part
-        of a graph replay."""
+        """Make step() capturable: hyper-parameters travel through a device table instead of kernel arguments.
+        Protocol per training step: `graph_prepare()` on the host (advances state['step'], folds the current
+        param_groups' lr / betas / ... into the next slot of a ring of pinned staging tables and enqueues its upload on
+        the current stream), then step() — eagerly, under capture, or as part of a graph replay.  The upload is NOT part
+        of the captured graph and every step has its own staging slot (recycled only after the upload that read it has
+        completed), so a host that runs several replays ahead cannot overwrite hyper-parameters a queued step has yet
+        to read."""
         if not self._ensure_plan():
             raise _lib.UniterHipError("enable_graph_mode needs gradients to exist (run one eager backward first)")
         dev = self._plan_groups[0][1][0].device
-        host = torch.zeros(16, 6, dtype=torch.float32).pin_memory()
-        self._graph = (host, torch.zeros(16, 6, dtype=torch.float32, device=dev))
+        n_slots = 8
+        slots = [torch.zeros(16, 6, dtype=torch.float32).pin_memory() for _ in range(n_slots)]
+        self._graph = (slots, torch.zeros(16, 6, dtype=torch.float32, device=dev))
+        self._graph_events = [None] * n_slots
+        self._graph_slot = -1
 
     def graph_prepare(self):
-        host = self._graph[0]
+        slots, dev = self._graph
+        self._graph_slot = (self._graph_slot + 1) % len(slots)
+        ev = self._graph_events[self._graph_slot]
+        if ev is not None:
+            ev.synchronize()                  # the upload that last read this slot (len(slots) steps ago) is done
+        host = slots[self._graph_slot]
         for ig, (gi, plist) in enumerate(self._plan_groups):
             group = self.param_groups[gi]
             for p in plist:
@@ -291,6 +302,10 @@ class AdamW(Optimizer):
                 step_size = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
             host[ig, 0], host[ig, 1], host[ig, 2] = lr, b1, b2
             host[ig, 3], host[ig, 4], host[ig, 5] = float(group['eps']), float(group['weight_decay']), step_size
+        dev.copy_(host, non_blocking=True)    # stream-ordered, ahead of the step that reads it
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev.device))
+        self._graph_events[self._graph_slot] = ev
 
     def step(self, closure=None):
         """One optimisation step over every parameter that has a gradient."""
@@ -300,8 +315,7 @@ class AdamW(Optimizer):
         if not self._ensure_plan(in_step=True):
             return loss           # nothing has a gradient: no-op, like the reference's dummy first step (pretrain.py:261-263)
         if self._graph is not None:
-            host, dev = self._graph
-            dev.copy_(host, non_blocking=True)
+            dev = self._graph[1]              # uploaded by graph_prepare()
             clip = self._clip
             self._clip = None
             C.uniter_adamw_step_dev(self._plan, ptr(dev), len(self._plan_groups), ptr(clip[1:]) if clip is not None else None,
