@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UNITER_HIP_ABI_VERSION 5
+#define UNITER_HIP_ABI_VERSION 6
 
 /* ------------------------------------------------------------------------------------------------
  * Library
@@ -137,6 +137,16 @@ int uniter_gemm_wgrad_group(int32_t n, const void* const* dy, const int64_t* ldd
  * uniter_gemm_wgrad_group_autotune times the legal tiles of such a group once (synchronous, set-up time) and remembers
  * the winner under kind 3, (M, sum N, sum K). */
 int uniter_gemm_wgrad_group_autotune(int32_t n, int64_t M, const int64_t* N, const int64_t* K, void* stream);
+/* The same with a workspace and an explicit tile.  When every N_q and K_q is a multiple of 256 the group may run on the
+ * 256 x 256 eight-phase tile (csrc/gemm8.cuh; tile index uniter_gemm_tile_count() - 1): with a workspace of
+ * uniter_gemm_wgrad_group_workspace_bytes(n, N, K) bytes (one fp32 slab per output tile) every tile is computed as TWO
+ * slices of the token contraction on two workgroups, which combine inside the launch — the first to finish parks its
+ * accumulators in the slab, the other adds them and writes the gradient — and the bias gradients are summed by extra
+ * workgroups of the same grid.  cfg < 0: the tuned choice (kind 3); splits: 0 = tuned, else 1 or 2. */
+size_t uniter_gemm_wgrad_group_workspace_bytes(int32_t n, const int64_t* N, const int64_t* K);
+int uniter_gemm_wgrad_group_ws(int32_t n, const void* const* dy, const int64_t* lddy, const void* const* x, const int64_t* ldx,
+                               void* const* dw, void* const* db, int64_t M, const int64_t* N, const int64_t* K, int accumulate,
+                               void* workspace, size_t workspace_bytes, int cfg, int splits, void* stream);
 
 /* Strided-operand variants (row stride in elements; operands may be column slices of a wider row-major matrix —
  * e.g. the q / k|v column blocks of a packed [T,3H] projection buffer).  Used by the NLVR2 paired cross-attention

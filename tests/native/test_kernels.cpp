@@ -259,19 +259,24 @@ static const int kTileBM[] = {128, 128, 64, 64, 96, 192, 192, 128, 96, 128, 96, 
                               96, 96, 128, 128, 64, 96, 128, 64, 96, 192,
                               96, 128, 192, 128,
                               128, 128, 192, 96, 192, 128, 192, 128, 64, 192,
-                              96, 96, 128, 128};
+                              96, 96, 128, 128,
+                              256};
 static const int kTileBN[] = {128, 64, 128, 64, 192, 96, 128, 192, 128, 96, 96, 64, 64, 64, 128, 64, 96, 64, 128, 96,
                               128, 192, 96, 64, 128, 96, 64, 128, 96, 64,
                               64, 128, 96, 128, 64, 64, 64, 128, 96, 64,
                               128, 96, 64, 128,
                               128, 128, 192, 192, 96, 192, 128, 64, 128, 64,
-                              128, 128, 96, 96};
-static const int kNumTiles = 58;     // 13..19 are 3-stage rings, 20..29 wave-specialised (4 compute + 4 loader waves)
+                              128, 128, 96, 96,
+                              256};
+static const int kNumTiles = 59;     // 13..19 are 3-stage rings, 20..29 wave-specialised (4 compute + 4 loader waves), 58 the eight-phase 256x256 tile
+static const int kTileG8 = 58;
 
 static void test_gemm(int M, int N, int K, int cfg, int splits) {
     char tag[128];
-    const bool pow2_bn = cfg < 0 || kTileBN[cfg] == 64 || kTileBN[cfg] == 128 || kTileBN[cfg] == 192;
-    const bool pow2_bm = cfg < 0 || kTileBM[cfg] == 64 || kTileBM[cfg] == 128;
+    const bool g8 = cfg == kTileG8;      // eight-phase tile: contraction % 64 == 0, output columns % 256 == 0, no bias gradient output
+    const bool pow2_bn = cfg < 0 || g8 || kTileBN[cfg] == 64 || kTileBN[cfg] == 128 || kTileBN[cfg] == 192;
+    const bool pow2_bm = cfg < 0 || g8 || kTileBM[cfg] == 64 || kTileBM[cfg] == 128;
+    if (g8 && K % 64 != 0) { printf("  (skip cfg%d for K=%d)\n", cfg, K); return; }
     if (cfg >= 0 && N % kTileBN[cfg] != 0) { printf("  (skip cfg%d for N=%d)\n", cfg, N); return; }
     HostBf X, W, Bv, R, DY;
     X.fill((size_t)M * K, 1.f); W.fill((size_t)N * K, 0.5f); Bv.fill(N, 1.f); R.fill((size_t)M * N, 1.f); DY.fill((size_t)M * N, 1.f);
@@ -315,7 +320,7 @@ static void test_gemm(int M, int N, int K, int cfg, int splits) {
         check(tag, download_bf(dY, (size_t)M * N), rz, 0.06f, 0.01f);
     }
     // --- dgrad: dx[M,K] = dy[M,N] * w[N,K] (+resid) ---  (needs K % 64 == 0; the K-strided weight side needs a 64/128 tile)
-    if (K % 64 == 0 && pow2_bn && (cfg < 0 || K % kTileBN[cfg] == 0)) {
+    if (K % 64 == 0 && pow2_bn && (cfg < 0 || K % kTileBN[cfg] == 0) && (!g8 || N % 64 == 0)) {
         uint16_t* dDX = dalloc<uint16_t>((size_t)M * K);
         HostBf RX, U;
         RX.fill((size_t)M * K, 1.f); U.fill((size_t)M * K, 2.f);
@@ -346,7 +351,7 @@ static void test_gemm(int M, int N, int K, int cfg, int splits) {
         HIPCHK(hipFree(dDX)); HIPCHK(hipFree(dRX)); HIPCHK(hipFree(dU));
     }
     // --- wgrad: dw[N,K] (+)= dy^T x ; db = colsum(dy) ---
-    if (K % 64 == 0 && pow2_bn && pow2_bm && (cfg < 0 || (N % kTileBM[cfg] == 0 && K % kTileBN[cfg] == 0))) {
+    if (K % 64 == 0 && pow2_bn && pow2_bm && (cfg < 0 || (N % kTileBM[cfg] == 0 && K % kTileBN[cfg] == 0)) && (!g8 || M % 64 == 0)) {
         const size_t wsb = uniter_gemm_wgrad_workspace_bytes(M, N, K);
         void* ws = dalloc<char>(wsb);
         HostBf Old, OldB;
@@ -361,20 +366,21 @@ static void test_gemm(int M, int N, int K, int cfg, int splits) {
                 float* o = &dwr[(size_t)n * K];
                 for (int k = 0; k < K; ++k) o[k] += d * x[k];
             }
-        UHCHK(uniter_gemm_wgrad(dDY, dX, dDW, dDB, M, N, K, 0, ws, wsb, 0));
+        uint16_t* dDBarg = g8 ? nullptr : dDB;
+        UHCHK(uniter_gemm_wgrad(dDY, dX, dDW, dDBarg, M, N, K, 0, ws, wsb, 0));
         HIPCHK(hipDeviceSynchronize());
         snprintf(tag, sizeof tag, "gemm_wgrad M%d N%d K%d cfg%d splits%d", M, N, K, cfg, splits);
         const float tol = 0.02f * sqrtf((float)M) + 0.05f;
         check(tag, download_bf(dDW, (size_t)N * K), dwr, tol, 0.01f);
-        check("  wgrad bias (colsum)", download_bf(dDB, N), dbr, tol, 0.01f);
+        if (!g8) check("  wgrad bias (colsum)", download_bf(dDB, N), dbr, tol, 0.01f);
         // accumulate on top of the result just written
         std::vector<float> cur = download_bf(dDW, (size_t)N * K), curb = download_bf(dDB, N);
-        UHCHK(uniter_gemm_wgrad(dDY, dX, dDW, dDB, M, N, K, 1, ws, wsb, 0));
+        UHCHK(uniter_gemm_wgrad(dDY, dX, dDW, dDBarg, M, N, K, 1, ws, wsb, 0));
         HIPCHK(hipDeviceSynchronize());
         for (size_t i = 0; i < cur.size(); ++i) cur[i] += dwr[i];
         for (int n = 0; n < N; ++n) curb[n] += dbr[n];
         check("  wgrad accumulate", download_bf(dDW, (size_t)N * K), cur, 2 * tol, 0.02f);
-        check("  wgrad bias accumulate", download_bf(dDB, N), curb, 2 * tol, 0.02f);
+        if (!g8) check("  wgrad bias accumulate", download_bf(dDB, N), curb, 2 * tol, 0.02f);
         HIPCHK(hipFree(ws)); HIPCHK(hipFree(dDW)); HIPCHK(hipFree(dDB));
     }
     uniter_gemm_debug_force(-1, -1);
@@ -513,6 +519,56 @@ static void test_wgrad_group(int M) {
         if (q == 2) check(tag, download_bf(dB2[q], (size_t)N[q]), B0[q].v, 0.f, 0.f);
         else check(tag, download_bf(dB2[q], (size_t)N[q]), download_bf(dB1[q], (size_t)N[q]), 0.13f, 0.02f);
     }
+}
+
+// grouped weight gradients on the eight-phase tile (one and two K slices, bias gradients from the appended strips) == the
+// individual launches on a 64x64 tile
+static void test_wgrad_group_g8(int M, int splits) {
+    const int n = 4;
+    const int64_t N[4] = {256, 512, 256, 768}, K[4] = {512, 256, 256, 256};
+    HostBf DY[4], X[4], W0[4], B0[4];
+    uint16_t *dDY[4], *dX[4], *dW1[4], *dW2[4], *dB1[4], *dB2[4];
+    size_t wsb = 0;
+    for (int q = 0; q < n; ++q) {
+        DY[q].fill((size_t)M * N[q], 1.f); X[q].fill((size_t)M * K[q], 1.f); W0[q].fill((size_t)N[q] * K[q], 0.5f);
+        dDY[q] = upload(DY[q]); dX[q] = upload(X[q]); dW1[q] = upload(W0[q]); dW2[q] = upload(W0[q]);
+        B0[q].fill((size_t)N[q], 0.5f); dB1[q] = upload(B0[q]); dB2[q] = upload(B0[q]);
+        wsb = std::max(wsb, uniter_gemm_wgrad_workspace_bytes(M, N[q], K[q]));
+    }
+    void* ws = dalloc<char>(wsb);
+    uniter_gemm_debug_force(3, 1);
+    for (int q = 0; q < n; ++q) UHCHK(uniter_gemm_wgrad(dDY[q], dX[q], dW1[q], dB1[q], M, N[q], K[q], 1, ws, wsb, 0));
+    uniter_gemm_debug_force(-1, -1);
+    const void* dyp[4] = {dDY[0], dDY[1], dDY[2], dDY[3]};
+    const void* xp[4] = {dX[0], dX[1], dX[2], dX[3]};
+    void* dwp[4] = {dW2[0], dW2[1], dW2[2], dW2[3]};
+    void* dbp[4] = {dB2[0], dB2[1], nullptr, dB2[3]};
+    const size_t gwb = uniter_gemm_wgrad_group_workspace_bytes(n, N, K);
+    void* gws = dalloc<char>(gwb);
+    for (int rep = 0; rep < 2; ++rep) {                  // twice: the tile counters must come back to zero
+        UHCHK(uniter_gemm_wgrad_group_ws(n, dyp, nullptr, xp, nullptr, dwp, dbp, M, N, K, 1, gws, gwb, kTileG8, splits, 0));
+        HIPCHK(hipDeviceSynchronize());
+        if (rep == 0) {
+            for (int q = 0; q < n; ++q) {
+                char tag[160];
+                snprintf(tag, sizeof(tag), "eight-phase wgrad group, %d slice(s), member %d (M%d N%lld K%lld, accumulate)", splits, q, M, (long long)N[q], (long long)K[q]);
+                check(tag, download_bf(dW2[q], (size_t)N[q] * K[q]), download_bf(dW1[q], (size_t)N[q] * K[q]), 0.13f, 0.02f);
+                snprintf(tag, sizeof(tag), "eight-phase wgrad group member %d bias gradient (appended column-sum strips)", q);
+                if (q == 2) check(tag, download_bf(dB2[q], (size_t)N[q]), B0[q].v, 0.f, 0.f);
+                else check(tag, download_bf(dB2[q], (size_t)N[q]), download_bf(dB1[q], (size_t)N[q]), 0.13f, 0.02f);
+            }
+        }
+    }
+    // second pass accumulated once more on top: 2x the gradient + the start value
+    for (int q = 0; q < n; ++q) UHCHK(uniter_gemm_wgrad(dDY[q], dX[q], dW1[q], dB1[q], M, N[q], K[q], 1, ws, wsb, 0));   // (tuned/default tile)
+    HIPCHK(hipDeviceSynchronize());
+    for (int q = 0; q < n; ++q) {
+        char tag[160];
+        snprintf(tag, sizeof(tag), "eight-phase wgrad group, %d slice(s), member %d, second accumulation", splits, q);
+        check(tag, download_bf(dW2[q], (size_t)N[q] * K[q]), download_bf(dW1[q], (size_t)N[q] * K[q]), 0.3f, 0.03f);
+    }
+    for (int q = 0; q < n; ++q) { HIPCHK(hipFree(dDY[q])); HIPCHK(hipFree(dX[q])); HIPCHK(hipFree(dW1[q])); HIPCHK(hipFree(dW2[q])); HIPCHK(hipFree(dB1[q])); HIPCHK(hipFree(dB2[q])); }
+    HIPCHK(hipFree(ws)); HIPCHK(hipFree(gws));
 }
 
 static void test_layernorm(int rows, int H, float p, int post) {
@@ -1161,6 +1217,148 @@ static int run_one(int argc, char** argv, int at) {
     return 0;
 }
 
+// --g8: the eight-phase 256x256 tile (cfg 58) at full size: agreement with the 128x128 tile, a race screen (repeated
+// launches must be bit-identical), timings against the tuned choice of the older tile family, and the grouped weight
+// gradients of a layer with one / two K slices
+static int run_g8(int argc, char** argv, int at) {
+    const bool big = !(at < argc && !strcmp(argv[at], "quick"));
+    load_tuned_json(getenv("UNITER_TUNED_JSON") ? getenv("UNITER_TUNED_JSON") : "uniter_amd/tuned/gfx950.json");
+    Timer tm;
+    struct Case { const char* kind; int64_t M, N, K; int splits; };
+    std::vector<Case> cases = {
+        {"fwd", 4096, 4096, 4096, 1}, {"fwd", 3072, 2304, 768, 1}, {"gelu", 3072, 3072, 768, 1}, {"dgelu", 3072, 768, 3072, 1},
+        {"dgrad", 3072, 2304, 768, 1}, {"dgrad", 3072, 3072, 768, 1}, {"fwd", 3072, 768, 3072, 1}, {"fwd", 3072, 768, 768, 1},
+        {"wgrad", 3072, 3072, 768, 1}, {"wgrad", 3072, 3072, 768, 2}, {"wgrad", 3072, 768, 3072, 2}, {"wgrad", 3072, 2304, 768, 2},
+        {"fwd", 3072, 3072, 1024, 1}, {"gelu", 3072, 4096, 1024, 1}, {"dgelu", 3072, 1024, 4096, 1}, {"fwd", 5696, 3072, 1024, 1},
+        {"gelu", 5696, 4096, 1024, 1}, {"wgrad", 5696, 4096, 1024, 2}, {"wgrad", 5696, 4096, 1024, 1}};
+    if (big) cases.push_back({"fwd", 8192, 8192, 8192, 1});
+    for (const Case& c : cases) {
+        const std::string kind = c.kind;
+        const int64_t M = c.M, N = c.N, K = c.K;
+        // buffers sized for every role: x [M,K] / dy [M,N], w [N,K], out [M,N] / [M,K] / [N,K]
+        const size_t e_mk = (size_t)M * K, e_mn = (size_t)M * N, e_nk = (size_t)N * K;
+        HostBf A, B, Bv;
+        A.fill(std::max(e_mk, e_mn), 1.f); B.fill(std::max(e_nk, e_mk), 0.05f); Bv.fill((size_t)std::max(N, K), 0.1f);
+        uint16_t *dA = upload(A), *dB = upload(B), *dBias = upload(Bv);
+        const size_t e_out = std::max(std::max(e_mn, e_mk), e_nk);
+        uint16_t *dO = dalloc<uint16_t>(e_out), *dO2 = dalloc<uint16_t>(e_out), *dU = upload(A);
+        const size_t wsb = uniter_gemm_wgrad_workspace_bytes(M, N, K);
+        void* ws = kind == "wgrad" ? dalloc<char>(wsb) : nullptr;
+        auto fn = [&](uint16_t* out) {
+            if (kind == "fwd") UHCHK(uniter_gemm_bias_fwd(dA, dB, dBias, out, M, N, K, 0));
+            else if (kind == "gelu") UHCHK(uniter_gemm_bias_gelu_fwd(dA, dB, dBias, out, dO2, M, N, K, 0));
+            else if (kind == "dgrad") UHCHK(uniter_gemm_dgrad(dA, dB, nullptr, out, M, N, K, 0));
+            else if (kind == "dgelu") UHCHK(uniter_gemm_dgrad_gelu(dA, dB, dU, out, M, N, K, 0));
+            else UHCHK(uniter_gemm_wgrad(dA, dB, out, nullptr, M, N, K, 0, ws, wsb, 0));      // dA = dy [M,N], dB = x [M,K]
+        };
+        const size_t n_out = kind == "wgrad" ? e_nk : ((kind == "dgrad" || kind == "dgelu") ? e_mk : e_mn);
+        const double fl = 2.0 * M * N * K;
+        // reference: the tuned / default tile of the older family
+        uniter_gemm_debug_force(-1, -1);
+        uint16_t* dRef = dalloc<uint16_t>(n_out);
+        fn(dRef);
+        HIPCHK(hipDeviceSynchronize());
+        const double t_old = tm.run([&] { fn(dRef); }, 3, 20);
+        uniter_gemm_debug_force(kTileG8, c.splits);
+        fn(dO);
+        HIPCHK(hipDeviceSynchronize());
+        std::vector<uint16_t> r0(n_out), r1(n_out), rr(n_out);
+        HIPCHK(hipMemcpy(r0.data(), dO, n_out * 2, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(rr.data(), dRef, n_out * 2, hipMemcpyDeviceToHost));
+        double maxd = 0, maxr = 0; size_t nbad = 0;
+        for (size_t k = 0; k < n_out; ++k) {
+            const float a = bf2f(r0[k]), b = bf2f(rr[k]);
+            const double d = fabs((double)a - b);
+            maxd = std::max(maxd, d); maxr = std::max(maxr, (double)fabsf(b));
+            if (!(d <= 0.02 * fabs(b) + 0.02 * sqrt((double)(kind == "wgrad" ? M : (kind == "fwd" || kind == "gelu" ? K : N))) * 0.05 + 0.05)) ++nbad;
+        }
+        char tag[200];
+        snprintf(tag, sizeof tag, "g8 %s M%lld N%lld K%lld s%d == older tile family (max |d| %.4f of max |ref| %.2f, %zu outside tolerance)", c.kind,
+                 (long long)M, (long long)N, (long long)K, c.splits, maxd, maxr, nbad);
+        printf("[%s] %s\n", nbad ? "FAIL" : " OK ", tag);
+        if (nbad) ++g_fail;
+        // race screen: 24 more launches, every one bit-identical to the first
+        size_t ndiff = 0;
+        for (int rep = 0; rep < 24; ++rep) {
+            HIPCHK(hipMemsetAsync(dO, 0xff, n_out * 2, 0));
+            fn(dO);
+            if (rep % 8 == 7) {
+                HIPCHK(hipMemcpy(r1.data(), dO, n_out * 2, hipMemcpyDeviceToHost));
+                for (size_t k = 0; k < n_out; ++k) if (r1[k] != r0[k]) ++ndiff;
+            }
+        }
+        printf("[%s] g8 %s repeated launches bit-identical (%zu differing elements)\n", ndiff ? "FAIL" : " OK ", c.kind, ndiff);
+        if (ndiff) ++g_fail;
+        const double t_new = tm.run([&] { fn(dO); }, 3, 20);
+        printf("  TIME %-5s M%-5lld N%-5lld K%-5lld splits%d : older family %7.2f us %7.1f TF | eight-phase %7.2f us %7.1f TF  (x%.2f)\n", c.kind, (long long)M,
+               (long long)N, (long long)K, c.splits, t_old, fl / t_old * 1e-6, t_new, fl / t_new * 1e-6, t_old / t_new);
+        uniter_gemm_debug_force(-1, -1);
+        HIPCHK(hipFree(dA)); HIPCHK(hipFree(dB)); HIPCHK(hipFree(dBias)); HIPCHK(hipFree(dO)); HIPCHK(hipFree(dO2)); HIPCHK(hipFree(dU)); HIPCHK(hipFree(dRef));
+        if (ws) HIPCHK(hipFree(ws));
+    }
+    // the four weight gradients (+ bias gradients) of a layer as one launch
+    struct GCase { const char* name; int64_t T, H, I; } gcases[] = {{"base-96", 3072, 768, 3072}, {"large-96", 3072, 1024, 4096}, {"large-178", 5696, 1024, 4096}};
+    for (const GCase& gc : gcases) {
+        const int64_t T = gc.T, H = gc.H, I = gc.I;
+        const int64_t gN[4] = {H, I, H, 3 * H}, gK[4] = {I, H, H, H};
+        uint16_t *dy[4], *x[4], *dw[4], *dwr[4], *db[4], *dbr[4];
+        for (int q = 0; q < 4; ++q) {
+            HostBf a, b;
+            a.fill((size_t)T * gN[q], 1.f); b.fill((size_t)T * gK[q], 1.f);
+            dy[q] = upload(a); x[q] = upload(b);
+            dw[q] = dalloc<uint16_t>((size_t)gN[q] * gK[q]); dwr[q] = dalloc<uint16_t>((size_t)gN[q] * gK[q]);
+            db[q] = dalloc<uint16_t>(gN[q]); dbr[q] = dalloc<uint16_t>(gN[q]);
+        }
+        const void* dyp[4] = {dy[0], dy[1], dy[2], dy[3]};
+        const void* xp[4] = {x[0], x[1], x[2], x[3]};
+        void* dwp[4] = {dw[0], dw[1], dw[2], dw[3]};
+        void* dbp[4] = {db[0], db[1], db[2], db[3]};
+        void* dwrp[4] = {dwr[0], dwr[1], dwr[2], dwr[3]};
+        void* dbrp[4] = {dbr[0], dbr[1], dbr[2], dbr[3]};
+        const size_t gwb = uniter_gemm_wgrad_group_workspace_bytes(4, gN, gK);
+        void* gws = dalloc<char>(gwb);
+        double fl = 0;
+        for (int q = 0; q < 4; ++q) fl += 2.0 * T * gN[q] * gK[q];
+        UHCHK(uniter_gemm_wgrad_group_ws(4, dyp, nullptr, xp, nullptr, dwrp, dbrp, T, gN, gK, 0, nullptr, 0, 33, 1, 0));   // 128x128, 4+4 waves
+        const double t_old = tm.run([&] { UHCHK(uniter_gemm_wgrad_group_ws(4, dyp, nullptr, xp, nullptr, dwrp, dbrp, T, gN, gK, 0, nullptr, 0, 33, 1, 0)); }, 3, 20);
+        for (int sp = 1; sp <= 2; ++sp) {
+            UHCHK(uniter_gemm_wgrad_group_ws(4, dyp, nullptr, xp, nullptr, dwp, dbp, T, gN, gK, 0, gws, gwb, kTileG8, sp, 0));
+            HIPCHK(hipDeviceSynchronize());
+            size_t nbad = 0, ndiff = 0;
+            double maxd = 0;
+            std::vector<std::vector<uint16_t>> first(4);
+            for (int q = 0; q < 4; ++q) {
+                const size_t ne = (size_t)gN[q] * gK[q];
+                std::vector<float> got = download_bf(dw[q], ne), ref = download_bf(dwr[q], ne);
+                for (size_t k = 0; k < ne; ++k) { const double d = fabs((double)got[k] - ref[k]); maxd = std::max(maxd, d); if (!(d <= 0.02 * fabs(ref[k]) + 0.02 * sqrt((double)T) + 0.05)) ++nbad; }
+                std::vector<float> gb = download_bf(db[q], gN[q]), rb = download_bf(dbr[q], gN[q]);
+                for (int64_t k = 0; k < gN[q]; ++k) if (!(fabs((double)gb[k] - rb[k]) <= 0.02 * fabs(rb[k]) + 0.02 * sqrt((double)T) + 0.05)) ++nbad;
+                first[q].resize(ne);
+                HIPCHK(hipMemcpy(first[q].data(), dw[q], ne * 2, hipMemcpyDeviceToHost));
+            }
+            printf("[%s] g8 group %s, %d slice(s) == 128x128 grouped launch (max |d| %.3f, %zu outside tolerance)\n", nbad ? "FAIL" : " OK ", gc.name, sp, maxd, nbad);
+            if (nbad) ++g_fail;
+            for (int rep = 0; rep < 16; ++rep) UHCHK(uniter_gemm_wgrad_group_ws(4, dyp, nullptr, xp, nullptr, dwp, dbp, T, gN, gK, 0, gws, gwb, kTileG8, sp, 0));
+            HIPCHK(hipDeviceSynchronize());
+            for (int q = 0; q < 4; ++q) {
+                const size_t ne = (size_t)gN[q] * gK[q];
+                std::vector<uint16_t> now(ne);
+                HIPCHK(hipMemcpy(now.data(), dw[q], ne * 2, hipMemcpyDeviceToHost));
+                for (size_t k = 0; k < ne; ++k) if (now[k] != first[q][k]) ++ndiff;
+            }
+            printf("[%s] g8 group %s, %d slice(s): 17th launch bit-identical to the first (%zu differing)\n", ndiff ? "FAIL" : " OK ", gc.name, sp, ndiff);
+            if (ndiff) ++g_fail;
+            const double t_new = tm.run([&] { UHCHK(uniter_gemm_wgrad_group_ws(4, dyp, nullptr, xp, nullptr, dwp, dbp, T, gN, gK, 0, gws, gwb, kTileG8, sp, 0)); }, 3, 20);
+            printf("  TIME group %-9s: 128x128 grouped %7.2f us %7.1f TF | eight-phase, %d slice(s) %7.2f us %7.1f TF (x%.2f)\n", gc.name, t_old, fl / t_old * 1e-6, sp,
+                   t_new, fl / t_new * 1e-6, t_old / t_new);
+        }
+        for (int q = 0; q < 4; ++q) { HIPCHK(hipFree(dy[q])); HIPCHK(hipFree(x[q])); HIPCHK(hipFree(dw[q])); HIPCHK(hipFree(dwr[q])); HIPCHK(hipFree(db[q])); HIPCHK(hipFree(dbr[q])); }
+        HIPCHK(hipFree(gws));
+    }
+    printf("== %d check(s) failed ==\n", g_fail);
+    return g_fail;
+}
+
 static void on_segv(int) {                 // where did it die: raw return addresses + symbols to stderr
     void* bt[48];
     const int n = backtrace(bt, 48);
@@ -1189,6 +1387,11 @@ int main(int argc, char** argv) {
             printf("== %d check(s) failed ==\n", g_fail);
             return g_fail;
         }
+        if (!strcmp(argv[i], "--g8")) {
+            int32_t inf[4];
+            UHCHK(uniter_hip_device_info(inf));
+            return run_g8(argc, argv, i + 1);
+        }
         if (!strcmp(argv[i], "--one")) {
             int32_t inf[4];
             UHCHK(uniter_hip_device_info(inf));
@@ -1204,6 +1407,13 @@ int main(int argc, char** argv) {
     for (int cfg = 4; cfg < kNumTiles; ++cfg) test_gemm(cfg >= 20 ? 320 : 300, 384, 128, cfg, 1);   // WS: contraction % 64 == 0 (wgrad contracts over M)
     for (int cfg = 0; cfg < kNumTiles; ++cfg)            // 192-wide K-strided N-side operand (dgrad / wgrad): two column tiles
         if (kTileBN[cfg] == 192) test_gemm(320, 384, 384, cfg, 1);
+    // the eight-phase 256x256 tile: partial last row tile, odd / even K tile counts, one K tile, one and two slices (in-launch
+    // combination) and four (fp32 partials + reduce kernel)
+    test_gemm(640, 512, 256, kTileG8, 1);
+    test_gemm(640, 512, 256, kTileG8, 2);
+    test_gemm(576, 256, 512, kTileG8, 2);
+    test_gemm(300, 256, 64, kTileG8, 1);
+    test_gemm(1024, 256, 256, kTileG8, 4);
     test_gemm(77, 128, 192, 3, 3);
     test_gemm(384, 384, 320, -1, -1);
     if (!quick) test_gemm(1000, 768, 768, -1, -1);
@@ -1221,6 +1431,9 @@ int main(int argc, char** argv) {
     printf("== grouped weight gradients ==\n");
     test_wgrad_group(320);
     test_wgrad_group(300);
+    test_wgrad_group_g8(320, 1);
+    test_wgrad_group_g8(320, 2);
+    test_wgrad_group_g8(576, 2);
     test_layernorm(37, 128, 0.f, 0);
     test_layernorm(300, 768, 0.2f, 0);
     test_layernorm(300, 768, 0.2f, 1);

@@ -24,11 +24,12 @@ def test_shipped_table_matches_the_build():
         assert 0 <= e["cfg"] < len(tiles) and e["splits"] >= 1
         bm, bn, _, ws = tiles[e["cfg"]]
         if e["kind"] == 1:                                   # dgrad: K-strided N-side operand, output columns K
-            assert bn in (64, 128, 192) and e["K"] % bn == 0
+            assert (bn in (64, 128, 192) or ws == 3) and e["K"] % bn == 0
         if e["kind"] == 0:
             assert e["N"] % bn == 0
         if e["kind"] == 3:                                   # grouped weight gradients: both operands K-strided
-            assert bm in (64, 128) and bn in (64, 128)
+            assert (bm in (64, 128) and bn in (64, 128)) or ws == 3
+            assert e["splits"] == 1 or (ws == 3 and e["splits"] == 2)   # two K slices: the eight-phase tile only
         if ws:
             contraction = {0: e["K"], 1: e["N"], 3: e["M"]}[e["kind"]]
             assert contraction % 64 == 0

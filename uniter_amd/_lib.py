@@ -11,7 +11,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "build", "libuniter_hip.so")
-ABI_VERSION = 5          # UNITER_HIP_ABI_VERSION of include/uniter_hip.h (struct layouts below must match it)
+ABI_VERSION = 6          # UNITER_HIP_ABI_VERSION of include/uniter_hip.h (struct layouts below must match it)
 
 
 class UniterHipError(RuntimeError):
@@ -91,6 +91,8 @@ SIGNATURES = {
     "uniter_gemm_wgrad_ld": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, c_int, _P, c_size_t, _P]),
     "uniter_gemm_wgrad_group": (c_int, [c_int32, _P, _P, _P, _P, _P, _P, _I, _P, _P, c_int, _P]),
     "uniter_gemm_wgrad_group_autotune": (c_int, [c_int32, _I, _P, _P, _P]),
+    "uniter_gemm_wgrad_group_workspace_bytes": (c_size_t, [c_int32, _P, _P]),
+    "uniter_gemm_wgrad_group_ws": (c_int, [c_int32, _P, _P, _P, _P, _P, _P, _I, _P, _P, c_int, _P, c_size_t, c_int, c_int, _P]),
     "uniter_attention_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
     "uniter_attention_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
     "uniter_attention_bwd_workspace_bytes": (c_size_t, [_I, _I, _I]),
@@ -157,6 +159,7 @@ SIGNATURES = {
 
 # functions that return a size / pointer rather than a status code
 _NO_STATUS = {"uniter_hip_abi_version", "uniter_gemm_tile_count", "uniter_hip_last_error", "uniter_gemm_wgrad_workspace_bytes",
+              "uniter_gemm_wgrad_group_workspace_bytes",
               "uniter_gemm_dgrad_splitk_workspace_bytes", "uniter_head_ce_save_bytes", "uniter_head_ce_workspace_bytes",
               "uniter_layernorm_bwd_workspace_bytes", "uniter_colsum_workspace_bytes", "uniter_embed_ws_bytes",
               "uniter_attn_pool_workspace_bytes",

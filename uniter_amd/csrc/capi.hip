@@ -250,6 +250,18 @@ int uniter_gemm_wgrad_group(int32_t n, const void* const* dy, const int64_t* ldd
     return uh::gemm_wgrad_group(n, dy, x, dw, db, M, N, K, accumulate, (hipStream_t)stream, -1, lddy, ldx);
 }
 
+size_t uniter_gemm_wgrad_group_workspace_bytes(int32_t n, const int64_t* N, const int64_t* K) {
+    if (N == nullptr || K == nullptr || n < 1 || n > 4) return 0;
+    return uh::gemm_wgrad_group_workspace_bytes(n, N, K);
+}
+int uniter_gemm_wgrad_group_ws(int32_t n, const void* const* dy, const int64_t* lddy, const void* const* x, const int64_t* ldx,
+                               void* const* dw, void* const* db, int64_t M, const int64_t* N, const int64_t* K, int accumulate,
+                               void* workspace, size_t workspace_bytes, int cfg, int splits, void* stream) {
+    UH_CHECK_ARG(dy && x && dw && N && K, "null pointer");
+    UH_CHECK_ARG(splits >= 0 && splits <= 2, "splits must be 0 (tuned), 1 or 2");
+    return uh::gemm_wgrad_group(n, dy, x, dw, db, M, N, K, accumulate, (hipStream_t)stream, cfg, lddy, ldx, workspace, workspace_bytes, splits);
+}
+
 int uniter_gemm_wgrad_group_autotune(int32_t n, int64_t M, const int64_t* N, const int64_t* K, void* stream) {
     UH_CHECK_ARG(N && K, "null pointer");
     return uh::gemm_group_autotune(n, M, N, K, (hipStream_t)stream);

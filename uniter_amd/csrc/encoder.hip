@@ -277,7 +277,7 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         void* gdb[4] = {Pg.g_b2, Pg.g_b1, Pg.g_bo, Pg.g_bqkv};
         const int64_t gN[4] = {H, I, H, 3 * H}, gK[4] = {I, H, H, H};
         RC(fork(3));
-        RC(uh::gemm_wgrad_group(4, gdy, gx, gdw, gdb, T, gN, gK, 1, ss));
+        RC(uh::gemm_wgrad_group(4, gdy, gx, gdw, gdb, T, gN, gK, 1, ss, -1, nullptr, nullptr, S + sl.wg, sl.wg_bytes));   // (workspace: the two-slice form of the eight-phase tile)
         RC(joined(pg));
         return 0;
     };

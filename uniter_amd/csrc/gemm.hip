@@ -18,7 +18,9 @@
 // with ds_read_b64_tr_b16, with a 32-byte-block XOR swizzle that makes those reads conflict free.
 #include "common.cuh"
 #include "kernels.h"
+#include "gemm_args.cuh"
 #include "gemm_lds.cuh"
+#include "gemm8.cuh"
 #ifndef UNITER_AUX_EARLY
 #define UNITER_AUX_EARLY 1
 #endif
@@ -32,31 +34,7 @@
 namespace {
 
 constexpr bool g_aux_early_dev = UNITER_AUX_EARLY;
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_DROP_RES = 2, EPI_RES = 3, EPI_GELU_BWD = 4, EPI_WGRAD = 5 };
-
-struct GemmArgs {
-    const bf16_t* R;      // M-side operand
-    const bf16_t* Cc;     // N-side operand
-    int64_t ldr, ldcc;    // leading dimensions (elements)
-    bf16_t* C;            // output [M][N]
-    bf16_t* C2;           // second output (EPI_BIAS_GELU: g; EPI_WGRAD: db[M] = sums of the M-side operand over the
-                          // contraction, i.e. the bias gradient that belongs to this weight gradient; nullptr = none)
-    int64_t ldc;
-    const bf16_t* bias;   // [N] or nullptr
-    const bf16_t* aux;    // residual [M][N] / pre-activation u [M][N] / nullptr
-    int64_t ldaux;
-    float* partial;       // split-K fp32 partials [splits][M][N] (nullptr when splits == 1)
-    int M, N, K;          // K = contraction length
-    int k_per_split;      // multiple of 64
-    int accumulate;       // EPI_WGRAD, splits == 1: C += result
-    int xr;               // 2-D XCD blocking: rows of the XCD grid (0 = 1-D contiguous ranges)
-    int relu;             // EPI_BIAS_DROP_RES: 1 = clamp at zero after the bias, before the dropout (Linear + ReLU + Dropout heads);
-                          // EPI_BIAS_GELU / EPI_GELU_BWD: the activation (UH_ACT_*: 0 = erf GELU, 1 = ReLU, 2 = swish)
-#ifdef UNITER_GEMM_PROBE
-    unsigned long long* probe;   // cycle stamps of wave 0 of every workgroup: [block][kt][5] (profiling builds only)
-#endif
-    DropoutCfg drop;
-};
+// GemmArgs, the epilogue kinds and the blockIdx -> tile maps: gemm_args.cuh
 
 // ---- LDS layouts and fragment reads: gemm_lds.cuh ---------------------------------------------------
 
@@ -156,15 +134,6 @@ struct Stage<192, true> {                       // [64][128] + [64][64] sub-tile
     }
 };
 
-// bijective XCD-aware block remap (cdna_hip_programming.md T1): consecutive hardware block ids go to
-// different XCDs; give each XCD a contiguous range of logical tiles so neighbours share an L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-    const int q = nblk >> 3, r = nblk & 7;
-    const int xcd = bid & 7, loc = bid >> 3;
-    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + loc;
-}
-
 // WS ("wave specialised"): 8 waves per workgroup — waves 0-3 only read LDS and issue MFMAs, waves 4-7 only issue
 // the LDS-DMA for the next tile and wait for it.  In the unspecialised kernel every wave spends ~470 cycles per K tile
 // issuing its 8 DMA instructions and ~490 waiting for them (cycle stamps, tests/native/build_probe.sh) before it can
@@ -204,23 +173,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     const int tiles_n = p.N / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     int tm, tn;
-    if (p.xr < 0) {                 // the caller chose the tile (grouped launch, compact per-XCD mapping)
-        tm = bx / tiles_n;
-        tn = bx % tiles_n;
-    } else if (p.xr > 0) {
-        // 2-D XCD blocking: hardware block b runs on XCD b % 8; XCD (xi, xj) of an xr x xc grid owns a
-        // (tiles_m/xr) x (tiles_n/xc) sub-block of tiles, so its private L2 holds only that sub-block's operand rows
-        const int xcd = bx & 7, loc = bx >> 3;
-        const int xc = 8 / p.xr;
-        const int sub_m = tiles_m / p.xr, sub_n = tiles_n / xc;
-        const int xi = xcd / xc, xj = xcd % xc;
-        tm = xi * sub_m + loc / sub_n;
-        tn = xj * sub_n + loc % sub_n;
-    } else {
-        const int tile = xcd_remap(bx, tiles_m * tiles_n);
-        tm = tile / tiles_n;
-        tn = tile % tiles_n;
-    }
+    tile_of_block(p.xr, bx, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int k_begin = by * p.k_per_split;
@@ -642,8 +595,70 @@ int pick_xr(int tiles_m, int tiles_n, int bm, int bn) {
     return best;
 }
 
+// ---- the eight-phase 256 x 256 tile (gemm8.cuh) -------------------------------------------------------------------------
+// Counters of the in-launch combination of two K slices (one per output tile, zero between launches): rotating slices of
+// one zero-initialised array per device, so that launches in flight on different streams never share a counter.
+unsigned* g8_pair_counters(int tiles) {
+    constexpr size_t CAP = 1u << 16;
+    static std::mutex mu;
+    static unsigned* base[16] = {nullptr};
+    static size_t cursor[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || tiles <= 0 || (size_t)tiles > CAP) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (base[dev] == nullptr) {
+        unsigned* p = nullptr;
+        if (hipMalloc(&p, CAP * sizeof(unsigned)) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, CAP * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
+        base[dev] = p;
+    }
+    if (cursor[dev] + (size_t)tiles > CAP) cursor[dev] = 0;
+    unsigned* r = base[dev] + cursor[dev];
+    cursor[dev] += (size_t)tiles;
+    return r;
+}
+
+bool g8_shape_ok(const GemmArgs& a, bool tra, bool trb) {
+    if (a.N % 256 != 0 || a.K % 64 != 0 || a.k_per_split % 64 != 0 || a.K < 64) return false;
+    if (tra && a.M % 256 != 0) return false;
+    // per-lane DMA offsets are 32-bit byte offsets from the K tile's origin
+    const int64_t span_r = tra ? (int64_t)64 * a.ldr + a.M : (int64_t)a.M * a.ldr;
+    const int64_t span_c = trb ? (int64_t)64 * a.ldcc + a.N : (int64_t)a.N * a.ldcc;
+    return span_r * 2 < ((int64_t)1 << 32) && span_c * 2 < ((int64_t)1 << 32);
+}
+
+template <bool TRA, bool TRB, int EPI>
+int launch_g8(const GemmArgs& a_in, int splits, hipStream_t st) {
+    GemmArgs a = a_in;
+    if (!g8_shape_ok(a, TRA, TRB)) {
+        uh_set_error("gemm: the 256x256 eight-phase tile needs N %% 256 == 0, a contraction (slice) that is a multiple of 64%s (M=%d N=%d K=%d)",
+                     TRA ? " and M %% 256 == 0" : "", a.M, a.N, a.K);
+        return -1;
+    }
+    if (EPI == EPI_WGRAD && a.C2 != nullptr) { uh_set_error("gemm: the eight-phase tile does not produce the bias gradient"); return -1; }
+    const int tiles_m = (a.M + 255) / 256, tiles_n = a.N / 256;
+    a.xr = pick_xr(tiles_m, tiles_n, 256, 256);
+    a.pair = nullptr;
+    if (EPI == EPI_WGRAD && splits == 2 && a.partial != nullptr) {
+        a.pair = g8_pair_counters(tiles_m * tiles_n);
+        if (a.pair == nullptr) { uh_set_error("gemm: no counters for the in-launch K-slice combination"); return -1; }
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+        UH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<TRA, TRB, EPI, 1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS_BYTES));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm8_kernel<TRA, TRB, EPI, 1>), dim3(tiles_m * tiles_n, splits, 1), dim3(G8_THREADS), G8_LDS_BYTES, st, a);
+    UH_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, int WS>
 int launch_cfg(const GemmArgs& a_in, int splits, hipStream_t st) {
+    if constexpr (WS == 3) {
+        return launch_g8<TRA, TRB, EPI>(a_in, splits, st);
+    } else {
     GemmArgs a = a_in;
     if (WS && (a.K % 64 != 0 || a.k_per_split % 64 != 0)) {
         uh_set_error("gemm: the wave-specialised tiles need a contraction length that is a multiple of 64");
@@ -665,6 +680,7 @@ int launch_cfg(const GemmArgs& a_in, int splits, hipStream_t st) {
     hipLaunchKernelGGL((gemm_kernel<BM, BN, TRA, TRB, EPI, NSTAGE, WS>), grid, dim3(WaveGrid<BM, BN, WS>::THREADS), lds, st, a);
     UH_LAUNCH_CHECK();
     return 0;
+    }
 }
 
 // Tile shapes.  Index 0..3 are the power-of-two tiles every layout supports; 4.. are the 96/192 shapes that let a
@@ -690,12 +706,16 @@ constexpr TileShape kTiles[] = {{128, 128, 2, 0}, {128, 64, 2, 0}, {64, 128, 2, 
                                 {128, 128, 3, 2}, {128, 128, 4, 2}, {192, 192, 2, 2}, {96, 192, 3, 2}, {192, 96, 3, 2},
                                 {128, 192, 3, 2}, {192, 128, 3, 2}, {128, 64, 4, 2}, {64, 128, 4, 2}, {192, 64, 4, 2},
                                 // 8 + 4 waves on the 96-wide tiles of the N = 768 problems (one 96x128 tile per CU)
-                                {96, 128, 3, 2}, {96, 128, 4, 2}, {128, 96, 3, 2}, {128, 96, 4, 2}};
+                                {96, 128, 3, 2}, {96, 128, 4, 2}, {128, 96, 3, 2}, {128, 96, 4, 2},
+                                // ws = 3: the eight-phase 256 x 256 tile (gemm8.cuh): 8 waves, two wave groups one barrier apart
+                                {256, 256, 2, 3}};
+constexpr int kTileG8 = 58;
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <bool TRA, bool TRB>
 constexpr bool tile_ok(int idx) {
     const int bm = kTiles[idx].bm, bn = kTiles[idx].bn;
+    if (kTiles[idx].ws == 3) return true;
     if (TRA && !(bm == 64 || bm == 128)) return false;
     if (TRB && !(bn == 64 || bn == 128 || bn == 192)) return false;
     return true;
@@ -772,6 +792,7 @@ int launch_gemm(const GemmArgs& a, int cfg, int splits, hipStream_t st) {
         case 55: return launch_idx<TRA, TRB, EPI, 55>(a, splits, st);
         case 56: return launch_idx<TRA, TRB, EPI, 56>(a, splits, st);
         case 57: return launch_idx<TRA, TRB, EPI, 57>(a, splits, st);
+        case 58: return launch_idx<TRA, TRB, EPI, 58>(a, splits, st);
         default: uh_set_error("gemm: bad tile index %d", cfg); return -1;
     }
 }
@@ -829,6 +850,24 @@ int launch_group(GemmGroupArgs& ga, int cfg, hipStream_t st) {
 #undef UH_GROUP_CASE
         default: uh_set_error("gemm group: tile index %d is not a wgrad tile", cfg); return -1;
     }
+}
+
+// Is tile `cfg` (with `splits` K slices) legal for the public call (kind, M, N, K)?  kind 0: fwd, out M x N, contraction K;
+// 1: dgrad, out M x K, contraction N; 2: wgrad, out N x K, contraction M.
+bool cfg_legal(int kind, int cfg, int64_t M, int64_t N, int64_t K, int splits) {
+    if (cfg < 0 || cfg >= kNumTiles || splits < 1) return false;
+    const TileShape& t = kTiles[cfg];
+    const int64_t contraction = kind == 0 ? K : (kind == 1 ? N : M);
+    const int64_t out_m = kind == 2 ? N : M, out_n = kind == 0 ? N : K;
+    if (t.ws == 3) {
+        if (out_n % 256 != 0 || contraction % 64 != 0 || contraction < (int64_t)64 * splits) return false;
+        return kind != 2 || out_m % 256 == 0;
+    }
+    const bool p2m = t.bm == 64 || t.bm == 128, p2n = t.bn == 64 || t.bn == 128 || t.bn == 192;
+    if (t.ws && contraction % (64 * (int64_t)splits) != 0) return false;
+    if (kind == 0) return N % t.bn == 0;
+    if (kind == 1) return p2n && K % t.bn == 0;
+    return p2m && p2n && N % t.bm == 0 && K % t.bn == 0;
 }
 
 int g_force_cfg = -1;      // test / tuning hook (uniter_gemm_debug_force)
@@ -1052,14 +1091,18 @@ int gemm_wgrad(const void* dy, const void* x, void* dw, int64_t M, int64_t N, in
     int splits = wgrad_splits(M, N, K, cfg);
     Tuned tn;
     if (g_force_cfg < 0 && g_force_splits < 0 && tuned_lookup(2, M, N, K, &tn)) { cfg = tn.cfg; splits = tn.splits; }
-    if (db != nullptr) splits = 1;
+    if (db != nullptr) {
+        splits = 1;
+        if (kTiles[cfg].ws == 3) cfg = pick_cfg((int)N, (int)K, true, true, M % 64 == 0);   // that tile has no bias-gradient output
+    }
     while (splits > 1 && (size_t)splits * N * K * sizeof(float) > ws_bytes) splits >>= 1;
+    const bool in_launch = kTiles[cfg].ws == 3 && splits == 2;     // two K slices combined by the tile's own workgroups
     const int64_t ktiles = (M + 63) / 64;
     a.k_per_split = (int)(((ktiles + splits - 1) / splits) * 64);
     a.partial = splits > 1 ? (float*)workspace : nullptr;
     int rc = launch_gemm<true, true, EPI_WGRAD>(a, cfg, splits, st);
     if (rc) return rc;
-    if (splits > 1) {
+    if (splits > 1 && !in_launch) {
         const int64_t mn = N * K;
         const int64_t nblk = (mn / 4 + 255) / 256;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, st,
@@ -1071,7 +1114,9 @@ int gemm_wgrad(const void* dy, const void* x, void* dw, int64_t M, int64_t N, in
 
 // Up to four weight gradients dw_q[N_q,K_q] (+)= dy_q[M,N_q]^T x_q[M,K_q] over the same M tokens in ONE launch.
 static const int kGroupCfgs[] = {0, 1, 2, 3, 13, 14, 15, 20, 23, 24, 26, 27, 29, 33, 34, 36, 37, 43, 44, 45, 49, 51, 52};
+static bool group_g8_ok(int n, int64_t M, const int64_t* N, const int64_t* K, int splits);
 static bool group_cfg_ok(int cfg, int n, int64_t M, const int64_t* N, const int64_t* K) {
+    if (kTiles[cfg].ws == 3) return group_g8_ok(n, M, N, K, 1);
     const int bm = kTiles[cfg].bm, bn = kTiles[cfg].bn;
     if (kTiles[cfg].ws && M % 64 != 0) return false;
     for (int q = 0; q < n; ++q)
@@ -1080,9 +1125,61 @@ static bool group_cfg_ok(int cfg, int n, int64_t M, const int64_t* N, const int6
 }
 static int64_t group_sum(int n, const int64_t* v) { int64_t s = 0; for (int q = 0; q < n; ++q) s += v[q]; return s; }
 
+// The grouped launch on the eight-phase tile: splits = 2 needs a workspace of 4 bytes per weight element (one fp32 slab per tile).
+static bool group_g8_ok(int n, int64_t M, const int64_t* N, const int64_t* K, int splits) {
+    if (M % 64 != 0 || M < (int64_t)64 * splits) return false;
+    for (int q = 0; q < n; ++q)
+        if (N[q] % 256 != 0 || K[q] % 256 != 0) return false;
+    return true;
+}
+size_t gemm_wgrad_group_workspace_bytes(int n, const int64_t* N, const int64_t* K) {
+    size_t e = 0;
+    for (int q = 0; q < n; ++q) e += (size_t)N[q] * (size_t)K[q];
+    return e * sizeof(float);
+}
+static int launch_group_g8(GemmGroupArgs& src, int n, int64_t M, int splits, void* workspace, hipStream_t st) {
+    G8GroupArgs ga{};
+    ga.n = n;
+    ga.splits = splits;
+    const int64_t ktiles = M / 64;
+    int tiles = 0, strips = 0;
+    for (int q = 0; q < n; ++q) {
+        GemmArgs& a = ga.g[q];
+        a = src.g[q];
+        a.xr = -1;
+        a.k_per_split = (int)(((ktiles + splits - 1) / splits) * 64);
+        if (!g8_shape_ok(a, true, true)) { uh_set_error("gemm group: problem %d does not fit the eight-phase tile", q); return -1; }
+        ga.tile_start[q] = tiles;
+        ga.strip_start[q] = strips;
+        tiles += (a.M / 256) * (a.N / 256);
+        if (a.C2 != nullptr) strips += a.M / 256;
+    }
+    for (int q = n; q <= 4; ++q) { ga.tile_start[q] = tiles; ga.strip_start[q] = strips; }
+    unsigned* cnt = nullptr;
+    if (splits == 2) {
+        cnt = g8_pair_counters(tiles);
+        if (cnt == nullptr || workspace == nullptr) { uh_set_error("gemm group: no workspace / counters for two K slices"); return -1; }
+    }
+    for (int q = 0; q < n; ++q) {
+        GemmArgs& a = ga.g[q];
+        a.partial = splits == 2 ? (float*)workspace + (size_t)ga.tile_start[q] * (256 * 256) : nullptr;
+        a.pair = splits == 2 ? cnt + ga.tile_start[q] : nullptr;
+    }
+    ga.per = (tiles * splits + 7) / 8;
+    ga.gemm_blocks = ga.per * 8;
+    static bool attr_done = false;
+    if (!attr_done) {
+        UH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS_BYTES));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm8_group_kernel, dim3(ga.gemm_blocks + strips), dim3(G8_THREADS), G8_LDS_BYTES, st, ga);
+    UH_LAUNCH_CHECK();
+    return 0;
+}
+
 int gemm_wgrad_group(int n, const void* const* dy, const void* const* x, void* const* dw, void* const* db, int64_t M,
                      const int64_t* N, const int64_t* K, int accumulate, hipStream_t st, int cfg_override,
-                     const int64_t* lddy, const int64_t* ldx) {
+                     const int64_t* lddy, const int64_t* ldx, void* workspace, size_t ws_bytes, int splits_override) {
     if (n < 1 || n > 4) { uh_set_error("gemm_wgrad_group: 1..4 problems"); return -1; }
     for (int q = 0; q < n; ++q) {
         if (check_common(M, N[q], K[q])) return -1;
@@ -1103,21 +1200,28 @@ int gemm_wgrad_group(int n, const void* const* dy, const void* const* x, void* c
         a.drop = make_dropout(0.f, 0, 0);
     }
     int cfg = cfg_override;
+    int splits = splits_override > 0 ? splits_override : 1;
     if (cfg < 0) {
         Tuned tn;
         static const int env_cfg = [] { const char* e = getenv("UNITER_AMD_GROUP_CFG"); return e ? atoi(e) : -1; }();   // experiment hook
-        if (env_cfg >= 0 && env_cfg < kNumTiles && group_cfg_ok(env_cfg, n, M, N, K)) cfg = env_cfg;
-        else if (tuned_lookup(3, M, group_sum(n, N), group_sum(n, K), &tn) && group_cfg_ok(tn.cfg, n, M, N, K)) cfg = tn.cfg;
+        static const int env_sp = [] { const char* e = getenv("UNITER_AMD_GROUP_SPLITS"); return e ? atoi(e) : 1; }();
+        if (env_cfg >= 0 && env_cfg < kNumTiles && group_cfg_ok(env_cfg, n, M, N, K)) { cfg = env_cfg; splits = env_sp; }
+        else if (tuned_lookup(3, M, group_sum(n, N), group_sum(n, K), &tn) && group_cfg_ok(tn.cfg, n, M, N, K)) { cfg = tn.cfg; splits = tn.splits; }
         else {
             const int prefer[] = {33, 29, 0, 3};                      // 128x128 ws, 64x64 ws, then the plain tiles
             for (int c : prefer)
                 if (group_cfg_ok(c, n, M, N, K)) { cfg = c; break; }
         }
     }
-    if (cfg < 0 || !group_cfg_ok(cfg, n, M, N, K)) { uh_set_error("gemm_wgrad_group: no legal tile"); return -1; }
+    if (splits_override > 0) splits = splits_override;
+    if (cfg < 0 || cfg >= kNumTiles || !group_cfg_ok(cfg, n, M, N, K)) { uh_set_error("gemm_wgrad_group: no legal tile"); return -1; }
     int64_t welems = 0;
     for (int i = 0; i < n; ++i) welems += N[i] * K[i];
     LaunchTimer lt(TIME_GEMM_WGRAD_GROUP, M, welems, n, st);
+    if (kTiles[cfg].ws == 3) {
+        if (splits != 2 || workspace == nullptr || ws_bytes < gemm_wgrad_group_workspace_bytes(n, N, K) || !group_g8_ok(n, M, N, K, 2)) splits = 1;
+        return launch_group_g8(ga, n, M, splits, workspace, st);
+    }
     return launch_group(ga, cfg, st);
 }
 
@@ -1150,9 +1254,18 @@ int gemm_group_autotune(int n, int64_t M, const int64_t* N, const int64_t* K, hi
     GT_HIP(hipEventCreate(&e1));
     std::vector<std::pair<float, Tuned>> ranked;
     int rc = 0;
-    for (int cfg : kGroupCfgs) {
+    void* gws = nullptr;
+    const size_t gws_bytes = gemm_wgrad_group_workspace_bytes(n, N, K);
+    if (group_g8_ok(n, M, N, K, 2) && hipMalloc(&gws, gws_bytes) != hipSuccess) gws = nullptr;
+    struct Cand { int cfg, splits; };
+    std::vector<Cand> cands;
+    for (int cfg : kGroupCfgs) cands.push_back({cfg, 1});
+    cands.push_back({kTileG8, 1});
+    if (gws != nullptr) cands.push_back({kTileG8, 2});
+    for (const Cand& cd : cands) {
+        const int cfg = cd.cfg;
         if (!group_cfg_ok(cfg, n, M, N, K)) continue;
-        auto run = [&]() { return gemm_wgrad_group(n, dyb, xb, dwb, dbb, M, N, K, 0, st, cfg); };
+        auto run = [&]() { return gemm_wgrad_group(n, dyb, xb, dwb, dbb, M, N, K, 0, st, cfg, nullptr, nullptr, gws, gws_bytes, cd.splits); };
         for (int i = 0; i < 2 && rc == 0; ++i) rc = run();
         if (rc) break;
         (void)hipEventRecord(e0, st);
@@ -1161,9 +1274,10 @@ int gemm_group_autotune(int n, int64_t M, const int64_t* N, const int64_t* K, hi
         if (hipEventSynchronize(e1) != hipSuccess) { rc = -3; break; }
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        ranked.push_back({ms, Tuned{cfg, 1}});
+        ranked.push_back({ms, Tuned{cfg, cd.splits}});
     }
 #undef GT_HIP
+    if (gws) (void)hipFree(gws);
     cleanup();
     if (rc) return rc;
     if (!ranked.empty()) {
@@ -1218,14 +1332,8 @@ int gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, hipStream_t st) {
     std::vector<std::pair<float, Tuned>> ranked;
     const DropoutCfg nodrop = make_dropout(0.f, 0, 0);
     for (int cfg = 0; cfg < kNumTiles && rc == 0; ++cfg) {
-        const int bm = kTiles[cfg].bm, bn = kTiles[cfg].bn;
-        const bool p2m = bm == 64 || bm == 128, p2n = bn == 64 || bn == 128 || bn == 192;
-        const int64_t contraction = kind == 0 ? K : (kind == 1 ? N : M);
-        if (kTiles[cfg].ws && contraction % 64 != 0) continue;
-        if (kind == 0 && N % bn != 0) continue;
-        if (kind == 1 && (!p2n || K % bn != 0)) continue;
-        if (kind == 2 && (!p2m || !p2n || N % bm != 0 || K % bn != 0)) continue;
         for (int sp = 1; sp <= (kind == 2 ? 4 : 1) && rc == 0; sp *= 2) {
+            if (!cfg_legal(kind, cfg, M, N, K, sp)) continue;
             g_force_cfg = cfg;
             g_force_splits = sp;
             auto run = [&]() -> int {
@@ -1279,7 +1387,7 @@ int gemm_tile_count() { return kNumTiles; }
 
 int gemm_set_tuned(int kind, int64_t M, int64_t N, int64_t K, int cfg, int splits) {
     if (kind == 3) {            // grouped wgrad: (M, sum N, sum K); legality is re-checked at launch against the members
-        if (cfg < 0 || cfg >= kNumTiles || splits != 1) { uh_set_error("gemm_set_tuned: bad grouped-wgrad tile"); return -1; }
+        if (cfg < 0 || cfg >= kNumTiles || (splits != 1 && !(kTiles[cfg].ws == 3 && splits == 2))) { uh_set_error("gemm_set_tuned: bad grouped-wgrad tile"); return -1; }
         std::lock_guard<std::mutex> lk(g_tuned_mu);
         g_tuned[std::make_tuple(kind, M, N, K)] = Tuned{cfg, splits};
         return 0;
@@ -1287,14 +1395,10 @@ int gemm_set_tuned(int kind, int64_t M, int64_t N, int64_t K, int cfg, int split
     if (kind < 0 || kind > 2 || cfg < 0 || cfg >= kNumTiles) { uh_set_error("gemm_set_tuned: bad kind / tile index"); return -1; }
     if (splits < 1 || splits > 4 || (kind != 2 && splits != 1)) { uh_set_error("gemm_set_tuned: bad split count (split-K is a wgrad option, <= 4)"); return -1; }
     // same legality rules as the autotune sweep
-    const int bm = kTiles[cfg].bm, bn = kTiles[cfg].bn;
-    const bool p2m = bm == 64 || bm == 128, p2n = bn == 64 || bn == 128 || bn == 192;
-    const int64_t contraction = kind == 0 ? K : (kind == 1 ? N : M);
-    bool ok = !(kTiles[cfg].ws && contraction % (64 * (int64_t)splits) != 0);
-    if (kind == 0) ok = ok && N % bn == 0;
-    if (kind == 1) ok = ok && p2n && K % bn == 0;
-    if (kind == 2) ok = ok && p2m && p2n && N % bm == 0 && K % bn == 0;
-    if (!ok) { uh_set_error("gemm_set_tuned: tile %d (%dx%d) is not legal for kind %d M=%lld N=%lld K=%lld", cfg, bm, bn, kind, (long long)M, (long long)N, (long long)K); return -1; }
+    if (!cfg_legal(kind, cfg, M, N, K, splits)) {
+        uh_set_error("gemm_set_tuned: tile %d (%dx%d) is not legal for kind %d M=%lld N=%lld K=%lld", cfg, kTiles[cfg].bm, kTiles[cfg].bn, kind, (long long)M, (long long)N, (long long)K);
+        return -1;
+    }
     std::lock_guard<std::mutex> lk(g_tuned_mu);
     g_tuned[std::make_tuple(kind, M, N, K)] = Tuned{cfg, splits};
     return 0;

@@ -1,0 +1,566 @@
+// gemm8.cuh — the deep-pipelined bf16 GEMM tile for gfx950: 256 x 256 x 64, eight waves, eight phases per two K tiles.
+//
+// Why a second tile family.  The 64...192-wide tiles of gemm.hip run one or two barriers per K step with every wave
+// doing the same thing at the same time; that structure tops out near 36 % of the MFMA peak however its ring is tuned
+// (DESIGN §7/§8).  This one follows the schedule cdna_hip_programming.md §5 "256² 8-phase template" describes:
+//
+//   * tile 256 x 256, K step 64, 8 waves as 2 (M) x 4 (N): a wave owns four 64 x 32 quadrants (mq, nq) of the output,
+//     rows mq*128 + wr*64 + [0,64), columns nq*128 + wc*32 + [0,32) — 128 accumulator registers;
+//   * a K tile is four HALF tiles of 16 KiB (A0, A1 = rows 0-127 / 128-255 of the M-side operand, B0, B1 = columns
+//     0-127 / 128-255 of the N-side operand), LDS = 2 buffers x 4 half tiles = 128 KiB, filled by LDS-DMA
+//     (global_load_lds_dwordx4, two instructions per wave per half tile, XOR swizzle applied on the source address);
+//   * four phases per K tile, one quadrant (16 MFMAs) each:   P1: read B0, A0 -> (0,0)   P2: read B1 -> (0,1)
+//     P3: read A1 -> (1,1)   P4: no read -> (1,0) (B0 is still in registers).  Every phase also issues the DMA of ONE half
+//     tile, seven half tiles ahead of the one being consumed;
+//   * a phase is  {ds_reads, DMA issue} s_barrier {s_waitcnt lgkmcnt(0), 16 MFMAs under s_setprio 1} s_barrier, and the
+//     two wave groups (waves 0-3 / 4-7: one wave of each on every SIMD) run ONE barrier apart, so that one wave of a SIMD
+//     reads LDS and issues DMA while the other owns the matrix pipe;
+//   * s_waitcnt vmcnt(6) once per K tile (P4), never 0 inside the loop: three half tiles stay in flight across the
+//     barriers.
+//
+// Hazards, by construction (phase numbers count from the consumer's point of view; S_j = j-th half tile in consumption
+// order B0 A0 B1 A1, issued in phase j-7, the first seven in the prologue):
+//   RAW  a half tile is waited for (vmcnt) before the FIRST barrier of P4 of the previous K tile by every wave, and first
+//        read in P1 of its own K tile: the lagging group's wait and the leading group's read are two barriers apart.
+//   WAR  S_j overwrites S_{j-8}.  B0 is last read in P1 and re-filled in P2: its reads are retired (lgkmcnt) before P1's
+//        first barrier, so both groups have them back before either group's P2 issue.  A0 (read P1, re-filled P3), B1
+//        (P2 -> P4) and A1 (P3 -> next P1) have two phases between their last read and the re-fill.
+#pragma once
+#include "gemm_args.cuh"
+#include "gemm_lds.cuh"
+
+namespace {
+
+constexpr int G8_HALF = 128 * 64;                    // elements of one half tile (16 KiB)
+constexpr int G8_BUF = 4 * G8_HALF;                  // one K tile in LDS: A0 A1 B0 B1
+constexpr int G8_LDS_BYTES = 2 * G8_BUF * 2;         // 131072
+constexpr int G8_THREADS = 512;
+
+template <int V> struct G8C { static constexpr int value = V; };
+
+// Byte offset (from the operand's origin of the current K tile) of the 16 bytes this lane fetches with LDS-DMA
+// instruction j (0..15) of half tile h.  K-contiguous operand [extent][ld]: instruction j covers tile rows 8j..8j+7, the
+// lane lands in physical chunk lane&7 and fetches logical chunk (lane&7) ^ swz(row) (kc_off's swizzle, gemm_lds.cuh);
+// rows beyond the matrix are clamped to the last one (their products land in rows the epilogue never stores).
+// K-strided operand [K][ld], `origin` = first tile column: instruction j covers k rows 4j..4j+3 (ks_off8<128>'s swizzle).
+template <bool TR>
+__device__ __forceinline__ uint32_t g8_src_off(int j, int lane, int h, int64_t ld, int origin, int extent) {
+    if constexpr (!TR) {
+        const int r = 8 * j + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int gr = origin + h * 128 + r;
+        gr = gr < extent ? gr : extent - 1;
+        return (uint32_t)(((int64_t)gr * ld + c * 8) * 2);
+    } else {
+        const int r = 4 * j + (lane >> 4);
+        const int c = (lane & 15) ^ (ks_swz<128>(r) << 1);
+        return (uint32_t)(((int64_t)r * ld + origin + h * 128 + c * 8) * 2);
+    }
+}
+
+__device__ __forceinline__ void g8_sc1_store16(void* p, const f32x4 v) {
+    // write-through store: the bytes leave this XCD's L2 while the kernel runs (the partner slice may sit on another XCD)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"((__attribute__((address_space(1))) f32x4*)p), "v"(v) : "memory");
+}
+
+// LDS-DMA of 64 lanes x 16 bytes: global address = uniform 64-bit origin (scalar registers) + per-lane 32-bit offset, LDS
+// destination = lds_addr (uniform, through M0) + lane * 16.  Inline asm: the builtin takes a flat 64-bit per-lane pointer,
+// which costs a 64-bit VALU add and a register pair per instruction in a kernel that has neither to spare; nothing else in
+// the kernel uses M0.  The loads are invisible to the compiler's vmcnt bookkeeping — every wait on them is written by hand.
+__device__ __forceinline__ void g8_glds16(uint32_t voff, const void* origin, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(origin), "s"(lds_addr) : "memory");
+}
+
+// One 256 x 256 output tile.  bx = tile slot, by = K slice.
+//   XCHG = 1: the two 16-column fragments of a quadrant row are exchanged between lane rows (v_permlane16_swap) so that a
+//             lane stores / loads 8 consecutive columns (16 bytes); XCHG = 0: two 8-byte pieces.
+template <bool TRA, bool TRB, int EPI, int XCHG>
+__device__ __forceinline__ void gemm8_tile(const GemmArgs& p, const int bx, const int by, char* smem_raw) {
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int g = lane >> 4, i = lane & 15;
+
+    const int tiles_n = p.N >> 8;
+    const int tiles_m = (p.M + 255) >> 8;
+    int tm, tn;
+    tile_of_block(p.xr, bx, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const int k_begin = by * p.k_per_split;
+    const int k_end = min(p.K, k_begin + p.k_per_split);
+    const int nk = (k_end - k_begin) >> 6;                  // whole K tiles (the launcher guarantees it)
+
+    // ---- LDS-DMA sources and destinations -------------------------------------------------------------------------------
+    uint32_t offA[2][2], offB[2][2];                        // [half][instruction of this wave]: byte offsets from the K tile's origin
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            offA[h][jj] = g8_src_off<TRA>(wid + 8 * jj, lane, h, p.ldr, m0, p.M);
+            offB[h][jj] = g8_src_off<TRB>(wid + 8 * jj, lane, h, p.ldcc, n0, p.N);
+        }
+    const char* gA = reinterpret_cast<const char*>(p.R + (TRA ? (int64_t)k_begin * p.ldr : (int64_t)k_begin));
+    const char* gB = reinterpret_cast<const char*>(p.Cc + (TRB ? (int64_t)k_begin * p.ldcc : (int64_t)k_begin));
+    const int64_t stepA = (TRA ? 64 * p.ldr : (int64_t)64) * 2, stepB = (TRB ? 64 * p.ldcc : (int64_t)64) * 2;   // bytes per K tile
+    typedef __attribute__((address_space(3))) char lds_char_t;
+    const uint32_t lds0 = (uint32_t)(size_t)(lds_char_t*)smem_raw + (uint32_t)wid * 1024u;   // this wave's first piece of buffer 0, slot 0
+
+    // half tile X of K tile kt into buffer kt & 1: X = 0: B0, 1: A0, 2: B1, 3: A1 (consumption order); LDS slots: A0 A1 B0 B1
+    auto stage = [&](auto xc, const int kt) {
+        constexpr int X = decltype(xc)::value;
+        constexpr bool isA = (X & 1) != 0;
+        constexpr int h = X >> 1;
+        const uint32_t dst = lds0 + (uint32_t)(kt & 1) * (G8_BUF * 2) + (uint32_t)((isA ? h : 2 + h) * G8_HALF * 2);
+        const char* origin = isA ? gA + (int64_t)kt * stepA : gB + (int64_t)kt * stepB;
+        g8_glds16(isA ? offA[h][0] : offB[h][0], origin, dst);
+        g8_glds16(isA ? offA[h][1] : offB[h][1], origin, dst + 8 * 1024);
+    };
+
+    // ---- fragment addresses (elements inside the current buffer; toggled between the buffers by XOR after every K tile) ---
+    // K-contiguous half tile [128][64]: row r, 16-byte chunk c at kc_off(r, c); the swizzle depends on (r >> 1) & 7 only, i.e.
+    // on the lane, so one address per k half serves all 16-row blocks through the instruction's offset field.
+    // K-strided half tile [64][128]: ks_off8<128>(k row, 8-byte chunk); the swizzle mixes into the column block, one address
+    // per 16-column block.
+    uint32_t aoff[TRA ? 4 : 2], boff[2];
+    if constexpr (TRA) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) aoff[b] = (uint32_t)ks_off8<128>(8 * g + (i >> 2), ((wr * 64 + b * 16) >> 2) + (i & 3));
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) aoff[ks] = (uint32_t)kc_off(wr * 64 + i, ks * 4 + g);
+    }
+    if constexpr (TRB) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) boff[a] = (uint32_t)ks_off8<128>(8 * g + (i >> 2), ((wc * 32 + a * 16) >> 2) + (i & 3)) + 2 * G8_HALF;
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) boff[ks] = (uint32_t)kc_off(wc * 32 + i, ks * 4 + g) + 2 * G8_HALF;
+    }
+    auto tr_pair = [&](uint32_t e) {                        // rows r0 and r0 + 4 of a K-strided tile -> one MFMA operand
+        const s16x4 lo = lds_read_tr(smem + e);
+        const s16x4 hi = lds_read_tr(smem + e + 4 * 128);
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    bf16x8 fA[2][4];                 // [k half of the tile][16-row block of the quadrant]
+    bf16x8 fB0[2][2], fB1[2][2];     // [k half][16-column block]
+    auto read_a = [&](const int h, const int ks) {          // half tile A_h, k half ks
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if constexpr (TRA) fA[ks][b] = tr_pair(aoff[b] + h * G8_HALF + ks * 32 * 128);
+            else               fA[ks][b] = lds_read_b128(smem + aoff[ks] + h * G8_HALF + b * 16 * 64);
+        }
+    };
+    auto read_b = [&](bf16x8 (&f)[2][2], const int h) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                if constexpr (TRB) f[ks][a] = tr_pair(boff[a] + h * G8_HALF + ks * 32 * 128);
+                else               f[ks][a] = lds_read_b128(smem + boff[ks] + h * G8_HALF + a * 16 * 64);
+            }
+    };
+    constexpr int A_HALF_READS = TRA ? 8 : 4;   // DS instructions of one read_a(., ks)
+
+    f32x4 acc[2][2][2][4];           // [mq][nq][a][b]
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[q >> 1][q & 1][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto mma = [&](f32x4 (&c)[2][4], const bf16x8 (&fb)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    c[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][a], fA[ks][b], c[a][b], 0, 0, 0);
+        // MFMAs are pure register operations: without a user on the side-effect chain LLVM sinks half of a cluster below the
+        // phase's closing barrier (seen in the optimised IR).  The empty statements emit nothing and pin the cluster here.
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) asm volatile("" : "+v"(c[a][b]));
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // first barrier of a phase (the reads and the DMA issue are behind us), then the reads' data
+    auto to_mma = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto end_phase = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if (nk > 0) {                                           // (an empty K slice contributes zeros)
+    // ---- prologue: seven half tiles in flight, K tile 0 landed -------------------------------------------------------------
+    stage(G8C<0>{}, 0);
+    stage(G8C<1>{}, 0);
+    stage(G8C<2>{}, 0);
+    stage(G8C<3>{}, 0);
+    if (nk > 1) {
+        stage(G8C<0>{}, 1);
+        stage(G8C<1>{}, 1);
+        stage(G8C<2>{}, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();              // the second wave group runs one barrier behind the first
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+        // ---- P1: B0, A0 -> quadrant (0,0); DMA: A1 of K tile kt+1 (the other buffer)
+        read_b(fB0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(0, 0);
+        if (more1) stage(G8C<3>{}, kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(A_HALF_READS) : "memory");      // B0's reads are back: B0 may be re-filled in P2
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(0, 1);
+        to_mma();
+        mma(acc[0][0], fB0);
+        end_phase();
+        // ---- P2: B1 -> (0,1); DMA: B0 of K tile kt+2
+        read_b(fB1, 1);
+        if (more2) stage(G8C<0>{}, kt + 2);
+        to_mma();
+        mma(acc[0][1], fB1);
+        end_phase();
+        // ---- P3: A1 -> (1,1); DMA: A0 of K tile kt+2
+        read_a(1, 0);
+        read_a(1, 1);
+        if (more2) stage(G8C<1>{}, kt + 2);
+        to_mma();
+        mma(acc[1][1], fB1);
+        end_phase();
+        // ---- P4: (1,0) from registers; DMA: B1 of K tile kt+2; K tile kt+1 has landed when three half tiles remain in flight
+        if (more2) {
+            stage(G8C<2>{}, kt + 2);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        to_mma();
+        mma(acc[1][0], fB0);
+        end_phase();
+        // the other buffer
+#pragma unroll
+        for (int k = 0; k < (TRA ? 4 : 2); ++k) aoff[k] ^= (uint32_t)G8_BUF;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) boff[k] ^= (uint32_t)G8_BUF;
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();              // the first group waits for the second group's last phase
+    __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- two K slices combined inside the launch ------------------------------------------------------------------------
+    // Whichever slice of a tile finishes first parks its accumulators in the tile's fp32 slab (thread-linear, write-through)
+    // and raises the tile's counter; the other adds them to its own and runs the epilogue.  fp32 addition commutes, so the
+    // result does not depend on the order of arrival.  Counter: 0 -> 1 (first ticket) -> 2 (slab written) -> 3 (second ticket);
+    // the combiner leaves it at 0 for the next launch.
+    if constexpr (EPI == EPI_WGRAD) {
+        if (p.pair != nullptr) {
+            unsigned* cnt = p.pair + (tm * tiles_n + tn);
+            float* slab = p.partial + (size_t)(tm * tiles_n + tn) * (256 * 256);
+            unsigned* lds_flag = reinterpret_cast<unsigned*>(smem_raw);
+            if (t == 0) *lds_flag = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const unsigned ticket = *lds_flag;
+            if (ticket == 0u) {                              // first to finish: park and leave
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            g8_sc1_store16(slab + ((size_t)((q * 2 + a) * 4 + b) * G8_THREADS + t) * 4, acc[q >> 1][q & 1][a][b]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (t == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            if (t == 0) {
+                // ticket 1: the slab is complete at 3 (our own increment included); ticket 2 (the partner had already
+                // finished writing when we drew): also 3
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 3u) __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                    // a quadrant's eight loads in flight at a time (register budget)
+                typedef __attribute__((address_space(1))) f32x4 gmem_f32x4;
+                f32x4 o[2][4];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        o[a][b] = __builtin_nontemporal_load((const gmem_f32x4*)(slab + ((size_t)((q * 2 + a) * 4 + b) * G8_THREADS + t) * 4));
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[q >> 1][q & 1][a][b] += o[a][b];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------------------
+    // A lane holds C[m][n..n+3] for m = m0 + mq*128 + wr*64 + b*16 + i, n = n0 + nq*128 + wc*32 + a*16 + 4g.  With XCHG the
+    // a = 0 / a = 1 pieces of lane rows g, g^1 are swapped so that the lane owns 8 consecutive columns of fragment (g & 1).
+    {
+#pragma clang fp contract(off)                              // bias, dropout, residual: the same roundings as gemm.hip's epilogue
+    constexpr bool HAS_BIAS = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RES);
+    constexpr bool HAS_AUX = (EPI == EPI_BIAS_DROP_RES || EPI == EPI_RES || EPI == EPI_GELU_BWD || EPI == EPI_WGRAD);
+    constexpr int W = XCHG ? 8 : 4;                        // consecutive columns per piece
+    constexpr int NP = XCHG ? 1 : 2;                       // pieces per (quadrant, b)
+    const bool to_partial = (EPI == EPI_WGRAD || EPI == EPI_RES) && p.partial != nullptr && (EPI != EPI_WGRAD || p.pair == nullptr);
+    const bf16_t* abase = nullptr;
+    int64_t ald = 0;
+    if constexpr (HAS_AUX) {
+        if (EPI == EPI_WGRAD) { abase = (p.accumulate && !to_partial) ? p.C : nullptr; ald = p.ldc; }
+        else { abase = to_partial ? nullptr : p.aux; ald = p.ldaux; }
+    }
+    auto col_of = [&](int nq, int pc) {                    // first column of piece pc of quadrant column nq
+        return XCHG ? n0 + nq * 128 + wc * 32 + (g & 1) * 16 + (g >> 1) * 8 : n0 + nq * 128 + wc * 32 + pc * 16 + 4 * g;
+    };
+    uint32_t biasw[2][NP][W / 2];
+    if constexpr (HAS_BIAS) {
+#pragma unroll
+        for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) {
+#pragma unroll
+                for (int e = 0; e < W / 2; ++e) biasw[nq][pc][e] = 0u;
+                if (p.bias != nullptr) {
+                    const uint32_t* bp = reinterpret_cast<const uint32_t*>(p.bias + col_of(nq, pc));
+#pragma unroll
+                    for (int e = 0; e < W / 2; ++e) biasw[nq][pc][e] = bp[e];
+                }
+            }
+    }
+#pragma unroll
+    for (int mq = 0; mq < 2; ++mq) {
+        uint32_t auxw[2][4][NP][W / 2];
+        if constexpr (HAS_AUX) {                            // all of this row half's operand loads at once
+#pragma unroll
+            for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int m = m0 + mq * 128 + wr * 64 + b * 16 + i;
+#pragma unroll
+                    for (int pc = 0; pc < NP; ++pc) {
+#pragma unroll
+                        for (int e = 0; e < W / 2; ++e) auxw[nq][b][pc][e] = 0u;
+                        if (abase != nullptr && m < p.M) {
+                            const bf16_t* ap = abase + (int64_t)m * ald + col_of(nq, pc);
+                            if constexpr (XCHG) {
+                                const u32x4 q = *reinterpret_cast<const u32x4*>(ap);
+                                auxw[nq][b][pc][0] = q[0]; auxw[nq][b][pc][1] = q[1]; auxw[nq][b][pc][2] = q[2]; auxw[nq][b][pc][3] = q[3];
+                            } else {
+                                const u32x2 q = *reinterpret_cast<const u32x2*>(ap);
+                                auxw[nq][b][pc][0] = q[0]; auxw[nq][b][pc][1] = q[1];
+                            }
+                        }
+                    }
+                }
+        }
+#pragma unroll
+        for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int m = m0 + mq * 128 + wr * 64 + b * 16 + i;
+                float vv[NP][W];
+                if constexpr (XCHG) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mq][nq][0][b][r]),
+                                                                         __float_as_uint(acc[mq][nq][1][b][r]), false, false);
+                        vv[0][r] = __uint_as_float(sw[0]);
+                        vv[0][4 + r] = __uint_as_float(sw[1]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { vv[0][r] = acc[mq][nq][0][b][r]; vv[NP - 1][r] = acc[mq][nq][1][b][r]; }
+                }
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) {
+                    float (&v)[W] = vv[pc];
+                    const int n = col_of(nq, pc);
+                    if (to_partial) {
+                        float* dst = p.partial + ((int64_t)by * p.M + m) * p.N + n;
+#pragma unroll
+                        for (int e = 0; e < W; e += 4) *reinterpret_cast<f32x4*>(dst + e) = f32x4{v[e], v[e + 1], v[e + 2], v[e + 3]};
+                        continue;
+                    }
+                    if constexpr (HAS_BIAS) {
+#pragma unroll
+                        for (int e = 0; e < W / 2; ++e) { v[2 * e] += bits2f_lo(biasw[nq][pc][e]); v[2 * e + 1] += bits2f_hi(biasw[nq][pc][e]); }
+                    }
+                    bf16_t* cptr = p.C + (int64_t)m * p.ldc + n;
+                    auto store = [&](bf16_t* dst, const float (&x)[W]) {
+                        if constexpr (XCHG) {
+                            float x8[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) x8[e] = x[e];
+                            out_store16(dst, pack8(x8));
+                        } else {
+                            float x4[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) x4[e] = x[e];
+                            out_store8(dst, pack4(x4));
+                        }
+                    };
+                    if constexpr (EPI == EPI_BIAS_GELU) {
+                        // the activation is applied to the bf16-rounded u so that backward (which only has u) is consistent
+                        float uq[W], gq[W];
+#pragma unroll
+                        for (int e = 0; e < W; ++e) uq[e] = bf2f(f2bf(v[e]));
+                        store(cptr, v);
+#pragma unroll
+                        for (int e = 0; e < W; ++e) gq[e] = act_fwd(p.relu, uq[e]);
+                        store(p.C2 + (int64_t)m * p.ldc + n, gq);
+                        continue;
+                    }
+                    if constexpr (EPI == EPI_BIAS_DROP_RES) {
+                        if (p.relu) {
+#pragma unroll
+                            for (int e = 0; e < W; ++e) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        if (p.drop.p > 0.f) {
+                            float mv[W];
+                            if constexpr (XCHG) dropout_mult8(p.drop, ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 3, reinterpret_cast<float (&)[8]>(mv));
+                            else                dropout_mult4(p.drop, ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 2, reinterpret_cast<float (&)[4]>(mv));
+#pragma unroll
+                            for (int e = 0; e < W; ++e) v[e] *= mv[e];
+                        }
+                    }
+                    if constexpr (HAS_AUX) {
+                        if (abase != nullptr) {
+#pragma unroll
+                            for (int e = 0; e < W / 2; ++e) {
+                                const float lo = bits2f_lo(auxw[nq][b][pc][e]), hi = bits2f_hi(auxw[nq][b][pc][e]);
+                                if constexpr (EPI == EPI_GELU_BWD) { v[2 * e] *= act_grad(p.relu, lo); v[2 * e + 1] *= act_grad(p.relu, hi); }
+                                else { v[2 * e] += lo; v[2 * e + 1] += hi; }
+                            }
+                        }
+                    }
+                    store(cptr, v);
+                }
+            }
+    }
+    }
+}
+
+// ---- grouped weight gradients on the eight-phase tile ------------------------------------------------------------------
+// Up to four weight gradients dw_q[M_q][N_q] (+)= R_q^T Cc_q over the same contraction (the tokens) in ONE launch, optionally
+// as two K slices per tile combined inside the launch, plus — on workgroups appended to the grid — the bias gradients: column
+// sums of the M-side operand (dy) in strips of 256 columns.  Tile order: slice-major, then problem after problem, each walked
+// with its longer tile dimension outermost; XCD x (hardware blocks b with b % 8 == x) runs the contiguous segment
+// [x*per, (x+1)*per) of that order, so an XCD's L2 holds the K slabs of one compact rectangle of tiles (as gemm_group_kernel).
+struct G8GroupArgs {
+    GemmArgs g[4];
+    int tile_start[5];     // cumulative tile counts (one K slice)
+    int strip_start[5];    // cumulative 256-column strip counts of the bias gradients
+    int n;
+    int splits;            // 1 or 2
+    int per;               // tiles per XCD segment
+    int gemm_blocks;       // 8 * per; blocks beyond it are column-sum strips
+};
+
+__device__ __forceinline__ void g8_colsum_strip(const GemmArgs& p, const int strip, char* smem_raw) {
+    // db[c] (+)= sum over the contraction of R[k][c], c in [256*strip, +256): thread = (row lane, 8-column chunk)
+    const int t = threadIdx.x;
+    const int cc = t & 31, rl = t >> 5;
+    const bf16_t* src = p.R + (int64_t)strip * 256 + cc * 8;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int r = rl;
+    for (; r + 48 < p.K; r += 64) {                         // four rows in flight per thread
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const u32x4*>(src + (int64_t)(r + 16 * u) * p.ldr);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float f[8];
+            unpack8(v[u], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += f[e];
+        }
+    }
+    for (; r < p.K; r += 16) {
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(src + (int64_t)r * p.ldr), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += f[e];
+    }
+    float* red = reinterpret_cast<float*>(smem_raw);        // [16][256]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl * 256 + cc * 8 + e] = s[e];
+    __syncthreads();
+    if (t < 256) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += red[k * 256 + t];
+        bf16_t* dst = p.C2 + strip * 256 + t;
+        if (p.accumulate) tot += bf2f(*dst);
+        *dst = f2bf(tot);
+    }
+}
+
+__global__ __launch_bounds__(G8_THREADS, 2) void gemm8_group_kernel(const G8GroupArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int b = (int)blockIdx.x;
+    if (b >= ga.gemm_blocks) {
+        const int s = b - ga.gemm_blocks;
+        int q = 0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if (k < ga.n && s >= ga.strip_start[k]) q = k;
+        g8_colsum_strip(ga.g[q], s - ga.strip_start[q], smem_raw);
+        return;
+    }
+    const int total = ga.tile_start[ga.n];
+    const int pos = (b & 7) * ga.per + (b >> 3);            // position in the linear order
+    if (pos >= total * ga.splits) return;                   // the last segment may be short
+    const int slice = pos >= total ? 1 : 0;
+    const int lin = pos - slice * total;
+    int q = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < ga.n && lin >= ga.tile_start[k]) q = k;
+    const GemmArgs& p = ga.g[q];
+    const int bx = lin - ga.tile_start[q];
+    const int tiles_m = p.M >> 8, tiles_n = p.N >> 8;
+    const int tm = tiles_n >= tiles_m ? bx % tiles_m : bx / tiles_n;      // longer tile dimension outermost
+    const int tn = tiles_n >= tiles_m ? bx / tiles_m : bx % tiles_n;
+    gemm8_tile<true, true, EPI_WGRAD, 1>(p, tm * tiles_n + tn, slice, smem_raw);
+}
+
+template <bool TRA, bool TRB, int EPI, int XCHG>
+__global__ __launch_bounds__(G8_THREADS, 2) void gemm8_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    gemm8_tile<TRA, TRB, EPI, XCHG>(p, (int)blockIdx.x, (int)blockIdx.y, smem_raw);
+}
+
+}  // namespace

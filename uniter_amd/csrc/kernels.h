@@ -41,7 +41,10 @@ int gemm_wgrad(const void* dy, const void* x, void* dw, int64_t M, int64_t N, in
                void* workspace, size_t ws_bytes, hipStream_t st, int64_t lddy = 0, int64_t ldx = 0, void* db = nullptr);
 int gemm_wgrad_group(int n, const void* const* dy, const void* const* x, void* const* dw, void* const* db, int64_t M,
                      const int64_t* N, const int64_t* K, int accumulate, hipStream_t st, int cfg_override = -1,
-                     const int64_t* lddy = nullptr, const int64_t* ldx = nullptr);
+                     const int64_t* lddy = nullptr, const int64_t* ldx = nullptr, void* workspace = nullptr, size_t ws_bytes = 0,
+                     int splits_override = 0);
+// fp32 slabs of the eight-phase tile's two-slice form (4 bytes per weight element); without it the grouped launch runs one slice
+size_t gemm_wgrad_group_workspace_bytes(int n, const int64_t* N, const int64_t* K);
 int gemm_group_autotune(int n, int64_t M, const int64_t* N, const int64_t* K, hipStream_t st);
 void gemm_debug_force(int cfg, int splits);
 int gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, hipStream_t st);
