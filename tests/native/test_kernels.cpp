@@ -260,20 +260,20 @@ static const int kTileBM[] = {128, 128, 64, 64, 96, 192, 192, 128, 96, 128, 96, 
                               96, 128, 192, 128,
                               128, 128, 192, 96, 192, 128, 192, 128, 64, 192,
                               96, 96, 128, 128,
-                              256};
+                              256, 192};
 static const int kTileBN[] = {128, 64, 128, 64, 192, 96, 128, 192, 128, 96, 96, 64, 64, 64, 128, 64, 96, 64, 128, 96,
                               128, 192, 96, 64, 128, 96, 64, 128, 96, 64,
                               64, 128, 96, 128, 64, 64, 64, 128, 96, 64,
                               128, 96, 64, 128,
                               128, 128, 192, 192, 96, 192, 128, 64, 128, 64,
                               128, 128, 96, 96,
-                              256};
-static const int kNumTiles = 59;     // 13..19 are 3-stage rings, 20..29 wave-specialised (4 compute + 4 loader waves), 58 the eight-phase 256x256 tile
-static const int kTileG8 = 58;
+                              256, 192};
+static const int kNumTiles = 60;     // 13..19 are 3-stage rings, 20..29 wave-specialised (4 compute + 4 loader waves), 58 the eight-phase 256x256 tile
+static const int kTileG8 = 58, kTileG6 = 59;   // the deep-pipelined 256x256 / 192x192 tiles
 
 static void test_gemm(int M, int N, int K, int cfg, int splits) {
     char tag[128];
-    const bool g8 = cfg == kTileG8;      // eight-phase tile: contraction % 64 == 0, output columns % 256 == 0, no bias gradient output
+    const bool g8 = cfg == kTileG8 || cfg == kTileG6;      // deep-pipelined tiles: contraction % 64 == 0, output columns % 256 == 0, no bias gradient output
     const bool pow2_bn = cfg < 0 || g8 || kTileBN[cfg] == 64 || kTileBN[cfg] == 128 || kTileBN[cfg] == 192;
     const bool pow2_bm = cfg < 0 || g8 || kTileBM[cfg] == 64 || kTileBM[cfg] == 128;
     if (g8 && K % 64 != 0) { printf("  (skip cfg%d for K=%d)\n", cfg, K); return; }
@@ -523,9 +523,10 @@ static void test_wgrad_group(int M) {
 
 // grouped weight gradients on the eight-phase tile (one and two K slices, bias gradients from the appended strips) == the
 // individual launches on a 64x64 tile
-static void test_wgrad_group_g8(int M, int splits) {
+static void test_wgrad_group_g8(int M, int splits, int tile = kTileG8) {
     const int n = 4;
-    const int64_t N[4] = {256, 512, 256, 768}, K[4] = {512, 256, 256, 256};
+    const int64_t e = tile == kTileG8 ? 256 : 192;
+    const int64_t N[4] = {e, 2 * e, e, 3 * e}, K[4] = {2 * e, e, e, e};
     HostBf DY[4], X[4], W0[4], B0[4];
     uint16_t *dDY[4], *dX[4], *dW1[4], *dW2[4], *dB1[4], *dB2[4];
     size_t wsb = 0;
@@ -546,12 +547,12 @@ static void test_wgrad_group_g8(int M, int splits) {
     const size_t gwb = uniter_gemm_wgrad_group_workspace_bytes(n, N, K);
     void* gws = dalloc<char>(gwb);
     for (int rep = 0; rep < 2; ++rep) {                  // twice: the tile counters must come back to zero
-        UHCHK(uniter_gemm_wgrad_group_ws(n, dyp, nullptr, xp, nullptr, dwp, dbp, M, N, K, 1, gws, gwb, kTileG8, splits, 0));
+        UHCHK(uniter_gemm_wgrad_group_ws(n, dyp, nullptr, xp, nullptr, dwp, dbp, M, N, K, 1, gws, gwb, tile, splits, 0));
         HIPCHK(hipDeviceSynchronize());
         if (rep == 0) {
             for (int q = 0; q < n; ++q) {
                 char tag[160];
-                snprintf(tag, sizeof(tag), "eight-phase wgrad group, %d slice(s), member %d (M%d N%lld K%lld, accumulate)", splits, q, M, (long long)N[q], (long long)K[q]);
+                snprintf(tag, sizeof(tag), "deep-pipelined wgrad group, tile %d, %d slice(s), member %d (M%d N%lld K%lld, accumulate)", tile, splits, q, M, (long long)N[q], (long long)K[q]);
                 check(tag, download_bf(dW2[q], (size_t)N[q] * K[q]), download_bf(dW1[q], (size_t)N[q] * K[q]), 0.13f, 0.02f);
                 snprintf(tag, sizeof(tag), "eight-phase wgrad group member %d bias gradient (appended column-sum strips)", q);
                 if (q == 2) check(tag, download_bf(dB2[q], (size_t)N[q]), B0[q].v, 0.f, 0.f);
@@ -1259,7 +1260,11 @@ static int run_g8(int argc, char** argv, int at) {
         fn(dRef);
         HIPCHK(hipDeviceSynchronize());
         const double t_old = tm.run([&] { fn(dRef); }, 3, 20);
-        uniter_gemm_debug_force(kTileG8, c.splits);
+        for (int tile : {kTileG8, kTileG6}) {
+        const int64_t edge = tile == kTileG8 ? 256 : 192;
+        const bool legal = (kind == "fwd" || kind == "gelu") ? N % edge == 0 : ((kind == "dgrad" || kind == "dgelu") ? K % edge == 0 : (N % edge == 0 && K % edge == 0));
+        if (!legal) continue;
+        uniter_gemm_debug_force(tile, c.splits);
         fn(dO);
         HIPCHK(hipDeviceSynchronize());
         std::vector<uint16_t> r0(n_out), r1(n_out), rr(n_out);
@@ -1273,7 +1278,7 @@ static int run_g8(int argc, char** argv, int at) {
             if (!(d <= 0.02 * fabs(b) + 0.02 * sqrt((double)(kind == "wgrad" ? M : (kind == "fwd" || kind == "gelu" ? K : N))) * 0.05 + 0.05)) ++nbad;
         }
         char tag[200];
-        snprintf(tag, sizeof tag, "g8 %s M%lld N%lld K%lld s%d == older tile family (max |d| %.4f of max |ref| %.2f, %zu outside tolerance)", c.kind,
+        snprintf(tag, sizeof tag, "tile %lld %s M%lld N%lld K%lld s%d == older tile family (max |d| %.4f of max |ref| %.2f, %zu outside tolerance)", (long long)edge, c.kind,
                  (long long)M, (long long)N, (long long)K, c.splits, maxd, maxr, nbad);
         printf("[%s] %s\n", nbad ? "FAIL" : " OK ", tag);
         if (nbad) ++g_fail;
@@ -1287,11 +1292,12 @@ static int run_g8(int argc, char** argv, int at) {
                 for (size_t k = 0; k < n_out; ++k) if (r1[k] != r0[k]) ++ndiff;
             }
         }
-        printf("[%s] g8 %s repeated launches bit-identical (%zu differing elements)\n", ndiff ? "FAIL" : " OK ", c.kind, ndiff);
+        printf("[%s] tile %lld %s repeated launches bit-identical (%zu differing elements)\n", ndiff ? "FAIL" : " OK ", (long long)edge, c.kind, ndiff);
         if (ndiff) ++g_fail;
         const double t_new = tm.run([&] { fn(dO); }, 3, 20);
-        printf("  TIME %-5s M%-5lld N%-5lld K%-5lld splits%d : older family %7.2f us %7.1f TF | eight-phase %7.2f us %7.1f TF  (x%.2f)\n", c.kind, (long long)M,
-               (long long)N, (long long)K, c.splits, t_old, fl / t_old * 1e-6, t_new, fl / t_new * 1e-6, t_old / t_new);
+        printf("  TIME %-5s M%-5lld N%-5lld K%-5lld splits%d : older family %7.2f us %7.1f TF | %lldx%lld deep-pipelined %7.2f us %7.1f TF  (x%.2f)\n", c.kind, (long long)M,
+               (long long)N, (long long)K, c.splits, t_old, fl / t_old * 1e-6, (long long)edge, (long long)edge, t_new, fl / t_new * 1e-6, t_old / t_new);
+        }
         uniter_gemm_debug_force(-1, -1);
         HIPCHK(hipFree(dA)); HIPCHK(hipFree(dB)); HIPCHK(hipFree(dBias)); HIPCHK(hipFree(dO)); HIPCHK(hipFree(dO2)); HIPCHK(hipFree(dU)); HIPCHK(hipFree(dRef));
         if (ws) HIPCHK(hipFree(ws));
@@ -1321,8 +1327,10 @@ static int run_g8(int argc, char** argv, int at) {
         for (int q = 0; q < 4; ++q) fl += 2.0 * T * gN[q] * gK[q];
         UHCHK(uniter_gemm_wgrad_group_ws(4, dyp, nullptr, xp, nullptr, dwrp, dbrp, T, gN, gK, 0, nullptr, 0, 33, 1, 0));   // 128x128, 4+4 waves
         const double t_old = tm.run([&] { UHCHK(uniter_gemm_wgrad_group_ws(4, dyp, nullptr, xp, nullptr, dwrp, dbrp, T, gN, gK, 0, nullptr, 0, 33, 1, 0)); }, 3, 20);
-        for (int sp = 1; sp <= 2; ++sp) {
-            UHCHK(uniter_gemm_wgrad_group_ws(4, dyp, nullptr, xp, nullptr, dwp, dbp, T, gN, gK, 0, gws, gwb, kTileG8, sp, 0));
+        for (int var = 0; var < 3; ++var) {
+            const int sp = var == 1 ? 2 : 1, kTileX = var == 2 ? kTileG6 : kTileG8;
+            if (var == 2 && (H % 192 != 0 || I % 192 != 0)) continue;
+            UHCHK(uniter_gemm_wgrad_group_ws(4, dyp, nullptr, xp, nullptr, dwp, dbp, T, gN, gK, 0, gws, gwb, kTileX, sp, 0));
             HIPCHK(hipDeviceSynchronize());
             size_t nbad = 0, ndiff = 0;
             double maxd = 0;
@@ -1336,9 +1344,9 @@ static int run_g8(int argc, char** argv, int at) {
                 first[q].resize(ne);
                 HIPCHK(hipMemcpy(first[q].data(), dw[q], ne * 2, hipMemcpyDeviceToHost));
             }
-            printf("[%s] g8 group %s, %d slice(s) == 128x128 grouped launch (max |d| %.3f, %zu outside tolerance)\n", nbad ? "FAIL" : " OK ", gc.name, sp, maxd, nbad);
+            printf("[%s] tile %d group %s, %d slice(s) == 128x128 grouped launch (max |d| %.3f, %zu outside tolerance)\n", nbad ? "FAIL" : " OK ", kTileX, gc.name, sp, maxd, nbad);
             if (nbad) ++g_fail;
-            for (int rep = 0; rep < 16; ++rep) UHCHK(uniter_gemm_wgrad_group_ws(4, dyp, nullptr, xp, nullptr, dwp, dbp, T, gN, gK, 0, gws, gwb, kTileG8, sp, 0));
+            for (int rep = 0; rep < 16; ++rep) UHCHK(uniter_gemm_wgrad_group_ws(4, dyp, nullptr, xp, nullptr, dwp, dbp, T, gN, gK, 0, gws, gwb, kTileX, sp, 0));
             HIPCHK(hipDeviceSynchronize());
             for (int q = 0; q < 4; ++q) {
                 const size_t ne = (size_t)gN[q] * gK[q];
@@ -1346,10 +1354,10 @@ static int run_g8(int argc, char** argv, int at) {
                 HIPCHK(hipMemcpy(now.data(), dw[q], ne * 2, hipMemcpyDeviceToHost));
                 for (size_t k = 0; k < ne; ++k) if (now[k] != first[q][k]) ++ndiff;
             }
-            printf("[%s] g8 group %s, %d slice(s): 17th launch bit-identical to the first (%zu differing)\n", ndiff ? "FAIL" : " OK ", gc.name, sp, ndiff);
+            printf("[%s] tile %d group %s, %d slice(s): 17th launch bit-identical to the first (%zu differing)\n", ndiff ? "FAIL" : " OK ", kTileX, gc.name, sp, ndiff);
             if (ndiff) ++g_fail;
-            const double t_new = tm.run([&] { UHCHK(uniter_gemm_wgrad_group_ws(4, dyp, nullptr, xp, nullptr, dwp, dbp, T, gN, gK, 0, gws, gwb, kTileG8, sp, 0)); }, 3, 20);
-            printf("  TIME group %-9s: 128x128 grouped %7.2f us %7.1f TF | eight-phase, %d slice(s) %7.2f us %7.1f TF (x%.2f)\n", gc.name, t_old, fl / t_old * 1e-6, sp,
+            const double t_new = tm.run([&] { UHCHK(uniter_gemm_wgrad_group_ws(4, dyp, nullptr, xp, nullptr, dwp, dbp, T, gN, gK, 0, gws, gwb, kTileX, sp, 0)); }, 3, 20);
+            printf("  TIME group %-9s: 128x128 grouped %7.2f us %7.1f TF | tile %d, %d slice(s) %7.2f us %7.1f TF (x%.2f)\n", gc.name, t_old, fl / t_old * 1e-6, kTileX, sp,
                    t_new, fl / t_new * 1e-6, t_old / t_new);
         }
         for (int q = 0; q < 4; ++q) { HIPCHK(hipFree(dy[q])); HIPCHK(hipFree(x[q])); HIPCHK(hipFree(dw[q])); HIPCHK(hipFree(dwr[q])); HIPCHK(hipFree(db[q])); HIPCHK(hipFree(dbr[q])); }
@@ -1414,6 +1422,10 @@ int main(int argc, char** argv) {
     test_gemm(576, 256, 512, kTileG8, 2);
     test_gemm(300, 256, 64, kTileG8, 1);
     test_gemm(1024, 256, 256, kTileG8, 4);
+    test_gemm(640, 384, 192, kTileG6, 1);
+    test_gemm(640, 384, 192, kTileG6, 2);
+    test_gemm(576, 192, 384, kTileG6, 2);
+    test_gemm(300, 192, 64, kTileG6, 1);
     test_gemm(77, 128, 192, 3, 3);
     test_gemm(384, 384, 320, -1, -1);
     if (!quick) test_gemm(1000, 768, 768, -1, -1);
@@ -1434,6 +1446,8 @@ int main(int argc, char** argv) {
     test_wgrad_group_g8(320, 1);
     test_wgrad_group_g8(320, 2);
     test_wgrad_group_g8(576, 2);
+    test_wgrad_group_g8(320, 1, kTileG6);
+    test_wgrad_group_g8(576, 1, kTileG6);
     test_layernorm(37, 128, 0.f, 0);
     test_layernorm(300, 768, 0.2f, 0);
     test_layernorm(300, 768, 0.2f, 1);

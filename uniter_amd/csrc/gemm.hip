@@ -645,11 +645,42 @@ int launch_g8(const GemmArgs& a_in, int splits, hipStream_t st) {
     }
     static bool attr_done = false;
     if (!attr_done) {
-        UH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<TRA, TRB, EPI, 1>),
+        UH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<TRA, TRB, EPI>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS_BYTES));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm8_kernel<TRA, TRB, EPI, 1>), dim3(tiles_m * tiles_n, splits, 1), dim3(G8_THREADS), G8_LDS_BYTES, st, a);
+    hipLaunchKernelGGL((gemm8_kernel<TRA, TRB, EPI>), dim3(tiles_m * tiles_n, splits, 1), dim3(G8_THREADS), G8_LDS_BYTES, st, a);
+    UH_LAUNCH_CHECK();
+    return 0;
+}
+
+bool g6_shape_ok(const GemmArgs& a, bool tra, bool trb) {
+    if (a.N % 192 != 0 || a.K % 64 != 0 || a.k_per_split % 64 != 0 || a.K < 64) return false;
+    if (tra && a.M % 192 != 0) return false;
+    const int64_t span_r = tra ? (int64_t)64 * a.ldr + a.M : (int64_t)a.M * a.ldr;
+    const int64_t span_c = trb ? (int64_t)64 * a.ldcc + a.N : (int64_t)a.N * a.ldcc;
+    return span_r * 2 < ((int64_t)1 << 32) && span_c * 2 < ((int64_t)1 << 32);
+}
+
+template <bool TRA, bool TRB, int EPI>
+int launch_g6(const GemmArgs& a_in, int splits, hipStream_t st) {
+    GemmArgs a = a_in;
+    if (!g6_shape_ok(a, TRA, TRB)) {
+        uh_set_error("gemm: the 192x192 three-phase tile needs N %% 192 == 0, a contraction (slice) that is a multiple of 64%s (M=%d N=%d K=%d)",
+                     TRA ? " and M %% 192 == 0" : "", a.M, a.N, a.K);
+        return -1;
+    }
+    if (EPI == EPI_WGRAD && a.C2 != nullptr) { uh_set_error("gemm: the three-phase tile does not produce the bias gradient"); return -1; }
+    const int tiles_m = (a.M + 191) / 192, tiles_n = a.N / 192;
+    a.xr = pick_xr(tiles_m, tiles_n, 192, 192);
+    a.pair = nullptr;
+    static bool attr_done = false;
+    if (!attr_done) {
+        UH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm6_kernel<TRA, TRB, EPI>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS_BYTES));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm6_kernel<TRA, TRB, EPI>), dim3(tiles_m * tiles_n, splits, 1), dim3(G8_THREADS), G6_LDS_BYTES, st, a);
     UH_LAUNCH_CHECK();
     return 0;
 }
@@ -658,6 +689,8 @@ template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, int WS>
 int launch_cfg(const GemmArgs& a_in, int splits, hipStream_t st) {
     if constexpr (WS == 3) {
         return launch_g8<TRA, TRB, EPI>(a_in, splits, st);
+    } else if constexpr (WS == 4) {
+        return launch_g6<TRA, TRB, EPI>(a_in, splits, st);
     } else {
     GemmArgs a = a_in;
     if (WS && (a.K % 64 != 0 || a.k_per_split % 64 != 0)) {
@@ -708,14 +741,16 @@ constexpr TileShape kTiles[] = {{128, 128, 2, 0}, {128, 64, 2, 0}, {64, 128, 2, 
                                 // 8 + 4 waves on the 96-wide tiles of the N = 768 problems (one 96x128 tile per CU)
                                 {96, 128, 3, 2}, {96, 128, 4, 2}, {128, 96, 3, 2}, {128, 96, 4, 2},
                                 // ws = 3: the eight-phase 256 x 256 tile (gemm8.cuh): 8 waves, two wave groups one barrier apart
-                                {256, 256, 2, 3}};
-constexpr int kTileG8 = 58;
+                                {256, 256, 2, 3},
+                                // ws = 4: its 192 x 192 sibling (three phases per K tile, three LDS buffers): 256 tiles for a 3072 x 3072 output
+                                {192, 192, 3, 4}};
+constexpr int kTileG8 = 58, kTileG6 = 59;
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <bool TRA, bool TRB>
 constexpr bool tile_ok(int idx) {
     const int bm = kTiles[idx].bm, bn = kTiles[idx].bn;
-    if (kTiles[idx].ws == 3) return true;
+    if (kTiles[idx].ws >= 3) return true;
     if (TRA && !(bm == 64 || bm == 128)) return false;
     if (TRB && !(bn == 64 || bn == 128 || bn == 192)) return false;
     return true;
@@ -793,6 +828,7 @@ int launch_gemm(const GemmArgs& a, int cfg, int splits, hipStream_t st) {
         case 56: return launch_idx<TRA, TRB, EPI, 56>(a, splits, st);
         case 57: return launch_idx<TRA, TRB, EPI, 57>(a, splits, st);
         case 58: return launch_idx<TRA, TRB, EPI, 58>(a, splits, st);
+        case 59: return launch_idx<TRA, TRB, EPI, 59>(a, splits, st);
         default: uh_set_error("gemm: bad tile index %d", cfg); return -1;
     }
 }
@@ -859,9 +895,9 @@ bool cfg_legal(int kind, int cfg, int64_t M, int64_t N, int64_t K, int splits) {
     const TileShape& t = kTiles[cfg];
     const int64_t contraction = kind == 0 ? K : (kind == 1 ? N : M);
     const int64_t out_m = kind == 2 ? N : M, out_n = kind == 0 ? N : K;
-    if (t.ws == 3) {
-        if (out_n % 256 != 0 || contraction % 64 != 0 || contraction < (int64_t)64 * splits) return false;
-        return kind != 2 || out_m % 256 == 0;
+    if (t.ws >= 3) {                                        // the deep-pipelined tiles: 256 x 256 (3) and 192 x 192 (4)
+        if (out_n % t.bn != 0 || contraction % 64 != 0 || contraction < (int64_t)64 * splits) return false;
+        return kind != 2 || out_m % t.bm == 0;
     }
     const bool p2m = t.bm == 64 || t.bm == 128, p2n = t.bn == 64 || t.bn == 128 || t.bn == 192;
     if (t.ws && contraction % (64 * (int64_t)splits) != 0) return false;
@@ -1093,7 +1129,7 @@ int gemm_wgrad(const void* dy, const void* x, void* dw, int64_t M, int64_t N, in
     if (g_force_cfg < 0 && g_force_splits < 0 && tuned_lookup(2, M, N, K, &tn)) { cfg = tn.cfg; splits = tn.splits; }
     if (db != nullptr) {
         splits = 1;
-        if (kTiles[cfg].ws == 3) cfg = pick_cfg((int)N, (int)K, true, true, M % 64 == 0);   // that tile has no bias-gradient output
+        if (kTiles[cfg].ws >= 3) cfg = pick_cfg((int)N, (int)K, true, true, M % 64 == 0);   // those tiles have no bias-gradient output
     }
     while (splits > 1 && (size_t)splits * N * K * sizeof(float) > ws_bytes) splits >>= 1;
     const bool in_launch = kTiles[cfg].ws == 3 && splits == 2;     // two K slices combined by the tile's own workgroups
@@ -1114,9 +1150,9 @@ int gemm_wgrad(const void* dy, const void* x, void* dw, int64_t M, int64_t N, in
 
 // Up to four weight gradients dw_q[N_q,K_q] (+)= dy_q[M,N_q]^T x_q[M,K_q] over the same M tokens in ONE launch.
 static const int kGroupCfgs[] = {0, 1, 2, 3, 13, 14, 15, 20, 23, 24, 26, 27, 29, 33, 34, 36, 37, 43, 44, 45, 49, 51, 52};
-static bool group_g8_ok(int n, int64_t M, const int64_t* N, const int64_t* K, int splits);
+static bool group_g8_ok(int n, int64_t M, const int64_t* N, const int64_t* K, int splits, int edge);
 static bool group_cfg_ok(int cfg, int n, int64_t M, const int64_t* N, const int64_t* K) {
-    if (kTiles[cfg].ws == 3) return group_g8_ok(n, M, N, K, 1);
+    if (kTiles[cfg].ws >= 3) return group_g8_ok(n, M, N, K, 1, kTiles[cfg].bm);
     const int bm = kTiles[cfg].bm, bn = kTiles[cfg].bn;
     if (kTiles[cfg].ws && M % 64 != 0) return false;
     for (int q = 0; q < n; ++q)
@@ -1126,10 +1162,10 @@ static bool group_cfg_ok(int cfg, int n, int64_t M, const int64_t* N, const int6
 static int64_t group_sum(int n, const int64_t* v) { int64_t s = 0; for (int q = 0; q < n; ++q) s += v[q]; return s; }
 
 // The grouped launch on the eight-phase tile: splits = 2 needs a workspace of 4 bytes per weight element (one fp32 slab per tile).
-static bool group_g8_ok(int n, int64_t M, const int64_t* N, const int64_t* K, int splits) {
+static bool group_g8_ok(int n, int64_t M, const int64_t* N, const int64_t* K, int splits, int edge) {
     if (M % 64 != 0 || M < (int64_t)64 * splits) return false;
     for (int q = 0; q < n; ++q)
-        if (N[q] % 256 != 0 || K[q] % 256 != 0) return false;
+        if (N[q] % edge != 0 || K[q] % edge != 0) return false;
     return true;
 }
 size_t gemm_wgrad_group_workspace_bytes(int n, const int64_t* N, const int64_t* K) {
@@ -1137,7 +1173,7 @@ size_t gemm_wgrad_group_workspace_bytes(int n, const int64_t* N, const int64_t* 
     for (int q = 0; q < n; ++q) e += (size_t)N[q] * (size_t)K[q];
     return e * sizeof(float);
 }
-static int launch_group_g8(GemmGroupArgs& src, int n, int64_t M, int splits, void* workspace, hipStream_t st) {
+static int launch_group_g8(GemmGroupArgs& src, int n, int64_t M, int splits, void* workspace, hipStream_t st, int edge) {
     G8GroupArgs ga{};
     ga.n = n;
     ga.splits = splits;
@@ -1148,11 +1184,11 @@ static int launch_group_g8(GemmGroupArgs& src, int n, int64_t M, int splits, voi
         a = src.g[q];
         a.xr = -1;
         a.k_per_split = (int)(((ktiles + splits - 1) / splits) * 64);
-        if (!g8_shape_ok(a, true, true)) { uh_set_error("gemm group: problem %d does not fit the eight-phase tile", q); return -1; }
+        if (!(edge == 256 ? g8_shape_ok(a, true, true) : g6_shape_ok(a, true, true))) { uh_set_error("gemm group: problem %d does not fit the %d-wide deep-pipelined tile", q, edge); return -1; }
         ga.tile_start[q] = tiles;
         ga.strip_start[q] = strips;
-        tiles += (a.M / 256) * (a.N / 256);
-        if (a.C2 != nullptr) strips += a.M / 256;
+        tiles += (a.M / edge) * (a.N / edge);
+        if (a.C2 != nullptr) strips += (a.M + 255) / 256;
     }
     for (int q = n; q <= 4; ++q) { ga.tile_start[q] = tiles; ga.strip_start[q] = strips; }
     unsigned* cnt = nullptr;
@@ -1170,9 +1206,11 @@ static int launch_group_g8(GemmGroupArgs& src, int n, int64_t M, int splits, voi
     static bool attr_done = false;
     if (!attr_done) {
         UH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS_BYTES));
+        UH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm6_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS_BYTES));
         attr_done = true;
     }
-    hipLaunchKernelGGL(gemm8_group_kernel, dim3(ga.gemm_blocks + strips), dim3(G8_THREADS), G8_LDS_BYTES, st, ga);
+    if (edge == 256) hipLaunchKernelGGL(gemm8_group_kernel, dim3(ga.gemm_blocks + strips), dim3(G8_THREADS), G8_LDS_BYTES, st, ga);
+    else             hipLaunchKernelGGL(gemm6_group_kernel, dim3(ga.gemm_blocks + strips), dim3(G8_THREADS), G6_LDS_BYTES, st, ga);
     UH_LAUNCH_CHECK();
     return 0;
 }
@@ -1219,9 +1257,10 @@ int gemm_wgrad_group(int n, const void* const* dy, const void* const* x, void* c
     for (int i = 0; i < n; ++i) welems += N[i] * K[i];
     LaunchTimer lt(TIME_GEMM_WGRAD_GROUP, M, welems, n, st);
     if (kTiles[cfg].ws == 3) {
-        if (splits != 2 || workspace == nullptr || ws_bytes < gemm_wgrad_group_workspace_bytes(n, N, K) || !group_g8_ok(n, M, N, K, 2)) splits = 1;
-        return launch_group_g8(ga, n, M, splits, workspace, st);
+        if (splits != 2 || workspace == nullptr || ws_bytes < gemm_wgrad_group_workspace_bytes(n, N, K) || !group_g8_ok(n, M, N, K, 2, 256)) splits = 1;
+        return launch_group_g8(ga, n, M, splits, workspace, st, 256);
     }
+    if (kTiles[cfg].ws == 4) return launch_group_g8(ga, n, M, 1, nullptr, st, 192);
     return launch_group(ga, cfg, st);
 }
 
@@ -1256,11 +1295,12 @@ int gemm_group_autotune(int n, int64_t M, const int64_t* N, const int64_t* K, hi
     int rc = 0;
     void* gws = nullptr;
     const size_t gws_bytes = gemm_wgrad_group_workspace_bytes(n, N, K);
-    if (group_g8_ok(n, M, N, K, 2) && hipMalloc(&gws, gws_bytes) != hipSuccess) gws = nullptr;
+    if (group_g8_ok(n, M, N, K, 2, 256) && hipMalloc(&gws, gws_bytes) != hipSuccess) gws = nullptr;
     struct Cand { int cfg, splits; };
     std::vector<Cand> cands;
     for (int cfg : kGroupCfgs) cands.push_back({cfg, 1});
     cands.push_back({kTileG8, 1});
+    cands.push_back({kTileG6, 1});
     if (gws != nullptr) cands.push_back({kTileG8, 2});
     for (const Cand& cd : cands) {
         const int cfg = cd.cfg;

@@ -71,10 +71,127 @@ __device__ __forceinline__ void g8_glds16(uint32_t voff, const void* origin, uin
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(origin), "s"(lds_addr) : "memory");
 }
 
+// ---- epilogue pieces shared by the tile shapes ------------------------------------------------------------------------------
+// Two accumulator fragments of one row block (columns 0-15 / 16-31 of a 32-column group): lane (g, i) holds columns 4g..4g+3
+// of row i in each.  v_permlane16_swap exchanges the odd lane rows of the first with the even lane rows of the second, after
+// which a lane owns 8 consecutive columns — (g & 1) * 16 + (g >> 1) * 8 ... + 7 — of row i: 16-byte stores and loads.
+__device__ __forceinline__ void g8_swap8(const f32x4& lo16, const f32x4& hi16, float (&v)[8]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo16[r]), __float_as_uint(hi16[r]), false, false);
+        v[r] = __uint_as_float(sw[0]);
+        v[4 + r] = __uint_as_float(sw[1]);
+    }
+}
+
+// The element-wise tail of a GEMM for one piece of W (4 or 8) consecutive output columns of row m starting at column n:
+// the arithmetic (and its roundings) of gemm.hip's epilogue.
+template <int EPI>
+struct G8Epi {
+    static constexpr bool HAS_BIAS = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RES);
+    static constexpr bool HAS_AUX = (EPI == EPI_BIAS_DROP_RES || EPI == EPI_RES || EPI == EPI_GELU_BWD || EPI == EPI_WGRAD);
+    bool to_partial;          // fp32 partials of a K slice (reduced by another kernel)
+    const bf16_t* abase;      // residual / pre-activation / the gradient a weight gradient accumulates into
+    int64_t ald;
+    __device__ __forceinline__ explicit G8Epi(const GemmArgs& p) {
+        to_partial = (EPI == EPI_WGRAD || EPI == EPI_RES) && p.partial != nullptr && (EPI != EPI_WGRAD || p.pair == nullptr);
+        abase = nullptr;
+        ald = 0;
+        if constexpr (HAS_AUX) {
+            if (EPI == EPI_WGRAD) { abase = (p.accumulate && !to_partial) ? p.C : nullptr; ald = p.ldc; }
+            else { abase = to_partial ? nullptr : p.aux; ald = p.ldaux; }
+        }
+    }
+    template <int W>
+    __device__ __forceinline__ void bias_words(const GemmArgs& p, const int n, uint32_t (&w)[W / 2]) const {
+#pragma unroll
+        for (int e = 0; e < W / 2; ++e) w[e] = 0u;
+        if constexpr (HAS_BIAS) {
+            if (p.bias != nullptr) {
+                const uint32_t* bp = reinterpret_cast<const uint32_t*>(p.bias + n);
+#pragma unroll
+                for (int e = 0; e < W / 2; ++e) w[e] = bp[e];
+            }
+        }
+    }
+    template <int W>
+    __device__ __forceinline__ void aux_words(const GemmArgs& p, const int m, const int n, uint32_t (&w)[W / 2]) const {
+#pragma unroll
+        for (int e = 0; e < W / 2; ++e) w[e] = 0u;
+        if constexpr (HAS_AUX) {
+            if (abase != nullptr && m < p.M) {
+                const bf16_t* ap = abase + (int64_t)m * ald + n;
+                if constexpr (W == 8) {
+                    const u32x4 q = *reinterpret_cast<const u32x4*>(ap);
+                    w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; w[3] = q[3];
+                } else {
+                    const u32x2 q = *reinterpret_cast<const u32x2*>(ap);
+                    w[0] = q[0]; w[1] = q[1];
+                }
+            }
+        }
+    }
+    template <int W>
+    __device__ __forceinline__ static void store(bf16_t* dst, const float (&x)[W]) {
+        if constexpr (W == 8) out_store16(dst, pack8(x));
+        else                  out_store8(dst, pack4(x));
+    }
+    template <int W>
+    __device__ __forceinline__ void emit(const GemmArgs& p, const int by, const int m, const int n, float (&v)[W],
+                                         const uint32_t (&auxw)[W / 2], const uint32_t (&biasw)[W / 2]) const {
+#pragma clang fp contract(off)                              // bias, dropout, residual: three roundings, the same in every tile family
+        if (m >= p.M) return;
+        if (to_partial) {
+            float* dst = p.partial + ((int64_t)by * p.M + m) * p.N + n;
+#pragma unroll
+            for (int e = 0; e < W; e += 4) *reinterpret_cast<f32x4*>(dst + e) = f32x4{v[e], v[e + 1], v[e + 2], v[e + 3]};
+            return;
+        }
+        if constexpr (HAS_BIAS) {
+#pragma unroll
+            for (int e = 0; e < W / 2; ++e) { v[2 * e] += bits2f_lo(biasw[e]); v[2 * e + 1] += bits2f_hi(biasw[e]); }
+        }
+        bf16_t* cptr = p.C + (int64_t)m * p.ldc + n;
+        if constexpr (EPI == EPI_BIAS_GELU) {
+            // the activation is applied to the bf16-rounded u so that backward (which only has u) is consistent
+            float uq[W], gq[W];
+#pragma unroll
+            for (int e = 0; e < W; ++e) uq[e] = bf2f(f2bf(v[e]));
+            store<W>(cptr, v);
+#pragma unroll
+            for (int e = 0; e < W; ++e) gq[e] = act_fwd(p.relu, uq[e]);
+            store<W>(p.C2 + (int64_t)m * p.ldc + n, gq);
+            return;
+        }
+        if constexpr (EPI == EPI_BIAS_DROP_RES) {
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < W; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (p.drop.p > 0.f) {
+                float mv[W];
+                if constexpr (W == 8) dropout_mult8(p.drop, ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 3, mv);
+                else                  dropout_mult4(p.drop, ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 2, mv);
+#pragma unroll
+                for (int e = 0; e < W; ++e) v[e] *= mv[e];
+            }
+        }
+        if constexpr (HAS_AUX) {
+            if (abase != nullptr) {
+#pragma unroll
+                for (int e = 0; e < W / 2; ++e) {
+                    const float lo = bits2f_lo(auxw[e]), hi = bits2f_hi(auxw[e]);
+                    if constexpr (EPI == EPI_GELU_BWD) { v[2 * e] *= act_grad(p.relu, lo); v[2 * e + 1] *= act_grad(p.relu, hi); }
+                    else { v[2 * e] += lo; v[2 * e + 1] += hi; }
+                }
+            }
+        }
+        store<W>(cptr, v);
+    }
+};
+
 // One 256 x 256 output tile.  bx = tile slot, by = K slice.
-//   XCHG = 1: the two 16-column fragments of a quadrant row are exchanged between lane rows (v_permlane16_swap) so that a
-//             lane stores / loads 8 consecutive columns (16 bytes); XCHG = 0: two 8-byte pieces.
-template <bool TRA, bool TRB, int EPI, int XCHG>
+template <bool TRA, bool TRB, int EPI>
 __device__ __forceinline__ void gemm8_tile(const GemmArgs& p, const int bx, const int by, char* smem_raw) {
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
     const int t = threadIdx.x;
@@ -204,6 +321,7 @@ __device__ __forceinline__ void gemm8_tile(const GemmArgs& p, const int bx, cons
     auto end_phase = [&]() {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");                      // (s_barrier alone does not order the compiler's LDS accesses)
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -302,7 +420,9 @@ __device__ __forceinline__ void gemm8_tile(const GemmArgs& p, const int bx, cons
             if (t == 0) {
                 // ticket 1: the slab is complete at 3 (our own increment included); ticket 2 (the partner had already
                 // finished writing when we drew): also 3
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 3u) __builtin_amdgcn_s_sleep(8);
+                // (bounded: a counter left dirty by an aborted launch must not hang the device; ~1 s)
+                for (int spin = 0; spin < (1 << 21) && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 3u; ++spin)
+                    __builtin_amdgcn_s_sleep(8);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -326,151 +446,275 @@ __device__ __forceinline__ void gemm8_tile(const GemmArgs& p, const int bx, cons
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------------
-    // A lane holds C[m][n..n+3] for m = m0 + mq*128 + wr*64 + b*16 + i, n = n0 + nq*128 + wc*32 + a*16 + 4g.  With XCHG the
-    // a = 0 / a = 1 pieces of lane rows g, g^1 are swapped so that the lane owns 8 consecutive columns of fragment (g & 1).
-    {
-#pragma clang fp contract(off)                              // bias, dropout, residual: the same roundings as gemm.hip's epilogue
-    constexpr bool HAS_BIAS = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RES);
-    constexpr bool HAS_AUX = (EPI == EPI_BIAS_DROP_RES || EPI == EPI_RES || EPI == EPI_GELU_BWD || EPI == EPI_WGRAD);
-    constexpr int W = XCHG ? 8 : 4;                        // consecutive columns per piece
-    constexpr int NP = XCHG ? 1 : 2;                       // pieces per (quadrant, b)
-    const bool to_partial = (EPI == EPI_WGRAD || EPI == EPI_RES) && p.partial != nullptr && (EPI != EPI_WGRAD || p.pair == nullptr);
-    const bf16_t* abase = nullptr;
-    int64_t ald = 0;
-    if constexpr (HAS_AUX) {
-        if (EPI == EPI_WGRAD) { abase = (p.accumulate && !to_partial) ? p.C : nullptr; ald = p.ldc; }
-        else { abase = to_partial ? nullptr : p.aux; ald = p.ldaux; }
-    }
-    auto col_of = [&](int nq, int pc) {                    // first column of piece pc of quadrant column nq
-        return XCHG ? n0 + nq * 128 + wc * 32 + (g & 1) * 16 + (g >> 1) * 8 : n0 + nq * 128 + wc * 32 + pc * 16 + 4 * g;
-    };
-    uint32_t biasw[2][NP][W / 2];
-    if constexpr (HAS_BIAS) {
+    // A lane holds C[m][n..n+3] for m = m0 + mq*128 + wr*64 + b*16 + i, n = n0 + nq*128 + wc*32 + a*16 + 4g.  The a = 0 / a = 1
+    // pieces of lane rows g, g^1 are swapped (v_permlane16_swap) so that the lane owns 8 consecutive columns of fragment (g & 1).
+    const G8Epi<EPI> ep(p);
+    const int ncol = n0 + wc * 32 + (g & 1) * 16 + (g >> 1) * 8;           // + nq * 128
+    uint32_t biasw[2][4];
 #pragma unroll
-        for (int nq = 0; nq < 2; ++nq)
-#pragma unroll
-            for (int pc = 0; pc < NP; ++pc) {
-#pragma unroll
-                for (int e = 0; e < W / 2; ++e) biasw[nq][pc][e] = 0u;
-                if (p.bias != nullptr) {
-                    const uint32_t* bp = reinterpret_cast<const uint32_t*>(p.bias + col_of(nq, pc));
-#pragma unroll
-                    for (int e = 0; e < W / 2; ++e) biasw[nq][pc][e] = bp[e];
-                }
-            }
-    }
+    for (int nq = 0; nq < 2; ++nq) ep.template bias_words<8>(p, ncol + nq * 128, biasw[nq]);
 #pragma unroll
     for (int mq = 0; mq < 2; ++mq) {
-        uint32_t auxw[2][4][NP][W / 2];
-        if constexpr (HAS_AUX) {                            // all of this row half's operand loads at once
+        uint32_t auxw[2][4][4];
 #pragma unroll
-            for (int nq = 0; nq < 2; ++nq)
+        for (int nq = 0; nq < 2; ++nq)                       // all of this row half's operand loads at once
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int m = m0 + mq * 128 + wr * 64 + b * 16 + i;
-#pragma unroll
-                    for (int pc = 0; pc < NP; ++pc) {
-#pragma unroll
-                        for (int e = 0; e < W / 2; ++e) auxw[nq][b][pc][e] = 0u;
-                        if (abase != nullptr && m < p.M) {
-                            const bf16_t* ap = abase + (int64_t)m * ald + col_of(nq, pc);
-                            if constexpr (XCHG) {
-                                const u32x4 q = *reinterpret_cast<const u32x4*>(ap);
-                                auxw[nq][b][pc][0] = q[0]; auxw[nq][b][pc][1] = q[1]; auxw[nq][b][pc][2] = q[2]; auxw[nq][b][pc][3] = q[3];
-                            } else {
-                                const u32x2 q = *reinterpret_cast<const u32x2*>(ap);
-                                auxw[nq][b][pc][0] = q[0]; auxw[nq][b][pc][1] = q[1];
-                            }
-                        }
-                    }
-                }
-        }
+            for (int b = 0; b < 4; ++b) ep.template aux_words<8>(p, m0 + mq * 128 + wr * 64 + b * 16 + i, ncol + nq * 128, auxw[nq][b]);
 #pragma unroll
         for (int nq = 0; nq < 2; ++nq)
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const int m = m0 + mq * 128 + wr * 64 + b * 16 + i;
-                float vv[NP][W];
-                if constexpr (XCHG) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mq][nq][0][b][r]),
-                                                                         __float_as_uint(acc[mq][nq][1][b][r]), false, false);
-                        vv[0][r] = __uint_as_float(sw[0]);
-                        vv[0][4 + r] = __uint_as_float(sw[1]);
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { vv[0][r] = acc[mq][nq][0][b][r]; vv[NP - 1][r] = acc[mq][nq][1][b][r]; }
-                }
-                if (m >= p.M) continue;
-#pragma unroll
-                for (int pc = 0; pc < NP; ++pc) {
-                    float (&v)[W] = vv[pc];
-                    const int n = col_of(nq, pc);
-                    if (to_partial) {
-                        float* dst = p.partial + ((int64_t)by * p.M + m) * p.N + n;
-#pragma unroll
-                        for (int e = 0; e < W; e += 4) *reinterpret_cast<f32x4*>(dst + e) = f32x4{v[e], v[e + 1], v[e + 2], v[e + 3]};
-                        continue;
-                    }
-                    if constexpr (HAS_BIAS) {
-#pragma unroll
-                        for (int e = 0; e < W / 2; ++e) { v[2 * e] += bits2f_lo(biasw[nq][pc][e]); v[2 * e + 1] += bits2f_hi(biasw[nq][pc][e]); }
-                    }
-                    bf16_t* cptr = p.C + (int64_t)m * p.ldc + n;
-                    auto store = [&](bf16_t* dst, const float (&x)[W]) {
-                        if constexpr (XCHG) {
-                            float x8[8];
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) x8[e] = x[e];
-                            out_store16(dst, pack8(x8));
-                        } else {
-                            float x4[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) x4[e] = x[e];
-                            out_store8(dst, pack4(x4));
-                        }
-                    };
-                    if constexpr (EPI == EPI_BIAS_GELU) {
-                        // the activation is applied to the bf16-rounded u so that backward (which only has u) is consistent
-                        float uq[W], gq[W];
-#pragma unroll
-                        for (int e = 0; e < W; ++e) uq[e] = bf2f(f2bf(v[e]));
-                        store(cptr, v);
-#pragma unroll
-                        for (int e = 0; e < W; ++e) gq[e] = act_fwd(p.relu, uq[e]);
-                        store(p.C2 + (int64_t)m * p.ldc + n, gq);
-                        continue;
-                    }
-                    if constexpr (EPI == EPI_BIAS_DROP_RES) {
-                        if (p.relu) {
-#pragma unroll
-                            for (int e = 0; e < W; ++e) v[e] = fmaxf(v[e], 0.f);
-                        }
-                        if (p.drop.p > 0.f) {
-                            float mv[W];
-                            if constexpr (XCHG) dropout_mult8(p.drop, ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 3, reinterpret_cast<float (&)[8]>(mv));
-                            else                dropout_mult4(p.drop, ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 2, reinterpret_cast<float (&)[4]>(mv));
-#pragma unroll
-                            for (int e = 0; e < W; ++e) v[e] *= mv[e];
-                        }
-                    }
-                    if constexpr (HAS_AUX) {
-                        if (abase != nullptr) {
-#pragma unroll
-                            for (int e = 0; e < W / 2; ++e) {
-                                const float lo = bits2f_lo(auxw[nq][b][pc][e]), hi = bits2f_hi(auxw[nq][b][pc][e]);
-                                if constexpr (EPI == EPI_GELU_BWD) { v[2 * e] *= act_grad(p.relu, lo); v[2 * e + 1] *= act_grad(p.relu, hi); }
-                                else { v[2 * e] += lo; v[2 * e + 1] += hi; }
-                            }
-                        }
-                    }
-                    store(cptr, v);
-                }
+                float v[8];
+                g8_swap8(acc[mq][nq][0][b], acc[mq][nq][1][b], v);
+                ep.template emit<8>(p, by, m0 + mq * 128 + wr * 64 + b * 16 + i, ncol + nq * 128, v, auxw[nq][b], biasw[nq]);
             }
     }
+}
+
+// ---- the 192 x 192 x 64 tile: three phases per K tile, three LDS buffers ----------------------------------------------------
+// The same machinery for outputs the 256-wide tile leaves half the chip idle on: a 3072 x 3072 output is exactly 256 tiles
+// of 192 x 192 (144 of 256 x 256).  8 waves as 2 (M) x 4 (N), a wave owns 96 rows x 48 columns = 6 x 3 accumulator fragments;
+// phase j of a K tile multiplies row third j (rows wr*96 + j*32 + [0,32)) with all 48 columns: 12 MFMAs.  The N-side
+// fragments (6 reads) are read in phase 0 and stay in registers, every phase reads its 4 M-side fragments.  A K tile is six
+// 8 KiB DMA units — M0 M1 M2 (the row thirds of both wave rows: 64 rows) and N0 N1 N2 (64 columns each) — one instruction
+// per wave per unit, two units per phase; with THREE buffers of 48 KiB the units of K tile t+2 are issued during K tile t
+// (N0 N1 | N2 M0 | M1 M2) into the buffer K tile t-1 has left, so no unit is re-filled sooner than three phases after its
+// last read, and `s_waitcnt vmcnt(6)` in the last phase of K tile t leaves exactly those six in flight: K tile t+1 has landed.
+constexpr int G6_UNIT = 64 * 64;                     // elements of one DMA unit (8 KiB)
+constexpr int G6_BUF = 6 * G6_UNIT;                  // one K tile: M0 M1 M2 N0 N1 N2
+constexpr int G6_LDS_BYTES = 3 * G6_BUF * 2;         // 147456
+
+// byte offset of this lane's 16 bytes of unit `u` (instruction = wave index w) from the operand's origin of the K tile
+template <bool TR, bool MSIDE>
+__device__ __forceinline__ uint32_t g6_src_off(int w, int lane, int u, int64_t ld, int origin, int extent) {
+    if constexpr (!TR) {                                    // K-contiguous unit [64 rows][64 k]
+        const int lr = 8 * w + (lane >> 3);
+        const int c = (lane & 7) ^ ((lr >> 1) & 7);
+        int row = MSIDE ? (lr >> 5) * 96 + u * 32 + (lr & 31) : 64 * u + lr;
+        row += origin;
+        row = row < extent ? row : extent - 1;
+        return (uint32_t)(((int64_t)row * ld + c * 8) * 2);
+    } else {                                                // K-strided unit [64 k][64 columns]
+        const int r = 8 * w + (lane >> 3);
+        const int c = (lane & 7) ^ (ks_swz<64>(r) << 1);
+        const int cc = c * 8;
+        const int col = MSIDE ? (cc >> 5) * 96 + u * 32 + (cc & 31) : 64 * u + cc;
+        return (uint32_t)(((int64_t)r * ld + origin + col) * 2);
     }
+}
+
+template <bool TRA, bool TRB, int EPI>
+__device__ __forceinline__ void gemm6_tile(const GemmArgs& p, const int bx, const int by, char* smem_raw) {
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int g = lane >> 4, i = lane & 15;
+
+    const int tiles_n = p.N / 192;
+    const int tiles_m = (p.M + 191) / 192;
+    int tm, tn;
+    tile_of_block(p.xr, bx, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * 192, n0 = tn * 192;
+
+    const int k_begin = by * p.k_per_split;
+    const int k_end = min(p.K, k_begin + p.k_per_split);
+    const int nk = (k_end - k_begin) >> 6;
+
+    uint32_t offM[3], offN[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        offM[u] = g6_src_off<TRA, true>(wid, lane, u, p.ldr, m0, p.M);
+        offN[u] = g6_src_off<TRB, false>(wid, lane, u, p.ldcc, n0, p.N);
+    }
+    const char* gA = reinterpret_cast<const char*>(p.R + (TRA ? (int64_t)k_begin * p.ldr : (int64_t)k_begin));
+    const char* gB = reinterpret_cast<const char*>(p.Cc + (TRB ? (int64_t)k_begin * p.ldcc : (int64_t)k_begin));
+    const int64_t stepA = (TRA ? 64 * p.ldr : (int64_t)64) * 2, stepB = (TRB ? 64 * p.ldcc : (int64_t)64) * 2;
+    typedef __attribute__((address_space(3))) char lds_char_t;
+    const uint32_t lds0 = (uint32_t)(size_t)(lds_char_t*)smem_raw + (uint32_t)wid * 1024u;
+
+    // unit X of K tile kt into buffer `buf` (= kt % 3): X = 0..2: N0 N1 N2, 3..5: M0 M1 M2; LDS slots: M0 M1 M2 N0 N1 N2
+    auto stage = [&](auto xc, const int kt, const int buf) {
+        constexpr int X = decltype(xc)::value;
+        constexpr bool isM = X >= 3;
+        constexpr int u = isM ? X - 3 : X;
+        const uint32_t dst = lds0 + (uint32_t)buf * (G6_BUF * 2) + (uint32_t)((isM ? u : 3 + u) * G6_UNIT * 2);
+        const char* origin = isM ? gA + (int64_t)kt * stepA : gB + (int64_t)kt * stepB;
+        g8_glds16(isM ? offM[u] : offN[u], origin, dst);
+    };
+
+    // fragment addresses inside a buffer (elements).  K-contiguous: the M units are [3][64 local rows][64 k] and the N units
+    // [192 columns][64 k], both plain kc_off arrays; K-strided: units [64 k][64], ks_off8<64>.
+    uint32_t aoff[2], boff[TRB ? 3 : 2];
+    if constexpr (TRA) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) aoff[b] = (uint32_t)ks_off8<64>(8 * g + (i >> 2), ((wr * 32 + b * 16) >> 2) + (i & 3));
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) aoff[ks] = (uint32_t)kc_off(wr * 32 + i, ks * 4 + g);
+    }
+    if constexpr (TRB) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int col = wc * 48 + a * 16;
+            boff[a] = (uint32_t)((col >> 6) * G6_UNIT + ks_off8<64>(8 * g + (i >> 2), ((col & 63) >> 2) + (i & 3))) + 3 * G6_UNIT;
+        }
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) boff[ks] = (uint32_t)kc_off(wc * 48 + i, ks * 4 + g) + 3 * G6_UNIT;
+    }
+    auto tr_pair = [&](uint32_t e) {
+        const s16x4 lo = lds_read_tr(smem + e);
+        const s16x4 hi = lds_read_tr(smem + e + 4 * 64);
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    bf16x8 fM[2][2];                 // [k half][16-row block of the row third]
+    bf16x8 fN[2][3];                 // [k half][16-column block]
+    auto read_m = [&](const uint32_t cur, const int j) {    // row third j of the buffer at element offset cur
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if constexpr (TRA) fM[ks][b] = tr_pair(cur + aoff[b] + j * G6_UNIT + ks * 32 * 64);
+                else               fM[ks][b] = lds_read_b128(smem + cur + aoff[ks] + j * G6_UNIT + b * 16 * 64);
+            }
+    };
+    auto read_n = [&](const uint32_t cur) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if constexpr (TRB) fN[ks][a] = tr_pair(cur + boff[a] + ks * 32 * 64);
+                else               fN[ks][a] = lds_read_b128(smem + cur + boff[ks] + a * 16 * 64);
+            }
+    };
+
+    f32x4 acc[3][3][2];              // [row third][a][b]
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[j][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto mma = [&](f32x4 (&c)[3][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    c[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fN[ks][a], fM[ks][b], c[a][b], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) asm volatile("" : "+v"(c[a][b]));   // pins the cluster above the closing barrier (see gemm8_tile)
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto to_mma = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto end_phase = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if (nk > 0) {
+    // prologue: K tiles 0 and 1 issued, K tile 0 landed
+    stage(G8C<0>{}, 0, 0); stage(G8C<1>{}, 0, 0); stage(G8C<2>{}, 0, 0);
+    stage(G8C<3>{}, 0, 0); stage(G8C<4>{}, 0, 0); stage(G8C<5>{}, 0, 0);
+    if (nk > 1) {
+        stage(G8C<0>{}, 1, 1); stage(G8C<1>{}, 1, 1); stage(G8C<2>{}, 1, 1);
+        stage(G8C<3>{}, 1, 1); stage(G8C<4>{}, 1, 1); stage(G8C<5>{}, 1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();              // the second wave group runs one barrier behind the first
+    __builtin_amdgcn_sched_barrier(0);
+
+    int cur_buf = 0, st_buf = 2;                            // kt % 3, (kt + 2) % 3
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more2 = kt + 2 < nk;
+        const uint32_t cur = (uint32_t)cur_buf * G6_BUF;
+        // ---- phase 0: all N fragments, row third 0; DMA: N0 N1 of K tile kt+2
+        read_n(cur);
+        read_m(cur, 0);
+        if (more2) { stage(G8C<0>{}, kt + 2, st_buf); stage(G8C<1>{}, kt + 2, st_buf); }
+        to_mma();
+        mma(acc[0]);
+        end_phase();
+        // ---- phase 1: row third 1; DMA: N2 M0
+        read_m(cur, 1);
+        if (more2) { stage(G8C<2>{}, kt + 2, st_buf); stage(G8C<3>{}, kt + 2, st_buf); }
+        to_mma();
+        mma(acc[1]);
+        end_phase();
+        // ---- phase 2: row third 2; DMA: M1 M2; K tile kt+1 has landed when only K tile kt+2's six units remain in flight
+        read_m(cur, 2);
+        if (more2) {
+            stage(G8C<4>{}, kt + 2, st_buf); stage(G8C<5>{}, kt + 2, st_buf);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        to_mma();
+        mma(acc[2]);
+        end_phase();
+        cur_buf = cur_buf == 2 ? 0 : cur_buf + 1;
+        st_buf = st_buf == 2 ? 0 : st_buf + 1;
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue: per row block an 8-column piece (fragments a = 0, 1 exchanged between lane rows) and a 4-column piece (a = 2)
+    const G8Epi<EPI> ep(p);
+    const int n8 = n0 + wc * 48 + (g & 1) * 16 + (g >> 1) * 8;
+    const int n4 = n0 + wc * 48 + 32 + 4 * g;
+    uint32_t bias8[4], bias4[2];
+    ep.template bias_words<8>(p, n8, bias8);
+    ep.template bias_words<4>(p, n4, bias4);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        uint32_t aux8[2][4], aux4[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int m = m0 + wr * 96 + j * 32 + b * 16 + i;
+            ep.template aux_words<8>(p, m, n8, aux8[b]);
+            ep.template aux_words<4>(p, m, n4, aux4[b]);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int m = m0 + wr * 96 + j * 32 + b * 16 + i;
+            float v8[8], v4[4];
+            g8_swap8(acc[j][0][b], acc[j][1][b], v8);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v4[r] = acc[j][2][b][r];
+            ep.template emit<8>(p, by, m, n8, v8, aux8[b], bias8);
+            ep.template emit<4>(p, by, m, n4, v4, aux4[b], bias4);
+        }
+    }
+}
+
+template <bool TRA, bool TRB, int EPI>
+__global__ __launch_bounds__(G8_THREADS, 2) void gemm6_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    gemm6_tile<TRA, TRB, EPI>(p, (int)blockIdx.x, (int)blockIdx.y, smem_raw);
 }
 
 // ---- grouped weight gradients on the eight-phase tile ------------------------------------------------------------------
@@ -495,7 +739,7 @@ __device__ __forceinline__ void g8_colsum_strip(const GemmArgs& p, const int str
     const int cc = t & 31, rl = t >> 5;
     const bf16_t* src = p.R + (int64_t)strip * 256 + cc * 8;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int r = rl;
+    int r = (strip * 256 + cc * 8 < p.M) ? rl : p.K;        // (the last strip may be narrower than 256 columns; p.M % 8 == 0)
     for (; r + 48 < p.K; r += 64) {                         // four rows in flight per thread
         u32x4 v[4];
 #pragma unroll
@@ -518,7 +762,7 @@ __device__ __forceinline__ void g8_colsum_strip(const GemmArgs& p, const int str
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[rl * 256 + cc * 8 + e] = s[e];
     __syncthreads();
-    if (t < 256) {
+    if (t < 256 && strip * 256 + t < p.M) {
         float tot = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) tot += red[k * 256 + t];
@@ -554,13 +798,39 @@ __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_group_kernel(const G8Grou
     const int tiles_m = p.M >> 8, tiles_n = p.N >> 8;
     const int tm = tiles_n >= tiles_m ? bx % tiles_m : bx / tiles_n;      // longer tile dimension outermost
     const int tn = tiles_n >= tiles_m ? bx / tiles_m : bx % tiles_n;
-    gemm8_tile<true, true, EPI_WGRAD, 1>(p, tm * tiles_n + tn, slice, smem_raw);
+    gemm8_tile<true, true, EPI_WGRAD>(p, tm * tiles_n + tn, slice, smem_raw);
 }
 
-template <bool TRA, bool TRB, int EPI, int XCHG>
+__global__ __launch_bounds__(G8_THREADS, 2) void gemm6_group_kernel(const G8GroupArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int b = (int)blockIdx.x;
+    if (b >= ga.gemm_blocks) {
+        const int s = b - ga.gemm_blocks;
+        int q = 0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if (k < ga.n && s >= ga.strip_start[k]) q = k;
+        g8_colsum_strip(ga.g[q], s - ga.strip_start[q], smem_raw);
+        return;
+    }
+    const int pos = (b & 7) * ga.per + (b >> 3);
+    if (pos >= ga.tile_start[ga.n]) return;
+    int q = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < ga.n && pos >= ga.tile_start[k]) q = k;
+    const GemmArgs& p = ga.g[q];
+    const int bx = pos - ga.tile_start[q];
+    const int tiles_m = p.M / 192, tiles_n = p.N / 192;
+    const int tm = tiles_n >= tiles_m ? bx % tiles_m : bx / tiles_n;
+    const int tn = tiles_n >= tiles_m ? bx / tiles_m : bx % tiles_n;
+    gemm6_tile<true, true, EPI_WGRAD>(p, tm * tiles_n + tn, 0, smem_raw);
+}
+
+template <bool TRA, bool TRB, int EPI>
 __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    gemm8_tile<TRA, TRB, EPI, XCHG>(p, (int)blockIdx.x, (int)blockIdx.y, smem_raw);
+    gemm8_tile<TRA, TRB, EPI>(p, (int)blockIdx.x, (int)blockIdx.y, smem_raw);
 }
 
 }  // namespace
