@@ -1222,7 +1222,7 @@ static int run_one(int argc, char** argv, int at) {
 // launches must be bit-identical), timings against the tuned choice of the older tile family, and the grouped weight
 // gradients of a layer with one / two K slices
 static int run_g8(int argc, char** argv, int at) {
-    const bool big = !(at < argc && !strcmp(argv[at], "quick"));
+    const bool big = !(at < argc && (!strcmp(argv[at], "quick") || !strcmp(argv[at], "short")));
     load_tuned_json(getenv("UNITER_TUNED_JSON") ? getenv("UNITER_TUNED_JSON") : "uniter_amd/tuned/gfx950.json");
     Timer tm;
     struct Case { const char* kind; int64_t M, N, K; int splits; };
@@ -1233,6 +1233,8 @@ static int run_g8(int argc, char** argv, int at) {
         {"fwd", 3072, 3072, 1024, 1}, {"gelu", 3072, 4096, 1024, 1}, {"dgelu", 3072, 1024, 4096, 1}, {"fwd", 5696, 3072, 1024, 1},
         {"gelu", 5696, 4096, 1024, 1}, {"wgrad", 5696, 4096, 1024, 2}, {"wgrad", 5696, 4096, 1024, 1}};
     if (big) cases.push_back({"fwd", 8192, 8192, 8192, 1});
+    const bool shortlist = at < argc && !strcmp(argv[at], "short");      // epilogue experiments: the 3072 x 3072 x 768 trio only
+    if (shortlist) cases = {{"fwd", 3072, 3072, 768, 1}, {"gelu", 3072, 3072, 768, 1}, {"dgelu", 3072, 768, 3072, 1}, {"fwd", 3072, 2304, 768, 1}};
     for (const Case& c : cases) {
         const std::string kind = c.kind;
         const int64_t M = c.M, N = c.N, K = c.K;
@@ -1302,6 +1304,7 @@ static int run_g8(int argc, char** argv, int at) {
         HIPCHK(hipFree(dA)); HIPCHK(hipFree(dB)); HIPCHK(hipFree(dBias)); HIPCHK(hipFree(dO)); HIPCHK(hipFree(dO2)); HIPCHK(hipFree(dU)); HIPCHK(hipFree(dRef));
         if (ws) HIPCHK(hipFree(ws));
     }
+    if (shortlist) { printf("== %d check(s) failed ==\n", g_fail); return g_fail; }
     // the four weight gradients (+ bias gradients) of a layer as one launch
     struct GCase { const char* name; int64_t T, H, I; } gcases[] = {{"base-96", 3072, 768, 3072}, {"large-96", 3072, 1024, 4096}, {"large-178", 5696, 1024, 4096}};
     for (const GCase& gc : gcases) {

@@ -126,6 +126,35 @@ def test_arena_layout_and_fused_qkv():
     assert float(att.query.weight.grad.abs().max()) == 0 and arena.check()
 
 
+def test_arena_grad_slot_is_cleared_when_reattached_after_zero_grad():
+    """Module.zero_grad() / Optimizer.zero_grad(set_to_none=True) only drop the reference to an arena gradient slot; the old
+    gradient stays in the slot.  Handing the slot out again must not carry it over (the kernels ACCUMULATE into `.grad`)."""
+    from uniter_amd import _lib, ops
+    from uniter_amd.utils.arena import ParamArena
+    model = _tiny()
+    ParamArena(model)
+    att = model.uniter.encoder.layer[0].attention.self
+    dense = model.uniter.encoder.layer[0].output.dense
+    e0 = _lib.grad_attach_epoch()
+    g = ops.ensure_grad(dense.weight)                       # first use: the slot is attached as it is (zeros)
+    gw, gb = att.fused_qkv_grad()
+    assert _lib.grad_attach_epoch() > e0                    # the optimizer's plan shortcut sees that gradients appeared
+    assert float(g.abs().sum()) == 0 and float(gw.abs().sum()) == 0
+    g += 1.0                                                # what a backward kernel does
+    gw += 1.0
+    gb += 1.0
+    model.zero_grad()                                       # torch default: set_to_none=True
+    assert dense.weight.grad is None and att.query.weight.grad is None
+    g2 = ops.ensure_grad(dense.weight)
+    gw2, gb2 = att.fused_qkv_grad()
+    assert g2.data_ptr() == g.data_ptr() and gw2.data_ptr() == gw.data_ptr()      # the same storage ...
+    assert float(g2.abs().sum()) == 0 and float(gw2.abs().sum()) == 0 and float(gb2.abs().sum()) == 0   # ... cleared
+    g2 += 1.0
+    assert float(g2.sum()) == g2.numel()                    # (was 2 * numel before the fix)
+    # a gradient that is merely kept (zero_grad(set_to_none=False) semantics) is not touched by ensure_grad
+    assert float(ops.ensure_grad(dense.weight).sum()) == g2.numel()
+
+
 def test_fused_qkv_without_arena_refuses_after_cast():
     model = _tiny()
     att = model.uniter.encoder.layer[0].attention.self

@@ -269,3 +269,19 @@ def device_info():
     out = (c_int32 * 4)()
     C.uniter_hip_device_info(out)
     return {"cus": out[0], "wave": out[1], "lds_per_cu": out[2], "gfx": out[3]}
+
+
+# ---- gradient attachment epoch ------------------------------------------------------------------------------------------
+# Bumped whenever a parameter gets a `.grad` tensor it did not have before (first use of an arena slot, a fresh zeros
+# tensor, a gradient adopted from autograd).  The optimizer compares it with the value it saw when it last validated its
+# device plan, so a gradient attached between grad_norm() and step() (or between two calls) is never missed.
+_grad_attach_epoch = 0
+
+
+def note_grad_attached():
+    global _grad_attach_epoch
+    _grad_attach_epoch += 1
+
+
+def grad_attach_epoch():
+    return _grad_attach_epoch

@@ -356,18 +356,22 @@ struct ParamTracker {
     hipEvent_t start = nullptr;
     std::vector<hipEvent_t> pool;
     std::vector<ParamSegment> pending;   // in issue order
-    int device = -1;
 };
-ParamTracker g_pt;                  // process-wide: the step is issued by the training thread, waits may come from
-std::mutex g_pt_mu;                 // autograd worker threads
+constexpr int MAX_TRACKED_DEVICES = 16;
+ParamTracker g_pts[MAX_TRACKED_DEVICES];   // one tracker (stream, events, pending segments) per device: events and streams
+std::mutex g_pt_mu;                        // belong to the device they were created on.  Process-wide: the step is issued by
+                                           // the training thread, waits may come from autograd worker threads
 
-int tracker_init() {
+int tracker_get(ParamTracker** out) {
     int dev = 0;
     UH_CHECK_HIP(hipGetDevice(&dev));
-    if (g_pt.stream != nullptr && g_pt.device == dev) return 0;
-    UH_CHECK_HIP(hipStreamCreateWithFlags(&g_pt.stream, hipStreamNonBlocking));
-    UH_CHECK_HIP(hipEventCreateWithFlags(&g_pt.start, hipEventDisableTiming));
-    g_pt.device = dev;
+    if (dev < 0 || dev >= MAX_TRACKED_DEVICES) { uh_set_error("adamw: device index %d out of range", dev); return -1; }
+    ParamTracker& t = g_pts[dev];
+    if (t.stream == nullptr) {
+        UH_CHECK_HIP(hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking));
+        UH_CHECK_HIP(hipEventCreateWithFlags(&t.start, hipEventDisableTiming));
+    }
+    *out = &t;
     return 0;
 }
 }  // namespace
@@ -381,20 +385,38 @@ int uniter_adamw_step_async(void* plan, const UniterAdamGroup* groups, int32_t n
     HyperTable ht{};
     { int rc = fill_hyper(groups, n_groups, &ht); if (rc) return rc; }
     std::lock_guard<std::mutex> lk(g_pt_mu);
-    { int rc = tracker_init(); if (rc) return rc; }
+    ParamTracker* ptp = nullptr;
+    { int rc = tracker_get(&ptp); if (rc) return rc; }
+    ParamTracker& g_pt = *ptp;
     hipStream_t main = (hipStream_t)stream, side = g_pt.stream;
+    // every segment end is computed and checked before anything is launched: a bad boundary list must not leave a
+    // partially applied step behind
+    std::vector<int64_t> ends;
+    {
+        int64_t begin = 0;
+        for (int sgm = 0; sgm <= n_bounds; ++sgm) {
+            int64_t end = p->n_chunks;
+            if (sgm < n_bounds) {
+                const uintptr_t b = (uintptr_t)bounds[sgm];
+                end = (int64_t)(std::lower_bound(p->chunk_addr.begin(), p->chunk_addr.end(), b) - p->chunk_addr.begin());
+                if (end < begin) { uh_set_error("uniter_adamw_step_async: boundaries must ascend"); return -1; }
+            }
+            ends.push_back(end);
+            begin = end;
+        }
+    }
+    while (g_pt.pool.size() < ends.size()) {
+        hipEvent_t e;
+        UH_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        g_pt.pool.push_back(e);
+    }
     // an earlier asynchronous step may still be pending on the side stream: it is ordered before this one there
     UH_CHECK_HIP(hipEventRecord(g_pt.start, main));              // gradients + clip coefficient are final here
     UH_CHECK_HIP(hipStreamWaitEvent(side, g_pt.start, 0));
     g_pt.pending.clear();
     int64_t begin = 0;
     for (int sgm = 0; sgm <= n_bounds; ++sgm) {
-        int64_t end = p->n_chunks;
-        if (sgm < n_bounds) {
-            const uintptr_t b = (uintptr_t)bounds[sgm];
-            end = (int64_t)(std::lower_bound(p->chunk_addr.begin(), p->chunk_addr.end(), b) - p->chunk_addr.begin());
-            if (end < begin) { uh_set_error("uniter_adamw_step_async: boundaries must ascend"); return -1; }
-        }
+        const int64_t end = ends[(size_t)sgm];
         if (end == begin) continue;
         const int64_t n = end - begin;
         // the first segments gate the start of the forward pass and run flat out; later ones only have to stay ahead of
@@ -409,11 +431,6 @@ int uniter_adamw_step_async(void* plan, const UniterAdamGroup* groups, int32_t n
                                (const ChunkRef*)p->d_chunks, begin, end, ht, (const GroupHyper*)nullptr, clip_coef, (int)zero_grads);
             UH_LAUNCH_CHECK();
         }
-        if ((size_t)g_pt.pending.size() >= g_pt.pool.size()) {
-            hipEvent_t e;
-            UH_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            g_pt.pool.push_back(e);
-        }
         hipEvent_t ev = g_pt.pool[g_pt.pending.size()];
         UH_CHECK_HIP(hipEventRecord(ev, side));
         const uintptr_t lo = p->chunk_addr[(size_t)begin];
@@ -426,6 +443,9 @@ int uniter_adamw_step_async(void* plan, const UniterAdamGroup* groups, int32_t n
 
 int uniter_params_wait(const void* addr, void* stream) {
     std::lock_guard<std::mutex> lk(g_pt_mu);
+    ParamTracker* ptp = nullptr;
+    { int rc = tracker_get(&ptp); if (rc) return rc; }
+    ParamTracker& g_pt = *ptp;
     if (g_pt.pending.empty()) return 0;
     const uintptr_t a = (uintptr_t)addr;
     for (const ParamSegment& sgm : g_pt.pending) {
@@ -439,6 +459,9 @@ int uniter_params_wait(const void* addr, void* stream) {
 
 int uniter_params_wait_all(void* stream) {
     std::lock_guard<std::mutex> lk(g_pt_mu);
+    ParamTracker* ptp = nullptr;
+    { int rc = tracker_get(&ptp); if (rc) return rc; }
+    ParamTracker& g_pt = *ptp;
     if (g_pt.pending.empty()) return 0;
     UH_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, g_pt.pending.back().ev, 0));
     g_pt.pending.clear();

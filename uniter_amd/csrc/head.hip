@@ -155,6 +155,7 @@ int uniter_cls_ce_bwd(const void* x, const void* w, const float* probs, const in
                       void* gw, void* gb, int64_t n, int64_t D, int64_t C, void* stream) {
     UH_CHECK_ARG(x && w && probs && target && gloss, "null pointer");
     UH_CHECK_ARG(n > 0 && n <= 4096 && D > 0 && C >= 1 && C <= CLS_MAX, "need 1..4096 rows and 1..8 classes");
+    UH_CHECK_ARG(n * C * (int64_t)sizeof(float) <= 64 * 1024, "rows x classes must fit the 64 KiB of LDS the kernel stages the probabilities in");
     hipLaunchKernelGGL(cls_ce_bwd_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), (size_t)(n * C) * sizeof(float),
                        (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, probs, target, gloss, (bf16_t*)dx, (bf16_t*)gw,
                        (bf16_t*)gb, (int)n, (int)D, (int)C);

@@ -124,8 +124,8 @@ class BertSelfAttention(nn.Module):
         H = ws[0].shape[1]
         n = ws[0].shape[0]
         for p in ws + bs:                          # a flat gradient arena hands out its (adjacent) slots on first use
-            if p.grad is None and getattr(p, '_uniter_grad_slot', None) is not None:
-                p.grad = p._uniter_grad_slot
+            if p.grad is None:                     # (cleared if the slot still holds a gradient from before a zero_grad
+                ops.attach_grad_slot(p)            #  that only dropped the reference)
         have = all(p.grad is not None for p in ws + bs)
         if have and self._adjacent([w.grad for w in ws]) and self._adjacent([b.grad for b in bs]):
             if not self._is_stacked([w.grad for w in ws], self._qkv_gw):

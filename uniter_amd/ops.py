@@ -95,11 +95,29 @@ def params_ready(*tensors):
             C.uniter_params_wait(t.data_ptr(), st)
 
 
+def attach_grad_slot(p):
+    """Make the parameter's slot of the flat gradient arena (utils.arena) its `.grad` — zeroed.  The slot is all zeros when
+    the arena is built, but `Module.zero_grad()` / `Optimizer.zero_grad(set_to_none=True)` only drop the reference and leave
+    the last gradient in the slot: handing that back would double-count it, so a slot that has been out before is cleared
+    when it is attached again.  Returns False if the parameter has no slot."""
+    slot = getattr(p, '_uniter_grad_slot', None)
+    if slot is None:
+        return False
+    if getattr(p, '_uniter_slot_used', False):
+        with torch.no_grad():
+            slot.zero_()
+    p._uniter_slot_used = True
+    p.grad = slot
+    _lib.note_grad_attached()
+    return True
+
+
 def ensure_grad(p):
     """param.grad as a zero-initialised contiguous tensor the kernels can accumulate into."""
     if p.grad is None:
-        slot = getattr(p, '_uniter_grad_slot', None)          # flat gradient arena (utils.arena): zero until first used
-        p.grad = slot if slot is not None else torch.zeros_like(p, memory_format=torch.contiguous_format)
+        if not attach_grad_slot(p):
+            p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            _lib.note_grad_attached()
     elif not p.grad.is_contiguous() or p.grad.dtype != p.dtype:
         raise _lib.UniterHipError("param.grad must be contiguous and of the parameter's dtype")
     return p.grad
@@ -1148,8 +1166,10 @@ def linear_cross_entropy(x, lin, targets):
     """x [n, D] bf16, lin = nn.Linear(D, C <= 8) bf16, targets [n] int64 -> per-row cross entropy [n] fp32."""
     _check_dev(x, "classifier input")
     _check_dev(lin.weight, "classifier weight")
-    if x.dim() != 2 or lin.weight.size(1) != x.size(1) or x.size(1) % 8 or lin.weight.size(0) > 8 or x.size(0) > 4096:
-        raise _lib.UniterHipError("linear_cross_entropy: x must be [n <= 4096, D % 8 == 0] and the classifier at most 8-way")
+    if (x.dim() != 2 or lin.weight.size(1) != x.size(1) or x.size(1) % 8 or lin.weight.size(0) > 8 or x.size(0) > 4096
+            or x.size(0) * lin.weight.size(0) * 4 > 64 * 1024):
+        raise _lib.UniterHipError("linear_cross_entropy: x must be [n <= 4096, D % 8 == 0], the classifier at most 8-way and "
+                                  "n * classes * 4 bytes at most 64 KiB (the backward kernel stages the probabilities in LDS)")
     t = targets.to(device=x.device, dtype=torch.int64).contiguous()
     anchor = next((q for q in lin.parameters() if q.requires_grad), None) if torch.is_grad_enabled() else None
     return _LinearCrossEntropyFn.apply(x.contiguous(), lin, t, *(() if anchor is None else (anchor,)))

@@ -159,8 +159,10 @@ class AdamW(Optimizer):
         cheap check catches the two things that happen in practice: a gradient tensor was replaced (set_to_none,
         first backward) -> identity test per parameter, or the parameter groups were edited."""
         self._calls = getattr(self, '_calls', 0) + 1
-        if in_step and self._plan is not None and getattr(self, '_checked_for_step', False):
-            # grad_norm() validated the plan a moment ago in this same optimizer step (clip_grad_norm_ -> step())
+        if (in_step and self._plan is not None and getattr(self, '_checked_for_step', False)
+                and getattr(self, '_checked_epoch', -1) == _lib.grad_attach_epoch()):
+            # grad_norm() validated the plan a moment ago in this same optimizer step (clip_grad_norm_ -> step()) and no
+            # parameter has been given a gradient tensor since (a backward that lazily attaches new ones bumps the epoch)
             self._checked_for_step = False
             return True
         self._checked_for_step = False
@@ -263,6 +265,8 @@ class AdamW(Optimizer):
         C.uniter_adamw_grad_norm(self._plan, float(grad_scale), float(max_norm), ptr(self._norm_buf), _lib.stream_ptr())
         self._clip = self._norm_buf
         self._checked_for_step = True
+        self._checked_epoch = _lib.grad_attach_epoch()
+        self._grads_zeroed = False        # gradients have been produced since a fused zeroing: a later zero_grad() is real work
         return self._norm_buf[0]
 
     # ---- hipGraph mode ----------------------------------------------------------------------------------
@@ -314,6 +318,7 @@ class AdamW(Optimizer):
             loss = closure()
         if not self._ensure_plan(in_step=True):
             return loss           # nothing has a gradient: no-op, like the reference's dummy first step (pretrain.py:261-263)
+        self._grads_zeroed = False    # whatever an earlier fused step zeroed has been written again by the backward in between
         if self._graph is not None:
             dev = self._graph[1]              # uploaded by graph_prepare()
             clip = self._clip
@@ -387,8 +392,15 @@ class AdamW(Optimizer):
 def overlap_boundaries(model):
     """Segment boundaries for `AdamW.enable_overlap`: the first parameter of every BertLayer and of whatever follows the
     last layer in module order.  With the parameters in a flat arena (utils.arena.flatten_model) these addresses ascend in
-    the order the forward pass consumes them; without an arena the result is still correct, only less overlapped."""
+    the order the forward pass consumes them.  The arena is REQUIRED: the encoder waits for a layer's segment through the
+    address of its fused query/key/value weight only (csrc/encoder.hip), which covers the layer's other parameters — and the
+    fused weight itself, a view of the arena rather than a re-stacked copy — only when all of them sit in one arena segment."""
     from ..model.layer import BertLayer
+    arena = getattr(model, '_uniter_arena', None)
+    if arena is None or not arena.check():
+        raise _lib.UniterHipError("overlap_boundaries: the model's parameters must live in a flat arena "
+                                  "(uniter_amd.utils.arena.flatten_model) that is still intact; the asynchronous optimizer step "
+                                  "orders a layer behind its update through one address per layer")
     layers = [m for m in model.modules() if isinstance(m, BertLayer)]
     out = []
     for lay in layers:

@@ -19,6 +19,8 @@ the slot (PyTorch modules).
 """
 import torch
 
+from .. import _lib
+
 from ..model.layer import BertSelfAttention
 
 ALIGN = 128
@@ -60,6 +62,8 @@ def _adopt_grad(param):
     with torch.no_grad():
         slot.copy_(g)
     param.grad = slot
+    param._uniter_slot_used = True
+    _lib.note_grad_attached()
 
 
 class ParamArena(object):
