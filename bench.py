@@ -91,6 +91,23 @@ def timed_pass(train_step, steps):
     return rows
 
 
+def segment_pass(runner, train_step, steps):
+    """GPU time of the forward and backward segments of `steps` more optimizer steps: HIP events recorded on the compute
+    stream around model(batch) and loss.backward() (uniter_amd/train.py records them when `segment_events` is a list).
+    The backward segment ends after the library's weight-gradient side stream has been joined.  ms per optimizer step."""
+    runner.segment_events = []
+    torch.cuda.synchronize()
+    for _ in range(steps):
+        train_step()
+    torch.cuda.synchronize()
+    ev, runner.segment_events = runner.segment_events, None
+    if not ev:
+        return None
+    fwd = sum(a.elapsed_time(b) for a, b, _ in ev) / steps
+    bwd = sum(b.elapsed_time(c) for _, b, c in ev) / steps
+    return fwd, bwd
+
+
 def pmc_traffic(kind_id, shape):
     """HBM bytes per launch of one encoder GEMM (flavour = epilogue id, shape = M, N, K of the C-ABI call) from the
     committed PMC passes (profiles/*_pmc_traffic.json, produced by scripts/profile_round.sh +
@@ -152,6 +169,25 @@ def _oracle_setup(seed):
     return sd, batch
 
 
+def _bf16_yardstick(sd, batch):
+    """Gradients of the oracle run with its plain torch ops in bf16 on the GPU (what an unfused PyTorch-bf16 implementation
+    of the same model reaches against the fp32 oracle) — the secondary yardstick of SURVEY.md section 8c.  Only in the
+    parity leg of the cpu_baseline subprocess, after the timed region of the parent; None without a GPU."""
+    if not torch.cuda.is_available():
+        return None
+    from oracle import uniter_oracle as O
+    try:
+        dev = torch.device("cuda", 0)
+        sdb = {k: v.detach().to(dev, torch.bfloat16).requires_grad_(True) for k, v in sd.items()}
+        b = {k: ((v.to(dev, torch.bfloat16) if v.is_floating_point() else v.to(dev)) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        loss, _ = O.nlvr2_paired_attn_loss(sdb, BASE_CFG, b)
+        loss.float().mean().backward()
+        return {k: v.grad.float().cpu() for k, v in sdb.items() if v.grad is not None}
+    except Exception as e:                                   # pragma: no cover - depends on the box
+        sys.stderr.write("bf16 yardstick unavailable (%s: %s)\n" % (type(e).__name__, e))
+        return None
+
+
 def cpu_baseline(seed=77, budget_s=20.0, parity_file=None):
     """The oracle (CPU port of the reference path) on the same workload: fwd + bwd + clip + AdamW, fp32.
     Runs in this process; main() calls it through a subprocess with a hard timeout.  With `parity_file` (loss and
@@ -194,7 +230,25 @@ def cpu_baseline(seed=77, budget_s=20.0, parity_file=None):
             cos_min = min(cos_min, cos)
             if rel > worst:
                 worst, worst_name = rel, k
+        yard = _bf16_yardstick(sd, batch)          # the oracle's own torch ops in bf16 on the GPU (tests' secondary yardstick)
+        strict, worst_yard = 0, None
+        if yard is not None:
+            for k, g in gpu['grads'].items():
+                ref = sd[k].grad
+                if ref is None or k not in yard or k.endswith('attention.self.key.bias') or float(ref.norm()) < 1e-6 * max(float(ref.numel()) ** 0.5, 1.0):
+                    continue
+                rel = float((g.float() - ref).norm()) / float(ref.norm())
+                limit = 5e-2 if k.startswith('uniter.') else 1e-1      # tests/test_gpu_parity.py GRAD_L2 / GRAD_L2_HEAD
+                if rel > limit:
+                    strict += 1
+            if worst_name in yard:
+                ref = sd[worst_name].grad
+                worst_yard = float((yard[worst_name] - ref).norm()) / float(ref.norm())
         parity = {"loss_rel_err": round(lrel, 6), "grad_rel_l2_max": round(worst, 5), "grad_rel_l2_max_tensor": worst_name,
+                  "grad_rel_l2_max_tensor_torch_bf16_yardstick": None if worst_yard is None else round(worst_yard, 5),
+                  "gradients_over_absolute_bound": None if yard is None else strict,
+                  "absolute_bounds": "rel-L2 <= 5e-2 (uniter.*) / 1e-1 (head); tensors over it are held to 2x (query / key: 3.5x) the "
+                                     "torch-bf16 yardstick by tests/test_gpu_parity.py::test_headline_nlvr2_base_step_vs_oracle",
                   "grad_cosine_min": round(cos_min, 6), "gradients_compared": n_cmp,
                   "zero_gradients_max_abs": float("%.3e" % zero_abs),
                   "what": "one dropout-free step of the headline workload (UNITER-base NLVR2 paired-attn, B=32, L=96, 12 layers) on "
@@ -382,8 +436,10 @@ def main():
     # In-situ per-launch timing for the roofline object: extra optimizer steps AFTER the timed region.  With several
     # ranks these steps contain the gradient collectives, so EVERY rank runs them (only rank 0 reports).
     kernels = None
+    segments = None
     if not args.no_kernel_timing and mode == "eager":
         tsteps = max(1, min(args.steps, 5))
+        segments = segment_pass(runner, train_step, max(tsteps, min(args.steps, 10)))
         kernels = timed_pass(train_step, tsteps)
         if world > 1:
             torch.distributed.barrier()
@@ -412,6 +468,15 @@ def main():
                         "step": {"algorithmic_tflop_per_step": round(flop_step * 1e-12, 4), "achieved": round(step_tf, 1),
                                  "frac": round(step_tf / MFMA_PEAK_TFLOPS, 4),
                                  "note": "encoder fwd+bwd algorithmic FLOP (heads, embeddings, optimizer excluded) / whole step time"}}
+            if segments is not None:
+                fwd_ms, bwd_ms = segments
+                fb_tf = flop_step / ((fwd_ms + bwd_ms) * 1e-3) * 1e-12
+                # the north star states its 40 % target on forward + backward: the same FLOP over the GPU time of those two
+                # segments only (they still contain the embeddings and the task head, so this is a lower bound for the encoder)
+                roofline["encoder_fwd_bwd"] = {"fwd_ms": round(fwd_ms, 3), "bwd_ms": round(bwd_ms, 3), "achieved": round(fb_tf, 1),
+                                               "frac": round(fb_tf / MFMA_PEAK_TFLOPS, 4), "unit": "TFLOP/s",
+                                               "measured": "HIP events on the compute stream around model(batch) and loss.backward() "
+                                                           "over extra optimizer steps after the timed region (per optimizer step)"}
         metric = "train examples/sec UNITER-base seq=60txt+36img bs32/GPU"
         if args.config != 'c2':
             metric = "train examples/sec (%s: %s seq=%dtxt+%dimg bs%dx%d/GPU)" % (

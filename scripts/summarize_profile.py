@@ -19,6 +19,28 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GEMM_RE = re.compile(r'gemm_kernel<(\d+), (\d+), (\w+), (\w+), (\d), (\d), (\w+)>')
+DEEP_RE = re.compile(r'gemm([86])_kernel<(\w+), (\w+), (\d)>')          # the deep-pipelined 256x256 / 192x192 tiles (gemm8.cuh)
+
+
+class _M(object):
+    """One parsed GEMM kernel name in the group() layout of GEMM_RE (bm, bn, tra, trb, epi, stages, ws)."""
+    def __init__(self, g):
+        self.g = g
+
+    def group(self, i):
+        return self.g[i - 1]
+
+
+def gemm_match(name):
+    n = name.replace('(anonymous namespace)::', '')
+    m = GEMM_RE.search(n)
+    if m:
+        return m
+    d = DEEP_RE.search(n)
+    if d:
+        edge = "256" if d.group(1) == "8" else "192"
+        return _M((edge, edge, d.group(2), d.group(3), d.group(4), "2" if d.group(1) == "8" else "3", "3" if d.group(1) == "8" else "4"))
+    return None
 EPI_KIND = {0: "gemm fwd +bias", 1: "gemm fwd +bias+gelu", 2: "gemm fwd +bias+dropout+residual", 3: "gemm dgrad",
             4: "gemm dgrad x gelu'", 5: "gemm wgrad"}
 
@@ -47,10 +69,11 @@ def kernel_stats(src, dst):
 
 def family(name):
     n = name.replace('(anonymous namespace)::', '')
-    m = GEMM_RE.search(n)
+    m = gemm_match(n)
     if m:
         return "%s  [tile %sx%s st%s %s]" % (EPI_KIND[int(m.group(5))], m.group(1), m.group(2), m.group(6),
-                                               {"0": "plain", "false": "plain", "1": "ws4+4", "true": "ws4+4", "2": "ws8+4"}.get(m.group(7), m.group(7)))
+                                               {"0": "plain", "false": "plain", "1": "ws4+4", "true": "ws4+4", "2": "ws8+4",
+                                                "3": "deep 8-phase", "4": "deep 3-phase"}.get(m.group(7), m.group(7)))
     if n.startswith("Cijk_"):
         return "rocBLAS/hipBLASLt GEMM (task heads, torch)"
     if "at::native" in n:
@@ -109,7 +132,7 @@ def pmc_traffic(fetch_csv, write_csv, dst):
     def by_kind(table):
         acc = collections.defaultdict(lambda: [0.0, 0, set()])
         for (name, grid), vals in table.items():
-            m = GEMM_RE.search(name.replace('(anonymous namespace)::', ''))
+            m = gemm_match(name)
             if not m:
                 continue
             a = acc[int(m.group(5))]
@@ -136,7 +159,7 @@ def pmc_traffic(fetch_csv, write_csv, dst):
     # per (kernel, grid) entries: a flavour that runs at several shapes is told apart by its dispatch grid
     per = []
     for (name, grid), fv in sorted(fetch.items(), key=lambda kv: (kv[0][0], kv[0][1])):
-        m = GEMM_RE.search(name.replace('(anonymous namespace)::', ''))
+        m = gemm_match(name)
         if not m:
             continue
         wv = write.get((name, grid), [])
@@ -150,10 +173,21 @@ def pmc_traffic(fetch_csv, write_csv, dst):
     # that share one template + grid are told apart by program order (they alternate in a fixed per-layer sequence).
     by_shape = {}
     cache_path = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(fetch_csv))), "tune_cache.json")
+    if not os.path.exists(cache_path):
+        # the passes ran with the shipped tile table (scripts/profile_round.sh): that IS the set of choices they used
+        cache_path = os.path.join(ROOT, "uniter_amd", "tuned", "gfx950.json")
     tiles = parse_tiles()
     if os.path.exists(cache_path) and tiles:
         # per-layer launch order of the encoder (encoder.hip): (kind, EPI, N, K) with H / I recovered from the cache
         entries = json.load(open(cache_path)).get("gemm", [])
+        # the table may hold several model sizes: keep the one whose token count the profiled run used (the grouped
+        # launch's grid tells; default: the headline shape, the smallest hidden size at M = 3072)
+        m_run = int(os.environ.get("UNITER_PROFILE_TOKENS", "3072"))
+        entries = [e for e in entries if e["M"] == m_run]
+        h_run = min([e["K"] for e in entries if e["kind"] == 0] or [0])
+        entries = [e for e in entries if e["kind"] == 3 or min(e["N"], e["K"]) == h_run]
+        g3all = [e for e in entries if e["kind"] == 3]
+        entries = [e for e in entries if e["kind"] != 3] + [e for e in g3all if e["N"] == 9 * h_run]   # N = 5H + I with I = 4H
         hs = sorted({e["K"] for e in entries if e["kind"] < 3} | {e["N"] for e in entries if e["kind"] < 3})
         H, I = (hs[0], hs[-1]) if hs else (0, 0)
         order = [(0, 0, 3 * H, H), (0, 2, H, H), (0, 1, I, H), (0, 2, H, I),                       # forward
@@ -169,10 +203,13 @@ def pmc_traffic(fetch_csv, write_csv, dst):
             M, cfg, splits = e["M"], e["cfg"], e["splits"]
             bm, bn, st, ws = tiles[cfg]
             rows, cols = (M, N) if kind == 0 else ((M, K) if kind == 1 else (N, K))      # output of the launch
-            threads = 256 if ws == 0 else (512 if ws == 1 else 768)
+            threads = 256 if ws == 0 else (512 if ws in (1, 3, 4) else 768)
             grid = ((rows + bm - 1) // bm) * (cols // bn) * threads * splits
             layout = {0: "false, false", 1: "false, true", 2: "true, true"}[kind]
-            want = "gemm_kernel<%d, %d, %s, %d, %d, %d>" % (bm, bn, layout, epi, st, ws)
+            if ws >= 3:
+                want = "gemm%d_kernel<%s, %d>" % (8 if ws == 3 else 6, layout, epi)
+            else:
+                want = "gemm_kernel<%d, %d, %s, %d, %d, %d>" % (bm, bn, layout, epi, st, ws)
             for (name, g2) in fetch:
                 if g2 == grid and want in name.replace('(anonymous namespace)::', ''):
                     groups[(name, grid)].append((epi, M, N, K))
@@ -194,7 +231,9 @@ def pmc_traffic(fetch_csv, write_csv, dst):
         if g3 and H and I:
             welems = H * I + I * H + H * H + 3 * H * H
             for (name, grid), fv in fetch.items():
-                if "gemm_group_kernel<" not in name:
+                if "gemm_group_kernel<" not in name and "gemm8_group_kernel" not in name and "gemm6_group_kernel" not in name:
+                    continue
+                if len(fv) < 8 * 4:            # (the NLVR2 head's small grouped launches share the template: 1-2 per step)
                     continue
                 wv = write.get((name, grid), [])
                 if len(fv) < 8 or not wv:
@@ -212,6 +251,71 @@ def pmc_traffic(fetch_csv, write_csv, dst):
                              "side, so Infinity-Cache hits are included",
                "by_kind": out}, open(dst, 'w'), indent=1)
     return len(out)
+
+
+def mfma_util(counter_csv, cal_csv, dst):
+    """MFMA utilisation of the most expensive kernels of a step: SQ_VALU_MFMA_BUSY_CYCLES (matrix-pipe busy cycles summed
+    over the chip's 1024 SIMDs) per dispatch / (dispatch duration x 1024 SIMDs x clock).  The clock is not a counter we
+    can read per dispatch, so the unit is calibrated on a GEMM of known size run under the same counters: a 4096^3 bf16
+    GEMM issues 4096^3 / (16*16*32) MFMAs of 16 busy cycles each."""
+    def load(path):
+        rows = list(csv.DictReader(open(path)))
+        per = collections.defaultdict(lambda: collections.defaultdict(float))   # dispatch -> counter -> value
+        meta = {}
+        for r in rows:
+            d = int(r["Dispatch_Id"])
+            per[d][r["Counter_Name"]] += float(r["Counter_Value"])
+            meta[d] = r
+        return per, meta
+
+    def durations(path):
+        tr = one(os.path.join(os.path.dirname(path), "*kernel_trace.csv"))
+        out = {}
+        if tr:
+            for r in csv.DictReader(open(tr)):
+                out[int(r["Dispatch_Id"])] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        return out
+
+    per, meta = load(counter_csv)
+    dur = durations(counter_csv)
+    cal = None
+    if cal_csv:
+        cper, cmeta = load(cal_csv)
+        cdur = durations(cal_csv)
+        busy = [v["SQ_VALU_MFMA_BUSY_CYCLES"] for d, v in cper.items() if "gemm8_kernel" in cmeta[d]["Kernel_Name"]]
+        ns = [cdur.get(d) for d in cper if "gemm8_kernel" in cmeta[d]["Kernel_Name"] and cdur.get(d)]
+        if busy and ns:
+            expect = 4096.0 ** 3 / (16 * 16 * 32) * 16.0          # busy SIMD-cycles one launch must account for
+            mean_busy = sum(busy) / len(busy)
+            cal = {"kernel": "gemm8_kernel<false, false, 0> 4096^3", "launches": len(busy), "counter_per_launch": mean_busy,
+                   "expected_busy_simd_cycles": expect, "counter_units_per_simd_cycle": mean_busy / expect,
+                   "avg_ns": sum(ns) / len(ns),
+                   "implied_clock_ghz_at_full_utilisation_of_busy_cycles": None}
+    unit = cal["counter_units_per_simd_cycle"] if cal else 1.0
+    acc = collections.defaultdict(lambda: [0.0, 0.0, 0, 0.0])     # name -> [busy, ns, launches, gui]
+    for d, v in per.items():
+        name = family(meta[d]["Kernel_Name"])
+        a = acc[name]
+        a[0] += v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / unit
+        a[1] += dur.get(d, 0)
+        a[2] += 1
+        a[3] += v.get("GRBM_GUI_ACTIVE", 0.0)
+    rows = []
+    for name, (busy, ns, n, gui) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:8]:
+        if ns <= 0:
+            continue
+        clock = 2.4
+        rows.append({"kernel": name, "launches": n, "avg_us": round(ns / n / 1e3, 2),
+                     "mfma_busy_simd_cycles_per_launch": round(busy / n),
+                     "mfma_util_at_2p4ghz": round(busy / (ns * clock * 1024.0), 4),
+                     "grbm_gui_active_per_launch": round(gui / n)})
+    json.dump({"kernels": rows, "calibration": cal,
+               "definition": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES (calibrated to SIMD-cycles) / (dispatch duration x 2.4 GHz x 1024 "
+                             "SIMDs): the fraction of the chip's matrix-pipe cycles at the nominal clock that were busy; the chip "
+                             "clocks below 2.4 GHz under load, so this is a lower bound of the in-kernel busy fraction",
+               "source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace over `python bench.py --steps 3 --warmup 2`"},
+              open(dst, 'w'), indent=1)
+    return len(rows)
 
 
 def parse_tiles():
@@ -238,6 +342,10 @@ def main():
     wc = one(os.path.join(src, "pmc_write", "*", "*counter_collection.csv"))
     if fc and wc:
         print("pmc kernels:", pmc_traffic(fc, wc, os.path.join(dst, tag + "_pmc_traffic.json")))
+    mc = one(os.path.join(src, "pmc_mfma", "*", "*counter_collection.csv"))
+    cc = one(os.path.join(src, "pmc_mfma_cal", "*", "*counter_collection.csv"))
+    if mc:
+        print("mfma util kernels:", mfma_util(mc, cc, os.path.join(dst, tag + "_mfma_util.json")))
 
 
 if __name__ == "__main__":

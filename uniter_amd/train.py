@@ -201,12 +201,21 @@ class StepRunner(object):
         accum = self.w['accum']
         self._schedule_lr()
         loss = None
+        seg = getattr(self, 'segment_events', None)                   # bench.py: GPU time of the forward / backward segments
         for micro in range(accum):
             last = micro == accum - 1
             if self.reducer is not None and last:
                 self.reducer.begin()                                  # earlier micro-steps only accumulate locally
+            if seg is not None:
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record()
             loss = self._loss(task, batch)
+            if seg is not None:
+                e1.record()
             loss.backward()
+            if seg is not None:
+                e2.record()
+                seg.append((e0, e1, e2))
         scale = self.reducer.finish() if self.reducer is not None else 1.0
         clip_grad_norm_(self.optimizer, self.opts.grad_norm, grad_scale=scale)
         self.optimizer.step()
