@@ -296,8 +296,10 @@ def cpu_baseline_subprocess(timeout_s=240, parity_file=None):
     if parity_file:
         cmd += ["--parity-file", parity_file]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True,
-                           timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+        env = dict(os.environ)
+        if not parity_file:                          # the timing leg is CPU-only; the parity leg also runs the oracle's torch ops
+            env.update(HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")   # in bf16 on the (now idle) GPU: the secondary yardstick
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
         for line in reversed(r.stdout.strip().splitlines()):
             if line.startswith("{"):
                 return json.loads(line)
