@@ -160,10 +160,50 @@ def _case_task_mix_and_retrieval_gather(rank, world, D):
         assert log == {}
 
 
+# Bound for the bf16 SUM over 8 ranks the reducer issues (distributed.py: in-place allreduce of the bf16 gradient arena, the
+# 1/world factor folded into clip / AdamW afterwards) against the mean of the same 8 gradients in fp32.  Whatever order the
+# collective adds in, every partial sum is rounded to bf16 once per hop (relative 2^-9 each, at most 7 hops), so the error of
+# an element is bounded by 7 * 2^-9 * sum_r |g_r| and behaves like a random walk of ~sqrt(7) such roundings in practice.
+BF16_SUM8_REL_L2 = 4e-3            # whole-vector relative L2 (measured over gloo: ~2.5e-3) — one bf16 epsilon (2^-8)
+BF16_SUM8_ABS_FACTOR = 7 * 2.0 ** -9
+
+
+def _case_bf16_sum_over_8_ranks(rank, world, D):
+    assert world == 8
+    n = 1 << 16
+    gens = [torch.Generator().manual_seed(900 + r) for r in range(world)]
+    # gradient-like values: heavy dynamic range per element across ranks (log-normal scale x normal)
+    per_rank = [(torch.randn(n, generator=g) * torch.exp(2.0 * torch.randn(n, generator=g))).to(torch.bfloat16) for g in gens]
+    mine = per_rank[rank].clone()
+    dist.all_reduce(mine, op=dist.ReduceOp.SUM)                      # what GradientReducer._reduce_range issues
+    got = mine.float() * (1.0 / world)                               # the averaging factor is applied in fp32 later
+    ref = sum(t.double() for t in per_rank) / world
+    err = (got.double() - ref)
+    rel = float(err.norm() / ref.norm())
+    assert rel <= BF16_SUM8_REL_L2, rel
+    bound = BF16_SUM8_ABS_FACTOR * sum(t.double().abs() for t in per_rank) / world + 1e-30
+    assert bool((err.abs() <= bound * 1.0001 + ref.abs() * 2.0 ** -9).all())   # + the final rounding of the sum itself
+    # and through the reducer itself (CPU arena in bf16, no encoder: one range)
+    class _Arena:
+        pass
+    a = _Arena()
+    a.grad = per_rank[rank].clone()
+    a.numel = n
+    red = D.GradientReducer(a, None)
+    red.begin()
+    scale = red.finish()
+    assert scale == 1.0 / world
+    torch.testing.assert_close(a.grad.float() * scale, got, rtol=0, atol=0)
+
+
 @pytest.mark.parametrize("case", ["_case_allreduce", "_case_broadcast_and_objects", "_case_gradient_reducer",
                                   "_case_task_mix_and_retrieval_gather"])
 def test_world_size_2(case, tmp_path):
     _spawn(case, tmp_path)
+
+
+def test_bf16_sum_allreduce_over_8_ranks_stays_within_the_stated_bound(tmp_path):
+    _spawn("_case_bf16_sum_over_8_ranks", tmp_path, world=8)
 
 
 def test_single_process_is_a_noop():

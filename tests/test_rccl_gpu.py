@@ -1,8 +1,8 @@
 """RCCL on the one GPU a test box has: (1) the gradient reducer's real backward-hook path over a forced one-rank RCCL
 group must reproduce the collective-free step bit for bit and must actually issue its bucket allreduces; (2) the raw
 C-ABI communicator (uniter_comm_*: unique id -> init -> allreduce / broadcast / allgather -> destroy) on a one-rank
-communicator.  Multi-rank behaviour is covered over gloo in tests/test_distributed_gloo.py; an N > 1 RCCL measurement needs
-the driver's 8-GPU node.  Reference: utils/distributed.py:16-43,100-148."""
+communicator.  Multi-rank behaviour is covered over gloo in tests/test_distributed_gloo.py; (3) on a box with at least two GPUs, two
+real RCCL ranks against a single process that averages the gradients itself (skipped on the one-GPU test boxes).  Reference: utils/distributed.py:16-43,100-148."""
 import json
 import os
 import subprocess
@@ -58,3 +58,39 @@ print("RCCL_OK")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def _two_rank_run(extra_env, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    env.pop("UNITER_DIST_FORCE", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "tests", "rccl_world2_script.py")],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_two_ranks_sharing_one_gpu_over_gloo_match_single_process_mean():
+    """The N = 2 data-parallel step with real kernels on the one GPU a test box has: two processes on GPU 0, bucketed
+    reduction over gloo (RCCL refuses two ranks on one device).  Same assertions as the RCCL world-2 test below."""
+    r, out = _two_rank_run({"UNITER_W2_BACKEND": "gloo", "UNITER_W2_ONE_GPU": "1"}, 29543)
+    if out is None and ("not supported" in r.stderr or "Unsupported" in r.stderr or "unsupported" in r.stderr):
+        pytest.skip("gloo cannot reduce bf16 device tensors in this build: " + r.stderr.strip().splitlines()[-1][:200])
+    assert r.returncode == 0 and out is not None, (r.stdout[-2000:], r.stderr[-3000:])
+    assert out["world"] == 2 and out["identical_across_ranks"], out
+    assert out["max_abs_diff_vs_single_process"] <= 2.0 ** -7 * max(out["max_abs_param"], 1.0), out
+
+
+def test_two_rank_rccl_step_matches_single_process_mean():
+    """World size 2 over RCCL (one process per GPU): skipped unless the box has two GPUs — `gpurun` boxes have one, the
+    driver's 8-GPU node runs it.  Both ranks must end with bit-identical parameters that match a single process averaging
+    the two ranks' gradients itself (differences only from the bf16 rounding of the summed gradient: <= one bf16 ulp of the
+    largest parameter after two steps at lr 1e-3)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL world size 2)")
+    r, out = _two_rank_run({}, 29541)
+    assert r.returncode == 0 and out is not None, (r.stdout[-2000:], r.stderr[-3000:])
+    assert out["backend"] == "nccl" and out["world"] == 2
+    assert out["identical_across_ranks"], out
+    assert out["max_abs_diff_vs_single_process"] <= 2.0 ** -7 * max(out["max_abs_param"], 1.0), out
