@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 T=$ROOT/tests/native/build/test_kernels
 export UNITER_BENCH_SKIP_XCD_CHECK=1
 cd $ROOT
-for v in A H G; do
+for v in ${VARIANTS:-A H G}; do
   if [ $v = A ]; then J=uniter_amd/tuned/gfx950.json; else J=aux_bin/tune_$v.json; fi
   UNITER_TUNED_JSON=$J timeout 200 rocprofv3 --kernel-trace --output-format csv -d "$OUT/tr_$v" -- $T --enc > "$OUT/tr_$v.log" 2>&1; echo "trace $v rc=$?"
   f=$(find "$OUT/tr_$v" -name "*kernel_trace.csv" | head -1)

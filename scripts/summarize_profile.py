@@ -266,6 +266,8 @@ def mfma_util(counter_csv, cal_csv, dst):
             d = int(r["Dispatch_Id"])
             per[d][r["Counter_Name"]] += float(r["Counter_Value"])
             meta[d] = r
+            if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                per[d]["_ns"] = float(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         return per, meta
 
     def durations(path):
@@ -278,10 +280,16 @@ def mfma_util(counter_csv, cal_csv, dst):
 
     per, meta = load(counter_csv)
     dur = durations(counter_csv)
+    for d, v in per.items():
+        if "_ns" in v:
+            dur[d] = v["_ns"]
     cal = None
     if cal_csv:
         cper, cmeta = load(cal_csv)
         cdur = durations(cal_csv)
+        for d, v in cper.items():
+            if "_ns" in v:
+                cdur[d] = v["_ns"]
         busy = [v["SQ_VALU_MFMA_BUSY_CYCLES"] for d, v in cper.items() if "gemm8_kernel" in cmeta[d]["Kernel_Name"]]
         ns = [cdur.get(d) for d in cper if "gemm8_kernel" in cmeta[d]["Kernel_Name"] and cdur.get(d)]
         if busy and ns:
