@@ -322,6 +322,8 @@ def gpu_parity_probe(runner, path):
     batch['img_pos_feat'] = batch['img_pos_feat'].to(torch.bfloat16)
     loss = model(batch, compute_loss=True)
     loss.mean().backward()
+    from uniter_amd import _lib
+    _lib.join_wgrads()                        # (the step runner lets backward return before the weight-gradient stream is joined)
     grads = {n: p.grad.detach().to('cpu') for n, p in model.named_parameters()
              if p.grad is not None and 'word_embeddings' not in n}
     torch.save({'loss': loss.detach().float().cpu(), 'grads': grads}, path)

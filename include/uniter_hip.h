@@ -398,6 +398,19 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
                             const void* x_in, const float* mask_bias, const void* dy, void* dx,
                             void* acts, void* scratch, uint64_t seed, uint64_t offset, void* stream);
 
+/* Deferred weight gradients.  Nothing downstream of backward needs a weight gradient before the optimizer (or the gradient
+ * bucket's allreduce), and one layer's four weight gradients fill less than half of an MI355X.  When the calling thread has
+ * registered a stage of at least uniter_encoder_wgrad_stage_bytes(s, layer_end - layer_begin) bytes, uniter_encoder_backward
+ * keeps the dy operands of EVERY layer of the call there (one set per layer: the gradients w.r.t. the outputs of the four
+ * nn.Linear of model/layer.py:64-66,112,140,153) and computes all their weight + bias gradients in ONE launch at the end of the
+ * call (hidden and intermediate sizes must be multiples of 256, the token count a multiple of 64; otherwise — and during
+ * stream capture, or with UNITER_AMD_WGRAD_MULTI=0 — the per-layer grouped launches run as before).  A stage of twice that size
+ * lets consecutive calls (layer ranges of one backward) alternate halves instead of waiting for each other's launch.  The
+ * registration is per calling thread (autograd runs backward on its own thread) and is read at the start of each call;
+ * buf = NULL unregisters. */
+size_t uniter_encoder_wgrad_stage_bytes(const UniterEncoderShape* s, int32_t n_layers);
+int uniter_encoder_set_wgrad_stage(void* buf, size_t bytes);
+
 /* Backward keeps the weight-gradient work on an internal side stream and, at the end of every call, makes `stream` wait for
  * it.  A caller that runs the stack as several layer ranges (one per gradient bucket of a data-parallel reducer) can avoid
  * serialising the two streams at every range boundary: uniter_encoder_defer_side_join(1) makes the following calls of THIS
@@ -407,6 +420,11 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
  * (model/model.py:282-292 has no counterpart: the reference's autograd runs layer by layer on one stream.) */
 int uniter_encoder_defer_side_join(int enable);
 int uniter_encoder_side_join(void* stream);
+/* The same from ANY thread: makes `stream` wait for the weight-gradient streams of every thread of this process that left a
+ * backward call un-joined on the current device (autograd runs backward on its own thread, the optimizer runs on the caller's).
+ * A training loop that defers the join of its one backward call lets the embedding backward overlap the deferred weight-gradient
+ * launch, and calls this before anything reads a weight gradient (clip_grad_norm_, optimizer.step, zero_grad). */
+int uniter_encoder_side_join_all(void* stream);
 
 /* Autotune the 12 GEMM shapes (4 forward, 4 dgrad, 4 wgrad) of one BertLayer for this (B, L, H, I): synchronous,
  * call once per shape at set-up time (the Python side does it on the first forward of a new shape). */

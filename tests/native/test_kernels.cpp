@@ -986,11 +986,13 @@ static void bench_encoder(int B, int L, int H, int heads, int I, int layers) {
     HostBf P;
     P.fill(per, 0.03f);
     std::vector<UniterLayerParams> lp(layers);
+    std::vector<uint16_t*> gbase(layers);
     const bool share_w = getenv("UNITER_BENCH_SHARE_WEIGHTS") != nullptr;   // experiment: every layer reads the same (cache-hot) weights
     uint16_t* p_shared = share_w ? upload(P) : nullptr;
     for (int l = 0; l < layers; ++l) {
         uint16_t* p = share_w ? p_shared : upload(P);
         uint16_t* g = dalloc<uint16_t>(per);
+        gbase[l] = g;
         HIPCHK(hipMemset(g, 0, per * 2));
         size_t o = 0;
         auto nxt = [&](size_t n) { size_t r = o; o += n; return r; };
@@ -1087,6 +1089,38 @@ static void bench_encoder(int B, int L, int H, int heads, int I, int layers) {
         }
     }
     if (getenv("UNITER_BENCH_XCD_ONLY")) return;
+    // deferred weight gradients (one launch for all layers of the call) against the per-layer grouped launches: every
+    // parameter gradient of every layer, same inputs, gradients zeroed before each run
+    const size_t stb = uniter_encoder_wgrad_stage_bytes(&sh, layers);
+    char* stage = stb ? dalloc<char>(stb) : nullptr;
+    if (stage != nullptr && !getenv("UNITER_BENCH_NO_STAGE")) {
+        UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0));
+        std::vector<std::vector<float>> ref(layers);
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int l = 0; l < layers; ++l) HIPCHK(hipMemset(gbase[l], 0, per * 2));
+            UHCHK(uniter_encoder_set_wgrad_stage(pass == 0 ? nullptr : stage, pass == 0 ? 0 : stb));
+            UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0));
+            HIPCHK(hipDeviceSynchronize());
+            size_t nbad = 0;
+            double maxd = 0, maxr = 0;
+            for (int l = 0; l < layers; ++l) {
+                std::vector<float> got = download_bf(gbase[l], per);
+                if (pass == 0) { ref[l] = got; continue; }
+                for (size_t k = 0; k < per; ++k) {
+                    const double d = fabs((double)got[k] - ref[l][k]);
+                    maxd = std::max(maxd, d); maxr = std::max(maxr, fabs((double)ref[l][k]));
+                    if (!(d <= 0.02 * fabs(ref[l][k]) + 0.004 * maxr + 1e-6)) ++nbad;
+                }
+            }
+            if (pass == 1) {
+                printf("[%s] deferred weight gradients (one launch, %d layers) == per-layer grouped launches: max |d| %.4g of max |ref| %.4g, %zu of %zu outside tolerance\n",
+                       nbad ? "FAIL" : " OK ", layers, maxd, maxr, nbad, per * (size_t)layers);
+                if (nbad) ++g_fail;
+            }
+        }
+        for (int l = 0; l < layers; ++l) HIPCHK(hipMemset(gbase[l], 0, per * 2));
+    }
+    if (getenv("UNITER_BENCH_NO_STAGE")) UHCHK(uniter_encoder_set_wgrad_stage(nullptr, 0));
     double tf = 1e30, tb = 1e30;
     for (int rep = 0; rep < 5; ++rep) {
         tf = std::min(tf, tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 20));

@@ -92,6 +92,9 @@ SIGNATURES = {
     "uniter_gemm_wgrad_group": (c_int, [c_int32, _P, _P, _P, _P, _P, _P, _I, _P, _P, c_int, _P]),
     "uniter_gemm_wgrad_group_autotune": (c_int, [c_int32, _I, _P, _P, _P]),
     "uniter_gemm_wgrad_group_workspace_bytes": (c_size_t, [c_int32, _P, _P]),
+    "uniter_encoder_wgrad_stage_bytes": (c_size_t, [_P, c_int32]),
+    "uniter_encoder_set_wgrad_stage": (c_int, [_P, c_size_t]),
+    "uniter_encoder_side_join_all": (c_int, [_P]),
     "uniter_gemm_wgrad_group_ws": (c_int, [c_int32, _P, _P, _P, _P, _P, _P, _I, _P, _P, c_int, _P, c_size_t, c_int, c_int, _P]),
     "uniter_attention_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
     "uniter_attention_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
@@ -159,7 +162,7 @@ SIGNATURES = {
 
 # functions that return a size / pointer rather than a status code
 _NO_STATUS = {"uniter_hip_abi_version", "uniter_gemm_tile_count", "uniter_hip_last_error", "uniter_gemm_wgrad_workspace_bytes",
-              "uniter_gemm_wgrad_group_workspace_bytes",
+              "uniter_gemm_wgrad_group_workspace_bytes", "uniter_encoder_wgrad_stage_bytes",
               "uniter_gemm_dgrad_splitk_workspace_bytes", "uniter_head_ce_save_bytes", "uniter_head_ce_workspace_bytes",
               "uniter_layernorm_bwd_workspace_bytes", "uniter_colsum_workspace_bytes", "uniter_embed_ws_bytes",
               "uniter_attn_pool_workspace_bytes",
@@ -285,3 +288,26 @@ def note_grad_attached():
 
 def grad_attach_epoch():
     return _grad_attach_epoch
+
+
+# ---- weight gradients still in flight on the library's side stream ------------------------------------------------------------
+# A training loop may let its backward call return without joining the weight-gradient stream (ops.defer_wgrad_join): the
+# embedding backward then overlaps the deferred weight-gradient launch.  Everything that reads or writes a weight gradient
+# afterwards (grad_norm / step / zero_grad of uniter_amd.optim.AdamW) calls join_wgrads() first.  The tensors that launch
+# still reads (the saved activations, the encoder input) are kept alive here until then.
+_wgrad_keepalive = []
+
+
+def wgrads_in_flight():
+    return bool(_wgrad_keepalive)
+
+
+def hold_until_wgrad_join(*tensors):
+    _wgrad_keepalive.append(tensors)
+
+
+def join_wgrads():
+    """Make the current stream wait for every un-joined weight-gradient launch; no-op when none is outstanding."""
+    if _wgrad_keepalive:
+        C.uniter_encoder_side_join_all(stream_ptr())
+        del _wgrad_keepalive[:]

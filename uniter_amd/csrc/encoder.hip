@@ -8,6 +8,7 @@
 // the caller's stream; activations needed by backward live in the caller-provided `acts` arena.
 #include "common.cuh"
 #include <vector>
+#include <mutex>
 #include "kernels.h"
 #include "../../include/uniter_hip.h"
 
@@ -97,6 +98,10 @@ struct SideStream {
     bool defer_request = false;   // the next call shall end that way
 };
 thread_local SideStream g_side;
+// every thread's side-stream record, so that a thread other than the one that ran backward (autograd has its own) can make
+// a stream wait for all outstanding weight-gradient work (uniter_encoder_side_join_all)
+std::mutex g_side_registry_mu;
+std::vector<SideStream*> g_side_registry;
 
 int side_init() {
     int dev = 0;
@@ -109,7 +114,44 @@ int side_init() {
     }
     UH_CHECK_HIP(hipEventCreateWithFlags(&g_side.done, hipEventDisableTiming));
     g_side.device = dev;
+    {
+        std::lock_guard<std::mutex> lk(g_side_registry_mu);
+        bool have = false;
+        for (SideStream* p : g_side_registry) have = have || p == &g_side;
+        if (!have) g_side_registry.push_back(&g_side);
+    }
     return 0;
+}
+
+// ---- deferred weight gradients ---------------------------------------------------------------------------------------------
+// With a caller-registered stage (uniter_encoder_set_wgrad_stage) every layer of a backward call keeps its four dy operands
+// (dd2, dpre, dd1, dqkv: one "set" per layer) instead of recycling two sets by layer parity, and the weight + bias gradients of
+// ALL layers of the call go out as ONE launch at its end (uh::gemm_wgrad_multi, 256 x 256 eight-phase tile: 12 layers = 1 296
+// tiles = five full rounds of the chip).  The per-layer grouped launch is a half-filled kernel that fights the data-gradient
+// chain for CUs for ~70 us per layer; nothing needs a weight gradient before the optimizer / the bucket's
+// allreduce.  A stage of twice the call's sets lets consecutive calls (gradient buckets) alternate halves, so the next range
+// does not wait for the previous range's launch.  UNITER_AMD_WGRAD_MULTI=0 keeps the per-layer launches.
+struct WgradStage {
+    char* buf = nullptr;
+    size_t bytes = 0;
+    int toggle = 0;
+    hipEvent_t busy[2] = {nullptr, nullptr};      // recorded on the side stream after the multi launch that read half k
+    bool pending[2] = {false, false};
+};
+thread_local WgradStage g_stage;
+int g_wgrad_multi = [] { const char* e = getenv("UNITER_AMD_WGRAD_MULTI"); return e ? atoi(e) : 1; }();
+struct StageSet { size_t dd, dd1, dqkv, dpre, total; };
+StageSet stage_set(const UniterEncoderShape& s) {
+    const size_t T = tokens(s), H = s.H, I = s.I;
+    StageSet l{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += align256(bytes); return r; };
+    l.dd = take(T * H * 2);
+    l.dd1 = take(T * H * 2);
+    l.dqkv = take(T * 3 * H * 2);
+    l.dpre = take(T * I * 2);
+    l.total = o;
+    return l;
 }
 
 int g_use_side_stream = 1;
@@ -231,11 +273,32 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
     const bool hdrop = s->p_hidden > 0.f;
     const bool side = g_use_side_stream != 0;
     const bool grouped = g_group_wgrad != 0;
+    // deferred weight gradients: every layer of this call gets its own set of dy buffers in the registered stage
+    const int nl = layer_end - layer_begin;
+    const StageSet sset = stage_set(*s);
+    bool defer_wg = false;
+    int stage_half = 0;
+    if (grouped && side && g_wgrad_multi != 0 && g_stage.buf != nullptr && g_stage.bytes >= (size_t)nl * sset.total &&
+        H % 256 == 0 && I % 256 == 0 && T % 64 == 0 && T >= 64) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) defer_wg = true;
+    }
     hipStream_t ss = st;
     if (side) {
         RC(side_init());
         ss = g_side.stream;
     }
+    if (defer_wg) {
+        for (int k = 0; k < 2; ++k)
+            if (g_stage.busy[k] == nullptr) UH_CHECK_HIP(hipEventCreateWithFlags(&g_stage.busy[k], hipEventDisableTiming));
+        const bool two = g_stage.bytes >= 2 * (size_t)nl * sset.total;
+        stage_half = two ? (g_stage.toggle ^= 1) : 0;
+        if (g_stage.pending[stage_half]) {          // the launch that last read this half of the stage must be through
+            UH_CHECK_HIP(hipStreamWaitEvent(st, g_stage.busy[stage_half], 0));
+            g_stage.pending[stage_half] = false;
+        }
+    }
+    auto stage_of = [&](int l) { return g_stage.buf + ((size_t)stage_half * (size_t)nl + (size_t)(l - layer_begin)) * sset.total; };
     // Event slots (main_ev[k]: "inputs of side job k are ready", side_ev[k]: "side job k has read its inputs"):
     //   0 / 1  the weight-gradient work of even / odd layers (reads dd2, dpre, dd1, dqkv of that parity's buffer set)
     //   2 / 3  the early column sums of the current layer (bias gradients of FFN1 / QKV read dpre / dqkv)   [ungrouped: wgrads too]
@@ -300,10 +363,10 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         const DropoutCfg d_h1 = make_dropout(s->p_hidden, seed, off + 1);
         const DropoutCfg d_h2 = make_dropout(s->p_hidden, seed, off + 2);
         const int par = l & 1;                     // buffer set / event slot of this layer's weight-gradient work
-        char* ddb2 = S + sl.dd[par];
-        char* ddb1 = S + sl.dd1[par];
-        char* dpre = S + sl.dpre[par];
-        char* dqkv = S + sl.dqkv[par];
+        char* ddb2 = defer_wg ? stage_of(l) + sset.dd : S + sl.dd[par];
+        char* ddb1 = defer_wg ? stage_of(l) + sset.dd1 : S + sl.dd1[par];
+        char* dpre = defer_wg ? stage_of(l) + sset.dpre : S + sl.dpre[par];
+        char* dqkv = defer_wg ? stage_of(l) + sset.dqkv : S + sl.dqkv[par];
 
         // ---- BertOutput backward (model/layer.py:152-156) ----
         // LayerNorm backward is split: the row half (dz, dd) stays on the critical path, the column sums
@@ -375,7 +438,9 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         // ---- BertSelfAttention backward (model/layer.py:75-101) ----
         RC(uh::attention_bwd(A + al.qkv, s->total_tokens > 0 ? nullptr : mask_bias, A + al.ctx, (const float*)(A + al.lse), dctx, dqkv,
                              s->B, s->L, s->heads, d_attn, st, s->total_tokens > 0 ? s->cu_seqlens : nullptr, S + sl.attn_ws));
-        if (grouped) {
+        if (grouped && defer_wg) {
+            // nothing here: the weight gradients of the whole call go out below, in one launch
+        } else if (grouped) {
             RC(tick());                        // (a still-pending earlier layer goes first)
             if (pending >= 0) RC(group_launch(pending));
             pending = l;                       // this layer's inputs are all final now
@@ -394,6 +459,35 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         dyl = dxl;
     }
     if (pending >= 0) RC(group_launch(pending));
+    if (defer_wg) {
+        // the four weight (+ bias) gradients of every layer of this call: one launch on the side stream
+        std::vector<const void*> vdy, vx;
+        std::vector<void*> vdw, vdb;
+        std::vector<int64_t> vN, vK;
+        for (int l = layer_end - 1; l >= layer_begin; --l) {
+            const UniterLayerParams& Pg = layers[l];
+            char* Ag = (char*)acts + (size_t)l * al.total;
+            const char* xg = (l == layer_begin) ? (const char*)x_in : ((char*)acts + (size_t)(l - 1) * al.total + al.y);
+            char* set = stage_of(l);
+            const void* gdy[4] = {set + sset.dd, set + sset.dpre, set + sset.dd1, set + sset.dqkv};
+            const void* gx[4] = {Ag + al.g, Ag + al.a, Ag + al.ctx, xg};
+            void* gdw[4] = {Pg.g_w2, Pg.g_w1, Pg.g_wo, Pg.g_wqkv};
+            void* gdb[4] = {Pg.g_b2, Pg.g_b1, Pg.g_bo, Pg.g_bqkv};
+            const int64_t gN[4] = {H, I, H, 3 * H}, gK[4] = {I, H, H, H};
+            for (int q = 0; q < 4; ++q) {
+                vdy.push_back(gdy[q]); vx.push_back(gx[q]); vdw.push_back(gdw[q]); vdb.push_back(gdb[q]);
+                vN.push_back(gN[q]); vK.push_back(gK[q]);
+            }
+        }
+        RC(fork(3));
+        const int mrc = uh::gemm_wgrad_multi((int)vdy.size(), vdy.data(), vx.data(), vdw.data(), vdb.data(), T, vN.data(), vK.data(), 1, ss);
+        if (mrc != 0) {
+            if (mrc == 1) uh_set_error("encoder backward: the deferred weight-gradient launch does not fit these shapes");
+            return mrc == 1 ? -1 : mrc;
+        }
+        UH_CHECK_HIP(hipEventRecord(g_stage.busy[stage_half], ss));
+        g_stage.pending[stage_half] = true;
+    }
     if (side) {
         if (g_side.defer_request) {
             // the caller continues with the next range of layers right away and joins later (uniter_encoder_side_join):
@@ -409,8 +503,31 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
     return 0;
 }
 
+size_t uniter_encoder_wgrad_stage_bytes(const UniterEncoderShape* s, int32_t n_layers) {
+    if (check_shape(s) || n_layers <= 0) return 0;
+    return (size_t)n_layers * stage_set(*s).total;
+}
+
+int uniter_encoder_set_wgrad_stage(void* buf, size_t bytes) {
+    g_stage.buf = (char*)buf;
+    g_stage.bytes = buf != nullptr ? bytes : 0;
+    return 0;
+}
+
 int uniter_encoder_defer_side_join(int enable) {
     g_side.defer_request = enable != 0;
+    return 0;
+}
+
+int uniter_encoder_side_join_all(void* stream) {
+    int dev = 0;
+    UH_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_side_registry_mu);
+    for (SideStream* p : g_side_registry) {
+        if (p->stream == nullptr || p->device != dev || !p->deferred) continue;
+        UH_CHECK_HIP(hipEventRecord(p->done, p->stream));
+        UH_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, p->done, 0));
+    }
     return 0;
 }
 
@@ -447,7 +564,9 @@ int uniter_encoder_autotune(const UniterEncoderShape* s, void* stream) {
     char *acts = nullptr, *scratch = nullptr, *prm = nullptr, *grd = nullptr, *io = nullptr;
     float* mask = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    char* tune_stage_free = nullptr;
     auto cleanup = [&]() {
+        if (tune_stage_free) { (void)hipDeviceSynchronize(); (void)hipFree(tune_stage_free); }
         if (acts) (void)hipFree(acts);
         if (scratch) (void)hipFree(scratch);
         if (prm) (void)hipFree(prm);
@@ -464,6 +583,18 @@ int uniter_encoder_autotune(const UniterEncoderShape* s, void* stream) {
     TN_HIP(hipMalloc((void**)&grd, per * 2 * NL));
     TN_HIP(hipMalloc((void**)&io, xb * 3));
     TN_HIP(hipMalloc((void**)&mask, (size_t)s->B * s->L * 4));
+    // the stack is timed the way training runs it: with the weight gradients deferred to one launch per call when a stage
+    // would be registered (the data-gradient chain then has the chip to itself, which changes its best tiles)
+    const WgradStage saved_stage = g_stage;
+    char* tune_stage = nullptr;
+    if (g_group_wgrad && g_wgrad_multi && H % 256 == 0 && I % 256 == 0 && T % 64 == 0 && T >= 64) {
+        const size_t stb = (size_t)NL * stage_set(*s).total;
+        TN_HIP(hipMalloc((void**)&tune_stage, stb));
+        g_stage = WgradStage{};
+        g_stage.buf = tune_stage;
+        g_stage.bytes = stb;
+        tune_stage_free = tune_stage;
+    }
     TN_HIP(hipMemsetAsync(prm, 0x3c, per * 2 * NL, st));        // bf16 0x3c3c = 0.0115: finite, non-zero
     TN_HIP(hipMemsetAsync(grd, 0, per * 2 * NL, st));
     TN_HIP(hipMemsetAsync(io, 0x3c, xb * 3, st));
@@ -528,6 +659,12 @@ int uniter_encoder_autotune(const UniterEncoderShape* s, void* stream) {
         if (!changed) break;
     }
 #undef TN_HIP
+    if (tune_stage != nullptr) {
+        (void)hipStreamSynchronize(st);
+        for (int k = 0; k < 2; ++k)
+            if (g_stage.busy[k]) (void)hipEventDestroy(g_stage.busy[k]);
+        g_stage = saved_stage;
+    }
     cleanup();
     return rc;
 }

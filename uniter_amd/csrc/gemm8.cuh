@@ -809,6 +809,45 @@ __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_group_kernel(const G8Grou
     gemm8_tile<true, true, EPI_WGRAD>(p, tm * tiles_n + tn, slice, smem_raw);
 }
 
+// ---- the weight gradients of SEVERAL layers in one launch ----------------------------------------------------------------
+// One layer's four weight gradients are 108 tiles of 256 x 256 — less than half the chip for 48 K tiles.  Nothing downstream
+// needs a weight gradient before the optimizer (or the bucket's allreduce), so the backward pass can keep every layer's dy
+// operands and hand ALL of them over at once: 12 layers = 1 296 tiles, five full rounds of 256 CUs on the tile whose K loop
+// runs at 80 % of the matrix pipe, instead of twelve half-filled launches that each fight the data-gradient chain for CUs.
+// The problems (up to 4 per layer) come from a table in device memory; tile order and XCD mapping as gemm8_group_kernel;
+// blocks beyond `gemm_blocks` are the bias-gradient column strips.  meta = tile_start[n+1] followed by strip_start[n+1].
+__global__ __launch_bounds__(G8_THREADS, 2) void gemm8_multi_kernel(const GemmArgs* __restrict__ tbl, const int* __restrict__ meta,
+                                                                    const int n, const int per, const int gemm_blocks) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int b = (int)blockIdx.x;
+    const int* tile_start = meta;
+    const int* strip_start = meta + n + 1;
+    auto find = [&](const int* starts, int v) {             // largest q with starts[q] <= v (starts ascend, starts[0] == 0)
+        int lo = 0, hi = n;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (starts[mid] <= v) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+    if (b >= gemm_blocks) {
+        const int s = b - gemm_blocks;
+        const int q = find(strip_start, s);
+        const GemmArgs p = tbl[q];
+        g8_colsum_strip(p, s - strip_start[q], smem_raw);
+        return;
+    }
+    const int pos = (b & 7) * per + (b >> 3);
+    if (pos >= tile_start[n]) return;
+    const int q = find(tile_start, pos);
+    const GemmArgs p = tbl[q];
+    const int bx = pos - tile_start[q];
+    const int tiles_m = p.M >> 8, tiles_n = p.N >> 8;
+    const int tm = tiles_n >= tiles_m ? bx % tiles_m : bx / tiles_n;      // longer tile dimension outermost
+    const int tn = tiles_n >= tiles_m ? bx / tiles_m : bx % tiles_n;
+    gemm8_tile<true, true, EPI_WGRAD>(p, tm * tiles_n + tn, 0, smem_raw);
+}
+
 __global__ __launch_bounds__(G8_THREADS, 2) void gemm6_group_kernel(const G8GroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int b = (int)blockIdx.x;

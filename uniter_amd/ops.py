@@ -124,6 +124,22 @@ def ensure_grad(p):
 
 
 _scratch_cache = {}
+_WGRAD_STAGE = os.environ.get("UNITER_AMD_WGRAD_STAGE", "1") != "0"     # 0: never register a stage (per-layer weight-gradient launches)
+
+
+class DeferWgradJoin(object):
+    """Set as `model.uniter.encoder.grad_ready_hook` by a TRAINING LOOP (uniter_amd/train.py) of a single process: encoder
+    backward calls then return WITHOUT making the compute stream wait for the library's weight-gradient stream, so that what
+    autograd runs next (the embedding backward) overlaps the deferred weight-gradient launch.  Contract: nothing reads or
+    writes an encoder weight gradient until `_lib.join_wgrads()` has run on the stream — uniter_amd.optim.AdamW does it at the
+    start of grad_norm() / step() / zero_grad().  Without it `.grad` is complete on the compute stream when backward() returns,
+    as in PyTorch.  (A data-parallel GradientReducer installs its own hook and joins per bucket.)"""
+    ready_layers = frozenset()
+    joins_side_stream = False
+    defer_wgrad_join = True
+
+    def __call__(self, layer_index):
+        return None
 
 
 def _scratch(key, nbytes, device):
@@ -459,6 +475,16 @@ class _EncoderFn(torch.autograd.Function):
                 x_in = ctx.acts.data_ptr() + (begin - 1) * act_bytes + out_off
             if defer:
                 C.uniter_encoder_defer_side_join(1 if begin > 0 else 0)
+            elif getattr(hook, "defer_wgrad_join", False) and os.environ.get("UNITER_AMD_DEFER_WGRAD_JOIN", "1") != "0":
+                C.uniter_encoder_defer_side_join(1)
+                _lib.hold_until_wgrad_join(ctx.acts, xc)          # the launch still reads them after this call returns
+            # deferred weight gradients (include/uniter_hip.h): one set of dy buffers per layer of this call; twice that when
+            # the stack is cut into several calls, so that consecutive ranges alternate halves of the stage
+            n_call = end - begin
+            st_bytes = C.uniter_encoder_wgrad_stage_bytes(ctypes.byref(s), n_call) * (1 if (begin == 0 and end == n) else 2)
+            if st_bytes > 0 and _WGRAD_STAGE:
+                stage = _scratch(("enc_wgrad_stage", xc.device.index), st_bytes, xc.device)
+                C.uniter_encoder_set_wgrad_stage(ptr(stage), st_bytes)
             C.uniter_encoder_backward(ctypes.byref(s), table, begin, end, x_in,
                                       None if ctx.packed is not None else ptr(mask_bias), ptr(dy), ptr(dx),
                                       ptr(ctx.acts), ptr(scratch), ctx.seed, ctx.off, st)

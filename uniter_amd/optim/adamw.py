@@ -257,6 +257,7 @@ class AdamW(Optimizer):
     def grad_norm(self, max_norm=0.0, grad_scale=1.0):
         """Global L2 norm of all gradients times `grad_scale`, as a 0-dim device tensor (no sync), and arm the fused
         clipping coefficient `grad_scale * min(1, max_norm / (norm + 1e-6))` for the next step()."""
+        _lib.join_wgrads()                # weight gradients a training loop left in flight (ops.defer_wgrad_join)
         if not self._ensure_plan():
             return torch.zeros((), device='cuda')
         dev = self._plan_groups[0][1][0].device
@@ -316,6 +317,7 @@ class AdamW(Optimizer):
         loss = None
         if closure is not None:
             loss = closure()
+        _lib.join_wgrads()
         if not self._ensure_plan(in_step=True):
             return loss           # nothing has a gradient: no-op, like the reference's dummy first step (pretrain.py:261-263)
         self._grads_zeroed = False    # whatever an earlier fused step zeroed has been written again by the backward in between
@@ -357,6 +359,7 @@ class AdamW(Optimizer):
     def zero_grad(self, set_to_none=False):
         """Zero the gradients IN PLACE by default: the kernels accumulate into `.grad` storages that may be views of
         one flat arena (utils.arena), which must survive the step."""
+        _lib.join_wgrads()
         if set_to_none:
             self.synchronize()
             self._grads_zeroed = False

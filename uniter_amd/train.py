@@ -128,6 +128,11 @@ class StepRunner(object):
             if 'feat_targets' in b:
                 b['feat_targets'] = b['feat_targets'].to(torch.bfloat16)
             self.batches[t] = b
+        if self.reducer is None:
+            # single process: the backward call returns without joining the weight-gradient stream; clip_grad_norm_ / step join
+            # it (uniter_amd.optim.AdamW), so the embedding backward overlaps the deferred weight-gradient launch
+            from . import ops as _ops
+            self.model.uniter.encoder.grad_ready_hook = _ops.DeferWgradJoin()
         self.pool = [t for t, r in w.get('mix', ((tasks[0], 1),)) for _ in range(int(r))]
         self.rng = random.Random(seed)                                # same draw on every rank (data/loader.py:42-47)
         self.global_step = 0
@@ -214,6 +219,8 @@ class StepRunner(object):
                 e1.record()
             loss.backward()
             if seg is not None:
+                from . import _lib as _l
+                _l.join_wgrads()                                      # the backward segment ends when every weight gradient is written
                 e2.record()
                 seg.append((e0, e1, e2))
         scale = self.reducer.finish() if self.reducer is not None else 1.0
