@@ -969,6 +969,86 @@ static int load_tuned_json(const char* path) {
     return cnt;
 }
 
+// Deferred weight gradients (uniter_encoder_set_wgrad_stage: one launch for all layers of a backward call, also as two calls
+// that alternate halves of a double-size stage) against the per-layer grouped launches: every parameter gradient of every
+// layer and the input gradient, same inputs, dropout on, gradients zeroed before each run.
+static void test_deferred_wgrad(int B, int L, int H, int heads, int I, int layers) {
+    const int64_t T = (int64_t)B * L;
+    HostBf X, DYh;
+    X.fill((size_t)T * H, 1.f); DYh.fill((size_t)T * H, 1.f);
+    uint16_t *dX = upload(X), *dY = upload(DYh);
+    UniterEncoderShape sh{B, L, H, heads, I, 0.1f, 0.1f, 1e-12f, 1};
+    const size_t act = uniter_encoder_layer_act_bytes(&sh), scr = uniter_encoder_scratch_bytes(&sh);
+    char* acts = dalloc<char>(act * layers);
+    char* scratch = dalloc<char>(scr);
+    const size_t per = (size_t)3 * H * H + 3 * H + (size_t)H * H + H + 2 * H + (size_t)I * H + I + (size_t)H * I + H + 2 * H;
+    HostBf P;
+    P.fill(per, 0.05f);
+    std::vector<UniterLayerParams> lp(layers);
+    std::vector<uint16_t*> gbase(layers);
+    for (int l = 0; l < layers; ++l) {
+        uint16_t* p = upload(P);
+        uint16_t* g = dalloc<uint16_t>(per);
+        gbase[l] = g;
+        size_t o = 0;
+        auto nxt = [&](size_t n) { size_t r = o; o += n; return r; };
+        size_t o_wqkv = nxt((size_t)3 * H * H), o_bqkv = nxt(3 * H), o_wo = nxt((size_t)H * H), o_bo = nxt(H), o_g1 = nxt(H), o_b1n = nxt(H);
+        size_t o_w1 = nxt((size_t)I * H), o_b1 = nxt(I), o_w2 = nxt((size_t)H * I), o_b2 = nxt(H), o_g2 = nxt(H), o_b2n = nxt(H);
+        lp[l] = UniterLayerParams{p + o_wqkv, p + o_bqkv, p + o_wo, p + o_bo, p + o_g1, p + o_b1n, p + o_w1, p + o_b1, p + o_w2, p + o_b2, p + o_g2, p + o_b2n,
+                                  g + o_wqkv, g + o_bqkv, g + o_wo, g + o_bo, g + o_g1, g + o_b1n, g + o_w1, g + o_b1, g + o_w2, g + o_b2, g + o_g2, g + o_b2n};
+    }
+    float* dMask = dalloc<float>((size_t)B * L);
+    HIPCHK(hipMemset(dMask, 0, (size_t)B * L * 4));
+    uint16_t* dDx = dalloc<uint16_t>((size_t)T * H);
+    uint16_t* dMid = dalloc<uint16_t>((size_t)T * H);
+    const size_t stb = uniter_encoder_wgrad_stage_bytes(&sh, layers);
+    char* stage = dalloc<char>(2 * stb);
+    UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 7, 3, 0));
+    const size_t out_off = uniter_encoder_layer_out_offset(&sh);
+    std::vector<std::vector<float>> ref(layers);
+    std::vector<float> ref_dx;
+    const char* names[3] = {"per-layer grouped launches (no stage)", "one deferred launch for the whole call", "two calls alternating halves of the stage"};
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int l = 0; l < layers; ++l) HIPCHK(hipMemset(gbase[l], 0, per * 2));
+        if (pass == 0) UHCHK(uniter_encoder_set_wgrad_stage(nullptr, 0));
+        if (pass == 1) UHCHK(uniter_encoder_set_wgrad_stage(stage, stb));
+        if (pass < 2) {
+            UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 7, 3, 0));
+        } else {                                            // the stack cut in two ranges, as a gradient-bucket hook does
+            const int cut = layers / 2;
+            const size_t half_bytes = 2 * uniter_encoder_wgrad_stage_bytes(&sh, layers - cut);
+            UHCHK(uniter_encoder_set_wgrad_stage(stage, half_bytes));
+            UHCHK(uniter_encoder_backward(&sh, lp.data(), cut, layers, acts + (size_t)(cut - 1) * act + out_off, dMask, dY, dMid, acts, scratch, 7, 3, 0));
+            UHCHK(uniter_encoder_set_wgrad_stage(stage, 2 * uniter_encoder_wgrad_stage_bytes(&sh, cut)));
+            UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, cut, dX, dMask, dMid, dDx, acts, scratch, 7, 3, 0));
+        }
+        HIPCHK(hipDeviceSynchronize());
+        size_t nbad = 0;
+        double maxd = 0, maxr = 0;
+        for (int l = 0; l < layers; ++l) {
+            std::vector<float> got = download_bf(gbase[l], per);
+            if (pass == 0) { ref[l] = got; continue; }
+            for (size_t k = 0; k < per; ++k) maxr = std::max(maxr, fabs((double)ref[l][k]));
+            for (size_t k = 0; k < per; ++k) {
+                const double d = fabs((double)got[k] - ref[l][k]);
+                maxd = std::max(maxd, d);
+                if (!(d <= 0.02 * fabs(ref[l][k]) + 0.004 * maxr + 1e-6)) ++nbad;
+            }
+        }
+        std::vector<float> dxv = download_bf(dDx, (size_t)T * H);
+        if (pass == 0) { ref_dx = dxv; continue; }
+        size_t ndx = 0;
+        for (size_t k = 0; k < dxv.size(); ++k) if (dxv[k] != ref_dx[k]) ++ndx;          // the data-gradient chain is untouched: bit-identical
+        printf("[%s] deferred weight gradients, %s (B%d L%d H%d I%d, %d layers) == %s: max |d| %.4g of max |ref| %.4g, %zu outside tolerance; dx differs in %zu elements\n",
+               (nbad || ndx) ? "FAIL" : " OK ", names[pass], B, L, H, I, layers, names[0], maxd, maxr, nbad, ndx);
+        if (nbad || ndx) ++g_fail;
+    }
+    UHCHK(uniter_encoder_set_wgrad_stage(nullptr, 0));
+    for (int l = 0; l < layers; ++l) { HIPCHK(hipFree(gbase[l])); HIPCHK(hipFree((void*)lp[l].wqkv)); }
+    HIPCHK(hipFree(acts)); HIPCHK(hipFree(scratch)); HIPCHK(hipFree(dX)); HIPCHK(hipFree(dY)); HIPCHK(hipFree(dMask)); HIPCHK(hipFree(dDx));
+    HIPCHK(hipFree(dMid)); HIPCHK(hipFree(stage));
+}
+
 static void bench_encoder(int B, int L, int H, int heads, int I, int layers) {
     printf("== encoder B%d L%d H%d I%d layers%d ==\n", B, L, H, I, layers);
     const int64_t T = (int64_t)B * L;
@@ -1490,6 +1570,9 @@ int main(int argc, char** argv) {
     test_layernorm(300, 768, 0.2f, 1);
     test_layernorm(129, 1024, 0.f, 0);
     test_layernorm(64, 2048, 0.1f, 0);
+    printf("== deferred weight gradients ==\n");
+    test_deferred_wgrad(4, 64, 256, 4, 512, 4);
+    test_deferred_wgrad(2, 96, 768, 12, 3072, 3);
     printf("== adamw ==\n");
     test_adamw();
     if (do_bench) {

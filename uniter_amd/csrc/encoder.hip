@@ -135,6 +135,7 @@ struct WgradStage {
     char* buf = nullptr;
     size_t bytes = 0;
     int toggle = 0;
+    int last_nl = 0;                              // layers of the previous call: the halves only tile the stage for equal calls
     hipEvent_t busy[2] = {nullptr, nullptr};      // recorded on the side stream after the multi launch that read half k
     bool pending[2] = {false, false};
 };
@@ -293,10 +294,12 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
             if (g_stage.busy[k] == nullptr) UH_CHECK_HIP(hipEventCreateWithFlags(&g_stage.busy[k], hipEventDisableTiming));
         const bool two = g_stage.bytes >= 2 * (size_t)nl * sset.total;
         stage_half = two ? (g_stage.toggle ^= 1) : 0;
-        if (g_stage.pending[stage_half]) {          // the launch that last read this half of the stage must be through
-            UH_CHECK_HIP(hipStreamWaitEvent(st, g_stage.busy[stage_half], 0));
-            g_stage.pending[stage_half] = false;
+        for (int k = 0; k < 2; ++k) {               // the launch that last read this half of the stage must be through; after a
+            if (!g_stage.pending[k] || (k != stage_half && nl == g_stage.last_nl)) continue;   // call of another size the halves
+            UH_CHECK_HIP(hipStreamWaitEvent(st, g_stage.busy[k], 0));                           // overlap differently: wait for both
+            g_stage.pending[k] = false;
         }
+        g_stage.last_nl = nl;
     }
     auto stage_of = [&](int l) { return g_stage.buf + ((size_t)stage_half * (size_t)nl + (size_t)(l - layer_begin)) * sset.total; };
     // Event slots (main_ev[k]: "inputs of side job k are ready", side_ev[k]: "side job k has read its inputs"):
