@@ -402,8 +402,9 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
  * bucket's allreduce), and one layer's four weight gradients fill less than half of an MI355X.  When the calling thread has
  * registered a stage of at least uniter_encoder_wgrad_stage_bytes(s, layer_end - layer_begin) bytes, uniter_encoder_backward
  * keeps the dy operands of EVERY layer of the call there (one set per layer: the gradients w.r.t. the outputs of the four
- * nn.Linear of model/layer.py:64-66,112,140,153) and computes all their weight + bias gradients in ONE launch at the end of the
- * call (hidden and intermediate sizes must be multiples of 256, the token count a multiple of 64; otherwise — and during
+ * nn.Linear of model/layer.py:64-66,112,140,153 and the inputs of the two LayerNorm backward passes) and computes all their weight
+ * + bias gradients and the LayerNorm weight / bias gradients in ONE launch at the end of the call (which also reads the caller's
+ * dy: keep it valid until the weight-gradient stream has been joined) (hidden and intermediate sizes must be multiples of 256, the token count a multiple of 64; otherwise — and during
  * stream capture, or with UNITER_AMD_WGRAD_MULTI=0 — the per-layer grouped launches run as before).  A stage of twice that size
  * lets consecutive calls (layer ranges of one backward) alternate halves instead of waiting for each other's launch.  The
  * registration is per calling thread (autograd runs backward on its own thread) and is read at the start of each call;

@@ -141,7 +141,7 @@ struct WgradStage {
 };
 thread_local WgradStage g_stage;
 int g_wgrad_multi = [] { const char* e = getenv("UNITER_AMD_WGRAD_MULTI"); return e ? atoi(e) : 1; }();
-struct StageSet { size_t dd, dd1, dqkv, dpre, total; };
+struct StageSet { size_t dd, dd1, dqkv, dpre, dy2, dy1, total; };
 StageSet stage_set(const UniterEncoderShape& s) {
     const size_t T = tokens(s), H = s.H, I = s.I;
     StageSet l{};
@@ -151,6 +151,10 @@ StageSet stage_set(const UniterEncoderShape& s) {
     l.dd1 = take(T * H * 2);
     l.dqkv = take(T * 3 * H * 2);
     l.dpre = take(T * I * 2);
+    // the inputs of the two LayerNorm backward passes — what the data-gradient GEMMs of the layer above / of this layer's FFN
+    // write anyway: kept per layer, they let the LayerNorm parameter gradients (dgamma, dbeta) ride on the deferred launch too
+    l.dy2 = take(T * H * 2);
+    l.dy1 = take(T * H * 2);
     l.total = o;
     return l;
 }
@@ -370,13 +374,16 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         char* ddb1 = defer_wg ? stage_of(l) + sset.dd1 : S + sl.dd1[par];
         char* dpre = defer_wg ? stage_of(l) + sset.dpre : S + sl.dpre[par];
         char* dqkv = defer_wg ? stage_of(l) + sset.dqkv : S + sl.dqkv[par];
+        // deferred mode: da (input of the attention block's LayerNorm backward) and this layer's dx (input of the LayerNorm
+        // backward of the layer below) go to their own per-layer buffers instead of the recycled bufB
+        char* dab = defer_wg ? stage_of(l) + sset.dy1 : bufB;
 
         // ---- BertOutput backward (model/layer.py:152-156) ----
         // LayerNorm backward is split: the row half (dz, dd) stays on the critical path, the column sums
         // (dgamma, dbeta and the dense bias gradient) go to the side stream.  dd is always materialised (a copy of dz
         // when there is no dropout) so that the weight-gradient work can read it after bufA has moved on.
         RC(before_overwrite(par));                 // weight gradients of layer l+2 used this buffer set
-        const bool lnf = g_ln_fused != 0 && grouped;
+        const bool lnf = g_ln_fused != 0 && grouped && !defer_wg;
         if (lnf) {
             int nbp = 0;
             RC(before_overwrite(4));               // the finalize of the previous LayerNorm still reads `red`
@@ -390,11 +397,13 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         RC(uh::layernorm_bwd_rows(dyl, nullptr, A + al.z2, (const float*)(A + al.mean2), (const float*)(A + al.rstd2),
                                   P.ln2_g, bufA, ddb2, T, H, d_h2, 0, st));
         RC(tick());
+        if (!defer_wg) {                       // (deferred: dgamma / dbeta come out of the one launch at the end of the call)
         RC(fork(4));
         RC(uh::layernorm_bwd_cols(dyl, nullptr, A + al.z2, (const float*)(A + al.mean2), (const float*)(A + al.rstd2),
                                   bufA, ddb2, P.g_ln2_g, P.g_ln2_b, grouped ? nullptr : P.g_b2, T, H, 1, d_h2, 0,
                                   side ? red2 : red, sl.red_bytes, ss));
         RC(joined(4));                         // dyl (bufB below the top layer) has been read
+        }
         }
         if (!grouped) {
             RC(uh::gemm_wgrad(ddb2, A + al.g, P.g_w2, T, H, I, 1, wg, sl.wg_bytes, ss));
@@ -410,7 +419,7 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
             RC(joined(par));
         }
         RC(before_overwrite(4));               // bufB is about to receive da
-        RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dpre, P.w1, bufA, bufB, T, I, H, st));          // da = dpre*W1 + dz2
+        RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dpre, P.w1, bufA, dab, T, I, H, st));           // da = dpre*W1 + dz2
         RC(tick());
         // ---- BertSelfOutput backward (model/layer.py:111-115) ----
         if (lnf) {
@@ -423,14 +432,16 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
             RC(uh::layernorm_bwd_fused_finalize(red2, nbp, P.g_ln1_g, P.g_ln1_b, H, 1, ss));
             RC(joined(5));
         } else {
-        RC(uh::layernorm_bwd_rows(bufB, nullptr, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1),
+        RC(uh::layernorm_bwd_rows(dab, nullptr, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1),
                                   P.ln1_g, bufA, ddb1, T, H, d_h1, 0, st));
         RC(tick());
+        if (!defer_wg) {
         RC(fork(5));
-        RC(uh::layernorm_bwd_cols(bufB, nullptr, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1),
+        RC(uh::layernorm_bwd_cols(dab, nullptr, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1),
                                   bufA, ddb1, P.g_ln1_g, P.g_ln1_b, grouped ? nullptr : P.g_bo, T, H, 1, d_h1, 0,
                                   side ? red2 : red, sl.red_bytes, ss));
         RC(joined(5));                         // bufB (da) has been read
+        }
         }
         if (!grouped) {
             RC(uh::gemm_wgrad(ddb1, A + al.ctx, P.g_wo, T, H, H, 1, wg, sl.wg_bytes, ss));
@@ -455,7 +466,7 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
             RC(uh::gemm_wgrad(dqkv, xin, P.g_wqkv, T, 3 * H, H, 1, wg, sl.wg_bytes, ss));
             RC(joined(par));
         }
-        char* dxl = (l == layer_begin) ? (char*)dx : bufB;
+        char* dxl = (l == layer_begin) ? (char*)dx : (defer_wg ? stage_of(l - 1) + sset.dy2 : bufB);
         RC(before_overwrite(5));               // bufB is about to receive this layer's dx
         RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dqkv, P.wqkv, bufA, dxl, T, 3 * H, H, st));     // dx = dqkv*Wqkv + dz1
         RC(tick());
@@ -482,8 +493,19 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
                 vN.push_back(gN[q]); vK.push_back(gK[q]);
             }
         }
+        // ... and the parameter gradients of both LayerNorms of every layer (column sums of dy * xhat and dy)
+        std::vector<uh::LnColsJob> ln;
+        for (int l = layer_end - 1; l >= layer_begin; --l) {
+            const UniterLayerParams& Pg = layers[l];
+            char* Ag = (char*)acts + (size_t)l * al.total;
+            const void* dy2 = (l == layer_end - 1) ? dy : (const void*)(stage_of(l) + sset.dy2);
+            ln.push_back(uh::LnColsJob{dy2, Ag + al.z2, (const float*)(Ag + al.mean2), (const float*)(Ag + al.rstd2), Pg.g_ln2_g, Pg.g_ln2_b, T, H});
+            ln.push_back(uh::LnColsJob{stage_of(l) + sset.dy1, Ag + al.z1, (const float*)(Ag + al.mean1), (const float*)(Ag + al.rstd1), Pg.g_ln1_g,
+                                       Pg.g_ln1_b, T, H});
+        }
         RC(fork(3));
-        const int mrc = uh::gemm_wgrad_multi((int)vdy.size(), vdy.data(), vx.data(), vdw.data(), vdb.data(), T, vN.data(), vK.data(), 1, ss);
+        const int mrc = uh::gemm_wgrad_multi((int)vdy.size(), vdy.data(), vx.data(), vdw.data(), vdb.data(), T, vN.data(), vK.data(), 1, ss,
+                                             (int)ln.size(), ln.data());
         if (mrc != 0) {
             if (mrc == 1) uh_set_error("encoder backward: the deferred weight-gradient launch does not fit these shapes");
             return mrc == 1 ? -1 : mrc;

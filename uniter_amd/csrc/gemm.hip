@@ -1286,7 +1286,7 @@ thread_local MultiState g_multi;
 }  // namespace
 
 int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* const* dw, void* const* db, int64_t M,
-                     const int64_t* N, const int64_t* K, int accumulate, hipStream_t st) {
+                     const int64_t* N, const int64_t* K, int accumulate, hipStream_t st, int n_ln, const LnColsJob* ln) {
     if (n < 1 || n > 128) { uh_set_error("gemm_wgrad_multi: 1..128 problems"); return -1; }
     if (M % 64 != 0 || M < 64) return 1;
     for (int q = 0; q < n; ++q)
@@ -1317,11 +1317,22 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
     }
     meta[(size_t)n] = tiles;
     meta[(size_t)(2 * n + 1)] = strips;
+    if (n_ln < 0 || (n_ln > 0 && ln == nullptr)) { uh_set_error("gemm_wgrad_multi: bad LayerNorm job list"); return -1; }
+    std::vector<G8LnJob> jobs((size_t)n_ln);
+    int ln_strips_per_job = 1;
+    for (int k = 0; k < n_ln; ++k) {
+        if (ln[k].H != ln[0].H || ln[k].H % 8 != 0 || ln[k].rows <= 0) { uh_set_error("gemm_wgrad_multi: LayerNorm jobs must share H (a multiple of 8)"); return -1; }
+        jobs[(size_t)k] = G8LnJob{(const bf16_t*)ln[k].dy, (const bf16_t*)ln[k].z, ln[k].mean, ln[k].rstd, (bf16_t*)ln[k].dgamma,
+                                  (bf16_t*)ln[k].dbeta, (int)ln[k].rows, (int)ln[k].H, accumulate, 0};
+        ln_strips_per_job = (int)((ln[k].H + 255) / 256);
+    }
     const size_t tbl_bytes = tbl.size() * sizeof(GemmArgs), meta_off = (tbl_bytes + 255) & ~(size_t)255;
-    const size_t bytes = meta_off + meta.size() * sizeof(int);
+    const size_t ln_off = (meta_off + meta.size() * sizeof(int) + 255) & ~(size_t)255;
+    const size_t bytes = ln_off + jobs.size() * sizeof(G8LnJob);
     std::vector<char> img(bytes, 0);
     memcpy(img.data(), tbl.data(), tbl_bytes);
     memcpy(img.data() + meta_off, meta.data(), meta.size() * sizeof(int));
+    if (n_ln > 0) memcpy(img.data() + ln_off, jobs.data(), jobs.size() * sizeof(G8LnJob));
     int dev = 0;
     UH_CHECK_HIP(hipGetDevice(&dev));
     MultiTable& T = g_multi.tables[std::make_pair(dev, (uint64_t)(uintptr_t)dw[0])];
@@ -1358,8 +1369,9 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
         attr_done = true;
     }
     LaunchTimer lt(TIME_GEMM_WGRAD_GROUP, M, welems, n, st);
-    hipLaunchKernelGGL(gemm8_multi_kernel, dim3(gemm_blocks + strips), dim3(G8_THREADS), G8_LDS_BYTES, st,
-                       (const GemmArgs*)T.dev, (const int*)((const char*)T.dev + meta_off), n, per, gemm_blocks);
+    hipLaunchKernelGGL(gemm8_multi_kernel, dim3(gemm_blocks + strips + n_ln * ln_strips_per_job), dim3(G8_THREADS), G8_LDS_BYTES, st,
+                       (const GemmArgs*)T.dev, (const int*)((const char*)T.dev + meta_off), n, per, gemm_blocks,
+                       (const G8LnJob*)((const char*)T.dev + ln_off), ln_strips_per_job, strips);
     UH_LAUNCH_CHECK();
     return 0;
 }

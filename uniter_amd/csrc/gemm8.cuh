@@ -816,8 +816,75 @@ __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_group_kernel(const G8Grou
 // runs at 80 % of the matrix pipe, instead of twelve half-filled launches that each fight the data-gradient chain for CUs.
 // The problems (up to 4 per layer) come from a table in device memory; tile order and XCD mapping as gemm8_group_kernel;
 // blocks beyond `gemm_blocks` are the bias-gradient column strips.  meta = tile_start[n+1] followed by strip_start[n+1].
+// A LayerNorm's parameter gradients as one more kind of column strip of the multi launch: dgamma[c] (+)= sum_t dy[t][c] * xhat[t][c],
+// dbeta[c] (+)= sum_t dy[t][c] with xhat = (z - mean[t]) * rstd[t] (model/layer.py:108,149: BertLayerNorm backward, parameter half;
+// the row half stays in layernorm.hip on the critical path).  Strips of 256 columns, thread = (row lane, 8-column chunk).
+struct G8LnJob {
+    const bf16_t* dy;
+    const bf16_t* z;
+    const float* mean;
+    const float* rstd;
+    bf16_t* dgamma;
+    bf16_t* dbeta;
+    int rows, H;
+    int accumulate, pad;
+};
+__device__ __forceinline__ void g8_ln_cols_strip(const G8LnJob& j, const int strip, char* smem_raw) {
+    const int t = threadIdx.x;
+    const int cc = t & 31, rl = t >> 5;
+    const int col = strip * 256 + cc * 8;
+    float ag[8], ab[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ag[e] = 0.f; ab[e] = 0.f; }
+    if (col < j.H) {
+        int r = rl;
+        for (; r + 16 < j.rows; r += 32) {                  // two rows in flight per thread
+            const u32x4 d0 = *reinterpret_cast<const u32x4*>(j.dy + (int64_t)r * j.H + col);
+            const u32x4 z0 = *reinterpret_cast<const u32x4*>(j.z + (int64_t)r * j.H + col);
+            const u32x4 d1 = *reinterpret_cast<const u32x4*>(j.dy + (int64_t)(r + 16) * j.H + col);
+            const u32x4 z1 = *reinterpret_cast<const u32x4*>(j.z + (int64_t)(r + 16) * j.H + col);
+            const float m0 = j.mean[r], s0 = j.rstd[r], m1 = j.mean[r + 16], s1 = j.rstd[r + 16];
+            float dv[8], zv[8];
+            unpack8(d0, dv); unpack8(z0, zv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ag[e] += dv[e] * ((zv[e] - m0) * s0); ab[e] += dv[e]; }
+            unpack8(d1, dv); unpack8(z1, zv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ag[e] += dv[e] * ((zv[e] - m1) * s1); ab[e] += dv[e]; }
+        }
+        for (; r < j.rows; r += 16) {
+            float dv[8], zv[8];
+            unpack8(*reinterpret_cast<const u32x4*>(j.dy + (int64_t)r * j.H + col), dv);
+            unpack8(*reinterpret_cast<const u32x4*>(j.z + (int64_t)r * j.H + col), zv);
+            const float m0 = j.mean[r], s0 = j.rstd[r];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ag[e] += dv[e] * ((zv[e] - m0) * s0); ab[e] += dv[e]; }
+        }
+    }
+    float* red = reinterpret_cast<float*>(smem_raw);        // [2][16][256]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[rl * 256 + cc * 8 + e] = ag[e]; red[16 * 256 + rl * 256 + cc * 8 + e] = ab[e]; }
+    __syncthreads();
+    {
+        const int k = t >> 8, c = t & 255;                  // threads 0-255: dgamma, 256-511: dbeta
+        if (strip * 256 + c < j.H) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) tot += red[k * 16 * 256 + w * 256 + c];
+            bf16_t* base = k == 0 ? j.dgamma : j.dbeta;
+            if (base != nullptr) {
+                bf16_t* dst = base + strip * 256 + c;
+                if (j.accumulate) tot += bf2f(*dst);
+                *dst = f2bf(tot);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_multi_kernel(const GemmArgs* __restrict__ tbl, const int* __restrict__ meta,
-                                                                    const int n, const int per, const int gemm_blocks) {
+                                                                    const int n, const int per, const int gemm_blocks,
+                                                                    const G8LnJob* __restrict__ ln_jobs, const int ln_strips_per_job,
+                                                                    const int bias_strips) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int b = (int)blockIdx.x;
     const int* tile_start = meta;
@@ -830,6 +897,12 @@ __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_multi_kernel(const GemmAr
         }
         return lo;
     };
+    if (b >= gemm_blocks + bias_strips) {                   // LayerNorm parameter gradients
+        const int s = b - gemm_blocks - bias_strips;
+        const G8LnJob j = ln_jobs[s / ln_strips_per_job];
+        g8_ln_cols_strip(j, s % ln_strips_per_job, smem_raw);
+        return;
+    }
     if (b >= gemm_blocks) {
         const int s = b - gemm_blocks;
         const int q = find(strip_start, s);

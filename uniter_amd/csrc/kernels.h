@@ -45,9 +45,11 @@ int gemm_wgrad_group(int n, const void* const* dy, const void* const* x, void* c
                      int splits_override = 0);
 // fp32 slabs of the eight-phase tile's two-slice form (4 bytes per weight element); without it the grouped launch runs one slice
 size_t gemm_wgrad_group_workspace_bytes(int n, const int64_t* N, const int64_t* K);
-// n problems (the weight gradients of several layers) in ONE launch on the 256 x 256 tile; 1 = not applicable (shape, capture)
+// n problems (the weight gradients of several layers) in ONE launch on the 256 x 256 tile; 1 = not applicable (shape, capture).
+// n_ln LayerNorm parameter-gradient jobs (dgamma, dbeta: column sums over `rows` tokens) ride along as extra workgroups.
+struct LnColsJob { const void* dy; const void* z; const float* mean; const float* rstd; void* dgamma; void* dbeta; int64_t rows, H; };
 int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* const* dw, void* const* db, int64_t M,
-                     const int64_t* N, const int64_t* K, int accumulate, hipStream_t st);
+                     const int64_t* N, const int64_t* K, int accumulate, hipStream_t st, int n_ln = 0, const LnColsJob* ln = nullptr);
 int gemm_group_autotune(int n, int64_t M, const int64_t* N, const int64_t* K, hipStream_t st);
 void gemm_debug_force(int cfg, int splits);
 int gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, hipStream_t st);

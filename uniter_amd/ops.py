@@ -457,6 +457,7 @@ class _EncoderFn(torch.autograd.Function):
         # a hook that joins the library's weight-gradient stream itself (uniter_encoder_side_join on its own stream) lets
         # the ranges below follow each other without serialising the two streams at every range boundary
         defer = hook is not None and getattr(hook, "joins_side_stream", False)
+        defer_only = False
         while end > 0:
             inner = [c for c in cuts if c + 1 < end]
             begin = (max(inner) + 1) if inner else 0
@@ -477,7 +478,11 @@ class _EncoderFn(torch.autograd.Function):
                 C.uniter_encoder_defer_side_join(1 if begin > 0 else 0)
             elif getattr(hook, "defer_wgrad_join", False) and os.environ.get("UNITER_AMD_DEFER_WGRAD_JOIN", "1") != "0":
                 C.uniter_encoder_defer_side_join(1)
-                _lib.hold_until_wgrad_join(ctx.acts, xc)          # the launch still reads them after this call returns
+                defer_only = True
+            if defer or defer_only:
+                # the call returns before the deferred launch (which reads the saved activations, the range's input and this
+                # call's dy) has run: keep them alive until the weight-gradient stream is joined (_lib.join_wgrads)
+                _lib.hold_until_wgrad_join(ctx.acts, xc, dy)
             # deferred weight gradients (include/uniter_hip.h): one set of dy buffers per layer of this call; twice that when
             # the stack is cut into several calls, so that consecutive ranges alternate halves of the stage
             n_call = end - begin

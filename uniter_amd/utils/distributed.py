@@ -328,6 +328,10 @@ class GradientReducer(object):
             w.wait()
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
+        if self.arena.grad.is_cuda:
+            from .. import _lib
+            _lib.join_wgrads()           # backward ranges returned without joining the weight-gradient stream (and kept the
+                                         # tensors its deferred launches read alive until now)
         self._pending = []
         self._armed = False
         return 1.0 / float(size())
