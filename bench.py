@@ -461,14 +461,21 @@ def main():
             dom = max(mfma, key=lambda k: k["us_per_step"])
             M, N, K = dom["shape"]
             traffic = pmc_traffic(dom["kind_id"], dom["shape"])
-            roofline = {"bound": "mfma", "kernel": "%s M%d N%d K%d" % (dom["kernel"], M, N, K), "achieved": dom["tflops"],
+            label = "%s M%d N%d K%d" % (dom["kernel"], M, N, K)
+            note = ("in the backward pass this kernel shares the GPU with the wgrad side stream, so the in-situ duration is "
+                    "longer than the kernel alone (DESIGN.md section 5)")
+            if dom["kind_id"] == 13 and K > 4:
+                # the deferred launch: every weight / bias / LayerNorm parameter gradient of one backward call (K problems
+                # = 4 per layer) over M tokens, N = weight elements of all its problems
+                label = "deferred weight gradients of %d layers in one launch (gemm8_multi_kernel): %d tokens x %d weight elements" % (K // 4, M, N)
+                note = ("the launch runs on the library's weight-gradient stream after the backward chain of the call; the "
+                        "embedding backward of the main stream overlaps its tail (DESIGN.md section 9.5)")
+            roofline = {"bound": "mfma", "kernel": label, "achieved": dom["tflops"],
                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4),
                         "traffic": None if traffic is None else traffic["hbm_bytes"],
                         "traffic_detail": traffic,
                         "avg_launch_us": dom["us"], "launches_per_step": dom["launches_per_step"],
-                        "measured": "HIP events around every launch on its own stream during %d extra optimizer steps; in the "
-                                    "backward pass this kernel shares the GPU with the wgrad side stream, so the in-situ "
-                                    "duration is longer than the kernel alone (DESIGN.md section 5)" % tsteps,
+                        "measured": "HIP events around every launch on its own stream during %d extra optimizer steps; %s" % (tsteps, note),
                         "step": {"algorithmic_tflop_per_step": round(flop_step * 1e-12, 4), "achieved": round(step_tf, 1),
                                  "frac": round(step_tf / MFMA_PEAK_TFLOPS, 4),
                                  "note": "encoder fwd+bwd algorithmic FLOP (heads, embeddings, optimizer excluded) / whole step time"}}

@@ -52,8 +52,8 @@ def short(name):
 
 
 def one(pattern):
-    files = glob.glob(pattern)
-    return files[0] if files else None
+    files = glob.glob(pattern)             # gpurun merges into existing directories: take the newest run
+    return max(files, key=os.path.getmtime) if files else None
 
 
 def kernel_stats(src, dst):
@@ -241,6 +241,21 @@ def pmc_traffic(fetch_csv, write_csv, dst):
                 rd = 2.0 * (sum(fv) / len(fv)) * 1024.0
                 wr = (sum(wv) / len(wv)) * 1024.0
                 by_shape["13:%d:%d:4" % (g3[0]["M"], welems)] = {
+                    "kernel": short(name), "grid": grid, "dispatches": len(fv), "shares_template_with": 0,
+                    "hbm_read_bytes": round(rd), "hbm_write_bytes": round(wr), "hbm_bytes": round(rd + wr)}
+        # the deferred launch (gemm8_multi_kernel): every weight / bias / LayerNorm parameter gradient of one backward call.
+        # Timing kind 13 reports it as M tokens, N = weight elements of all its problems, K = problems (4 per layer).
+        if g3 and H and I:
+            layers = int(os.environ.get("UNITER_PROFILE_LAYERS", "12"))
+            for (name, grid), fv in fetch.items():
+                if "gemm8_multi_kernel" not in name:
+                    continue
+                wv = write.get((name, grid), [])
+                if len(fv) < 3 or not wv:
+                    continue
+                rd = 2.0 * (sum(fv) / len(fv)) * 1024.0
+                wr = (sum(wv) / len(wv)) * 1024.0
+                by_shape["13:%d:%d:%d" % (g3[0]["M"], layers * (H * I + I * H + H * H + 3 * H * H), 4 * layers)] = {
                     "kernel": short(name), "grid": grid, "dispatches": len(fv), "shares_template_with": 0,
                     "hbm_read_bytes": round(rd), "hbm_write_bytes": round(wr), "hbm_bytes": round(rd + wr)}
     json.dump({"by_shape": by_shape, "per_kernel": per,

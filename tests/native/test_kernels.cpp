@@ -1032,7 +1032,20 @@ static void test_deferred_wgrad(int B, int L, int H, int heads, int I, int layer
             for (size_t k = 0; k < per; ++k) {
                 const double d = fabs((double)got[k] - ref[l][k]);
                 maxd = std::max(maxd, d);
-                if (!(d <= 0.02 * fabs(ref[l][k]) + 0.004 * maxr + 1e-6)) ++nbad;
+                if (!(d <= 0.02 * fabs(ref[l][k]) + 0.004 * maxr + 1e-6)) {
+                    if (nbad < 12 || (nbad % 397) == 0) {
+                        const size_t seg[13] = {0, (size_t)3 * H * H, (size_t)3 * H * H + 3 * H, (size_t)3 * H * H + 3 * H + (size_t)H * H, (size_t)3 * H * H + 3 * H + (size_t)H * H + H,
+                                                (size_t)3 * H * H + 3 * H + (size_t)H * H + 2 * H, (size_t)3 * H * H + 3 * H + (size_t)H * H + 3 * H,
+                                                (size_t)3 * H * H + 3 * H + (size_t)H * H + 3 * H + (size_t)I * H, (size_t)3 * H * H + 3 * H + (size_t)H * H + 3 * H + (size_t)I * H + I,
+                                                (size_t)3 * H * H + 3 * H + (size_t)H * H + 3 * H + (size_t)I * H + I + (size_t)H * I, (size_t)3 * H * H + 3 * H + (size_t)H * H + 3 * H + (size_t)I * H + I + (size_t)H * I + H,
+                                                (size_t)3 * H * H + 3 * H + (size_t)H * H + 3 * H + (size_t)I * H + I + (size_t)H * I + 2 * H, per};
+                        const char* sn[12] = {"wqkv", "bqkv", "wo", "bo", "ln1.g", "ln1.b", "w1", "b1", "w2", "b2", "ln2.g", "ln2.b"};
+                        int q = 0;
+                        while (q < 11 && k >= seg[q + 1]) ++q;
+                        printf("    layer %d %s[%zu]: got %.4f ref %.4f\n", l, sn[q], k - seg[q], got[k], ref[l][k]);
+                    }
+                    ++nbad;
+                }
             }
         }
         std::vector<float> dxv = download_bf(dDx, (size_t)T * H);
@@ -1491,6 +1504,65 @@ static void on_segv(int) {                 // where did it die: raw return addre
     _exit(139);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// attention alone: forward / backward launch time at a given shape (--attn B L heads p)
+// ---------------------------------------------------------------------------------------------
+static int run_attn(int argc, char** argv, int at) {
+    const int B = at < argc ? atoi(argv[at]) : 32, L = at + 1 < argc ? atoi(argv[at + 1]) : 96, heads = at + 2 < argc ? atoi(argv[at + 2]) : 12;
+    const float p = at + 3 < argc ? (float)atof(argv[at + 3]) : 0.1f;
+    const int H = heads * 64;
+    const size_t T = (size_t)B * L;
+    HostBf QKV, DO;
+    QKV.fill(T * 3 * H, 1.5f); DO.fill(T * H, 1.f);
+    std::vector<float> mask(B * L, 0.f);
+    uint16_t *dQKV = upload(QKV), *dDO = upload(DO);
+    float* dMask = dalloc<float>(B * L);
+    HIPCHK(hipMemcpy(dMask, mask.data(), mask.size() * 4, hipMemcpyHostToDevice));
+    uint16_t* dCtx = dalloc<uint16_t>(T * H);
+    uint16_t* dDQKV = dalloc<uint16_t>(T * 3 * H);
+    float* dLse = dalloc<float>((size_t)B * heads * L);
+    const size_t awsb = uniter_attention_bwd_workspace_bytes(B, L, heads);
+    const size_t stamp_words = (size_t)B * heads * 64;
+    void* aws = dalloc<char>(awsb + 16 + stamp_words * 8);
+    HIPCHK(hipMemset(aws, 0, awsb + 16 + stamp_words * 8));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    auto timeit = [&](const char* what, auto&& fn) {
+        for (int i = 0; i < 5; ++i) fn();
+        float best = 1e9f, sum = 0.f;
+        for (int rep = 0; rep < 5; ++rep) {
+            HIPCHK(hipEventRecord(e0, 0));
+            for (int i = 0; i < 20; ++i) fn();
+            HIPCHK(hipEventRecord(e1, 0));
+            HIPCHK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            best = std::min(best, ms / 20.f); sum += ms / 20.f;
+        }
+        printf("attn %s B%d L%d heads%d p=%.2f: best %.2f us, mean %.2f us (back-to-back launches)\n", what, B, L, heads, p, best * 1e3f, sum / 5.f * 1e3f);
+    };
+    timeit("fwd", [&] { UHCHK(uniter_attention_fwd(dQKV, dMask, dCtx, dLse, B, L, heads, p, 99, 5, 0)); });
+    timeit("bwd", [&] { UHCHK(uniter_attention_bwd_ws(dQKV, dMask, nullptr, dCtx, dLse, dDO, dDQKV, B, L, heads, p, 99, 5, aws, awsb + 16 + stamp_words * 8, 0)); });
+    if (getenv("UNITER_AMD_ATTN_DBG") && (atoi(getenv("UNITER_AMD_ATTN_DBG")) & 8)) {
+        HIPCHK(hipDeviceSynchronize());
+        std::vector<unsigned long long> st(stamp_words);
+        HIPCHK(hipMemcpy(st.data(), aws, stamp_words * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (size_t w = 0; w < stamp_words / 8; ++w) if (st[w * 8] && (w & 7) < 6) { t0 = std::min(t0, st[w * 8]); t1 = std::max(t1, st[w * 8 + 6]); }
+        printf("stamps (last launch): first wave start -> last wave end %llu ticks\n", t1 - t0);
+        for (int bh : {0, 1, 100, 255, 256, 300, 383}) {
+            if (bh >= B * heads) continue;
+            for (int w = 0; w < 6; w += 5) {
+                const unsigned long long* q = &st[((size_t)bh * 8 + w) * 8];
+                printf("  bh %3d wave %d: start +%6llu | loads+commit %5llu | barrier %5llu | query sweep %5llu | barrier %5llu | key sweep %5llu | drain %5llu\n", bh, w,
+                       q[0] - t0, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[6] - q[5]);
+            }
+        }
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     setvbuf(stdout, nullptr, _IONBF, 0);   // keep the log complete if a later test dies
     signal(SIGSEGV, on_segv);
@@ -1516,6 +1588,11 @@ int main(int argc, char** argv) {
             int32_t inf[4];
             UHCHK(uniter_hip_device_info(inf));
             return run_g8(argc, argv, i + 1);
+        }
+        if (!strcmp(argv[i], "--attn")) {
+            int32_t inf[4];
+            UHCHK(uniter_hip_device_info(inf));
+            return run_attn(argc, argv, i + 1);
         }
         if (!strcmp(argv[i], "--one")) {
             int32_t inf[4];

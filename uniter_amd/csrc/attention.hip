@@ -31,6 +31,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
+template <int UNR>
 __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int Lp = p.Lp, Lm = p.L;
@@ -53,6 +54,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
     const bf16_t* base = p.qkv + row0 * ld + h * DH;
     const bf16_t* dO = p.dctx + row0 * H + h * DH;
     const bf16_t* O = p.ctx + row0 * H + h * DH;
+    unsigned long long* stamp = (p.dbg & 8) ? reinterpret_cast<unsigned long long*>(p.dsum) + ((size_t)bh * 8 + (threadIdx.x >> 6)) * 8 : nullptr;
+    if (stamp && (threadIdx.x & 63) == 0) stamp[0] = __builtin_readcyclecounter();
 
     {
         // prologue: Q, K, V, dO, O, the mask and lse all leave in one burst, then go to LDS (see tile_fetch)
@@ -96,7 +99,9 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
             }
         }
     }
+    if (stamp && (threadIdx.x & 63) == 0) stamp[1] = __builtin_readcyclecounter();
     __syncthreads();
+    if (stamp && (threadIdx.x & 63) == 0) stamp[2] = __builtin_readcyclecounter();
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -105,6 +110,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
     const bool drop = p.drop.p > 0.f;
 
     // ---- sweep 1: query-tile owners -> dQ ----
+    if (!(p.dbg & 4))
     for (int qt = wid; qt < nt; qt += nw) {
         const int q = qt * 16 + i;
         const bf16x8 qf0 = at_frag(Qs, q, 0, g), qf1 = at_frag(Qs, q, 1, g);
@@ -114,39 +120,57 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int u = 0; u < npair; ++u) {
-            float ds[2][4];
-            // one Philox call per key-tile pair (same element groups as the forward kernel)
-            const uint32_t keep8 = drop ? dropout_keep8(p.drop, (drow + (uint64_t)u) * 4 + (uint64_t)g) : 0xffu;
+        // UNR key-tile pairs at a time: their score / dP products are independent MFMA chains the scheduler can interleave
+        // (one pair per loop trip left a wave waiting on every LDS read and MFMA result in turn: 1 900-2 500 cycles per pair)
+        for (int u0 = 0; u0 < npair; u0 += UNR) {
+            f32x4 s[2 * UNR], dp[2 * UNR];
+            uint32_t keep8[UNR];
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int kt = 2 * u + hf;
-                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Ks, kt * 16 + i, 0, g), qf0, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Ks, kt * 16 + i, 1, g), qf1, s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Vs, kt * 16 + i, 0, g), of0, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Vs, kt * 16 + i, 1, g), of1, dp, 0, 0, 0);
-                const f32x4 mv = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
-                float mult[4] = {1.f, 1.f, 1.f, 1.f};
-                if (drop) {
-                    // the keep bits are parked in LDS for the key-owner sweep
-                    const uint32_t keep = (keep8 >> (4 * hf)) & 0xfu;
-                    keep_s[q * kstride + kt * 4 + g] = (uint8_t)keep;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) mult[r] = ((keep >> r) & 1u) ? p.drop.scale : 0.f;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pr = __expf(s[r] * 0.125f + mv[r] - lse_q);
-                    ds[hf][r] = pr * (dp[r] * mult[r] - D_q) * 0.125f;
+            for (int j = 0; j < 2 * UNR; ++j) {
+                const int kt = 2 * u0 + j;
+                s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (kt < 2 * npair) {
+                    s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Ks, kt * 16 + i, 0, g), qf0, s[j], 0, 0, 0);
+                    s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Ks, kt * 16 + i, 1, g), qf1, s[j], 0, 0, 0);
+                    dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Vs, kt * 16 + i, 0, g), of0, dp[j], 0, 0, 0);
+                    dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Vs, kt * 16 + i, 1, g), of1, dp[j], 0, 0, 0);
                 }
             }
-            const bf16x8 dsf = pack_frag(ds[0], ds[1]);
+            // one Philox call per key-tile pair (same element groups as the forward kernel)
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Ks, u, dt, g, i), dsf, dq[dt], 0, 0, 0);
+            for (int uu = 0; uu < UNR; ++uu)
+                keep8[uu] = (drop && u0 + uu < npair) ? dropout_keep8(p.drop, (drow + (uint64_t)(u0 + uu)) * 4 + (uint64_t)g) : 0xffu;
+#pragma unroll
+            for (int uu = 0; uu < UNR; ++uu) {
+                if (u0 + uu < npair) {
+                    float ds[2][4];
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int kt = 2 * (u0 + uu) + hf;
+                        const f32x4 mv = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
+                        float mult[4] = {1.f, 1.f, 1.f, 1.f};
+                        if (drop) {
+                            // the keep bits are parked in LDS for the key-owner sweep
+                            const uint32_t keep = (keep8[uu] >> (4 * hf)) & 0xfu;
+                            keep_s[q * kstride + kt * 4 + g] = (uint8_t)keep;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) mult[r] = ((keep >> r) & 1u) ? p.drop.scale : 0.f;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pr = __expf(s[2 * uu + hf][r] * 0.125f + mv[r] - lse_q);
+                            ds[hf][r] = pr * (dp[2 * uu + hf][r] * mult[r] - D_q) * 0.125f;
+                        }
+                    }
+                    const bf16x8 dsf = pack_frag(ds[0], ds[1]);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Ks, u0 + uu, dt, g, i), dsf, dq[dt], 0, 0, 0);
+                }
+            }
         }
-        if (q < L) {
+        if (q < L && !((p.dbg & 1) && dq[0][0] != 12345.f)) {
             bf16_t* dst = p.dqkv + (row0 + q) * ld + h * DH + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -156,8 +180,11 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
         }
     }
 
+    if (stamp && lane == 0) { asm volatile("s_nop 0" ::: "memory"); stamp[3] = __builtin_readcyclecounter(); }
     if (drop) __syncthreads();         // keep_s complete before the key-owner sweep reads it
+    if (stamp && lane == 0) stamp[4] = __builtin_readcyclecounter();
     // ---- sweep 2: key-tile owners -> dK, dV ----
+    if (!(p.dbg & 2))
     for (int kt = wid; kt < nt; kt += nw) {
         const int key = kt * 16 + i;
         const bf16x8 kf0 = at_frag(Ks, key, 0, g), kf1 = at_frag(Ks, key, 1, g);
@@ -166,38 +193,50 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
         f32x4 dk[4], dv[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        for (int u = 0; u < npair; ++u) {
-            float ds[2][4], pd[2][4];
+        for (int u0 = 0; u0 < npair; u0 += UNR) {
+            f32x4 s[2 * UNR], dp[2 * UNR];
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int qt = 2 * u + hf;
-                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-                // S[query 4g+r][key i]
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Qs, qt * 16 + i, 0, g), kf0, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Qs, qt * 16 + i, 1, g), kf1, s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Os, qt * 16 + i, 0, g), vf0, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Os, qt * 16 + i, 1, g), vf1, dp, 0, 0, 0);
-                const int qb = qt * 16 + 4 * g;
-                const f32x4 lv = *reinterpret_cast<const f32x4*>(lse_s + qb);
-                const f32x4 Dv = *reinterpret_cast<const f32x4*>(D_s + qb);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float mult = 1.f;
-                    if (drop) mult = ((keep_s[(qb + r) * kstride + (key >> 2)] >> (key & 3)) & 1u) ? p.drop.scale : 0.f;
-                    const float pr = __expf(s[r] * 0.125f + mb_k - lv[r]);
-                    pd[hf][r] = pr * mult;
-                    ds[hf][r] = pr * (dp[r] * mult - Dv[r]) * 0.125f;
+            for (int j = 0; j < 2 * UNR; ++j) {
+                const int qt = 2 * u0 + j;
+                s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (qt < 2 * npair) {
+                    // S[query 4g+r][key i]
+                    s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Qs, qt * 16 + i, 0, g), kf0, s[j], 0, 0, 0);
+                    s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Qs, qt * 16 + i, 1, g), kf1, s[j], 0, 0, 0);
+                    dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Os, qt * 16 + i, 0, g), vf0, dp[j], 0, 0, 0);
+                    dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Os, qt * 16 + i, 1, g), vf1, dp[j], 0, 0, 0);
                 }
             }
-            const bf16x8 pdf = pack_frag(pd[0], pd[1]);
-            const bf16x8 dsf = pack_frag(ds[0], ds[1]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Os, u, dt, g, i), pdf, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Qs, u, dt, g, i), dsf, dk[dt], 0, 0, 0);
+            for (int uu = 0; uu < UNR; ++uu) {
+                if (u0 + uu < npair) {
+                    float ds[2][4], pd[2][4];
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int qb = (2 * (u0 + uu) + hf) * 16 + 4 * g;
+                        const f32x4 lv = *reinterpret_cast<const f32x4*>(lse_s + qb);
+                        const f32x4 Dv = *reinterpret_cast<const f32x4*>(D_s + qb);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float mult = 1.f;
+                            if (drop) mult = ((keep_s[(qb + r) * kstride + (key >> 2)] >> (key & 3)) & 1u) ? p.drop.scale : 0.f;
+                            const float pr = __expf(s[2 * uu + hf][r] * 0.125f + mb_k - lv[r]);
+                            pd[hf][r] = pr * mult;
+                            ds[hf][r] = pr * (dp[2 * uu + hf][r] * mult - Dv[r]) * 0.125f;
+                        }
+                    }
+                    const bf16x8 pdf = pack_frag(pd[0], pd[1]);
+                    const bf16x8 dsf = pack_frag(ds[0], ds[1]);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Os, u0 + uu, dt, g, i), pdf, dv[dt], 0, 0, 0);
+                        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Qs, u0 + uu, dt, g, i), dsf, dk[dt], 0, 0, 0);
+                    }
+                }
             }
         }
-        if (key < L) {
+        if (key < L && !((p.dbg & 1) && dk[0][0] != 12345.f)) {
             bf16_t* dst = p.dqkv + (row0 + key) * ld + h * DH + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -207,7 +246,9 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
                 __builtin_nontemporal_store(pack4(vv), reinterpret_cast<u32x2*>(dst + 2 * H + dt * 16));
             }
         }
+        if (stamp && lane == 0) { asm volatile("s_nop 0" ::: "memory"); stamp[5] = __builtin_readcyclecounter(); }
     }
+    if (stamp && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[6] = __builtin_readcyclecounter(); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -424,6 +465,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const AttnArgs p) {
     }
 }
 
+int attn_dbg() {
+    static const int v = [] { const char* e = getenv("UNITER_AMD_ATTN_DBG"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 int pick_waves(int nt) {
     const int rounds = (nt + 7) / 8;
     for (int w = 1; w <= 8; ++w)
@@ -462,6 +508,7 @@ int attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse
     a.B = (int)B; a.L = (int)L; a.heads = (int)heads; a.Lp = (int)((L + 31) / 32 * 32);
     a.drop = drop;
     a.cu = cu;
+    a.dbg = attn_dbg();
     if (cu == nullptr && mask_bias == nullptr) { uh_set_error("attention: dense mode needs mask_bias"); return -1; }
     const int nkt = a.Lp / 16;
     const int nw = L > LMAX ? 8 : pick_waves((int)((L + 15) / 16));
@@ -505,6 +552,7 @@ int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, cons
     a.B = (int)B; a.L = (int)L; a.heads = (int)heads; a.Lp = (int)((L + 31) / 32 * 32);
     a.drop = drop;
     a.cu = cu;
+    a.dbg = attn_dbg();
     if (cu == nullptr && mask_bias == nullptr) { uh_set_error("attention: dense mode needs mask_bias"); return -1; }
     if (L > LMAX) {            // two launches: dQ (+ D) with K, V in LDS, then dK / dV with Q, dO in LDS
         if (workspace == nullptr) { uh_set_error("attention_bwd: L > %d needs the workspace of uniter_attention_bwd_workspace_bytes", LMAX); return -1; }
@@ -520,12 +568,23 @@ int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, cons
         UH_LAUNCH_CHECK();
         return 0;
     }
+    if (a.dbg & 8) a.dsum = (float*)workspace;          // harness profiling: cycle stamps, [B*heads][8 waves][8]
     const int nw = pick_waves((int)((L + 15) / 16));
     if (a.Lp * 8 > TILE_IT * nw * 64 || a.Lp > 2 * nw * 64) { uh_set_error("attention: prologue staging does not cover L=%lld with %d waves", (long long)L, nw); return -1; }
     const size_t lds = (size_t)a.Lp * 64 * 2 * 4 + (size_t)a.Lp * 4 * 3 + (size_t)a.Lp * (a.Lp / 4);
     int rc;
-    if ((rc = set_lds(attn_bwd_kernel, lds))) return rc;
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * heads)), dim3(nw * 64), lds, st, a);
+    const int npair = a.Lp / 32;
+    // key / query tile pairs handled per loop trip (independent MFMA chains in flight): the whole row at L <= 128
+    if (npair % 3 == 0) {
+        if ((rc = set_lds(attn_bwd_kernel<3>, lds))) return rc;
+        hipLaunchKernelGGL(attn_bwd_kernel<3>, dim3((unsigned)(B * heads)), dim3(nw * 64), lds, st, a);
+    } else if (npair <= 2) {
+        if ((rc = set_lds(attn_bwd_kernel<2>, lds))) return rc;
+        hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3((unsigned)(B * heads)), dim3(nw * 64), lds, st, a);
+    } else {
+        if ((rc = set_lds(attn_bwd_kernel<4>, lds))) return rc;
+        hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3((unsigned)(B * heads)), dim3(nw * 64), lds, st, a);
+    }
     UH_LAUNCH_CHECK();
     return 0;
 }

@@ -88,6 +88,7 @@ struct AttnArgs {
     int B, L, heads, Lp;   // L = rows per example (dense) or the longest example (packed); Lp = L rounded up to 32
     const int32_t* cu;     // packed mode: example b owns rows cu[b] .. cu[b+1]-1 of qkv / ctx (NULL = dense [B, L])
     DropoutCfg drop;
+    int dbg;               // profiling builds of the harness only (UNITER_AMD_ATTN_DBG): bit 0 = no output stores, 1 = no key sweep, 2 = no query sweep
 };
 
 // ------------------------------------------------------------------------------------------------

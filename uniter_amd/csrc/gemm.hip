@@ -1312,7 +1312,7 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
         meta[(size_t)q] = tiles;
         meta[(size_t)(n + 1 + q)] = strips;
         tiles += (a.M / 256) * (a.N / 256);
-        if (a.C2 != nullptr) strips += (a.M + 255) / 256;
+        // (no column-strip workgroups: the tiles of a problem's first tile column produce its bias gradient, gemm8_tile COLSUM)
         welems += N[q] * K[q];
     }
     meta[(size_t)n] = tiles;

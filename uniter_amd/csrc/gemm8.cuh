@@ -199,7 +199,11 @@ struct G8Epi {
 };
 
 // One 256 x 256 output tile.  bx = tile slot, by = K slice.
-template <bool TRA, bool TRB, int EPI>
+// COLSUM (weight gradients): the tiles of the first tile column also produce p.C2[m] (+)= sum_k R[k][m] — the bias gradient
+// that belongs to the weight gradient — from the M-side fragments they hold in registers anyway (v_dot2c with a pair of ones
+// per register, waves of the first wave column only), instead of a second pass over dy by column-strip workgroups: in the
+// twelve-layer launch those strips were a quarter of the launch's HBM reads (510 MB of 2 053, PMC).
+template <bool TRA, bool TRB, int EPI, bool COLSUM = false>
 __device__ __forceinline__ void gemm8_tile(const GemmArgs& p, const int bx, const int by, char* smem_raw) {
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
     const int t = threadIdx.x;
@@ -302,6 +306,30 @@ __device__ __forceinline__ void gemm8_tile(const GemmArgs& p, const int bx, cons
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[q >> 1][q & 1][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    float csum[2][4];                // COLSUM: partial sums of this lane's k values, [row half][16-row block]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) csum[h][b] = 0.f;
+    const bool do_colsum = COLSUM && p.C2 != nullptr && tn == 0 && wc == 0;
+    auto colsum = [&](const int h) {                        // the fragments of row half h are in fA
+        if constexpr (COLSUM) {
+            if (do_colsum) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const u32x4 w = __builtin_bit_cast(u32x4, fA[ks][b]);
+                        // acc += lo(w) + hi(w): v_dot2c with the bf16 pair (1, 1).  (Inline asm: with the builtin,
+                        // __builtin_amdgcn_fdot2_f32_bf16, this LLVM read the fragment's FIRST register four times.)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            asm("v_dot2c_f32_bf16 %0, 0x3f803f80, %1" : "+v"(csum[h][b]) : "v"(w[e]));
+                    }
+            }
+        }
+    };
+
     auto mma = [&](f32x4 (&c)[2][4], const bf16x8 (&fb)[2][2]) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -365,6 +393,7 @@ __device__ __forceinline__ void gemm8_tile(const GemmArgs& p, const int bx, cons
         read_a(0, 1);
         to_mma();
         mma(acc[0][0], fB0);
+        colsum(0);
         end_phase();
         // ---- P2: B1 -> (0,1); DMA: B0 of K tile kt+2
         read_b(fB1, 1);
@@ -378,6 +407,7 @@ __device__ __forceinline__ void gemm8_tile(const GemmArgs& p, const int bx, cons
         if (more2) stage(G8C<1>{}, kt + 2);
         to_mma();
         mma(acc[1][1], fB1);
+        colsum(1);
         end_phase();
         // ---- P4: (1,0) from registers; DMA: B1 of K tile kt+2; K tile kt+1 has landed when three half tiles remain in flight
         if (more2) {
@@ -450,6 +480,25 @@ __device__ __forceinline__ void gemm8_tile(const GemmArgs& p, const int bx, cons
                     for (int b = 0; b < 4; ++b) acc[q >> 1][q & 1][a][b] += o[a][b];
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+    }
+
+    if constexpr (COLSUM) {
+        if (do_colsum) {                                     // lanes g = 0..3 of a row hold the four k quarters
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    float v = csum[h][b];
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    const int m = m0 + h * 128 + wr * 64 + b * 16 + i;
+                    if (g == 0 && m < p.M) {
+                        bf16_t* dst = p.C2 + m;
+                        if (p.accumulate) v += bf2f(*dst);
+                        *dst = f2bf(v);
+                    }
+                }
         }
     }
 
@@ -918,7 +967,7 @@ __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_multi_kernel(const GemmAr
     const int tiles_m = p.M >> 8, tiles_n = p.N >> 8;
     const int tm = tiles_n >= tiles_m ? bx % tiles_m : bx / tiles_n;      // longer tile dimension outermost
     const int tn = tiles_n >= tiles_m ? bx / tiles_m : bx % tiles_n;
-    gemm8_tile<true, true, EPI_WGRAD>(p, tm * tiles_n + tn, 0, smem_raw);
+    gemm8_tile<true, true, EPI_WGRAD, true>(p, tm * tiles_n + tn, 0, smem_raw);
 }
 
 __global__ __launch_bounds__(G8_THREADS, 2) void gemm6_group_kernel(const G8GroupArgs ga) {
