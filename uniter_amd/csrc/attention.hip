@@ -31,10 +31,19 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
-template <int UNR>
-__global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+// HP = (example, head) units per workgroup.  One unit at L = 96 is six 16-row tiles = six waves, and a six-wave workgroup
+// leaves two of a CU's four SIMDs with one wave while the other two carry two (the kernel is VALU-issue bound: ~3 000
+// instructions per wave, cycle stamps in the harness), and a second workgroup does not fit beside it — 384 workgroups ran as
+// two rounds of 256 / 128.  Two units per workgroup = 12 waves = three per SIMD on 192 CUs in ONE round.
+template <int HP>
+__global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
     const int Lp = p.Lp, Lm = p.L;
+    const int nthr = (int)blockDim.x / HP;                     // threads of one unit's team
+    const int slot = HP == 2 ? (int)(threadIdx.x >= (unsigned)nthr) : 0;
+    const int tid = (int)threadIdx.x - slot * nthr;
+    const size_t unit_bytes = ((size_t)Lp * 64 * 2 * 4 + (size_t)Lp * 4 * 3 + (size_t)Lp * (Lp / 4) + 15) & ~(size_t)15;
+    char* smem_raw = smem_all + (size_t)slot * unit_bytes;
     bf16_t* Qs = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* Ks = Qs + Lp * 64;
     bf16_t* Vs = Ks + Lp * 64;
@@ -45,7 +54,9 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
     uint8_t* keep_s = reinterpret_cast<uint8_t*>(D_s + Lp);     // dropout keep nibbles [q][Lp/4], written by sweep 1
     const int kstride = Lp >> 2;
 
-    const int bh = blockIdx.x;
+    const int bh_raw = (int)blockIdx.x * HP + slot;
+    const bool live = bh_raw < p.B * p.heads;                   // (an odd unit count leaves the last workgroup's second team idle)
+    const int bh = live ? bh_raw : 0;
     const int b = bh / p.heads, h = bh % p.heads;
     const int H = p.heads * DH;
     const int64_t ld = 3 * (int64_t)H;
@@ -54,37 +65,38 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
     const bf16_t* base = p.qkv + row0 * ld + h * DH;
     const bf16_t* dO = p.dctx + row0 * H + h * DH;
     const bf16_t* O = p.ctx + row0 * H + h * DH;
-    unsigned long long* stamp = (p.dbg & 8) ? reinterpret_cast<unsigned long long*>(p.dsum) + ((size_t)bh * 8 + (threadIdx.x >> 6)) * 8 : nullptr;
-    if (stamp && (threadIdx.x & 63) == 0) stamp[0] = __builtin_readcyclecounter();
+    unsigned long long* stamp = ((p.dbg & 8) && live) ? reinterpret_cast<unsigned long long*>(p.dsum) + ((size_t)bh * 8 + (tid >> 6)) * 8 : nullptr;
+    if (stamp && (tid & 63) == 0) stamp[0] = __builtin_readcyclecounter();
 
+    if (live)
     {
         // prologue: Q, K, V, dO, O, the mask and lse all leave in one burst, then go to LDS (see tile_fetch)
         u32x4 rq[TILE_IT], rk[TILE_IT], rv[TILE_IT], rdo[TILE_IT], ro[TILE_IT];
-        tile_fetch(rq, base, ld, L, Lp);
-        tile_fetch(rk, base + H, ld, L, Lp);
-        tile_fetch(rv, base + 2 * H, ld, L, Lp);
-        tile_fetch(rdo, dO, H, L, Lp);
-        tile_fetch(ro, O, H, L, Lp);
+        tile_fetch(rq, base, ld, L, Lp, tid, nthr);
+        tile_fetch(rk, base + H, ld, L, Lp, tid, nthr);
+        tile_fetch(rv, base + 2 * H, ld, L, Lp, tid, nthr);
+        tile_fetch(rdo, dO, H, L, Lp, tid, nthr);
+        tile_fetch(ro, O, H, L, Lp, tid, nthr);
         float mbv[2], lsv[2];
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-            const int k = threadIdx.x + it * blockDim.x;
+            const int k = tid + it * nthr;
             mbv[it] = (k < L) ? (p.mask_bias ? p.mask_bias[(int64_t)b * Lm + k] : 0.f) : -INFINITY;
             lsv[it] = (k < L) ? p.lse[(int64_t)bh * Lm + k] : INFINITY;
         }
-        tile_commit(Qs, rq, Lp);
-        tile_commit(Ks, rk, Lp);
-        tile_commit(Vs, rv, Lp);
-        tile_commit(Os, rdo, Lp);
+        tile_commit(Qs, rq, Lp, tid, nthr);
+        tile_commit(Ks, rk, Lp, tid, nthr);
+        tile_commit(Vs, rv, Lp, tid, nthr);
+        tile_commit(Os, rdo, Lp, tid, nthr);
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-            const int k = threadIdx.x + it * blockDim.x;
+            const int k = tid + it * nthr;
             if (k < Lp) { mb[k] = mbv[it]; lse_s[k] = lsv[it]; }
         }
         // D[q] = sum_d dO[q][d] * O[q][d]   (rows >= L were fetched as zeros; whole waves are in or out of range)
 #pragma unroll
         for (int it = 0; it < TILE_IT; ++it) {
-            const int idx = threadIdx.x + it * blockDim.x;
+            const int idx = tid + it * nthr;
             if (idx < Lp * 8) {
                 float a[8], o[8];
                 unpack8(rdo[it], a);
@@ -99,18 +111,18 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
             }
         }
     }
-    if (stamp && (threadIdx.x & 63) == 0) stamp[1] = __builtin_readcyclecounter();
+    if (stamp && (tid & 63) == 0) stamp[1] = __builtin_readcyclecounter();
     __syncthreads();
-    if (stamp && (threadIdx.x & 63) == 0) stamp[2] = __builtin_readcyclecounter();
+    if (stamp && (tid & 63) == 0) stamp[2] = __builtin_readcyclecounter();
 
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = tid & 63, wid = tid >> 6, nw = nthr >> 6;
     const int g = lane >> 4, i = lane & 15;
     const int npair = Lp >> 5;             // pairs of 16-row tiles
     const int nt = (L + 15) >> 4;          // tiles that contain real rows
     const bool drop = p.drop.p > 0.f;
 
     // ---- sweep 1: query-tile owners -> dQ ----
-    if (!(p.dbg & 4))
+    if (live && !(p.dbg & 4))
     for (int qt = wid; qt < nt; qt += nw) {
         const int q = qt * 16 + i;
         const bf16x8 qf0 = at_frag(Qs, q, 0, g), qf1 = at_frag(Qs, q, 1, g);
@@ -120,55 +132,37 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // UNR key-tile pairs at a time: their score / dP products are independent MFMA chains the scheduler can interleave
-        // (one pair per loop trip left a wave waiting on every LDS read and MFMA result in turn: 1 900-2 500 cycles per pair)
-        for (int u0 = 0; u0 < npair; u0 += UNR) {
-            f32x4 s[2 * UNR], dp[2 * UNR];
-            uint32_t keep8[UNR];
-#pragma unroll
-            for (int j = 0; j < 2 * UNR; ++j) {
-                const int kt = 2 * u0 + j;
-                s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                dp[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (kt < 2 * npair) {
-                    s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Ks, kt * 16 + i, 0, g), qf0, s[j], 0, 0, 0);
-                    s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Ks, kt * 16 + i, 1, g), qf1, s[j], 0, 0, 0);
-                    dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Vs, kt * 16 + i, 0, g), of0, dp[j], 0, 0, 0);
-                    dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Vs, kt * 16 + i, 1, g), of1, dp[j], 0, 0, 0);
-                }
-            }
+        for (int u = 0; u < npair; ++u) {
+            float ds[2][4];
             // one Philox call per key-tile pair (same element groups as the forward kernel)
+            const uint32_t keep8 = drop ? dropout_keep8(p.drop, (drow + (uint64_t)u) * 4 + (uint64_t)g) : 0xffu;
 #pragma unroll
-            for (int uu = 0; uu < UNR; ++uu)
-                keep8[uu] = (drop && u0 + uu < npair) ? dropout_keep8(p.drop, (drow + (uint64_t)(u0 + uu)) * 4 + (uint64_t)g) : 0xffu;
+            for (int hf = 0; hf < 2; ++hf) {
+                const int kt = 2 * u + hf;
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Ks, kt * 16 + i, 0, g), qf0, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Ks, kt * 16 + i, 1, g), qf1, s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Vs, kt * 16 + i, 0, g), of0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Vs, kt * 16 + i, 1, g), of1, dp, 0, 0, 0);
+                const f32x4 mv = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
+                float mult[4] = {1.f, 1.f, 1.f, 1.f};
+                if (drop) {
+                    // the keep bits are parked in LDS for the key-owner sweep
+                    const uint32_t keep = (keep8 >> (4 * hf)) & 0xfu;
+                    keep_s[q * kstride + kt * 4 + g] = (uint8_t)keep;
 #pragma unroll
-            for (int uu = 0; uu < UNR; ++uu) {
-                if (u0 + uu < npair) {
-                    float ds[2][4];
+                    for (int r = 0; r < 4; ++r) mult[r] = ((keep >> r) & 1u) ? p.drop.scale : 0.f;
+                }
 #pragma unroll
-                    for (int hf = 0; hf < 2; ++hf) {
-                        const int kt = 2 * (u0 + uu) + hf;
-                        const f32x4 mv = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
-                        float mult[4] = {1.f, 1.f, 1.f, 1.f};
-                        if (drop) {
-                            // the keep bits are parked in LDS for the key-owner sweep
-                            const uint32_t keep = (keep8[uu] >> (4 * hf)) & 0xfu;
-                            keep_s[q * kstride + kt * 4 + g] = (uint8_t)keep;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) mult[r] = ((keep >> r) & 1u) ? p.drop.scale : 0.f;
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float pr = __expf(s[2 * uu + hf][r] * 0.125f + mv[r] - lse_q);
-                            ds[hf][r] = pr * (dp[2 * uu + hf][r] * mult[r] - D_q) * 0.125f;
-                        }
-                    }
-                    const bf16x8 dsf = pack_frag(ds[0], ds[1]);
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt)
-                        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Ks, u0 + uu, dt, g, i), dsf, dq[dt], 0, 0, 0);
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = __expf(s[r] * 0.125f + mv[r] - lse_q);
+                    ds[hf][r] = pr * (dp[r] * mult[r] - D_q) * 0.125f;
                 }
             }
+            const bf16x8 dsf = pack_frag(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Ks, u, dt, g, i), dsf, dq[dt], 0, 0, 0);
         }
         if (q < L && !((p.dbg & 1) && dq[0][0] != 12345.f)) {
             bf16_t* dst = p.dqkv + (row0 + q) * ld + h * DH + 4 * g;
@@ -184,7 +178,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
     if (drop) __syncthreads();         // keep_s complete before the key-owner sweep reads it
     if (stamp && lane == 0) stamp[4] = __builtin_readcyclecounter();
     // ---- sweep 2: key-tile owners -> dK, dV ----
-    if (!(p.dbg & 2))
+    if (live && !(p.dbg & 2))
     for (int kt = wid; kt < nt; kt += nw) {
         const int key = kt * 16 + i;
         const bf16x8 kf0 = at_frag(Ks, key, 0, g), kf1 = at_frag(Ks, key, 1, g);
@@ -193,47 +187,35 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs p) {
         f32x4 dk[4], dv[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        for (int u0 = 0; u0 < npair; u0 += UNR) {
-            f32x4 s[2 * UNR], dp[2 * UNR];
+        for (int u = 0; u < npair; ++u) {
+            float ds[2][4], pd[2][4];
 #pragma unroll
-            for (int j = 0; j < 2 * UNR; ++j) {
-                const int qt = 2 * u0 + j;
-                s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                dp[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (qt < 2 * npair) {
-                    // S[query 4g+r][key i]
-                    s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Qs, qt * 16 + i, 0, g), kf0, s[j], 0, 0, 0);
-                    s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Qs, qt * 16 + i, 1, g), kf1, s[j], 0, 0, 0);
-                    dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Os, qt * 16 + i, 0, g), vf0, dp[j], 0, 0, 0);
-                    dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Os, qt * 16 + i, 1, g), vf1, dp[j], 0, 0, 0);
+            for (int hf = 0; hf < 2; ++hf) {
+                const int qt = 2 * u + hf;
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                // S[query 4g+r][key i]
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Qs, qt * 16 + i, 0, g), kf0, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Qs, qt * 16 + i, 1, g), kf1, s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Os, qt * 16 + i, 0, g), vf0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Os, qt * 16 + i, 1, g), vf1, dp, 0, 0, 0);
+                const int qb = qt * 16 + 4 * g;
+                const f32x4 lv = *reinterpret_cast<const f32x4*>(lse_s + qb);
+                const f32x4 Dv = *reinterpret_cast<const f32x4*>(D_s + qb);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float mult = 1.f;
+                    if (drop) mult = ((keep_s[(qb + r) * kstride + (key >> 2)] >> (key & 3)) & 1u) ? p.drop.scale : 0.f;
+                    const float pr = __expf(s[r] * 0.125f + mb_k - lv[r]);
+                    pd[hf][r] = pr * mult;
+                    ds[hf][r] = pr * (dp[r] * mult - Dv[r]) * 0.125f;
                 }
             }
+            const bf16x8 pdf = pack_frag(pd[0], pd[1]);
+            const bf16x8 dsf = pack_frag(ds[0], ds[1]);
 #pragma unroll
-            for (int uu = 0; uu < UNR; ++uu) {
-                if (u0 + uu < npair) {
-                    float ds[2][4], pd[2][4];
-#pragma unroll
-                    for (int hf = 0; hf < 2; ++hf) {
-                        const int qb = (2 * (u0 + uu) + hf) * 16 + 4 * g;
-                        const f32x4 lv = *reinterpret_cast<const f32x4*>(lse_s + qb);
-                        const f32x4 Dv = *reinterpret_cast<const f32x4*>(D_s + qb);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float mult = 1.f;
-                            if (drop) mult = ((keep_s[(qb + r) * kstride + (key >> 2)] >> (key & 3)) & 1u) ? p.drop.scale : 0.f;
-                            const float pr = __expf(s[2 * uu + hf][r] * 0.125f + mb_k - lv[r]);
-                            pd[hf][r] = pr * mult;
-                            ds[hf][r] = pr * (dp[2 * uu + hf][r] * mult - Dv[r]) * 0.125f;
-                        }
-                    }
-                    const bf16x8 pdf = pack_frag(pd[0], pd[1]);
-                    const bf16x8 dsf = pack_frag(ds[0], ds[1]);
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
-                        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Os, u0 + uu, dt, g, i), pdf, dv[dt], 0, 0, 0);
-                        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Qs, u0 + uu, dt, g, i), dsf, dk[dt], 0, 0, 0);
-                    }
-                }
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Os, u, dt, g, i), pdf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Qs, u, dt, g, i), dsf, dk[dt], 0, 0, 0);
             }
         }
         if (key < L && !((p.dbg & 1) && dk[0][0] != 12345.f)) {
@@ -573,17 +555,15 @@ int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, cons
     if (a.Lp * 8 > TILE_IT * nw * 64 || a.Lp > 2 * nw * 64) { uh_set_error("attention: prologue staging does not cover L=%lld with %d waves", (long long)L, nw); return -1; }
     const size_t lds = (size_t)a.Lp * 64 * 2 * 4 + (size_t)a.Lp * 4 * 3 + (size_t)a.Lp * (a.Lp / 4);
     int rc;
-    const int npair = a.Lp / 32;
-    // key / query tile pairs handled per loop trip (independent MFMA chains in flight): the whole row at L <= 128
-    if (npair % 3 == 0) {
-        if ((rc = set_lds(attn_bwd_kernel<3>, lds))) return rc;
-        hipLaunchKernelGGL(attn_bwd_kernel<3>, dim3((unsigned)(B * heads)), dim3(nw * 64), lds, st, a);
-    } else if (npair <= 2) {
-        if ((rc = set_lds(attn_bwd_kernel<2>, lds))) return rc;
-        hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3((unsigned)(B * heads)), dim3(nw * 64), lds, st, a);
+    // two units per workgroup while that keeps it at 12 waves or fewer (three per SIMD at the kernel's register count)
+    const int64_t units = B * heads;
+    const size_t unit_bytes = (lds + 15) & ~(size_t)15;
+    if (2 * nw <= 12 && 2 * unit_bytes <= 156 * 1024) {     // (and both units' tiles fit the CU's 160 KiB of LDS)
+        if ((rc = set_lds(attn_bwd_kernel<2>, 2 * unit_bytes))) return rc;
+        hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3((unsigned)((units + 1) / 2)), dim3(2 * nw * 64), 2 * unit_bytes, st, a);
     } else {
-        if ((rc = set_lds(attn_bwd_kernel<4>, lds))) return rc;
-        hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3((unsigned)(B * heads)), dim3(nw * 64), lds, st, a);
+        if ((rc = set_lds(attn_bwd_kernel<1>, lds))) return rc;
+        hipLaunchKernelGGL(attn_bwd_kernel<1>, dim3((unsigned)units), dim3(nw * 64), lds, st, a);
     }
     UH_LAUNCH_CHECK();
     return 0;

@@ -54,23 +54,32 @@ __device__ __forceinline__ void load_tile(bf16_t* tile, const bf16_t* src, int64
 // a load -> wait -> write loop would pay one full memory round trip per iteration and tile (measured: 10 serialized
 // round trips were most of the backward kernel's 20 us).
 constexpr int TILE_IT = 4;
+// (tid / nthr: the calling team — the whole workgroup, or the threads of one head when a workgroup holds two)
 template <int NIT, bool COH = false>
-__device__ __forceinline__ void tile_fetch(u32x4 (&r)[NIT], const bf16_t* src, int64_t ld, int L, int Lp) {
+__device__ __forceinline__ void tile_fetch(u32x4 (&r)[NIT], const bf16_t* src, int64_t ld, int L, int Lp, int tid, int nthr) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int idx = threadIdx.x + it * blockDim.x;
+        const int idx = tid + it * nthr;
         const int row = idx >> 3, c = idx & 7;
         r[it] = u32x4{0u, 0u, 0u, 0u};
         if (idx < Lp * 8 && row < L) r[it] = ldg16<COH>(src + (int64_t)row * ld + c * 8);
     }
 }
+template <int NIT, bool COH = false>
+__device__ __forceinline__ void tile_fetch(u32x4 (&r)[NIT], const bf16_t* src, int64_t ld, int L, int Lp) {
+    tile_fetch<NIT, COH>(r, src, ld, L, Lp, (int)threadIdx.x, (int)blockDim.x);
+}
 template <int NIT>
-__device__ __forceinline__ void tile_commit(bf16_t* tile, const u32x4 (&r)[NIT], int Lp) {
+__device__ __forceinline__ void tile_commit(bf16_t* tile, const u32x4 (&r)[NIT], int Lp, int tid, int nthr) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int idx = threadIdx.x + it * blockDim.x;
+        const int idx = tid + it * nthr;
         if (idx < Lp * 8) *reinterpret_cast<u32x4*>(tile + at_off8(idx >> 3, 2 * (idx & 7))) = r[it];
     }
+}
+template <int NIT>
+__device__ __forceinline__ void tile_commit(bf16_t* tile, const u32x4 (&r)[NIT], int Lp) {
+    tile_commit<NIT>(tile, r, Lp, (int)threadIdx.x, (int)blockDim.x);
 }
 
 // dropout element groups per query row: one per pair of 16-key tiles, 8 up to L = 256 (the layout every shorter sequence
