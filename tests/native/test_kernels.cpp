@@ -1555,7 +1555,7 @@ static int run_attn(int argc, char** argv, int at) {
             if (bh >= B * heads) continue;
             for (int w = 0; w < 6; w += 5) {
                 const unsigned long long* q = &st[((size_t)bh * 8 + w) * 8];
-                printf("  bh %3d wave %d: start +%6llu | loads+commit %5llu | barrier %5llu | query sweep %5llu | barrier %5llu | key sweep %5llu | drain %5llu\n", bh, w,
+                printf("  bh %3d wave %d: start +%6llu | loads+commit %5llu | barrier %5llu | query sweep %5llu | barrier(s) %5llu | key sweep %5llu | drain %5llu\n", bh, w,
                        q[0] - t0, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[6] - q[5]);
             }
         }

@@ -234,6 +234,215 @@ __global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_kernel(const Att
 }
 
 // ------------------------------------------------------------------------------------------------
+// backward, L <= 128: the probabilities and score gradients computed ONCE
+// ------------------------------------------------------------------------------------------------
+// attn_bwd_kernel's key-owner sweep recomputes S, P, dP and dS in the other orientation (24 more MFMAs, 48 more exps and the
+// dropout-bit lookups per wave at L = 96) — and the kernel is bound by the instructions a wave issues, not by the matrix pipe.
+// Here the query-tile owners keep their tile's P~ = dropout(P) and dS rows as packed bf16 (the rounding the MFMA operands
+// get anyway), and once every wave is done with K and V they write them over those two tiles (P~) and into one more tile
+// pair (dS) as [query][key] panels of 64 keys in the operand tile layout; the key-tile owners then read their operands with
+// the same transposing loads that fetch Q^T and dO^T.  dK / dV see exactly the P~ / dS that dQ saw.
+template <int HP>
+__global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_share_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    const int Lp = p.Lp, Lm = p.L;
+    const int nthr = (int)blockDim.x / HP;                     // threads of one unit's team
+    const int slot = HP == 2 ? (int)(threadIdx.x >= (unsigned)nthr) : 0;
+    const int tid = (int)threadIdx.x - slot * nthr;
+    const int npanel = (Lp + 63) >> 6;                         // 64-key panels of the P~ / dS matrices (<= 2)
+    const size_t unit_bytes = ((size_t)Lp * 64 * 2 * (4 + npanel) + (size_t)Lp * 4 * 3 + 15) & ~(size_t)15;
+    char* smem_raw = smem_all + (size_t)slot * unit_bytes;
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* Ks = Qs + Lp * 64;
+    bf16_t* Vs = Ks + Lp * 64;
+    bf16_t* Os = Vs + Lp * 64;            // dO
+    bf16_t* DSs = Os + Lp * 64;           // dS [query][key], npanel panels of [Lp][64]
+    bf16_t* PTs = Ks;                     // P~ [query][key], written over K (and V) after the barrier that ends their use
+    float* mb = reinterpret_cast<float*>(DSs + (size_t)npanel * Lp * 64);
+    float* lse_s = mb + Lp;
+    float* D_s = lse_s + Lp;
+
+    const int bh_raw = (int)blockIdx.x * HP + slot;
+    const bool live = bh_raw < p.B * p.heads;                   // (an odd unit count leaves the last workgroup's second team idle)
+    const int bh = live ? bh_raw : 0;
+    const int b = bh / p.heads, h = bh % p.heads;
+    const int H = p.heads * DH;
+    const int64_t ld = 3 * (int64_t)H;
+    const int64_t row0 = p.cu ? (int64_t)p.cu[b] : (int64_t)b * Lm;
+    const int L = p.cu ? (p.cu[b + 1] - p.cu[b]) : Lm;         // real rows of this example
+    const bf16_t* base = p.qkv + row0 * ld + h * DH;
+    const bf16_t* dO = p.dctx + row0 * H + h * DH;
+    const bf16_t* O = p.ctx + row0 * H + h * DH;
+    unsigned long long* stamp = ((p.dbg & 8) && live) ? reinterpret_cast<unsigned long long*>(p.dsum) + ((size_t)bh * 8 + (tid >> 6)) * 8 : nullptr;
+    if (stamp && (tid & 63) == 0) stamp[0] = __builtin_readcyclecounter();
+
+    if (live) {
+        // prologue: Q, K, V, dO, O, the mask and lse all leave in one burst, then go to LDS (see tile_fetch)
+        u32x4 rq[TILE_IT], rk[TILE_IT], rv[TILE_IT], rdo[TILE_IT], ro[TILE_IT];
+        tile_fetch(rq, base, ld, L, Lp, tid, nthr);
+        tile_fetch(rk, base + H, ld, L, Lp, tid, nthr);
+        tile_fetch(rv, base + 2 * H, ld, L, Lp, tid, nthr);
+        tile_fetch(rdo, dO, H, L, Lp, tid, nthr);
+        tile_fetch(ro, O, H, L, Lp, tid, nthr);
+        float mbv[2], lsv[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int k = tid + it * nthr;
+            mbv[it] = (k < L) ? (p.mask_bias ? p.mask_bias[(int64_t)b * Lm + k] : 0.f) : -INFINITY;
+            lsv[it] = (k < L) ? p.lse[(int64_t)bh * Lm + k] : INFINITY;
+        }
+        tile_commit(Qs, rq, Lp, tid, nthr);
+        tile_commit(Ks, rk, Lp, tid, nthr);
+        tile_commit(Vs, rv, Lp, tid, nthr);
+        tile_commit(Os, rdo, Lp, tid, nthr);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int k = tid + it * nthr;
+            if (k < Lp) { mb[k] = mbv[it]; lse_s[k] = lsv[it]; }
+        }
+        // D[q] = sum_d dO[q][d] * O[q][d]   (rows >= L were fetched as zeros; whole waves are in or out of range)
+#pragma unroll
+        for (int it = 0; it < TILE_IT; ++it) {
+            const int idx = tid + it * nthr;
+            if (idx < Lp * 8) {
+                float a[8], o[8];
+                unpack8(rdo[it], a);
+                unpack8(ro[it], o);
+                float part = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) part += a[e] * o[e];
+                part += __shfl_xor(part, 1, WAVE);
+                part += __shfl_xor(part, 2, WAVE);
+                part += __shfl_xor(part, 4, WAVE);
+                if ((idx & 7) == 0) D_s[idx >> 3] = part;
+            }
+        }
+    }
+    if (stamp && (tid & 63) == 0) stamp[1] = __builtin_readcyclecounter();
+    __syncthreads();
+    if (stamp && (tid & 63) == 0) stamp[2] = __builtin_readcyclecounter();
+
+    const int lane = tid & 63, wid = tid >> 6, nw = nthr >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int npair = Lp >> 5;             // pairs of 16-row tiles (<= 4)
+    const int nt = (L + 15) >> 4;          // tiles that contain real rows; the launch gives every one of them its own wave
+    const bool drop = p.drop.p > 0.f;
+    const bool owner = live && wid < nt;
+
+    // ---- query-tile owners: P~, dS (kept in registers) and dQ ----
+    u32x2 ppk[8], dspk[8];                 // this wave's query rows x key tile kt: lane holds keys kt*16 + 4g .. + 3 of query i
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) { ppk[kt] = u32x2{0u, 0u}; dspk[kt] = u32x2{0u, 0u}; }
+    if (owner) {
+        const int q = wid * 16 + i;
+        const bf16x8 qf0 = at_frag(Qs, q, 0, g), qf1 = at_frag(Qs, q, 1, g);
+        const bf16x8 of0 = at_frag(Os, q, 0, g), of1 = at_frag(Os, q, 1, g);
+        const float lse_q = lse_s[q], D_q = D_s[q];
+        const uint64_t drow = ((uint64_t)bh * (uint64_t)Lm + (uint64_t)q) * (uint64_t)pair_stride(Lm);
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u < npair) {
+                float ds[2][4];
+                // one Philox call per key-tile pair (same element groups as the forward kernel)
+                const uint32_t keep8 = drop ? dropout_keep8(p.drop, (drow + (uint64_t)u) * 4 + (uint64_t)g) : 0xffu;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int kt = 2 * u + hf;
+                    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Ks, kt * 16 + i, 0, g), qf0, s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Ks, kt * 16 + i, 1, g), qf1, s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Vs, kt * 16 + i, 0, g), of0, dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Vs, kt * 16 + i, 1, g), of1, dp, 0, 0, 0);
+                    const f32x4 mv = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
+                    const uint32_t keep = (keep8 >> (4 * hf)) & 0xfu;
+                    float pd[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float mult = drop ? (((keep >> r) & 1u) ? p.drop.scale : 0.f) : 1.f;
+                        const float pr = __expf(s[r] * 0.125f + mv[r] - lse_q);
+                        pd[r] = pr * mult;
+                        ds[hf][r] = pr * (dp[r] * mult - D_q) * 0.125f;
+                    }
+                    ppk[kt] = pack4(pd);
+                    dspk[kt] = pack4(ds[hf]);
+                }
+                u32x4 w;
+                w[0] = dspk[2 * u][0]; w[1] = dspk[2 * u][1]; w[2] = dspk[2 * u + 1][0]; w[3] = dspk[2 * u + 1][1];
+                const bf16x8 dsf = __builtin_bit_cast(bf16x8, w);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Ks, u, dt, g, i), dsf, dq[dt], 0, 0, 0);
+            }
+        }
+        if (q < L) {
+            bf16_t* dst = p.dqkv + (row0 + q) * ld + h * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const float v[4] = {dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]};
+                __builtin_nontemporal_store(pack4(v), reinterpret_cast<u32x2*>(dst + dt * 16));
+            }
+        }
+    }
+    if (stamp && lane == 0) { asm volatile("s_nop 0" ::: "memory"); stamp[3] = __builtin_readcyclecounter(); }
+    __syncthreads();                       // nobody reads K or V any more
+    if (live) {
+        // rows of this wave's query tile; tiles beyond the real rows (padding up to Lp) are cleared by whoever gets there first
+        for (int qt = wid; qt < 2 * npair; qt += nw) {
+            const int q = qt * 16 + i;
+            const bool mine = (qt == wid) && owner;
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) {
+                if (kt < 2 * npair) {
+                    const int off = (kt >> 2) * Lp * 64 + at_off8(q, (kt & 3) * 4 + g);
+                    *reinterpret_cast<u32x2*>(PTs + off) = mine ? ppk[kt] : u32x2{0u, 0u};
+                    *reinterpret_cast<u32x2*>(DSs + off) = mine ? dspk[kt] : u32x2{0u, 0u};
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (stamp && lane == 0) stamp[4] = __builtin_readcyclecounter();
+
+    // ---- key-tile owners -> dK, dV ----
+    if (live)
+    for (int kt = wid; kt < nt; kt += nw) {
+        const int key = kt * 16 + i;
+        const bf16_t* Pp = PTs + (kt >> 2) * Lp * 64;
+        const bf16_t* Dp = DSs + (kt >> 2) * Lp * 64;
+        f32x4 dk[4], dv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u < npair) {
+                const bf16x8 pdf = at_frag_tr(Pp, u, kt & 3, g, i);
+                const bf16x8 dsf = at_frag_tr(Dp, u, kt & 3, g, i);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Os, u, dt, g, i), pdf, dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Qs, u, dt, g, i), dsf, dk[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (key < L) {
+            bf16_t* dst = p.dqkv + (row0 + key) * ld + h * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const float kv[4] = {dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]};
+                const float vv[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
+                __builtin_nontemporal_store(pack4(kv), reinterpret_cast<u32x2*>(dst + H + dt * 16));
+                __builtin_nontemporal_store(pack4(vv), reinterpret_cast<u32x2*>(dst + 2 * H + dt * 16));
+            }
+        }
+    }
+    if (stamp && lane == 0) { asm volatile("s_nop 0" ::: "memory"); stamp[5] = __builtin_readcyclecounter(); }
+    if (stamp && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[6] = __builtin_readcyclecounter(); }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward for 256 < L <= 512: Q, K, V and dO of a head no longer fit one CU's LDS together, so the two sweeps of
 // attn_bwd_kernel become two launches that each keep only the operands they re-read in LDS (K, V / Q, dO: 128 KiB at
 // L = 512) and take their own 16-row tile straight from global memory as MFMA fragments.  The dropout keep bits are
@@ -555,8 +764,23 @@ int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, cons
     if (a.Lp * 8 > TILE_IT * nw * 64 || a.Lp > 2 * nw * 64) { uh_set_error("attention: prologue staging does not cover L=%lld with %d waves", (long long)L, nw); return -1; }
     const size_t lds = (size_t)a.Lp * 64 * 2 * 4 + (size_t)a.Lp * 4 * 3 + (size_t)a.Lp * (a.Lp / 4);
     int rc;
-    // two units per workgroup while that keeps it at 12 waves or fewer (three per SIMD at the kernel's register count)
     const int64_t units = B * heads;
+    const int nt = (int)((L + 15) / 16);
+    if (a.Lp <= 128 && nt <= nw && !(a.dbg & 16)) {
+        // L <= 128: P~ and dS are computed once and handed from the query-tile owners to the key-tile owners through LDS
+        const int npanel = (a.Lp + 63) / 64;
+        const size_t ub = ((size_t)a.Lp * 64 * 2 * (4 + npanel) + (size_t)a.Lp * 4 * 3 + 15) & ~(size_t)15;
+        if (2 * nw <= 12 && 2 * ub <= 156 * 1024) {          // two units per workgroup: 12 waves, three per SIMD (see attn_bwd_kernel)
+            if ((rc = set_lds(attn_bwd_share_kernel<2>, 2 * ub))) return rc;
+            hipLaunchKernelGGL(attn_bwd_share_kernel<2>, dim3((unsigned)((units + 1) / 2)), dim3(2 * nw * 64), 2 * ub, st, a);
+        } else {
+            if ((rc = set_lds(attn_bwd_share_kernel<1>, ub))) return rc;
+            hipLaunchKernelGGL(attn_bwd_share_kernel<1>, dim3((unsigned)units), dim3(nw * 64), ub, st, a);
+        }
+        UH_LAUNCH_CHECK();
+        return 0;
+    }
+    // two units per workgroup while that keeps it at 12 waves or fewer (three per SIMD at the kernel's register count)
     const size_t unit_bytes = (lds + 15) & ~(size_t)15;
     if (2 * nw <= 12 && 2 * unit_bytes <= 156 * 1024) {     // (and both units' tiles fit the CU's 160 KiB of LDS)
         if ((rc = set_lds(attn_bwd_kernel<2>, 2 * unit_bytes))) return rc;
