@@ -58,4 +58,7 @@ def test_committed_pmc_traffic_files_attribute_bytes_to_shapes():
         assert shapes, "%s: empty by_shape" % os.path.basename(f)
         assert any(k.startswith("13:") for k in shapes), "%s: the grouped weight-gradient launch is missing" % os.path.basename(f)
         for k, e in shapes.items():
-            assert len(k.split(":")) == 4 and e["hbm_bytes"] > 0 and e["dispatches"] >= 8, (f, k)
+            parts = k.split(":")
+            # (the deferred weight-gradient launch — kind 13 with more than one layer's four problems — runs once per step)
+            need = 3 if parts[0] == "13" and int(parts[3]) > 4 else 8
+            assert len(parts) == 4 and e["hbm_bytes"] > 0 and e["dispatches"] >= need, (f, k)
