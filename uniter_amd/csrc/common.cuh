@@ -236,31 +236,47 @@ __device__ __forceinline__ float dropout_mult1(const DropoutCfg& d, uint64_t idx
 // Phi(x) = 0.5*(1+erf(x/sqrt2)) and phi(x) = exp(-x^2/2)/sqrt(2 pi) from ONE exponential:
 // erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1/(1 + p z)  (Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7,
 // far below the bf16 resolution of the stored result) with z = |x|/sqrt2, so exp(-z^2) = exp(-x^2/2) serves both.
-__device__ __forceinline__ void normal_cdf_pdf(float x, float& cdf, float& pdf) {
+// Two elements at a time: the GEMM epilogues that apply it are VALU-bound on it (a 3072 x 3072 output is 5-6 us of
+// nothing but this on every SIMD), so the multiplies and fused multiply-adds are packed (v_pk_fma_f32 / v_pk_mul_f32: two
+// elements per issue slot), the reciprocal is the hardware's v_rcp_f32 (1 ulp: __frcp_rn expands to a ten-instruction
+// correctly rounded division) and the exponential is one multiply + v_exp_f32.  The scalar entry points run the same
+// instruction sequence on a duplicated pair, so an element gets the same bits from every caller.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void normal_cdf_pdf2(const f32x2_t x, f32x2_t& cdf, f32x2_t& pdf) {
     // every multiply-add is spelled out (and nothing else may be contracted): the same bits wherever this is inlined
 #pragma clang fp contract(off)
-    const float ax = fabsf(x);
-    const float e = __expf(-0.5f * ax * ax);
-    const float t = __frcp_rn(__fmaf_rn(0.23164189f, ax, 1.0f));          // p / sqrt2 = 0.3275911 / 1.41421356
-    float poly = __fmaf_rn(t, 1.061405429f, -1.453152027f);
-    poly = __fmaf_rn(t, poly, 1.421413741f);
-    poly = __fmaf_rn(t, poly, -0.284496736f);
-    poly = __fmaf_rn(t, poly, 0.254829592f);
+    const f32x2_t ax = __builtin_elementwise_abs(x);
+    const f32x2_t h = (ax * ax) * -0.72134752044448170368f;              // -x^2/2 * log2(e)
+    f32x2_t e, t;
+    e.x = __builtin_amdgcn_exp2f(h.x);
+    e.y = __builtin_amdgcn_exp2f(h.y);
+    const f32x2_t d = __builtin_elementwise_fma(f32x2_t{0.23164189f, 0.23164189f}, ax, f32x2_t{1.0f, 1.0f});   // p / sqrt2 = 0.3275911 / 1.41421356
+    t.x = __builtin_amdgcn_rcpf(d.x);
+    t.y = __builtin_amdgcn_rcpf(d.y);
+    f32x2_t poly = __builtin_elementwise_fma(t, f32x2_t{1.061405429f, 1.061405429f}, f32x2_t{-1.453152027f, -1.453152027f});
+    poly = __builtin_elementwise_fma(t, poly, f32x2_t{1.421413741f, 1.421413741f});
+    poly = __builtin_elementwise_fma(t, poly, f32x2_t{-0.284496736f, -0.284496736f});
+    poly = __builtin_elementwise_fma(t, poly, f32x2_t{0.254829592f, 0.254829592f});
     poly = t * poly;
-    const float tail = 0.5f * poly * e;                            // = 0.5 * erfc(|x| / sqrt2)
-    cdf = x >= 0.f ? 1.0f - tail : tail;
+    const f32x2_t tail = (0.5f * poly) * e;                              // = 0.5 * erfc(|x| / sqrt2)
+    const f32x2_t upper = 1.0f - tail;
+    cdf.x = x.x >= 0.f ? upper.x : tail.x;
+    cdf.y = x.y >= 0.f ? upper.y : tail.y;
     pdf = 0.39894228040143267794f * e;
 }
-__device__ __forceinline__ float gelu_erf(float x) {
-    float cdf, pdf;
-    normal_cdf_pdf(x, cdf, pdf);
+__device__ __forceinline__ f32x2_t gelu_erf2(const f32x2_t x) {
+#pragma clang fp contract(off)
+    f32x2_t cdf, pdf;
+    normal_cdf_pdf2(x, cdf, pdf);
     return x * cdf;
 }
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-    float cdf, pdf;
-    normal_cdf_pdf(x, cdf, pdf);
-    return __fmaf_rn(x, pdf, cdf);
+__device__ __forceinline__ f32x2_t gelu_erf_grad2(const f32x2_t x) {
+    f32x2_t cdf, pdf;
+    normal_cdf_pdf2(x, cdf, pdf);
+    return __builtin_elementwise_fma(x, pdf, cdf);
 }
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2(f32x2_t{x, x}).x; }
+__device__ __forceinline__ float gelu_erf_grad(float x) { return gelu_erf_grad2(f32x2_t{x, x}).x; }
 
 // hidden_act of the config (model/layer.py:44 ACT2FN): 0 = gelu (erf form), 1 = relu, 2 = swish (x * sigmoid(x))
 enum { UH_ACT_GELU = 0, UH_ACT_RELU = 1, UH_ACT_SWISH = 2 };
@@ -274,6 +290,15 @@ __device__ __forceinline__ float act_grad(int act, float x) {
     if (act == UH_ACT_RELU) return x > 0.f ? 1.f : 0.f;
     if (act == UH_ACT_SWISH) { const float s = __frcp_rn(1.0f + __expf(-x)); return s * (1.0f + x * (1.0f - s)); }
     return gelu_erf_grad(x);
+}
+// the same for two elements (the GEMM epilogues): GELU on the packed path, the other activations element by element
+__device__ __forceinline__ f32x2_t act_fwd2(int act, const f32x2_t x) {
+    if (act == UH_ACT_GELU) return gelu_erf2(x);
+    return f32x2_t{act_fwd(act, x.x), act_fwd(act, x.y)};
+}
+__device__ __forceinline__ f32x2_t act_grad2(int act, const f32x2_t x) {
+    if (act == UH_ACT_GELU) return gelu_erf_grad2(x);
+    return f32x2_t{act_grad(act, x.x), act_grad(act, x.y)};
 }
 
 // ---------------------------------------------------------------------------------------------

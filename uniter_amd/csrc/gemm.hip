@@ -465,7 +465,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                     float uq[8], gq[8];
                     unpack8(uq_bits, uq);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) gq[e] = act_fwd(p.relu, uq[e]);
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2_t gp = act_fwd2(p.relu, f32x2_t{uq[e], uq[e + 1]});
+                        gq[e] = gp.x; gq[e + 1] = gp.y;
+                    }
                     out_store16(p.C2 + (int64_t)m * p.ldc + n, pack8(gq));
                     continue;
                 }
@@ -493,7 +496,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                     float uv[8];
                     unpack8(auxr[b][it], uv);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= act_grad(p.relu, uv[e]);
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2_t gp = act_grad2(p.relu, f32x2_t{uv[e], uv[e + 1]});
+                        v[e] *= gp.x; v[e + 1] *= gp.y;
+                    }
                 }
                 if (EPI == EPI_WGRAD && p.accumulate) {
                     float ov[8];

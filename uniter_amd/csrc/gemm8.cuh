@@ -167,7 +167,10 @@ struct G8Epi {
             for (int e = 0; e < W; ++e) uq[e] = bf2f(f2bf(v[e]));
             store<W>(cptr, v);
 #pragma unroll
-            for (int e = 0; e < W; ++e) gq[e] = act_fwd(p.relu, uq[e]);
+            for (int e = 0; e < W; e += 2) {
+                const f32x2_t gp = act_fwd2(p.relu, f32x2_t{uq[e], uq[e + 1]});
+                gq[e] = gp.x; gq[e + 1] = gp.y;
+            }
             store<W>(p.C2 + (int64_t)m * p.ldc + n, gq);
             return;
         }
@@ -189,7 +192,10 @@ struct G8Epi {
 #pragma unroll
                 for (int e = 0; e < W / 2; ++e) {
                     const float lo = bits2f_lo(auxw[e]), hi = bits2f_hi(auxw[e]);
-                    if constexpr (EPI == EPI_GELU_BWD) { v[2 * e] *= act_grad(p.relu, lo); v[2 * e + 1] *= act_grad(p.relu, hi); }
+                    if constexpr (EPI == EPI_GELU_BWD) {
+                        const f32x2_t gp = act_grad2(p.relu, f32x2_t{lo, hi});
+                        v[2 * e] *= gp.x; v[2 * e + 1] *= gp.y;
+                    }
                     else { v[2 * e] += lo; v[2 * e + 1] += hi; }
                 }
             }
