@@ -377,7 +377,7 @@ def main():
     rank = D.rank()
 
     cfg_path = os.path.join("/tmp", "uniter_bench_%d.json" % os.getpid())
-    lpb = int(os.environ.get("UNITER_BENCH_LAYERS_PER_BUCKET", "3"))
+    lpb = int(os.environ["UNITER_BENCH_LAYERS_PER_BUCKET"]) if "UNITER_BENCH_LAYERS_PER_BUCKET" in os.environ else None
     overlap = bool(args.overlap and not args.graph)
     runner = StepRunner(args.config, device, rank=rank, world=world, seed=77, ragged=args.ragged, pack=args.pack,
                         overlap=overlap, cfg_path=cfg_path, reducer_layers_per_bucket=lpb)
