@@ -645,6 +645,13 @@ def test_graphed_step_matches_eager(golden):
         for a, b in zip(results[0][0], results[1][0]):
             assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (results[0][0], results[1][0])
         for k in results[0][1]:
+            if k.endswith('attention.self.key.bias'):
+                # softmax is invariant to a key bias: its true gradient is identically zero, what the kernels produce is the
+                # rounding noise of dK's column sums, and Adam turns noise into full-size steps of arbitrary sign.  Replay
+                # computes the weight / bias gradients layer by layer, eager in the deferred launch (another summation
+                # order), so the two may walk apart by at most the sum of the learning rates of the three steps, each way.
+                assert (results[1][1][k] - results[0][1][k]).abs().max().item() <= 2 * 1e-3 * (0.25 + 0.5 + 0.75) + 1e-6, k
+                continue
             assert rel_l2(results[1][1][k], results[0][1][k]) < 2e-3, k
         # dropout under replay: fresh masks every replay
         model = _prep(UniterForPretraining.from_pretrained(TINY_CONFIG, golden.pretrain_sd(), img_dim=IMG_DIM, img_label_dim=LABEL_DIM))
