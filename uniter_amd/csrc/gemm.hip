@@ -1287,8 +1287,10 @@ struct MultiState {
     size_t pinned_cap[4] = {0, 0, 0, 0};
     hipEvent_t pinned_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int next = 0;
+    float* tail_slabs[16] = {nullptr};                       // per device: fp32 slabs of the tiles that run as two K slices (64 x 256 KiB)
 };
 thread_local MultiState g_multi;
+constexpr int kMultiTailMax = 8;                             // tiles per XCD beyond whole rounds that are split (more: they run whole)
 }  // namespace
 
 int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* const* dw, void* const* db, int64_t M,
@@ -1330,7 +1332,7 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
         if (ln[k].H != ln[0].H || ln[k].H % 8 != 0 || ln[k].rows <= 0) { uh_set_error("gemm_wgrad_multi: LayerNorm jobs must share H (a multiple of 8)"); return -1; }
         jobs[(size_t)k] = G8LnJob{(const bf16_t*)ln[k].dy, (const bf16_t*)ln[k].z, ln[k].mean, ln[k].rstd, (bf16_t*)ln[k].dgamma,
                                   (bf16_t*)ln[k].dbeta, (int)ln[k].rows, (int)ln[k].H, accumulate, 0};
-        ln_strips_per_job = (int)((ln[k].H + 255) / 256);
+        ln_strips_per_job = (int)((ln[k].H + G8_LN_STRIP - 1) / G8_LN_STRIP);
     }
     const size_t tbl_bytes = tbl.size() * sizeof(GemmArgs), meta_off = (tbl_bytes + 255) & ~(size_t)255;
     const size_t ln_off = (meta_off + meta.size() * sizeof(int) + 255) & ~(size_t)255;
@@ -1366,9 +1368,32 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
         T.last = img;
     }
     const int per = (tiles + 7) / 8;
-    const int gemm_blocks = per * 8;
-    // (computing the tiles of each XCD's last, mostly empty round as two K slices combined in the launch was built and
-    //  measured: 2 413 vs 2 413-2 451 us of backward — neutral, not kept)
+    // tiles of an XCD's segment beyond whole rounds of its 32 CUs: when they are few they run as two K slices each (see the kernel)
+    int full = per;
+    unsigned* tail_pairs = nullptr;
+    float* tail_slabs = nullptr;
+    {
+        static const bool split_tail = [] { const char* e = getenv("UNITER_AMD_MULTI_TAIL_SPLIT"); return e == nullptr || atoi(e) != 0; }();
+        const int tail = per % 32;
+        if (split_tail && per > 32 && tail > 0 && tail <= kMultiTailMax && M >= 256 && dev >= 0 && dev < 16) {
+            if (g_multi.tail_slabs[dev] == nullptr &&
+                hipMalloc(&g_multi.tail_slabs[dev], (size_t)8 * kMultiTailMax * 256 * 256 * sizeof(float)) != hipSuccess)
+                g_multi.tail_slabs[dev] = nullptr;
+            tail_slabs = g_multi.tail_slabs[dev];
+            tail_pairs = tail_slabs != nullptr ? g8_pair_counters(8 * tail) : nullptr;
+            if (tail_pairs != nullptr) full = per - tail;
+        }
+    }
+    const int gemm_blocks = (full + 2 * (per - full)) * 8;
+    unsigned long long* stamp_dev = nullptr;
+    {
+        static const bool want = [] { const char* e = getenv("UNITER_AMD_MULTI_STAMPS"); return e != nullptr && atoi(e) != 0; }();
+        static unsigned long long* buf = nullptr;
+        if (want) {
+            if (buf == nullptr && (hipMalloc(&buf, (size_t)2 * 8192 * 8) != hipSuccess || hipMemset(buf, 0, (size_t)2 * 8192 * 8) != hipSuccess)) buf = nullptr;
+            if (gemm_blocks + strips + n_ln * 32 <= 8192) stamp_dev = buf;
+        }
+    }
     static bool attr_done = false;
     if (!attr_done) {
         UH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS_BYTES));
@@ -1376,9 +1401,49 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
     }
     LaunchTimer lt(TIME_GEMM_WGRAD_GROUP, M, welems, n, st);
     hipLaunchKernelGGL(gemm8_multi_kernel, dim3(gemm_blocks + strips + n_ln * ln_strips_per_job), dim3(G8_THREADS), G8_LDS_BYTES, st,
-                       (const GemmArgs*)T.dev, (const int*)((const char*)T.dev + meta_off), n, per, gemm_blocks,
-                       (const G8LnJob*)((const char*)T.dev + ln_off), ln_strips_per_job, strips);
+                       (const GemmArgs*)T.dev, (const int*)((const char*)T.dev + meta_off), n, per, full, gemm_blocks,
+                       (const G8LnJob*)((const char*)T.dev + ln_off), ln_strips_per_job, strips, tail_pairs, tail_slabs, stamp_dev);
     UH_LAUNCH_CHECK();
+    if (stamp_dev != nullptr) {                              // harness profiling: synchronous, prints the launch's schedule
+        const int nb = gemm_blocks + strips + n_ln * ln_strips_per_job;
+        std::vector<unsigned long long> hs((size_t)2 * nb);
+        if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(hs.data(), stamp_dev, hs.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int b = 0; b < nb; ++b) if (hs[2 * (size_t)b]) { t0 = std::min(t0, hs[2 * (size_t)b]); t1 = std::max(t1, hs[2 * (size_t)b + 1]); }
+            auto us = [&](unsigned long long v) { return (double)(v - t0) * 0.01; };
+            fprintf(stderr, "multi launch schedule: %d workgroups (%d whole tiles + %d half-K + %d LayerNorm strips), first start -> last end %.1f us\n",
+                    nb, 8 * full, gemm_blocks - 8 * full, n_ln * ln_strips_per_job, us(t1));
+            // whole tiles: duration statistics per round of dispatch (position inside the XCD segment / 32)
+            for (int round = 0; round * 32 < full; ++round) {
+                double dsum = 0, dmax = 0, smin = 1e30, emax = 0; int cnt = 0;
+                for (int b = 0; b < 8 * full; ++b) {
+                    const int loc = b >> 3;
+                    if (loc / 32 != round || hs[2 * (size_t)b] == 0) continue;
+                    const double s0 = us(hs[2 * (size_t)b]), e0 = us(hs[2 * (size_t)b + 1]);
+                    dsum += e0 - s0; dmax = std::max(dmax, e0 - s0); smin = std::min(smin, s0); emax = std::max(emax, e0); ++cnt;
+                }
+                if (cnt) fprintf(stderr, "  round %d: %3d tiles, start >= %.1f us, end <= %.1f us, duration avg %.1f max %.1f us\n", round, cnt, smin, emax, dsum / cnt, dmax);
+            }
+            auto span = [&](int lo, int hi, const char* what) {
+                double dsum = 0, smin = 1e30, emax = 0; int cnt = 0;
+                for (int b = lo; b < hi; ++b) {
+                    if (hs[2 * (size_t)b] == 0) continue;
+                    const double s0 = us(hs[2 * (size_t)b]), e0 = us(hs[2 * (size_t)b + 1]);
+                    dsum += e0 - s0; smin = std::min(smin, s0); emax = std::max(emax, e0); ++cnt;
+                }
+                if (cnt) fprintf(stderr, "  %s: %d workgroups, start >= %.1f us, end <= %.1f us, duration avg %.1f us\n", what, cnt, smin, emax, dsum / cnt);
+            };
+            span(8 * full, gemm_blocks, "half-K tail tiles");
+            span(gemm_blocks + strips, nb, "LayerNorm strips");
+            // per XCD: when its last whole tile ended
+            for (int x = 0; x < 8; ++x) {
+                double emax = 0;
+                for (int b = x; b < 8 * full; b += 8) if (hs[2 * (size_t)b]) emax = std::max(emax, us(hs[2 * (size_t)b + 1]));
+                fprintf(stderr, "  XCD %d: last whole tile ends at %.1f us\n", x, emax);
+            }
+        }
+        (void)hipMemsetAsync(stamp_dev, 0, (size_t)2 * nb * 8, st);
+    }
     return 0;
 }
 

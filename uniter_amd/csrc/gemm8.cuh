@@ -873,7 +873,7 @@ __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_group_kernel(const G8Grou
 // blocks beyond `gemm_blocks` are the bias-gradient column strips.  meta = tile_start[n+1] followed by strip_start[n+1].
 // A LayerNorm's parameter gradients as one more kind of column strip of the multi launch: dgamma[c] (+)= sum_t dy[t][c] * xhat[t][c],
 // dbeta[c] (+)= sum_t dy[t][c] with xhat = (z - mean[t]) * rstd[t] (model/layer.py:108,149: BertLayerNorm backward, parameter half;
-// the row half stays in layernorm.hip on the critical path).  Strips of 256 columns, thread = (row lane, 8-column chunk).
+// the row half stays in layernorm.hip on the critical path).
 struct G8LnJob {
     const bf16_t* dy;
     const bf16_t* z;
@@ -884,30 +884,38 @@ struct G8LnJob {
     int rows, H;
     int accumulate, pad;
 };
+// Strips of 64 columns: thread = (one of 64 row lanes, 8-column chunk), four rows in flight per thread — 12 trips over 3 072
+// rows.  (256-column strips with 16 row lanes took 96 dependent trips of ~1 us each: longer than a GEMM tile of the same
+// launch, and since the strips are dispatched last they WERE the launch's tail.)
+constexpr int G8_LN_STRIP = 64;
 __device__ __forceinline__ void g8_ln_cols_strip(const G8LnJob& j, const int strip, char* smem_raw) {
     const int t = threadIdx.x;
-    const int cc = t & 31, rl = t >> 5;
-    const int col = strip * 256 + cc * 8;
+    const int cc = t & 7, rl = t >> 3;
+    const int col = strip * G8_LN_STRIP + cc * 8;
     float ag[8], ab[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ag[e] = 0.f; ab[e] = 0.f; }
     if (col < j.H) {
         int r = rl;
-        for (; r + 16 < j.rows; r += 32) {                  // two rows in flight per thread
-            const u32x4 d0 = *reinterpret_cast<const u32x4*>(j.dy + (int64_t)r * j.H + col);
-            const u32x4 z0 = *reinterpret_cast<const u32x4*>(j.z + (int64_t)r * j.H + col);
-            const u32x4 d1 = *reinterpret_cast<const u32x4*>(j.dy + (int64_t)(r + 16) * j.H + col);
-            const u32x4 z1 = *reinterpret_cast<const u32x4*>(j.z + (int64_t)(r + 16) * j.H + col);
-            const float m0 = j.mean[r], s0 = j.rstd[r], m1 = j.mean[r + 16], s1 = j.rstd[r + 16];
-            float dv[8], zv[8];
-            unpack8(d0, dv); unpack8(z0, zv);
+        for (; r + 192 < j.rows; r += 256) {
+            u32x4 d[4], z[4];
+            float m[4], sd[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { ag[e] += dv[e] * ((zv[e] - m0) * s0); ab[e] += dv[e]; }
-            unpack8(d1, dv); unpack8(z1, zv);
+            for (int u = 0; u < 4; ++u) {
+                d[u] = *reinterpret_cast<const u32x4*>(j.dy + (int64_t)(r + 64 * u) * j.H + col);
+                z[u] = *reinterpret_cast<const u32x4*>(j.z + (int64_t)(r + 64 * u) * j.H + col);
+                m[u] = j.mean[r + 64 * u];
+                sd[u] = j.rstd[r + 64 * u];
+            }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { ag[e] += dv[e] * ((zv[e] - m1) * s1); ab[e] += dv[e]; }
+            for (int u = 0; u < 4; ++u) {
+                float dv[8], zv[8];
+                unpack8(d[u], dv); unpack8(z[u], zv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ag[e] += dv[e] * ((zv[e] - m[u]) * sd[u]); ab[e] += dv[e]; }
+            }
         }
-        for (; r < j.rows; r += 16) {
+        for (; r < j.rows; r += 64) {
             float dv[8], zv[8];
             unpack8(*reinterpret_cast<const u32x4*>(j.dy + (int64_t)r * j.H + col), dv);
             unpack8(*reinterpret_cast<const u32x4*>(j.z + (int64_t)r * j.H + col), zv);
@@ -916,19 +924,18 @@ __device__ __forceinline__ void g8_ln_cols_strip(const G8LnJob& j, const int str
             for (int e = 0; e < 8; ++e) { ag[e] += dv[e] * ((zv[e] - m0) * s0); ab[e] += dv[e]; }
         }
     }
-    float* red = reinterpret_cast<float*>(smem_raw);        // [2][16][256]
+    float* red = reinterpret_cast<float*>(smem_raw);        // [2][64 row lanes][64 columns]
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { red[rl * 256 + cc * 8 + e] = ag[e]; red[16 * 256 + rl * 256 + cc * 8 + e] = ab[e]; }
+    for (int e = 0; e < 8; ++e) { red[rl * 64 + cc * 8 + e] = ag[e]; red[64 * 64 + rl * 64 + cc * 8 + e] = ab[e]; }
     __syncthreads();
-    {
-        const int k = t >> 8, c = t & 255;                  // threads 0-255: dgamma, 256-511: dbeta
-        if (strip * 256 + c < j.H) {
+    if (t < 128) {
+        const int k = t >> 6, c = t & 63;                   // threads 0-63: dgamma, 64-127: dbeta
+        if (strip * G8_LN_STRIP + c < j.H) {
             float tot = 0.f;
-#pragma unroll
-            for (int w = 0; w < 16; ++w) tot += red[k * 16 * 256 + w * 256 + c];
+            for (int w = 0; w < 64; ++w) tot += red[k * 64 * 64 + w * 64 + c];
             bf16_t* base = k == 0 ? j.dgamma : j.dbeta;
             if (base != nullptr) {
-                bf16_t* dst = base + strip * 256 + c;
+                bf16_t* dst = base + strip * G8_LN_STRIP + c;
                 if (j.accumulate) tot += bf2f(*dst);
                 *dst = f2bf(tot);
             }
@@ -937,11 +944,18 @@ __device__ __forceinline__ void g8_ln_cols_strip(const G8LnJob& j, const int str
 }
 
 __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_multi_kernel(const GemmArgs* __restrict__ tbl, const int* __restrict__ meta,
-                                                                    const int n, const int per, const int gemm_blocks,
+                                                                    const int n, const int per, const int full, const int gemm_blocks,
                                                                     const G8LnJob* __restrict__ ln_jobs, const int ln_strips_per_job,
-                                                                    const int bias_strips) {
+                                                                    const int bias_strips, unsigned* __restrict__ tail_pairs,
+                                                                    float* __restrict__ tail_slabs, unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int b = (int)blockIdx.x;
+    // profiling (UNITER_AMD_MULTI_STAMPS, harness only): start / end of every workgroup on the chip-wide 100 MHz clock
+    struct Stamp {
+        unsigned long long* p;
+        __device__ explicit Stamp(unsigned long long* q) : p(q) { if (p && threadIdx.x == 0) p[0] = __builtin_amdgcn_s_memrealtime(); }
+        __device__ ~Stamp() { if (p && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p[1] = __builtin_amdgcn_s_memrealtime(); } }
+    } stamp(stamps ? stamps + 2 * (size_t)b : nullptr);
     const int* tile_start = meta;
     const int* strip_start = meta + n + 1;
     auto find = [&](const int* starts, int v) {             // largest q with starts[q] <= v (starts ascend, starts[0] == 0)
@@ -965,15 +979,39 @@ __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_multi_kernel(const GemmAr
         g8_colsum_strip(p, s - strip_start[q], smem_raw);
         return;
     }
-    const int pos = (b & 7) * per + (b >> 3);
+    // XCD x (hardware blocks with b % 8 == x) walks the contiguous segment [x*per, (x+1)*per) of the tile order.  Its first
+    // `full` tiles fill whole rounds of the XCD's 32 CUs; the few left over (full < per only when they are at most a quarter of a
+    // round) would be a round of their own at one tile per handful of CUs — they run as TWO K slices combined in the launch
+    // (gemm8_tile's pair path: half the K tiles each, one fp32 slab per tile), twice as many workgroups for half as long.
+    const int xcd = b & 7, loc = b >> 3;
+    int pos = xcd * per + loc, slice = 0, slot = -1;
+    if (loc >= full) {
+        const int t = loc - full;
+        pos = xcd * per + full + (t >> 1);
+        slice = t & 1;
+        slot = xcd * (per - full) + (t >> 1);
+    }
     if (pos >= tile_start[n]) return;
     const int q = find(tile_start, pos);
-    const GemmArgs p = tbl[q];
+    GemmArgs p = tbl[q];
     const int bx = pos - tile_start[q];
     const int tiles_m = p.M >> 8, tiles_n = p.N >> 8;
     const int tm = tiles_n >= tiles_m ? bx % tiles_m : bx / tiles_n;      // longer tile dimension outermost
     const int tn = tiles_n >= tiles_m ? bx / tiles_m : bx % tiles_n;
-    gemm8_tile<true, true, EPI_WGRAD, true>(p, tm * tiles_n + tn, 0, smem_raw);
+    const int tile = tm * tiles_n + tn;
+    if (slot >= 0) {
+        if (tn == 0 && p.C2 != nullptr) {                   // this tile also sums the bias gradient over the WHOLE contraction
+            if (slice == 1) return;
+        } else {
+            p.k_per_split = (p.K >> 7) << 6;                // two slices of whole K tiles (the second takes an odd one)
+            if (p.K - p.k_per_split > p.k_per_split) p.k_per_split += 64;
+            p.pair = tail_pairs + slot - tile;              // gemm8_tile indexes both by the tile number
+            p.partial = tail_slabs + ((int64_t)slot - tile) * (256 * 256);
+        }
+        gemm8_tile<true, true, EPI_WGRAD, true>(p, tile, slice, smem_raw);
+        return;
+    }
+    gemm8_tile<true, true, EPI_WGRAD, true>(p, tile, 0, smem_raw);
 }
 
 __global__ __launch_bounds__(G8_THREADS, 2) void gemm6_group_kernel(const G8GroupArgs ga) {
