@@ -870,7 +870,9 @@ __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_group_kernel(const G8Grou
 // operands and hand ALL of them over at once: 12 layers = 1 296 tiles, five full rounds of 256 CUs on the tile whose K loop
 // runs at 80 % of the matrix pipe, instead of twelve half-filled launches that each fight the data-gradient chain for CUs.
 // The problems (up to 4 per layer) come from a table in device memory; tile order and XCD mapping as gemm8_group_kernel;
-// blocks beyond `gemm_blocks` are the bias-gradient column strips.  meta = tile_start[n+1] followed by strip_start[n+1].
+// the bias gradients come from the tiles of each problem's first tile column (gemm8_tile COLSUM; `bias_strips` = 0 — the
+// column-strip form of gemm8_group_kernel is still understood); blocks beyond them are the LayerNorm strips.
+// meta = tile_start[n+1] followed by strip_start[n+1].
 // A LayerNorm's parameter gradients as one more kind of column strip of the multi launch: dgamma[c] (+)= sum_t dy[t][c] * xhat[t][c],
 // dbeta[c] (+)= sum_t dy[t][c] with xhat = (z - mean[t]) * rstd[t] (model/layer.py:108,149: BertLayerNorm backward, parameter half;
 // the row half stays in layernorm.hip on the critical path).
