@@ -388,6 +388,50 @@ def test_full_size_backward_linearity_and_accumulation(full_model):
         assert rel_l2(g11[name], 2 * g1[name]) < 2e-2, name
 
 
+def test_deferred_parameter_gradients_match_per_layer_launches(full_model, monkeypatch):
+    """The backward call's one deferred launch (every weight / bias / LayerNorm-parameter gradient of its layers on the 256 x 256
+    tile, after the data-gradient chain) against the per-layer grouped launches beside the chain (no stage registered) — the
+    same numbers up to the summation order of the bias / LayerNorm column sums — and with the join of that launch left to the
+    consumer (`ops.DeferWgradJoin` + `_lib.join_wgrads()`, what the training loop does) exactly the same bits again."""
+    from uniter_amd import _lib, ops
+    full_model.train()
+    b = _full_batch(seed=21)
+    params = dict(full_model.uniter.named_parameters())
+
+    def grads():
+        for p in params.values():
+            p.grad = None
+        y = _run(full_model, b)
+        y.float().pow(2).mean().backward()
+        _lib.join_wgrads()
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().float().clone() for n, p in params.items() if p.grad is not None}
+
+    assert ops._WGRAD_STAGE, "the stage is on by default"
+    g_def = grads()
+    enc = full_model.uniter.encoder
+    old_hook = enc.grad_ready_hook
+    try:
+        enc.grad_ready_hook = ops.DeferWgradJoin()
+        g_join = grads()
+    finally:
+        enc.grad_ready_hook = old_hook
+    monkeypatch.setattr(ops, "_WGRAD_STAGE", False)
+    g_layer = grads()
+    assert set(g_def) == set(g_layer) == set(g_join)
+    worst = ("", 0.0)
+    for n in g_def:
+        assert torch.equal(g_def[n], g_join[n]), n                 # who waits for the launch does not change what it computes
+        if not n.startswith('encoder.'):
+            assert torch.equal(g_def[n], g_layer[n]), n            # the data-gradient chain is untouched: embeddings bit-identical
+            continue
+        r = rel_l2(g_def[n], g_layer[n])
+        worst = max(worst, (n, r), key=lambda t: t[1])
+        # weights: the same products summed tile by tile in fp32 either way; biases / LayerNorm: fp32 column sums in another order
+        assert r < (1e-3 if n.endswith('weight') and 'LayerNorm' not in n else 4e-3), (n, r)
+    print("deferred vs per-layer parameter gradients: %d tensors, worst rel-L2 %.2e (%s)" % (len(g_def), worst[1], worst[0]))
+
+
 def test_full_size_dropout_statistics():
     """Philox dropout: kept fraction ~ 1-p, scaled by 1/(1-p), same (seed, offset) -> same mask; different offset -> different."""
     import ctypes

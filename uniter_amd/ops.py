@@ -490,6 +490,8 @@ class _EncoderFn(torch.autograd.Function):
             if st_bytes > 0 and _WGRAD_STAGE:
                 stage = _scratch(("enc_wgrad_stage", xc.device.index), st_bytes, xc.device)
                 C.uniter_encoder_set_wgrad_stage(ptr(stage), st_bytes)
+            else:
+                C.uniter_encoder_set_wgrad_stage(None, 0)       # (the registration is per thread and outlives a call)
             C.uniter_encoder_backward(ctypes.byref(s), table, begin, end, x_in,
                                       None if ctx.packed is not None else ptr(mask_bias), ptr(dy), ptr(dx),
                                       ptr(ctx.acts), ptr(scratch), ctx.seed, ctx.off, st)
