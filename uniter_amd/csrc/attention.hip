@@ -22,8 +22,8 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // forward: one workgroup per (example, head) — the unit itself lives in attention_fwd.cuh
 // ------------------------------------------------------------------------------------------------
-template <int MAXKT>
-__global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
+template <int MAXKT, int MAXT = 512>
+__global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     attn_fwd_unit<MAXKT, false>(p, (int)blockIdx.x, smem_raw);
 }
@@ -35,8 +35,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
 // leaves two of a CU's four SIMDs with one wave while the other two carry two (the kernel is VALU-issue bound: ~3 000
 // instructions per wave, cycle stamps in the harness), and a second workgroup does not fit beside it — 384 workgroups ran as
 // two rounds of 256 / 128.  Two units per workgroup = 12 waves = three per SIMD on 192 CUs in ONE round.
-template <int HP>
-__global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_kernel(const AttnArgs p) {
+template <int HP, int MAXT = (HP == 2 ? 768 : 512)>
+__global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     const int Lp = p.Lp, Lm = p.L;
     const int nthr = (int)blockDim.x / HP;                     // threads of one unit's team
@@ -661,11 +661,11 @@ int attn_dbg() {
     return v;
 }
 
-int pick_waves(int nt) {
-    const int rounds = (nt + 7) / 8;
-    for (int w = 1; w <= 8; ++w)
+int pick_waves(int nt, int maxw = 8) {
+    const int rounds = (nt + maxw - 1) / maxw;
+    for (int w = 1; w <= maxw; ++w)
         if ((nt + w - 1) / w == rounds) return w < 2 ? 2 : w;
-    return 8;
+    return maxw;
 }
 
 template <typename K>
@@ -702,7 +702,9 @@ int attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse
     a.dbg = attn_dbg();
     if (cu == nullptr && mask_bias == nullptr) { uh_set_error("attention: dense mode needs mask_bias"); return -1; }
     const int nkt = a.Lp / 16;
-    const int nw = L > LMAX ? 8 : pick_waves((int)((L + 15) / 16));
+    const int nqt_all = (int)((L + 15) / 16);
+    // (one 16-query tile per wave up to 12 tiles: see attention_bwd)
+    const int nw = L > LMAX ? 8 : ((nqt_all > 8 && nqt_all <= 12) ? pick_waves(nqt_all, 12) : pick_waves(nqt_all));
     const int nit = L > LMAX ? 2 * TILE_IT : TILE_IT;
     if (a.Lp * 8 > nit * nw * 64 || a.Lp > 2 * nw * 64) { uh_set_error("attention: prologue staging does not cover L=%lld with %d waves", (long long)L, nw); return -1; }
     const size_t lds = (size_t)a.Lp * 64 * 2 * 2 + (size_t)a.Lp * 4;
@@ -717,6 +719,9 @@ int attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse
     } else if (nkt <= 8) {
         if ((rc = set_lds(attn_fwd_kernel<8>, lds))) return rc;
         hipLaunchKernelGGL(attn_fwd_kernel<8>, grid, block, lds, st, a);
+    } else if (nkt <= 12 && nw > 8) {
+        if ((rc = set_lds(attn_fwd_kernel<12, 768>, lds))) return rc;
+        hipLaunchKernelGGL((attn_fwd_kernel<12, 768>), grid, block, lds, st, a);
     } else if (nkt <= 12) {
         if ((rc = set_lds(attn_fwd_kernel<12>, lds))) return rc;
         hipLaunchKernelGGL(attn_fwd_kernel<12>, grid, block, lds, st, a);
@@ -760,7 +765,10 @@ int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, cons
         return 0;
     }
     if (a.dbg & 8) a.dsum = (float*)workspace;          // harness profiling: cycle stamps, [B*heads][8 waves][8]
-    const int nw = pick_waves((int)((L + 15) / 16));
+    // up to 12 waves (three per SIMD at the kernel's register count) when that gives every 16-row tile its own wave: at
+    // L = 178 twelve tiles on six waves left two SIMDs with four tile-sweeps and two with two
+    const int nt_all = (int)((L + 15) / 16);
+    const int nw = (nt_all > 8 && nt_all <= 12) ? pick_waves(nt_all, 12) : pick_waves(nt_all);
     if (a.Lp * 8 > TILE_IT * nw * 64 || a.Lp > 2 * nw * 64) { uh_set_error("attention: prologue staging does not cover L=%lld with %d waves", (long long)L, nw); return -1; }
     const size_t lds = (size_t)a.Lp * 64 * 2 * 4 + (size_t)a.Lp * 4 * 3 + (size_t)a.Lp * (a.Lp / 4);
     int rc;
@@ -786,8 +794,13 @@ int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, cons
         if ((rc = set_lds(attn_bwd_kernel<2>, 2 * unit_bytes))) return rc;
         hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3((unsigned)((units + 1) / 2)), dim3(2 * nw * 64), 2 * unit_bytes, st, a);
     } else {
-        if ((rc = set_lds(attn_bwd_kernel<1>, lds))) return rc;
-        hipLaunchKernelGGL(attn_bwd_kernel<1>, dim3((unsigned)units), dim3(nw * 64), lds, st, a);
+        if (nw > 8) {
+            if ((rc = set_lds(attn_bwd_kernel<1, 768>, lds))) return rc;
+            hipLaunchKernelGGL((attn_bwd_kernel<1, 768>), dim3((unsigned)units), dim3(nw * 64), lds, st, a);
+        } else {
+            if ((rc = set_lds(attn_bwd_kernel<1>, lds))) return rc;
+            hipLaunchKernelGGL(attn_bwd_kernel<1>, dim3((unsigned)units), dim3(nw * 64), lds, st, a);
+        }
     }
     UH_LAUNCH_CHECK();
     return 0;
