@@ -62,3 +62,63 @@ def test_committed_pmc_traffic_files_attribute_bytes_to_shapes():
             # (the deferred weight-gradient launch — kind 13 with more than one layer's four problems — runs once per step)
             need = 3 if parts[0] == "13" and int(parts[3]) > 4 else 8
             assert len(parts) == 4 and e["hbm_bytes"] > 0 and e["dispatches"] >= need, (f, k)
+
+
+def test_summariser_attributes_synthetic_pmc_passes_to_every_shape(tmp_path):
+    """scripts/summarize_profile.pmc_traffic on synthetic FETCH_SIZE / WRITE_SIZE passes built from the SHIPPED tile table:
+    every encoder GEMM of the benchmark shape (kernel template + dispatch grid derived from the table, shapes that share a
+    template told apart by program order) and the once-per-step deferred launch must come out under their bench.py keys."""
+    import csv
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("summarize_profile", os.path.join(ROOT, "scripts", "summarize_profile.py"))
+    sp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sp)
+    tiles = _tiles_in_source()
+    table = json.load(open(ops.FACTORY_TUNE))
+    H, I, M = 768, 3072, 3072
+    lookup = {(e["kind"], e["N"], e["K"]): e for e in table["gemm"] if e["M"] == M and e["kind"] != 3 and min(e["N"], e["K"]) == H}
+    order = [(0, 0, 3 * H, H), (0, 2, H, H), (0, 1, I, H), (0, 2, H, I), (1, 4, H, I), (1, 3, I, H), (1, 3, H, H), (1, 3, 3 * H, H)]
+    launches = []                                             # (kernel name, grid size) of one layer, in program order
+    for kind, epi, N, K in order:
+        e = lookup[(kind, N, K)]
+        bm, bn, st, ws = tiles[e["cfg"]]
+        rows, cols = (M, N) if kind == 0 else (M, K)
+        threads = 256 if ws == 0 else (512 if ws in (1, 3, 4) else 768)
+        grid = ((rows + bm - 1) // bm) * (cols // bn) * threads * e["splits"]
+        layout = {0: "false, false", 1: "false, true"}[kind]
+        if ws >= 3:
+            name = "void (anonymous namespace)::gemm%d_kernel<%s, %d>((anonymous namespace)::GemmArgs)" % (8 if ws == 3 else 6, layout, epi)
+        else:
+            name = "void (anonymous namespace)::gemm_kernel<%d, %d, %s, %d, %d, %d>((anonymous namespace)::GemmArgs)" % (bm, bn, layout, epi, st, ws)
+        launches.append((name, grid, epi, N, K))
+    multi = ("(anonymous namespace)::gemm8_multi_kernel((anonymous namespace)::GemmArgs const*, int const*, int, int, int, int)", 1600 * 512)
+
+    def write_pass(path, counter, base):
+        with open(path, "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Dispatch_Id", "Kernel_Name", "Grid_Size", "Counter_Name", "Counter_Value"])
+            did = 0
+            for step in range(5):
+                for layer in range(12):
+                    for j, (name, grid, epi, N, K) in enumerate(launches):
+                        did += 1
+                        w.writerow([did, name, grid, counter, base + 100.0 * j])      # KiB; distinct per position in the layer
+                did += 1
+                w.writerow([did, multi[0], multi[1], counter, 1000.0 * base])
+
+    run = tmp_path / "prof" / "pmc_x" / "runc"
+    run.mkdir(parents=True)
+    fcsv, wcsv = str(run / "1_fetch.csv"), str(run / "1_write.csv")
+    write_pass(fcsv, "FETCH_SIZE", 1000.0)
+    write_pass(wcsv, "WRITE_SIZE", 500.0)
+    dst = str(tmp_path / "out.json")
+    sp.pmc_traffic(fcsv, wcsv, dst)
+    shapes = json.load(open(dst))["by_shape"]
+    for j, (name, grid, epi, N, K) in enumerate(launches):
+        key = "%d:%d:%d:%d" % (epi, M, N, K)
+        assert key in shapes, (key, sorted(shapes))
+        assert shapes[key]["hbm_read_bytes"] == round(2.0 * (1000.0 + 100.0 * j) * 1024.0), key     # gfx950: FETCH_SIZE doubled
+        assert shapes[key]["hbm_write_bytes"] == round((500.0 + 100.0 * j) * 1024.0), key
+    key = "13:%d:%d:%d" % (M, 12 * (2 * H * I + 4 * H * H), 48)
+    assert key in shapes and shapes[key]["dispatches"] == 5, sorted(shapes)
+
