@@ -1385,6 +1385,13 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
         }
     }
     const int gemm_blocks = (full + 2 * (per - full)) * 8;
+    // LayerNorm strips that go first (see the kernel): half the chip's CUs, when the launch is long enough for it to matter
+    int lead_strips = 0;
+    {
+        static const int lead_cfg = [] { const char* e = getenv("UNITER_AMD_MULTI_LEAD_STRIPS"); return e ? atoi(e) : 128; }();
+        const int n_ln_strips = n_ln * ln_strips_per_job;
+        if (per > 64) lead_strips = std::min(lead_cfg, n_ln_strips) & ~7;
+    }
     unsigned long long* stamp_dev = nullptr;
     {
         static const bool want = [] { const char* e = getenv("UNITER_AMD_MULTI_STAMPS"); return e != nullptr && atoi(e) != 0; }();
@@ -1402,7 +1409,8 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
     LaunchTimer lt(TIME_GEMM_WGRAD_GROUP, M, welems, n, st);
     hipLaunchKernelGGL(gemm8_multi_kernel, dim3(gemm_blocks + strips + n_ln * ln_strips_per_job), dim3(G8_THREADS), G8_LDS_BYTES, st,
                        (const GemmArgs*)T.dev, (const int*)((const char*)T.dev + meta_off), n, per, full, gemm_blocks,
-                       (const G8LnJob*)((const char*)T.dev + ln_off), ln_strips_per_job, strips, tail_pairs, tail_slabs, stamp_dev);
+                       (const G8LnJob*)((const char*)T.dev + ln_off), ln_strips_per_job, strips, tail_pairs, tail_slabs, stamp_dev,
+                       lead_strips);
     UH_LAUNCH_CHECK();
     if (stamp_dev != nullptr) {                              // harness profiling: synchronous, prints the launch's schedule
         const int nb = gemm_blocks + strips + n_ln * ln_strips_per_job;

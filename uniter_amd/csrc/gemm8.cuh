@@ -949,9 +949,19 @@ __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_multi_kernel(const GemmAr
                                                                     const int n, const int per, const int full, const int gemm_blocks,
                                                                     const G8LnJob* __restrict__ ln_jobs, const int ln_strips_per_job,
                                                                     const int bias_strips, unsigned* __restrict__ tail_pairs,
-                                                                    float* __restrict__ tail_slabs, unsigned long long* __restrict__ stamps) {
+                                                                    float* __restrict__ tail_slabs, unsigned long long* __restrict__ stamps,
+                                                                    const int lead_strips) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int b = (int)blockIdx.x;
+    // Block order: `lead_strips` LayerNorm strips FIRST (a multiple of 8, at most half the chip), then the tiles, then the other
+    // strips.  The CUs that start with a 28 us strip run their 83 us tiles that much later than the rest for the whole launch, so
+    // CUs come free in two phases per tile time instead of one — which is when the small kernels of the caller's stream (the
+    // embedding backward runs beside this launch) get to run at all: nothing can share a CU with a tile.
+    int b = (int)blockIdx.x;
+    const int n_ln_strips = (int)gridDim.x - gemm_blocks - bias_strips;
+    if (b < lead_strips) b = gemm_blocks + bias_strips + b;                                  // a leading LayerNorm strip
+    else if (b < lead_strips + gemm_blocks + bias_strips) b -= lead_strips;                 // tile / bias strip
+    // (else: one of the remaining LayerNorm strips, already at its index)
+    (void)n_ln_strips;
     // profiling (UNITER_AMD_MULTI_STAMPS, harness only): start / end of every workgroup on the chip-wide 100 MHz clock
     struct Stamp {
         unsigned long long* p;
