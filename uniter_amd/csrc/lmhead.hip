@@ -133,7 +133,10 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
         unpack8(*reinterpret_cast<const u32x4*>(dy + i * 8), a);
         unpack8(*reinterpret_cast<const u32x4*>(u + i * 8), b);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] *= gelu_erf_grad(b[e]);
+        for (int e = 0; e < 8; e += 2) {
+            const f32x2_t gp = gelu_erf_grad2(f32x2_t{b[e], b[e + 1]});
+            a[e] *= gp.x; a[e + 1] *= gp.y;
+        }
         *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(a);
     }
 }
