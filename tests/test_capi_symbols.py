@@ -50,3 +50,13 @@ def test_checked_wrapper_raises():
     import pytest
     with pytest.raises(_lib.UniterHipError):
         _lib.C.uniter_attention_fwd(None, None, None, None, 1, 1, 1, 0.0, 0, 0, None)
+
+
+def test_size_queries_are_not_status_checked():
+    """A C-ABI function that returns a byte count must never go through the status-code wrapper (a non-zero size would
+    read as an error)."""
+    import ctypes
+    from uniter_amd import _lib
+    sized = [n for n, (res, _a) in _lib.SIGNATURES.items() if res is ctypes.c_size_t]
+    assert "uniter_attention_bwd_workspace_bytes" in sized
+    assert all(n in _lib._NO_STATUS for n in sized)

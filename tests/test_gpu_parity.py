@@ -803,9 +803,11 @@ def test_large_config_vqa_l178_vs_oracle(tmp_path):
         torch.testing.assert_close(master, want, rtol=1e-5, atol=1e-7)
 
 
-def test_paired_cross_attention_fused_equals_module_path(tmp_path):
-    """The fused NLVR2 cross-attention op (strided GEMMs + the encoder's attention kernel on the packed partner layout)
-    against the plain MultiheadAttention module path of the same model (torch bf16 ops), ragged pairs, base width."""
+@pytest.mark.parametrize("long_seq", [False, True], ids=["96", "300"])
+def test_paired_cross_attention_fused_equals_module_path(tmp_path, long_seq):
+    """The fused NLVR2 cross-attention op (strided GEMMs + the encoder's attention kernel on the packed partner layout) and
+    the fused pooling against the plain module path of the same model (torch bf16 ops), ragged pairs, base width; at 60 + 36
+    tokens and at up to 200 + 100 (beyond 256 the attention backward is the two-launch form; model/nlvr2.py:65-107 formats reach it)."""
     import json
     from uniter_amd.model.nlvr2 import UniterForNlvr2PairedAttn
     from uniter_amd.utils.synthetic import make_batch
@@ -816,10 +818,15 @@ def test_paired_cross_attention_fused_equals_module_path(tmp_path):
     model = UniterForNlvr2PairedAttn.from_pretrained(str(path), {}, img_dim=2048)
     model.init_type_embedding()
     _prep(model)
-    batch = _to_dev(make_batch('nlvr2', 8, seed=4, ragged=True))
+    if long_seq:
+        batch = _to_dev(make_batch('nlvr2', 4, max_txt_len=200, num_bb=100, seed=4, ragged=True, min_txt_len=170, min_bb=90))
+        assert 256 < batch['attn_masks'].shape[1] <= 300
+    else:
+        batch = _to_dev(make_batch('nlvr2', 8, seed=4, ragged=True))
 
     def run(fused):
         model._fused_pair_attention = (lambda seq: fused)
+        model.attn_pool.force_module_path = not fused
         for p in model.parameters():
             p.grad = None
         loss = model(batch, compute_loss=True)
@@ -1064,11 +1071,12 @@ def test_packed_attention_kernel_matches_dense_masked():
     torch.testing.assert_close(got, dqkv_z.view(B * L, -1).index_select(0, rows).float(), rtol=0, atol=0)
 
 
-def test_attention_pool_kernel_vs_torch_fp32():
+@pytest.mark.parametrize("L", [96, 400])
+def test_attention_pool_kernel_vs_torch_fp32(L):
     """uniter_attn_pool_{fwd,bwd} (model/nlvr2.py:110-125) against the same formula in torch fp32 on the bf16 inputs."""
     from uniter_amd import ops
     dev = _dev()
-    B, L, H = 6, 96, 768
+    B, H = 6, 768
     g = torch.Generator().manual_seed(5)
     x = torch.randn(B, L, H, generator=g).to(dev, torch.bfloat16).requires_grad_(True)
     lin = torch.nn.Linear(H, 1).to(dev).bfloat16()
@@ -1077,7 +1085,7 @@ def test_attention_pool_kernel_vs_torch_fp32():
         lin.bias.fill_(0.1)
     pad = torch.zeros(B, L, dtype=torch.bool)
     for b in range(1, B):
-        pad[b, 30 + 10 * b:] = True
+        pad[b, (30 + 10 * b) * L // 96:] = True
     pad = pad.to(dev)
     w_out = torch.randn(B, H, generator=g).to(dev)
     out = ops.attention_pool(x, pad, lin, 0.0, True)

@@ -167,6 +167,8 @@ _NO_STATUS = {"uniter_hip_abi_version", "uniter_gemm_tile_count", "uniter_hip_la
               "uniter_layernorm_bwd_workspace_bytes", "uniter_colsum_workspace_bytes", "uniter_embed_ws_bytes",
               "uniter_attn_pool_workspace_bytes",
               "uniter_encoder_layer_act_bytes", "uniter_encoder_scratch_bytes", "uniter_encoder_layer_out_offset"}
+# every size query returns a byte count, not a status (a name missing from the list above must not turn a size into an "error")
+_NO_STATUS |= {name for name, (res, _args) in SIGNATURES.items() if res is c_size_t}
 
 _lib = None
 

@@ -10,7 +10,7 @@
 namespace {
 
 constexpr int PT = 256;                 // threads per workgroup
-constexpr int PMAXL = 256;
+constexpr int PMAXL = 512;            // max_position_embeddings: the longest sequence the encoder itself takes
 
 struct PoolArgs {
     const bf16_t* x;        // [B, L, H]
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(PT) void pool_finalize_kernel(const float* __restri
 
 int check(int64_t B, int64_t L, int64_t H) {
     if (B <= 0 || L <= 0 || H <= 0) { uh_set_error("attn_pool: non-positive dimension"); return -1; }
-    if (L > PMAXL || H > 1024 || H % 8 != 0) { uh_set_error("attn_pool: need L <= 256, H <= 1024, H %% 8 == 0"); return -1; }
+    if (L > PMAXL || H > 1024 || H % 8 != 0) { uh_set_error("attn_pool: need L <= 512, H <= 1024, H %% 8 == 0"); return -1; }
     return 0;
 }
 

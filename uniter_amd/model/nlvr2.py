@@ -83,10 +83,11 @@ class AttentionPool(nn.Module):
         super().__init__()
         self.fc = nn.Sequential(nn.Linear(hidden_size, 1), nn.ReLU())
         self.dropout = nn.Dropout(drop)
+        self.force_module_path = False          # tests: the plain PyTorch ops below even where the fused kernel applies
 
     def forward(self, input_, mask=None):
         """input_ [B, T, D], mask [B, T] (True = padding)."""
-        if (input_.is_cuda and input_.dtype == torch.bfloat16 and input_.size(1) <= 256 and input_.size(2) <= 1024
+        if (not self.force_module_path and input_.is_cuda and input_.dtype == torch.bfloat16 and input_.size(1) <= 512 and input_.size(2) <= 1024
                 and input_.size(2) % 8 == 0 and self.fc[0].weight.dtype == torch.bfloat16):
             from .. import ops
             return ops.attention_pool(input_, mask, self.fc[0], self.dropout.p, self.training)   # one fused kernel
@@ -147,6 +148,6 @@ class UniterForNlvr2PairedAttn(_Nlvr2Base):
         return self._finish(self.nlvr2_output(pooled), batch, compute_loss)
 
     def _fused_pair_attention(self, seq):
-        """The HIP path covers the shipped configuration (bf16 on the GPU, 64-wide heads, L <= 256)."""
-        return (seq.is_cuda and seq.dtype == torch.bfloat16 and self.attn1.head_dim == 64 and seq.size(1) <= 256
+        """The HIP path covers the shipped configuration (bf16 on the GPU, 64-wide heads, L <= 512 = max_position_embeddings)."""
+        return (seq.is_cuda and seq.dtype == torch.bfloat16 and self.attn1.head_dim == 64 and seq.size(1) <= 512
                 and self.attn1.in_proj_weight.dtype == torch.bfloat16)

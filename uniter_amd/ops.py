@@ -875,8 +875,11 @@ class _PairedCrossAttnFn(torch.autograd.Function):
                     [ptr(grad_of(attn1.out_proj.weight)), ptr(grad_of(attn2.out_proj.weight))],
                     [ptr(grad_of(attn1.out_proj.bias)), ptr(grad_of(attn2.out_proj.bias))], T2, [H, H], [H, H])
         # ---- attention core ----
-        C.uniter_attention_bwd(ptr(P), ptr(mask_bias_p), ptr(cx), ptr(lse), ptr(dcx), ptr(dP), 2 * n, L, heads,
-                               ctx.p, ctx.seed, ctx.off, st)
+        # (beyond 256 tokens the attention backward is two launches and needs its small workspace)
+        awb = C.uniter_attention_bwd_workspace_bytes(2 * n, L, heads)
+        aws = _scratch(("pca_attn", dev.index), max(awb, 16), dev)
+        C.uniter_attention_bwd_ws(ptr(P), ptr(mask_bias_p), None, ptr(cx), ptr(lse), ptr(dcx), ptr(dP), 2 * n, L, heads,
+                                  ctx.p, ctx.seed, ctx.off, ptr(aws), awb, st)
         # ---- in_proj (model/attention.py:103-127, the kv_same branch) ----
         x_l, x_r = xs.data_ptr(), xs.data_ptr() + half
         dx_l, dx_r = dxs.data_ptr(), dxs.data_ptr() + half
