@@ -247,7 +247,7 @@ def cpu_baseline(seed=77, budget_s=20.0, parity_file=None):
         parity = {"loss_rel_err": round(lrel, 6), "grad_rel_l2_max": round(worst, 5), "grad_rel_l2_max_tensor": worst_name,
                   "grad_rel_l2_max_tensor_torch_bf16_yardstick": None if worst_yard is None else round(worst_yard, 5),
                   "gradients_over_absolute_bound": None if yard is None else strict,
-                  "absolute_bounds": "rel-L2 <= 5e-2 (uniter.*) / 1e-1 (head); tensors over it are held to 2x (query / key: 3.5x) the "
+                  "absolute_bounds": "rel-L2 <= 5e-2 (uniter.*) / 1e-1 (head); tensors over it are held to 2x the "
                                      "torch-bf16 yardstick by tests/test_gpu_parity.py::test_headline_nlvr2_base_step_vs_oracle",
                   "grad_cosine_min": round(cos_min, 6), "gradients_compared": n_cmp,
                   "zero_gradients_max_abs": float("%.3e" % zero_abs),
@@ -269,6 +269,21 @@ def cpu_baseline(seed=77, budget_s=20.0, parity_file=None):
                 O.adamw_step_(v.data, v.grad, m, s, i + 1, lr, TRAIN['betas'], 1e-6,
                               0.0 if O.no_decay(k) else TRAIN['weight_decay'])
 
+    # what is timed: the reference's own modules when build() staged them (oracle/_ref, see oracle/make_ref.py) — else the port
+    from oracle import ref_runner
+    kind = "port"
+    if ref_runner.available():
+        try:
+            cfg_path = os.path.join("/tmp", "uniter_base_ref_%d.json" % os.getpid())
+            write_cfg(cfg_path)
+            ref = ref_runner.ReferenceNlvr2Step(cfg_path, {k: v.detach().clone() for k, v in sd.items()}, TRAIN)
+            os.remove(cfg_path)
+
+            def step(i):                          # noqa: F811  (train_nlvr2.py:153-195 with the reference's model and AdamW)
+                ref.step(batch, i + 1)
+            kind = "reference"
+        except Exception as e:                    # pragma: no cover - a staged tree that does not import: fall back, say so
+            sys.stderr.write("staged reference unusable (%s: %s): timing the oracle port\n" % (type(e).__name__, e))
     t0 = time.time()
     step(0)                                   # warm-up
     warm = time.time() - t0
@@ -280,11 +295,14 @@ def cpu_baseline(seed=77, budget_s=20.0, parity_file=None):
         times.append(time.time() - t0)
         i += 1
     best = min(times) if times else warm
-    out = {"value": round(B / best, 2), "unit": "examples/s", "cores": cores, "kind": "port",
-           "sample": "oracle/uniter_oracle.py (fp32 torch-CPU port of the reference NLVR2 paired-attn step: fwd+bwd+clip+AdamW; "
-                     "the GPU box has no /root/reference, the oracle is pinned to the reference by tests/golden) "
-                     "on the same UNITER-base workload, B=%d x (60+36), 1 warm-up + %d timed step(s), best %.2f s/step, "
-                     "%d torch threads" % (B, len(times), best, cores)}
+    what = ("the reference's own model/nlvr2.py UniterForNlvr2PairedAttn + optim/adamw.py AdamW (staged by build() into the git-ignored "
+            "oracle/_ref/, apex FusedLayerNorm -> torch.nn.LayerNorm, fp32, dropout 0.1, train_nlvr2.py:153-195 step order)"
+            if kind == "reference" else
+            "oracle/uniter_oracle.py (fp32 torch-CPU port of the reference NLVR2 paired-attn step: fwd+bwd+clip+AdamW; no staged "
+            "reference on this box, the oracle is pinned to the reference by tests/golden)")
+    out = {"value": round(B / best, 2), "unit": "examples/s", "cores": cores, "kind": kind,
+           "sample": "%s on the same UNITER-base workload, B=%d x (60+36), 1 warm-up + %d timed step(s), best %.2f s/step, "
+                     "%d torch threads" % (what, B, len(times), best, cores)}
     if parity is not None:
         out["parity"] = parity
     return out
@@ -506,6 +524,10 @@ def main():
                        "task_draws": runner.task_counts},
             "final_loss": round(final_loss, 4),
             "roofline": roofline,
+            # `roofline.achieved` / `avg_launch_us` are measured in THIS run (HIP events); `roofline.traffic` is not: it is the
+            # per-launch PMC figure of the committed rocprofv3 passes (profiles/*_pmc_traffic.json, separate --pmc runs)
+            "traffic_source": None if roofline is None or roofline.get("traffic") is None else
+                              "committed (%s; not measured in this run)" % roofline["traffic_detail"].get("source", "profiles/*_pmc_traffic.json"),
         }
         if kernels is not None:
             result["kernels"] = kernels

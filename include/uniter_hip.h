@@ -426,6 +426,11 @@ int uniter_encoder_side_join(void* stream);
  * A training loop that defers the join of its one backward call lets the embedding backward overlap the deferred weight-gradient
  * launch, and calls this before anything reads a weight gradient (clip_grad_norm_, optimizer.step, zero_grad). */
 int uniter_encoder_side_join_all(void* stream);
+/* The calling thread's weight-gradient stream (created on first use), as a raw hipStream_t.  A deferred launch reads the
+ * call's activations / input / dy after uniter_encoder_backward has returned; a caller whose allocator recycles memory per
+ * stream (PyTorch: Tensor.record_stream on an ExternalStream of this handle) uses it to keep those buffers from being handed
+ * out again before the launch is through, instead of holding references until the join.  (ABI v7) */
+int uniter_encoder_side_stream(void** stream_out);
 
 /* Autotune the 12 GEMM shapes (4 forward, 4 dgrad, 4 wgrad) of one BertLayer for this (B, L, H, I): synchronous,
  * call once per shape at set-up time (the Python side does it on the first forward of a new shape). */

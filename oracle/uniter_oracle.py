@@ -296,8 +296,9 @@ def _mha(sd, prefix, query, key, value, key_padding_mask, num_heads):
     return linear(out, sd[prefix + 'out_proj.weight'], sd[prefix + 'out_proj.bias'])
 
 
-def nlvr2_paired_attn_loss(sd, cfg, batch):
-    """model/nlvr2.py:163-204 UniterForNlvr2PairedAttn.forward + :110-125 AttentionPool (dropout off)."""
+def nlvr2_paired_attn_loss(sd, cfg, batch, taps=None):
+    """model/nlvr2.py:163-204 UniterForNlvr2PairedAttn.forward + :110-125 AttentionPool (dropout off).
+    `taps` (a dict, tests only) receives the attention pool's inputs and outputs: 'pool_in' [left, right], 'pool_pad', 'pooled'."""
     seq = uniter_model(sd, cfg, batch['input_ids'], batch['position_ids'], batch['img_feat'], batch['img_pos_feat'],
                        batch['attn_masks'], batch['gather_index'], img_type_ids=batch['img_type_ids'])
     bs, tl, d = seq.shape
@@ -321,6 +322,8 @@ def nlvr2_paired_attn_loss(sd, cfg, batch):
         return torch.softmax(score, dim=1).unsqueeze(1).matmul(x).squeeze(1)
 
     pooled = torch.cat([pool(left, lpad), pool(right, rpad)], dim=-1)
+    if taps is not None:
+        taps.update(pool_in=[left, right], pool_pad=[lpad, rpad], pooled=pooled)
     scores = linear(pooled, sd['nlvr2_output.weight'], sd['nlvr2_output.bias'])
     return F.cross_entropy(scores, batch['targets'], reduction='none'), seq
 

@@ -85,13 +85,13 @@ def _check_loss(loss, ref, atol=2e-2):
     torch.testing.assert_close(got, ref, rtol=LOSS_RTOL, atol=atol)
 
 
-# The two parameters of AttentionPool's Linear(H, 1) collect  sum_t p_t (dp_t - sum_s p_s dp_s) [relu]  over 96 tokens: the
-# softmax backward cancels to a small remainder, so the bf16 rounding of the 12-layer hidden states it is computed from
-# shows up amplified (measured 0.10-0.13 at UNITER-base size with the kernel itself in fp32; 1e-2 at the golden size)
-GRAD_L2_ILL_CONDITIONED = {'attn_pool.fc.0.weight': 0.2, 'attn_pool.fc.0.bias': 0.2}
-
-
 def _check_grad(name, g, g_ref, yard=None):
+    """SURVEY.md section 8c, nothing else: cosine >= 0.99 and relative L2 <= 5e-2 (1e-1 for parameters that unmodified PyTorch
+    bf16 ops update); where stacked bf16 layers exceed the absolute bound, at most 2x the error of the oracle's own torch ops run
+    in bf16 on the GPU.  (Round 3 carried two exceptions — 3.5x for query / key parameters and 0.2 for AttentionPool's
+    Linear(H, 1).  The first went away with the exact softmax row term of the attention backward, attention.hip; the second
+    was never needed beside the 2x yardstick: test_attention_pool_gradient_conditioning shows the kernel is exact to 1e-2 on
+    identical inputs and that one bf16 rounding of its INPUT alone already moves that gradient by 3e-2.)"""
     g = g.float().cpu()
     scale = float(g_ref.abs().max())
     if scale < 1e-6:                               # mathematically zero gradients (e.g. key bias): absolute check
@@ -99,14 +99,8 @@ def _check_grad(name, g, g_ref, yard=None):
         return
     assert cosine(g, g_ref) >= GRAD_COS, (name, cosine(g, g_ref))
     limit = GRAD_L2 if name.startswith(('uniter.', 'encoder.', 'embeddings.', 'img_embeddings.')) else GRAD_L2_HEAD
-    limit = GRAD_L2_ILL_CONDITIONED.get(name, limit)
     if yard is not None:
-        # query / key parameters: the fused attention backward takes D = rowsum(dO * O) from the STORED bf16 O (as every
-        # flash-style backward does) while unfused torch-bf16 forms sum(P * dP) from its rounded P; where the softmax is
-        # nearly uniform and only a few query rows carry gradient (top layers of a 24-layer random-init model under a
-        # [CLS]-only head) dS = P (dP - D) is a small difference and ours is up to ~3x the unfused error
-        factor = 3.5 if ('.attention.self.query.' in name or '.attention.self.key.' in name) else 2.0
-        limit = max(limit, factor * rel_l2(yard, g_ref))
+        limit = max(limit, 2.0 * rel_l2(yard, g_ref))
     assert rel_l2(g, g_ref) <= limit, (name, rel_l2(g, g_ref), None if yard is None else rel_l2(yard, g_ref))
 
 
@@ -1230,26 +1224,36 @@ def _check_all_grads(named, leaf, ygrads, scale=1.0, min_checked=1):
 # --------------------------------------------------------------------------------------------------------------
 # (6) the headline workload itself and the other pre-training tasks at UNITER-base size, UNITER-large at full depth
 # --------------------------------------------------------------------------------------------------------------
-def test_headline_nlvr2_base_step_vs_oracle(tmp_path):
-    """The benchmarked step (bench.py / BASELINE.json configs[1]): UNITER-base NLVR2 paired-attention, 12 layers, B=32
-    sequences (16 pairs), L=60+36, dropout 0 — per-pair loss, every gradient and the parameters after one clipped AdamW
-    step against the oracle (model/nlvr2.py:163-204, train_nlvr2.py:153-195)."""
-    from uniter_amd.optim import build_optimizer, clip_grad_norm_
+@pytest.fixture(scope="module")
+def c2_oracle(tmp_path_factory):
+    """The oracle's forward + backward of the benchmarked step, run once for the two tests that need it (~40 s of CPU)."""
     from uniter_amd.train import WORKLOADS, build_model
-    from uniter_amd.utils.arena import flatten_model
-    from uniter_amd.utils.misc import Struct
     from uniter_amd.utils.synthetic import make_batch
     w = WORKLOADS['c2']
     cfg = w['cfg']
-    model = build_model('nlvr2', cfg, torch.device('cpu'), 77, str(tmp_path / "base.json")).float()
+    model = build_model('nlvr2', cfg, torch.device('cpu'), 77, str(tmp_path_factory.mktemp("c2") / "base.json")).float()
     with torch.no_grad():
         for p in model.parameters():
             p.copy_(p.to(torch.bfloat16).float())           # (build_model already rounded the weights to bf16)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     batch = make_batch('nlvr2', w['batch'], w['max_txt_len'], w['num_bb'], seed=1000)
     leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    ref_loss, _ = O.nlvr2_paired_attn_loss(leaf, cfg, batch)
+    taps = {}
+    ref_loss, _ = O.nlvr2_paired_attn_loss(leaf, cfg, batch, taps)
+    taps['pooled'].retain_grad()
     ref_loss.mean().backward()
+    return dict(w=w, cfg=cfg, model=model, sd=sd, batch=batch, leaf=leaf, taps=taps, ref_loss=ref_loss.detach())
+
+
+def test_headline_nlvr2_base_step_vs_oracle(c2_oracle):
+    """The benchmarked step (bench.py / BASELINE.json configs[1]): UNITER-base NLVR2 paired-attention, 12 layers, B=32
+    sequences (16 pairs), L=60+36, dropout 0 — per-pair loss, every gradient and the parameters after one clipped AdamW
+    step against the oracle (model/nlvr2.py:163-204, train_nlvr2.py:153-195)."""
+    from uniter_amd.optim import build_optimizer, clip_grad_norm_
+    from uniter_amd.utils.arena import flatten_model
+    from uniter_amd.utils.misc import Struct
+    w, cfg, sd, batch, leaf, ref_loss = (c2_oracle[k] for k in ('w', 'cfg', 'sd', 'batch', 'leaf', 'ref_loss'))
+    model = copy.deepcopy(c2_oracle['model'])
 
     _prep(model)
     arena = flatten_model(model)
@@ -1257,7 +1261,7 @@ def test_headline_nlvr2_base_step_vs_oracle(tmp_path):
     d['img_feat'] = d['img_feat'].to(torch.bfloat16)
     d['img_pos_feat'] = d['img_pos_feat'].to(torch.bfloat16)
     loss = model(d, compute_loss=True)
-    _check_loss(loss, ref_loss.detach(), atol=3e-2)
+    _check_loss(loss, ref_loss, atol=3e-2)
     loss.mean().backward()
     _, _, ygrads = _yardstick(O.nlvr2_paired_attn_loss, sd, cfg, batch)
     named = dict(model.named_parameters())
@@ -1299,18 +1303,25 @@ def test_headline_nlvr2_base_step_vs_oracle(tmp_path):
     assert arena.check()
 
 
-@pytest.mark.parametrize("task", ['mrfr', 'mrckl', 'itm_ot'])
-def test_base_model_other_tasks_vs_oracle(tmp_path, task):
-    """MRFR, MRC-KL and ITM + 0.1 * OT (pretrain.py:270-290) at UNITER-base size, 12 layers, ragged batch of 4."""
+@pytest.mark.parametrize("task,bsz", [('mrfr', 4), ('mrckl', 4), ('itm_ot', 4), ('mlm', 32), ('mrfr', 32), ('mrckl', 32), ('itm_ot', 32)])
+def test_base_model_other_tasks_vs_oracle(tmp_path, task, bsz):
+    """MLM, MRFR, MRC-KL and ITM + 0.1 * OT (pretrain.py:270-290) at UNITER-base size, 12 layers: a ragged batch of 4, and the
+    c3 micro-batch itself — 32 full-length examples = 3 072 tokens, the shape at which every parameter gradient of the
+    encoder comes out of the ONE deferred launch (gemm8_multi_kernel) — against the oracle."""
     from uniter_amd.utils.synthetic import make_batch
     model, cfg = _base_model(tmp_path)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     tname = 'itm' if task == 'itm_ot' else task
-    batch = make_batch(tname, 4, seed=21, ragged=True, with_ot=(task == 'itm_ot'))
+    batch = make_batch(tname, bsz, seed=21, ragged=(bsz == 4), with_ot=(task == 'itm_ot'))
+    if bsz == 32:
+        assert batch['attn_masks'].shape == (32, 96) and int(batch['attn_masks'].sum()) == 3072
     leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != 'cls.predictions.decoder.weight'}
     leaf['cls.predictions.decoder.weight'] = leaf['uniter.embeddings.word_embeddings.weight']
 
     def ref_objective(sd_, cfg_, b_):
+        if task == 'mlm':
+            loss, seq = O.mlm_loss(sd_, cfg_, b_)
+            return loss, seq, loss.mean()
         if task == 'mrfr':
             loss, seq = O.mrfr_loss(sd_, cfg_, b_)
             return loss, seq, loss.mean()
@@ -1379,6 +1390,129 @@ def test_large_full_depth_vqa_vs_oracle(tmp_path):
         p.grad = None
     (model(d, compute_loss=True).float().mean() * N_ANS).backward()
     _check_all_grads(dict(model.named_parameters()), leaf, ygrads, scale=1.0 / N_ANS, min_checked=390)
+
+
+@pytest.mark.parametrize("task", ['mlm', 'itm_ot'])
+def test_c5_large_24_layers_l178_pretrain_accum2_vs_oracle(tmp_path, task):
+    """BASELINE.json configs[4] as itself: config/uniter-large.json at its full 24 layers with the pre-training heads, text up to
+    128 tokens + 50 regions (L = 178, config/pretrain-alldata-large-16gpu.json), gradient accumulation 2 (pretrain.py:298-312:
+    the two micro-batches' gradients are SUMMED) — MLM, and ITM + 0.1 * OT (pretrain.py:270-290).  Per-example losses of both
+    micro-batches and every accumulated gradient against the oracle; no tolerance beyond SURVEY 8c's (5e-2, or 2x the
+    torch-bf16 yardstick)."""
+    import json
+    from uniter_amd.model.pretrain import UniterForPretraining
+    from uniter_amd.utils.synthetic import make_batch
+    cfg = dict(LARGE_CFG)
+    assert cfg['num_hidden_layers'] == 24
+    path = tmp_path / "large24pre.json"
+    path.write_text(json.dumps(cfg))
+    torch.manual_seed(23)
+    model = UniterForPretraining.from_pretrained(str(path), {}, img_dim=2048, img_label_dim=1601)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(24)
+        for n, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn(p.shape, generator=g) * 0.02)
+            p.copy_(p.to(torch.bfloat16).float())
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    tname = 'itm' if task == 'itm_ot' else task
+    batches = [make_batch(tname, 2, max_txt_len=128, num_bb=50, seed=31 + k, ragged=True, min_txt_len=90, min_bb=30,
+                          with_ot=(task == 'itm_ot')) for k in range(2)]
+    assert all(b['attn_masks'].shape[1] == 178 for b in batches)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != 'cls.predictions.decoder.weight'}
+    leaf['cls.predictions.decoder.weight'] = leaf['uniter.embeddings.word_embeddings.weight']
+
+    def ref_objective(sd_, cfg_, b_):
+        if task == 'mlm':
+            loss, seq = O.mlm_loss(sd_, cfg_, b_)
+            return loss, seq, loss.mean()
+        out = O.itm_ot_loss(sd_, cfg_, b_, ot_lambda=0.1)           # (scalar objective, itm losses, ot distances, seq)
+        return out[0], out[3], out[0]
+
+    refs = []
+    for b in batches:                                               # accumulation: backward twice into the same leaves
+        ref_loss, ref_seq, ref_obj = ref_objective(leaf, cfg, b)
+        ref_obj.backward()
+        refs.append((ref_loss.detach(), ref_seq.detach(), ref_obj.detach()))
+
+    _prep(model)
+    for p in model.parameters():
+        p.grad = None
+    for b, (ref_loss, ref_seq, ref_obj) in zip(batches, refs):
+        d = _to_dev(b)
+        out = model(d, task=tname, compute_loss=True)
+        if task == 'itm_ot':
+            itm_loss, (ot_pos, ot_neg) = out
+            obj = itm_loss.mean() + 0.1 * (ot_pos.sum() - ot_neg.sum()) / (ot_pos.size(0) + ot_neg.size(0))
+            torch.testing.assert_close(obj.detach().float().cpu(), ref_obj, rtol=3e-2, atol=3e-2)
+        else:
+            _check_loss(out, ref_loss, atol=3e-2)
+            obj = out.float().mean()
+        obj.backward()                                              # accumulates into .grad (no zero_grad in between)
+
+    # torch-bf16 yardstick of the same accumulated objective
+    dev = _dev()
+    ysd = {k: v.detach().to(dev, torch.bfloat16).requires_grad_(True) for k, v in sd.items() if k != 'cls.predictions.decoder.weight'}
+    ysd['cls.predictions.decoder.weight'] = ysd['uniter.embeddings.word_embeddings.weight']
+    ygrads = {}
+    if task != 'itm_ot':            # (50 IPOT iterations in bf16 are not a meaningful reference: absolute bounds only)
+        for b in batches:
+            yb = {k: ((v.to(dev, torch.bfloat16) if v.is_floating_point() else v.to(dev)) if torch.is_tensor(v) else v) for k, v in b.items()}
+            ref_objective(ysd, cfg, yb)[2].float().backward()
+        ygrads = {k: v.grad.float().cpu() for k, v in ysd.items() if v.grad is not None}
+    named = dict(model.named_parameters())
+    n_yard = sum(1 for n, p in named.items() if p.grad is not None and n in leaf and leaf[n].grad is not None
+                 and float(leaf[n].grad.abs().max()) >= 1e-6
+                 and rel_l2(p.grad.float().cpu(), leaf[n].grad) > (GRAD_L2 if n.startswith('uniter.') else GRAD_L2_HEAD))
+    checked = _check_all_grads(named, leaf, ygrads, min_checked=400)
+    print("c5 parity (%s, 24 layers, L=178, accumulation 2): %d gradients checked, %d over the absolute bound "
+          "(held to 2x the torch-bf16 yardstick)" % (task, checked, n_yard))
+
+
+def test_attention_pool_gradient_conditioning(c2_oracle):
+    """Why the two parameters of AttentionPool's Linear(H, 1) (model/nlvr2.py:110-125) sit at ~0.13 relative L2 on the headline
+    workload while every other tensor is under 5e-2: the gradient is sum_t p_t (dp_t - sum_s p_s dp_s) [relu'] x_t over 96
+    tokens — the softmax backward cancels to a small remainder.  Shown on the oracle's own fp32 activations of the c2 step:
+      (a) the HIP pooling kernels fed the oracle's pool input (rounded to the bf16 they take) reproduce the fp32 formula ON THAT
+          SAME INPUT to <= 2e-2 — the kernel is not the source;
+      (b) that single bf16 rounding of the input alone moves the fp32 formula's gradient by ~3e-2 (amplification ~20 over the
+          input's 1.7e-3; measured on the CPU: weight 0.033, bias 0.028), so 12 stacked bf16 layers upstream land where the
+          headline test sees them — inside 2x the torch-bf16 yardstick, without any tensor-specific exception."""
+    from uniter_amd import ops
+    cfg, sd, leaf, taps = (c2_oracle[k] for k in ('cfg', 'sd', 'leaf', 'taps'))
+    g_out = taps['pooled'].grad.detach()                        # [pairs, 2H] = d loss / d pooled, left | right
+    ref_w, ref_b = leaf['attn_pool.fc.0.weight'].grad, leaf['attn_pool.fc.0.bias'].grad
+    H = cfg['hidden_size']
+
+    def formula(xs):                                            # the oracle's pool() in fp32 on given inputs
+        W = sd['attn_pool.fc.0.weight'].clone().requires_grad_(True)
+        b = sd['attn_pool.fc.0.bias'].clone().requires_grad_(True)
+        outs = []
+        for x, m in zip(xs, taps['pool_pad']):
+            score = torch.relu(torch.nn.functional.linear(x, W, b)).squeeze(-1) + m.float() * -1e4
+            outs.append(torch.softmax(score, dim=1).unsqueeze(1).matmul(x).squeeze(1))
+        (torch.cat(outs, -1) * g_out).sum().backward()
+        return W.grad, b.grad
+
+    x32 = [x.detach() for x in taps['pool_in']]
+    xbf = [x.to(torch.bfloat16).float() for x in x32]
+    in_err = max(rel_l2(a, b) for a, b in zip(xbf, x32))
+    fw, fb = formula(xbf)
+    amp_w, amp_b = rel_l2(fw, ref_w), rel_l2(fb, ref_b)
+
+    dev = _dev()
+    lin = torch.nn.Linear(H, 1).to(dev).bfloat16()
+    with torch.no_grad():
+        lin.weight.copy_(sd['attn_pool.fc.0.weight'].to(dev, torch.bfloat16))
+        lin.bias.copy_(sd['attn_pool.fc.0.bias'].to(dev, torch.bfloat16))
+    for k, (x, m) in enumerate(zip(xbf, taps['pool_pad'])):
+        out = ops.attention_pool(x.to(dev, torch.bfloat16), m.to(dev), lin, 0.0, True)
+        (out.float() * g_out[:, k * H:(k + 1) * H].to(dev)).sum().backward()
+    kw, kb = lin.weight.grad.float().cpu(), lin.bias.grad.float().cpu()
+    print("attention pool conditioning: input rounding %.2e -> fp32 formula moves by w %.3f b %.3f; HIP kernel vs formula on the "
+          "same input: w %.4f b %.4f" % (in_err, amp_w, amp_b, rel_l2(kw, fw), rel_l2(kb, fb)))
+    assert rel_l2(kw, fw) <= 2e-2 and rel_l2(kb, fb) <= 2e-2, (rel_l2(kw, fw), rel_l2(kb, fb))
+    assert amp_w >= 5 * in_err and amp_b >= 5 * in_err, (in_err, amp_w, amp_b)      # ill-conditioned: >= 5x amplification
 
 
 def test_long_sequences_up_to_512_dense_and_packed_vs_oracle(tmp_path):

@@ -176,3 +176,39 @@ def test_golden_recipe_regenerates_committed_fixture(tmp_path, script, fixture):
         a, b = new[k], old[k]
         assert a.dtype == b.dtype and a.shape == b.shape, k
         assert a.tobytes() == b.tobytes(), "array %s differs from the committed fixture" % k
+
+
+def test_staged_reference_runs_one_nlvr2_step(tmp_path):
+    """oracle/make_ref.py + oracle/ref_runner.py (bench.py's cpu_baseline.kind == "reference"): the staged copy of the reference
+    imports under private package names and runs the train_nlvr2.py step on a tiny configuration; without dropout its loss is the
+    oracle's."""
+    import json
+    import os
+    import pytest
+    from oracle import make_ref, ref_runner, uniter_oracle as O
+    if make_ref.stage() is None and not ref_runner.available():
+        pytest.skip("no reference checkout and nothing staged")
+    from uniter_amd.utils.synthetic import make_batch
+    cfg = dict(vocab_size=96, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128,
+               hidden_act="gelu", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, max_position_embeddings=32,
+               type_vocab_size=2, initializer_range=0.02)
+    path = tmp_path / "tiny.json"
+    path.write_text(json.dumps(cfg))
+    train = dict(learning_rate=1e-3, betas=(0.9, 0.98), weight_decay=0.01, warmup_steps=1, num_train_steps=10, grad_norm=2.0)
+    import torch
+    torch.manual_seed(0)
+    nlvr2, _, _ = ref_runner._import_reference()
+    seed_model = nlvr2.UniterForNlvr2PairedAttn.from_pretrained(str(path), {}, img_dim=64)
+    seed_model.init_type_embedding()
+    sd = {k: v.detach().clone() for k, v in seed_model.state_dict().items()}
+    runner = ref_runner.ReferenceNlvr2Step(str(path), sd, train, img_dim=64)
+    for m in runner.model.modules():
+        if hasattr(m, 'dropout') and isinstance(m.dropout, float):
+            m.dropout = 0.0
+    batch = make_batch('nlvr2', 4, max_txt_len=9, num_bb=6, img_dim=64, vocab_size=96, seed=3, ragged=True, min_txt_len=4, min_bb=2)
+    ref_loss, _ = O.nlvr2_paired_attn_loss(sd, cfg, batch)
+    before = {k: v.detach().clone() for k, v in runner.model.state_dict().items()}
+    loss = runner.step(batch, 1)
+    assert abs(loss - float(ref_loss.mean())) <= 1e-4 * max(1.0, abs(loss))
+    moved = sum(1 for k, v in runner.model.state_dict().items() if not torch.equal(v, before[k]))
+    assert moved > 20                                   # the reference's AdamW really stepped

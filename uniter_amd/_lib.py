@@ -131,6 +131,7 @@ SIGNATURES = {
     "uniter_encoder_debug_side_stream": (c_int, [c_int]),
     "uniter_encoder_defer_side_join": (c_int, [c_int]),
     "uniter_encoder_side_join": (c_int, [c_void_p]),
+    "uniter_encoder_side_stream": (c_int, [POINTER(c_void_p)]),
     "uniter_encoder_debug_xcd_forward": (c_int, [c_int]),
     "uniter_encoder_debug_xcd_probe": (c_int, [c_void_p]),
     "uniter_encoder_debug_tune_in_situ": (c_int, [c_int]),
@@ -296,20 +297,37 @@ def grad_attach_epoch():
 # A training loop may let its backward call return without joining the weight-gradient stream (ops.defer_wgrad_join): the
 # embedding backward then overlaps the deferred weight-gradient launch.  Everything that reads or writes a weight gradient
 # afterwards (grad_norm / step / zero_grad of uniter_amd.optim.AdamW) calls join_wgrads() first.  The tensors that launch
-# still reads (the saved activations, the encoder input) are kept alive here until then.
-_wgrad_keepalive = []
+# still reads (the saved activations, the encoder input, the incoming gradient) are handed to the caching allocator with
+# record_stream on that stream: their memory is not given out again before the launch is through, but no Python reference
+# outlives the backward call (round 3 parked the tensors in a list until the join — with gradient accumulation 4 on
+# UNITER-large that was four micro-steps' activation arenas alive at once).
+_wgrads_pending = False
+_side_streams = {}
 
 
 def wgrads_in_flight():
-    return bool(_wgrad_keepalive)
+    return _wgrads_pending
 
 
 def hold_until_wgrad_join(*tensors):
-    _wgrad_keepalive.append(tensors)
+    """Called on the thread that ran uniter_encoder_backward (the side stream is per thread), right before the call."""
+    global _wgrads_pending
+    import torch
+    h = ctypes.c_void_p()
+    C.uniter_encoder_side_stream(ctypes.byref(h))
+    dev = tensors[0].device
+    key = (h.value, dev.index)
+    ext = _side_streams.get(key)
+    if ext is None:
+        ext = _side_streams[key] = torch.cuda.ExternalStream(h.value, device=dev)
+    for t in tensors:
+        t.record_stream(ext)
+    _wgrads_pending = True
 
 
 def join_wgrads():
     """Make the current stream wait for every un-joined weight-gradient launch; no-op when none is outstanding."""
-    if _wgrad_keepalive:
+    global _wgrads_pending
+    if _wgrads_pending:
         C.uniter_encoder_side_join_all(stream_ptr())
-        del _wgrad_keepalive[:]
+        _wgrads_pending = False

@@ -19,6 +19,15 @@
 
 namespace {
 
+// Profiling switches of the backward kernels (skip a sweep, skip the stores, cycle stamps through AttnArgs::dsum) exist only in
+// builds with -DUNITER_ATTN_PROBE (tests/native/build_probe.sh); in the product library a stray UNITER_AMD_ATTN_DBG cannot
+// silently drop gradients or make a kernel write stamps through a null workspace.
+#ifdef UNITER_ATTN_PROBE
+#define ATTN_DBG(p) ((p).dbg)
+#else
+#define ATTN_DBG(p) 0
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // forward: one workgroup per (example, head) — the unit itself lives in attention_fwd.cuh
 // ------------------------------------------------------------------------------------------------
@@ -65,7 +74,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const AttnArgs p) {
     const bf16_t* base = p.qkv + row0 * ld + h * DH;
     const bf16_t* dO = p.dctx + row0 * H + h * DH;
     const bf16_t* O = p.ctx + row0 * H + h * DH;
-    unsigned long long* stamp = ((p.dbg & 8) && live) ? reinterpret_cast<unsigned long long*>(p.dsum) + ((size_t)bh * 8 + (tid >> 6)) * 8 : nullptr;
+    unsigned long long* stamp = ((ATTN_DBG(p) & 8) && live) ? reinterpret_cast<unsigned long long*>(p.dsum) + ((size_t)bh * 8 + (tid >> 6)) * 8 : nullptr;
     if (stamp && (tid & 63) == 0) stamp[0] = __builtin_readcyclecounter();
 
     if (live)
@@ -122,18 +131,23 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const AttnArgs p) {
     const bool drop = p.drop.p > 0.f;
 
     // ---- sweep 1: query-tile owners -> dQ ----
-    if (live && !(p.dbg & 4))
+    // The row term D[q] = sum_k P~ dP~ is only known once the whole key row has been seen, and this sweep streams over the keys.
+    // It runs against D0 (the prologue's dot product with the stored bf16 O), sums the exact D in fp32 on the side and carries
+    // one more accumulator PK = P K: dS = dS0 - P (D - D0) / 8, so dQ = dS0 K - (D - D0) / 8 * PK.  The exact D replaces D0 in
+    // LDS for the key-owner sweep (see attn_bwd_share_kernel's header for why the stored O is not good enough).
+    if (live && !(ATTN_DBG(p) & 4))
     for (int qt = wid; qt < nt; qt += nw) {
         const int q = qt * 16 + i;
         const bf16x8 qf0 = at_frag(Qs, q, 0, g), qf1 = at_frag(Qs, q, 1, g);
         const bf16x8 of0 = at_frag(Os, q, 0, g), of1 = at_frag(Os, q, 1, g);
         const float lse_q = lse_s[q], D_q = D_s[q];
         const uint64_t drow = ((uint64_t)bh * (uint64_t)Lm + (uint64_t)q) * (uint64_t)pair_stride(Lm);
-        f32x4 dq[4];
+        f32x4 dq[4], pk[4];
+        float dacc = 0.f;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < 4; ++dt) { dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; pk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         for (int u = 0; u < npair; ++u) {
-            float ds[2][4];
+            float ds[2][4], pv[2][4];
             // one Philox call per key-tile pair (same element groups as the forward kernel)
             const uint32_t keep8 = drop ? dropout_keep8(p.drop, (drow + (uint64_t)u) * 4 + (uint64_t)g) : 0xffu;
 #pragma unroll
@@ -156,15 +170,30 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const AttnArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float pr = __expf(s[r] * 0.125f + mv[r] - lse_q);
-                    ds[hf][r] = pr * (dp[r] * mult[r] - D_q) * 0.125f;
+                    const float dpm = dp[r] * mult[r];
+                    pv[hf][r] = pr;
+                    dacc = fmaf(pr, dpm, dacc);
+                    ds[hf][r] = pr * (dpm - D_q) * 0.125f;
                 }
             }
             const bf16x8 dsf = pack_frag(ds[0], ds[1]);
+            const bf16x8 prf = pack_frag(pv[0], pv[1]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Ks, u, dt, g, i), dsf, dq[dt], 0, 0, 0);
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 kfr = at_frag_tr(Ks, u, dt, g, i);
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, dsf, dq[dt], 0, 0, 0);
+                pk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, prf, pk[dt], 0, 0, 0);
+            }
         }
-        if (q < L && !((p.dbg & 1) && dq[0][0] != 12345.f)) {
+        dacc += __shfl_xor(dacc, 16, WAVE);
+        dacc += __shfl_xor(dacc, 32, WAVE);
+        const float shift = (dacc - D_q) * 0.125f;
+        if (g == 0) D_s[q] = dacc;             // (each query row belongs to exactly one wave; the barrier below publishes it)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dq[dt][r] = fmaf(-shift, pk[dt][r], dq[dt][r]);
+        if (q < L && !((ATTN_DBG(p) & 1) && dq[0][0] != 12345.f)) {
             bf16_t* dst = p.dqkv + (row0 + q) * ld + h * DH + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -175,10 +204,10 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const AttnArgs p) {
     }
 
     if (stamp && lane == 0) { asm volatile("s_nop 0" ::: "memory"); stamp[3] = __builtin_readcyclecounter(); }
-    if (drop) __syncthreads();         // keep_s complete before the key-owner sweep reads it
+    __syncthreads();                   // keep_s and the exact D_s complete before the key-owner sweep reads them
     if (stamp && lane == 0) stamp[4] = __builtin_readcyclecounter();
     // ---- sweep 2: key-tile owners -> dK, dV ----
-    if (live && !(p.dbg & 2))
+    if (live && !(ATTN_DBG(p) & 2))
     for (int kt = wid; kt < nt; kt += nw) {
         const int key = kt * 16 + i;
         const bf16x8 kf0 = at_frag(Ks, key, 0, g), kf1 = at_frag(Ks, key, 1, g);
@@ -218,7 +247,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const AttnArgs p) {
                 dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Qs, u, dt, g, i), dsf, dk[dt], 0, 0, 0);
             }
         }
-        if (key < L && !((p.dbg & 1) && dk[0][0] != 12345.f)) {
+        if (key < L && !((ATTN_DBG(p) & 1) && dk[0][0] != 12345.f)) {
             bf16_t* dst = p.dqkv + (row0 + key) * ld + h * DH + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -242,7 +271,15 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const AttnArgs p) {
 // get anyway), and once every wave is done with K and V they write them over those two tiles (P~) and into one more tile
 // pair (dS) as [query][key] panels of 64 keys in the operand tile layout; the key-tile owners then read their operands with
 // the same transposing loads that fetch Q^T and dO^T.  dK / dV see exactly the P~ / dS that dQ saw.
-template <int HP>
+//
+// Row term D[q] of the softmax backward (round 4).  dS = P (dP - D) with D = sum_k P~[q][k] dP~[q][k] = dO[q] . O[q]: the
+// prologue can only form the dot product from the STORED bf16 O, and where the softmax is nearly uniform dP - D is a small
+// difference in which the 2^-9 rounding of O shows up amplified (top layers of a 24-layer model: query / key gradients at
+// 3x the error of unfused bf16 ops).  The query-tile owner has the whole key row of its queries in registers, so it sums
+// P~ dP~ itself in fp32 while it computes dS against the approximate D0 (which keeps dP - D0 small, i.e. exactly representable
+// work for the packed bf16 it is parked in), then shifts its dS by P (D - D0) / 8 before anything consumes it.
+// NKT = key tiles a query row can have (6: L <= 96, the two-unit workgroup; 8: L <= 128).
+template <int HP, int NKT>
 __global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_share_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     const int Lp = p.Lp, Lm = p.L;
@@ -273,7 +310,7 @@ __global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_share_kernel(con
     const bf16_t* base = p.qkv + row0 * ld + h * DH;
     const bf16_t* dO = p.dctx + row0 * H + h * DH;
     const bf16_t* O = p.ctx + row0 * H + h * DH;
-    unsigned long long* stamp = ((p.dbg & 8) && live) ? reinterpret_cast<unsigned long long*>(p.dsum) + ((size_t)bh * 8 + (tid >> 6)) * 8 : nullptr;
+    unsigned long long* stamp = ((ATTN_DBG(p) & 8) && live) ? reinterpret_cast<unsigned long long*>(p.dsum) + ((size_t)bh * 8 + (tid >> 6)) * 8 : nullptr;
     if (stamp && (tid & 63) == 0) stamp[0] = __builtin_readcyclecounter();
 
     if (live) {
@@ -330,22 +367,19 @@ __global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_share_kernel(con
     const bool owner = live && wid < nt;
 
     // ---- query-tile owners: P~, dS (kept in registers) and dQ ----
-    u32x2 ppk[8], dspk[8];                 // this wave's query rows x key tile kt: lane holds keys kt*16 + 4g .. + 3 of query i
+    u32x2 ppk[NKT], dspk[NKT], prk[NKT];   // this wave's query rows x key tile kt: lane holds keys kt*16 + 4g .. + 3 of query i
 #pragma unroll
-    for (int kt = 0; kt < 8; ++kt) { ppk[kt] = u32x2{0u, 0u}; dspk[kt] = u32x2{0u, 0u}; }
+    for (int kt = 0; kt < NKT; ++kt) { ppk[kt] = u32x2{0u, 0u}; dspk[kt] = u32x2{0u, 0u}; prk[kt] = u32x2{0u, 0u}; }
     if (owner) {
         const int q = wid * 16 + i;
         const bf16x8 qf0 = at_frag(Qs, q, 0, g), qf1 = at_frag(Qs, q, 1, g);
         const bf16x8 of0 = at_frag(Os, q, 0, g), of1 = at_frag(Os, q, 1, g);
-        const float lse_q = lse_s[q], D_q = D_s[q];
+        const float lse_q = lse_s[q], D0 = D_s[q];
         const uint64_t drow = ((uint64_t)bh * (uint64_t)Lm + (uint64_t)q) * (uint64_t)pair_stride(Lm);
-        f32x4 dq[4];
+        float dacc = 0.f;                  // sum over this lane's keys of P~ dP~ (fp32, unrounded operands)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NKT / 2; ++u) {
             if (u < npair) {
-                float ds[2][4];
                 // one Philox call per key-tile pair (same element groups as the forward kernel)
                 const uint32_t keep8 = drop ? dropout_keep8(p.drop, (drow + (uint64_t)u) * 4 + (uint64_t)g) : 0xffu;
 #pragma unroll
@@ -358,16 +392,41 @@ __global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_share_kernel(con
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Vs, kt * 16 + i, 1, g), of1, dp, 0, 0, 0);
                     const f32x4 mv = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
                     const uint32_t keep = (keep8 >> (4 * hf)) & 0xfu;
-                    float pd[4];
+                    float pd[4], pv[4], ds0[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float mult = drop ? (((keep >> r) & 1u) ? p.drop.scale : 0.f) : 1.f;
                         const float pr = __expf(s[r] * 0.125f + mv[r] - lse_q);
+                        pv[r] = pr;
                         pd[r] = pr * mult;
-                        ds[hf][r] = pr * (dp[r] * mult - D_q) * 0.125f;
+                        dacc = fmaf(pd[r], dp[r], dacc);
+                        ds0[r] = pr * (dp[r] * mult - D0) * 0.125f;
                     }
                     ppk[kt] = pack4(pd);
-                    dspk[kt] = pack4(ds[hf]);
+                    dspk[kt] = pack4(ds0);
+                    prk[kt] = drop ? pack4(pv) : ppk[kt];
+                }
+            }
+        }
+        // the exact row term: the other three lane groups hold the rest of query i's keys
+        dacc += __shfl_xor(dacc, 16, WAVE);
+        dacc += __shfl_xor(dacc, 32, WAVE);
+        const float shift = (dacc - D0) * 0.125f;
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NKT / 2; ++u) {
+            if (u < npair) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int kt = 2 * u + hf;
+                    float a[4], b[4];
+                    unpack4(dspk[kt], a);
+                    unpack4(prk[kt], b);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[r] = fmaf(-shift, b[r], a[r]);
+                    dspk[kt] = pack4(a);
                 }
                 u32x4 w;
                 w[0] = dspk[2 * u][0]; w[1] = dspk[2 * u][1]; w[2] = dspk[2 * u + 1][0]; w[3] = dspk[2 * u + 1][1];
@@ -394,7 +453,7 @@ __global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_share_kernel(con
             const int q = qt * 16 + i;
             const bool mine = (qt == wid) && owner;
 #pragma unroll
-            for (int kt = 0; kt < 8; ++kt) {
+            for (int kt = 0; kt < NKT; ++kt) {
                 if (kt < 2 * npair) {
                     const int off = (kt >> 2) * Lp * 64 + at_off8(q, (kt & 3) * 4 + g);
                     *reinterpret_cast<u32x2*>(PTs + off) = mine ? ppk[kt] : u32x2{0u, 0u};
@@ -416,7 +475,7 @@ __global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_share_kernel(con
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NKT / 2; ++u) {
             if (u < npair) {
                 const bf16x8 pdf = at_frag_tr(Pp, u, kt & 3, g, i);
                 const bf16x8 dsf = at_frag_tr(Dp, u, kt & 3, g, i);
@@ -504,7 +563,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnArgs p) {
         frag_global(base, ld, q, L, g, qf);
         frag_global(dO, H, q, L, g, of);
         frag_global(O, H, q, L, g, oo);
-        // D[q] = sum_d dO*O: this lane holds 16 of the 64 columns of row q, the other three lane groups the rest
+        // D0[q] = sum_d dO*O from the stored bf16 O: this lane holds 16 of the 64 columns of row q, the other three lane groups
+        // the rest.  The sweep runs against D0 and is corrected by the exact row term at its end (see attn_bwd_kernel).
         float D_q = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -512,14 +572,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnArgs p) {
             for (int e = 0; e < 8; ++e) D_q += (float)of[ks][e] * (float)oo[ks][e];
         D_q += __shfl_xor(D_q, 16, WAVE);
         D_q += __shfl_xor(D_q, 32, WAVE);
-        if (g == 0 && q < L) p.dsum[(int64_t)bh * Lm + q] = D_q;
         const float lse_q = (q < L) ? p.lse[(int64_t)bh * Lm + q] : INFINITY;
         const uint64_t drow = ((uint64_t)bh * (uint64_t)Lm + (uint64_t)q) * (uint64_t)pair_stride(Lm);
-        f32x4 dq[4];
+        f32x4 dq[4], pk[4];
+        float dacc = 0.f;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < 4; ++dt) { dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; pk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         for (int u = 0; u < npair; ++u) {
-            float ds[2][4];
+            float ds[2][4], pv[2][4];
             const uint32_t keep8 = drop ? dropout_keep8(p.drop, (drow + (uint64_t)u) * 4 + (uint64_t)g) : 0xffu;
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
@@ -535,14 +595,29 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnArgs p) {
                 for (int r = 0; r < 4; ++r) {
                     const float mult = drop ? (((keep >> r) & 1u) ? p.drop.scale : 0.f) : 1.f;
                     const float pr = __expf(s[r] * 0.125f + mv[r] - lse_q);
-                    ds[hf][r] = pr * (dp[r] * mult - D_q) * 0.125f;
+                    const float dpm = dp[r] * mult;
+                    pv[hf][r] = pr;
+                    dacc = fmaf(pr, dpm, dacc);
+                    ds[hf][r] = pr * (dpm - D_q) * 0.125f;
                 }
             }
             const bf16x8 dsf = pack_frag(ds[0], ds[1]);
+            const bf16x8 prf = pack_frag(pv[0], pv[1]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Ks, u, dt, g, i), dsf, dq[dt], 0, 0, 0);
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 kfr = at_frag_tr(Ks, u, dt, g, i);
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, dsf, dq[dt], 0, 0, 0);
+                pk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, prf, pk[dt], 0, 0, 0);
+            }
         }
+        dacc += __shfl_xor(dacc, 16, WAVE);
+        dacc += __shfl_xor(dacc, 32, WAVE);
+        const float shift = (dacc - D_q) * 0.125f;
+        if (g == 0 && q < L) p.dsum[(int64_t)bh * Lm + q] = dacc;     // the exact row term, for the dK / dV launch
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dq[dt][r] = fmaf(-shift, pk[dt][r], dq[dt][r]);
         if (q < L) {
             bf16_t* dst = p.dqkv + (row0 + q) * ld + h * DH + 4 * g;
 #pragma unroll
@@ -657,8 +732,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const AttnArgs p) {
 }
 
 int attn_dbg() {
+#ifdef UNITER_ATTN_PROBE
     static const int v = [] { const char* e = getenv("UNITER_AMD_ATTN_DBG"); return e ? atoi(e) : 0; }();
     return v;
+#else
+    return 0;
+#endif
 }
 
 int pick_waves(int nt, int maxw = 8) {
@@ -764,7 +843,10 @@ int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, cons
         UH_LAUNCH_CHECK();
         return 0;
     }
-    if (a.dbg & 8) a.dsum = (float*)workspace;          // harness profiling: cycle stamps, [B*heads][8 waves][8]
+    if (a.dbg & 8) {                                    // probe builds only: cycle stamps, [B*heads][8 waves][8]
+        if (workspace == nullptr) { uh_set_error("attention_bwd: the stamp probe needs a workspace"); return -1; }
+        a.dsum = (float*)workspace;
+    }
     // up to 12 waves (three per SIMD at the kernel's register count) when that gives every 16-row tile its own wave: at
     // L = 178 twelve tiles on six waves left two SIMDs with four tile-sweeps and two with two
     const int nt_all = (int)((L + 15) / 16);
@@ -778,12 +860,12 @@ int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, cons
         // L <= 128: P~ and dS are computed once and handed from the query-tile owners to the key-tile owners through LDS
         const int npanel = (a.Lp + 63) / 64;
         const size_t ub = ((size_t)a.Lp * 64 * 2 * (4 + npanel) + (size_t)a.Lp * 4 * 3 + 15) & ~(size_t)15;
-        if (2 * nw <= 12 && 2 * ub <= 156 * 1024) {          // two units per workgroup: 12 waves, three per SIMD (see attn_bwd_kernel)
-            if ((rc = set_lds(attn_bwd_share_kernel<2>, 2 * ub))) return rc;
-            hipLaunchKernelGGL(attn_bwd_share_kernel<2>, dim3((unsigned)((units + 1) / 2)), dim3(2 * nw * 64), 2 * ub, st, a);
+        if (2 * nw <= 12 && 2 * ub <= 156 * 1024 && a.Lp <= 96) {   // two units per workgroup: 12 waves, three per SIMD (see attn_bwd_kernel)
+            if ((rc = set_lds(attn_bwd_share_kernel<2, 6>, 2 * ub))) return rc;
+            hipLaunchKernelGGL((attn_bwd_share_kernel<2, 6>), dim3((unsigned)((units + 1) / 2)), dim3(2 * nw * 64), 2 * ub, st, a);
         } else {
-            if ((rc = set_lds(attn_bwd_share_kernel<1>, ub))) return rc;
-            hipLaunchKernelGGL(attn_bwd_share_kernel<1>, dim3((unsigned)units), dim3(nw * 64), ub, st, a);
+            if ((rc = set_lds(attn_bwd_share_kernel<1, 8>, ub))) return rc;
+            hipLaunchKernelGGL((attn_bwd_share_kernel<1, 8>), dim3((unsigned)units), dim3(nw * 64), ub, st, a);
         }
         UH_LAUNCH_CHECK();
         return 0;

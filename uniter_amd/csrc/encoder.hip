@@ -9,6 +9,7 @@
 #include "common.cuh"
 #include <vector>
 #include <mutex>
+#include <atomic>
 #include "kernels.h"
 #include "../../include/uniter_hip.h"
 
@@ -94,14 +95,36 @@ struct SideStream {
     // state that outlives one uniter_encoder_backward call when the caller defers the end-of-call join (see
     // uniter_encoder_defer_side_join): which side jobs may still be reading their input buffers
     bool pending[6] = {false, false, false, false, false, false};
-    bool deferred = false;        // the previous call ended without making the caller's stream wait for the side stream
+    std::atomic<bool> deferred{false};   // the previous call ended without making the caller's stream wait for the side stream
     bool defer_request = false;   // the next call shall end that way
 };
-thread_local SideStream g_side;
 // every thread's side-stream record, so that a thread other than the one that ran backward (autograd has its own) can make
-// a stream wait for all outstanding weight-gradient work (uniter_encoder_side_join_all)
+// a stream wait for all outstanding weight-gradient work (uniter_encoder_side_join_all).  A record lives on the heap, is
+// entered in the registry under the mutex and leaves it — under the same mutex — when its thread exits, so the registry never
+// holds a pointer into a dead thread's storage; `deferred` is the one field another thread reads while the owner may be inside
+// a backward call, hence atomic.
 std::mutex g_side_registry_mu;
 std::vector<SideStream*> g_side_registry;
+struct SideHolder {
+    SideStream* p = nullptr;
+    SideStream& get() {
+        if (p == nullptr) p = new SideStream();
+        return *p;
+    }
+    ~SideHolder() {
+        if (p == nullptr) return;
+        {
+            std::lock_guard<std::mutex> lk(g_side_registry_mu);
+            for (size_t i = 0; i < g_side_registry.size(); ++i)
+                if (g_side_registry[i] == p) { g_side_registry.erase(g_side_registry.begin() + (long)i); break; }
+        }
+        // (the stream and events are left to the runtime: destroying them from a thread-exit handler can run after the HIP
+        // runtime itself has been torn down)
+        delete p;
+    }
+};
+thread_local SideHolder g_side_holder;
+#define g_side (g_side_holder.get())
 
 int side_init() {
     int dev = 0;
@@ -556,6 +579,13 @@ int uniter_encoder_side_join_all(void* stream) {
     return 0;
 }
 
+int uniter_encoder_side_stream(void** stream_out) {
+    if (stream_out == nullptr) { uh_set_error("encoder_side_stream: null pointer"); return -1; }
+    RC(side_init());
+    *stream_out = (void*)g_side.stream;
+    return 0;
+}
+
 int uniter_encoder_side_join(void* stream) {
     if (g_side.stream == nullptr) return 0;                         // nothing was ever put on a side stream by this thread
     UH_CHECK_HIP(hipEventRecord(g_side.done, g_side.stream));
@@ -590,8 +620,17 @@ int uniter_encoder_autotune(const UniterEncoderShape* s, void* stream) {
     float* mask = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     char* tune_stage_free = nullptr;
+    const WgradStage saved_stage = g_stage;
     auto cleanup = [&]() {
-        if (tune_stage_free) { (void)hipDeviceSynchronize(); (void)hipFree(tune_stage_free); }
+        if (tune_stage_free) {
+            // (every exit path: the thread's stage registration must not keep pointing at the temporary stage freed here)
+            (void)hipDeviceSynchronize();
+            for (int k = 0; k < 2; ++k)
+                if (g_stage.busy[k] && g_stage.busy[k] != saved_stage.busy[k]) (void)hipEventDestroy(g_stage.busy[k]);
+            g_stage = saved_stage;
+            (void)hipFree(tune_stage_free);
+            tune_stage_free = nullptr;
+        }
         if (acts) (void)hipFree(acts);
         if (scratch) (void)hipFree(scratch);
         if (prm) (void)hipFree(prm);
@@ -610,7 +649,6 @@ int uniter_encoder_autotune(const UniterEncoderShape* s, void* stream) {
     TN_HIP(hipMalloc((void**)&mask, (size_t)s->B * s->L * 4));
     // the stack is timed the way training runs it: with the weight gradients deferred to one launch per call when a stage
     // would be registered (the data-gradient chain then has the chip to itself, which changes its best tiles)
-    const WgradStage saved_stage = g_stage;
     char* tune_stage = nullptr;
     if (g_group_wgrad && g_wgrad_multi && H % 256 == 0 && I % 256 == 0 && T % 64 == 0 && T >= 64) {
         const size_t stb = (size_t)NL * stage_set(*s).total;
@@ -684,12 +722,6 @@ int uniter_encoder_autotune(const UniterEncoderShape* s, void* stream) {
         if (!changed) break;
     }
 #undef TN_HIP
-    if (tune_stage != nullptr) {
-        (void)hipStreamSynchronize(st);
-        for (int k = 0; k < 2; ++k)
-            if (g_stage.busy[k]) (void)hipEventDestroy(g_stage.busy[k]);
-        g_stage = saved_stage;
-    }
     cleanup();
     return rc;
 }

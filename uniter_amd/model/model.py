@@ -5,6 +5,10 @@ Kept identical to the reference: `UniterConfig` fields and (de)
 prefix, lenient missing / unexpected keys), module attribute paths, state_dict keys and the
 `UniterModel.forward` signature.  The embeddings, the compaction gather, the additive mask and the whole
 encoder stack run as HIP kernels (uniter_amd/ops.py -> include/uniter_hip.h).
+
+Attribution: `UniterConfig` and `UniterPreTrainedModel.{init_weights, from_pretrained}` restate the interface of
+ChenRocks/UNITER model/model.py (Copyright (c) Microsoft Corporation, MIT license; itself modified from HuggingFace
+transformers, Apache-2.0) line for line, because checkpoints, configs and the task heads depend on exactly that surface.
 """
 import copy
 import os

@@ -474,11 +474,14 @@ class _EncoderFn(torch.autograd.Function):
                 x_in = ptr(xc)
             else:
                 x_in = ctx.acts.data_ptr() + (begin - 1) * act_bytes + out_off
+            # the library's flag is per thread and sticky, and this is the (shared) autograd thread: state it on EVERY call, so
+            # that a backward without a hook — a second model, a removed hook — ends with the join it relies on
             if defer:
-                C.uniter_encoder_defer_side_join(1 if begin > 0 else 0)
-            elif getattr(hook, "defer_wgrad_join", False) and os.environ.get("UNITER_AMD_DEFER_WGRAD_JOIN", "1") != "0":
-                C.uniter_encoder_defer_side_join(1)
-                defer_only = True
+                want_defer = begin > 0
+            else:
+                defer_only = bool(getattr(hook, "defer_wgrad_join", False)) and os.environ.get("UNITER_AMD_DEFER_WGRAD_JOIN", "1") != "0"
+                want_defer = defer_only
+            C.uniter_encoder_defer_side_join(1 if want_defer else 0)
             if defer or defer_only:
                 # the call returns before the deferred launch (which reads the saved activations, the range's input and this
                 # call's dy) has run: keep them alive until the weight-gradient stream is joined (_lib.join_wgrads)

@@ -1,36 +1,10 @@
 """Small helpers the training loops use (reference utils/misc.py:17-70)."""
-import json
 import random
-import sys
 
 import numpy as np
 import torch
 
 from .. import ops
-
-
-class NoOp(object):
-    """Swallows every method call; stands in for loggers / savers on non-zero ranks."""
-
-    def __getattr__(self, name):
-        return self.noop
-
-    def noop(self, *args, **kwargs):
-        return
-
-
-def parse_with_config(parser):
-    """argparse defaults < JSON --config < flags given explicitly on the command line."""
-    args = parser.parse_args()
-    if args.config is not None:
-        with open(args.config) as f:
-            config_args = json.load(f)
-        explicit = {arg[2:].split('=')[0] for arg in sys.argv[1:] if arg.startswith('--')}
-        for key, value in config_args.items():
-            if key not in explicit:
-                setattr(args, key, value)
-    del args.config
-    return args
 
 
 class Struct(object):
