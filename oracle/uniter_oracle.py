@@ -209,8 +209,8 @@ def ot_ipot(C, x_len, x_pad, y_len, y_pad, joint_pad, beta=0.5, iteration=50, k=
     C [B,M,N]; returns the transport plan T [B,N,M]; no gradient (the reference decorates it with no_grad)."""
     with torch.no_grad():
         b, m, n = C.shape
-        sigma = torch.ones(b, m, dtype=C.dtype) / x_len.unsqueeze(1)                    # :39-40
-        T = torch.ones(b, n, m, dtype=C.dtype)                                           # :41
+        sigma = torch.ones(b, m, dtype=C.dtype, device=C.device) / x_len.unsqueeze(1)                    # :39-40
+        T = torch.ones(b, n, m, dtype=C.dtype, device=C.device)                                     # :41
         A = torch.exp(-C.transpose(1, 2) / beta)                                         # :42
         sigma = sigma.masked_fill(x_pad, 0)                                              # :45
         jp = joint_pad.transpose(1, 2)                                                   # :46
@@ -248,7 +248,7 @@ def ot_scatter_split(seq, ot_scatter, scatter_max, tl, il):
     b, _, h = seq.shape
     max_l = max(int(scatter_max) + 1, tl + il)
     index = ot_scatter.unsqueeze(-1).expand_as(seq)
-    ctx = torch.zeros(b, max_l, h, dtype=seq.dtype).scatter(1, index, seq)
+    ctx = torch.zeros(b, max_l, h, dtype=seq.dtype, device=seq.device).scatter(1, index, seq)
     return ctx[:, :tl, :], ctx[:, tl:tl + il, :]
 
 

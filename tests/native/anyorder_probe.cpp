@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <chrono>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(2); } } while (0)
 
@@ -36,6 +37,7 @@ struct P {
     int store_mode;            // 0 plain + release fence before the signal, 1 sc1 stores, 2 plain, no fence
     int load_mode;             // 0 plain, 1 plain after an acquire fence, 2 sc1
     int work_us;               // busy work per workgroup, skewed by blockIdx
+    unsigned long long* stamps; // [2]: earliest workgroup start, latest workgroup end of this kernel (100 MHz wall clock)
 };
 
 __device__ __forceinline__ unsigned ld_sc1(const unsigned* p) {
@@ -50,6 +52,7 @@ __device__ __forceinline__ void st_sc1(unsigned* p, unsigned v) {
 __global__ __launch_bounds__(kThreads) void step_kernel(const P p) {
     const int rb = ((int)blockIdx.x + p.shift) % kBlocks;
     __shared__ unsigned s_ok;
+    if (threadIdx.x == 0 && p.stamps) atomicMin(p.stamps, wall_clock64());
     if (threadIdx.x == 0) {
         unsigned ok = 1;
         if (p.wait != nullptr) {
@@ -111,6 +114,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const P p) {
     if (threadIdx.x == 0) {
         if (p.store_mode == 0) __hip_atomic_fetch_add(p.sig + rb, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // buffer_wbl2 sc1 first
         else __hip_atomic_fetch_add(p.sig + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p.stamps) atomicMax(p.stamps + 1, wall_clock64());
     }
 }
 
@@ -145,6 +149,9 @@ int main(int argc, char** argv) {
     hipStream_t st;
     CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     unsigned *bufs, *cnt, *err, *timeout;
+    unsigned long long* stamps;
+    CK(hipMalloc(&stamps, (size_t)(K + 1) * 16));
+    std::vector<unsigned long long> hst((size_t)(K + 1) * 2);
     const size_t bufWords = (size_t)kBlocks * kWords;
     CK(hipMalloc(&bufs, bufWords * 4 * (size_t)(K + 1)));
     CK(hipMalloc(&cnt, (size_t)(K + 1) * kBlocks * 4));
@@ -159,9 +166,14 @@ int main(int argc, char** argv) {
         CK(hipMemsetAsync(err, 0, 16, st));
         CK(hipMemsetAsync(timeout, 0, 4, st));
         float best = 1e30f;
+        double host_us = 0;
         unsigned herr[2] = {0, 0};
         for (int trial = 0; trial < 3; ++trial) {
             CK(hipMemsetAsync(cnt, 0, (size_t)(K + 1) * kBlocks * 4, st));
+            for (int k = 0; k <= K; ++k) { hst[2 * k] = ~0ull; hst[2 * k + 1] = 0; }
+            CK(hipMemcpyAsync(stamps, hst.data(), (size_t)(K + 1) * 16, hipMemcpyHostToDevice, st));
+            CK(hipStreamSynchronize(st));
+            const auto h0 = std::chrono::steady_clock::now();
             CK(hipEventRecord(e0, st));
             for (int k = 0; k < K; ++k) {
                 P p{};
@@ -176,6 +188,7 @@ int main(int argc, char** argv) {
                 p.store_mode = store_mode;
                 p.load_mode = load_mode;
                 p.work_us = work_us;
+                p.stamps = stamps + 2 * k;
                 if (anyorder && k > 0) {
                     void* args[] = {(void*)&p};
                     CK(hipExtLaunchKernel((const void*)step_kernel, dim3(kBlocks), dim3(kThreads), args, 0, st, nullptr, nullptr, hipExtAnyOrderLaunch));
@@ -184,29 +197,36 @@ int main(int argc, char** argv) {
                 }
             }
             CK(hipEventRecord(e1, st));
+            const auto h1 = std::chrono::steady_clock::now();
             CK(hipEventSynchronize(e1));
             float ms = 0;
             CK(hipEventElapsedTime(&ms, e0, e1));
-            if (ms < best) best = ms;
+            if (ms < best) { best = ms; host_us = std::chrono::duration<double, std::micro>(h1 - h0).count(); }
         }
         CK(hipMemcpy(herr, err, 8, hipMemcpyDeviceToHost));
-        printf("%-58s %7.2f us/kernel   wrong words %u   timeouts %u\n", label, best * 1000.f / K, herr[0], herr[1]);
+        CK(hipMemcpy(hst.data(), stamps, (size_t)(K + 1) * 16, hipMemcpyDeviceToHost));
+        // of the last trial: how long a kernel lives (first workgroup start -> last workgroup end) and how far the next kernel's
+        // first workgroup starts before (negative gap) or after (positive) this kernel's last workgroup ends
+        double live = 0, gap = 0, period = 0;
+        for (int k = 10; k < K - 1; ++k) {
+            live += (double)(hst[2 * k + 1] - hst[2 * k]) * 0.01;
+            gap += ((double)hst[2 * (k + 1)] - (double)hst[2 * k + 1]) * 0.01;
+            period += ((double)hst[2 * (k + 1)] - (double)hst[2 * k]) * 0.01;
+        }
+        const int nk = K - 11;
+        printf("%-58s %7.2f us/kernel (host issue %5.2f)  live %5.2f  next-start minus end %+6.2f  start-to-start %5.2f   wrong %u  timeouts %u\n",
+               label, best * 1000.f / K, host_us / K, live / nk, gap / nk, period / nk, herr[0], herr[1]);
         fflush(stdout);
         return herr[1] == 0;
     };
 
     printf("T1: chain of %d dependent kernels, 256 workgroups, busy work %d us x (1 .. 1.75)\n", K, work_us);
     run(false, 2, 0, K, "normal launches, plain stores / loads, fresh buffers");
-    run(false, 2, 0, 2, "normal launches, plain stores / loads, 2 buffers");
-    const char* sm[3] = {"plain+release", "sc1 stores", "plain, no fence"};
-    const char* lm[3] = {"plain loads", "acquire+plain", "sc1 loads"};
-    for (int nb : {K, 2})
-        for (int s = 0; s < 3; ++s)
-            for (int l = 0; l < 3; ++l) {
-                char label[128];
-                snprintf(label, sizeof label, "any-order + flags: %s / %s, %s", sm[s], lm[l], nb == 2 ? "2 buffers" : "fresh buffers");
-                if (!run(true, s, l, nb, label)) { printf("  (timeouts: stopping T1)\n"); goto t2; }
-            }
+    run(false, 1, 0, K, "normal launches, sc1 stores / plain loads, fresh buffers");
+    run(true, 1, 0, K, "any-order + flags: sc1 stores / plain loads, fresh buffers");
+    run(true, 1, 0, 2, "any-order + flags: sc1 stores / plain loads, 2 buffers");
+    run(true, 0, 0, K, "any-order + flags: plain+release / plain loads, fresh");
+    run(true, 1, 1, K, "any-order + flags: sc1 stores / acquire+plain, fresh");
 t2:
     {
         printf("T2: 256 workgroups re-read one L2-sized region 16 times\n");
