@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UNITER_HIP_ABI_VERSION 6
+#define UNITER_HIP_ABI_VERSION 7
 
 /* ------------------------------------------------------------------------------------------------
  * Library
@@ -439,13 +439,16 @@ int uniter_encoder_autotune(const UniterEncoderShape* s, void* stream);
 /* Test / tuning hook: backward runs the weight-gradient GEMMs and bias column sums on an internal side stream
  * (ordered against `stream` purely by events) unless disabled with 0. */
 int uniter_encoder_debug_side_stream(int enable);
-/* The forward of an eligible shape (H = 768, L <= 128, B >= 8, training or not) runs as ONE persistent launch with one team of
- * workgroups per XCD (csrc/xcd_forward.hip) — bit-identical to the kernel-per-operation path, which 0 selects for every shape
- * (default 0 while it is the slower of the two; the environment variable UNITER_AMD_XCD_FWD=1 switches it on). */
-int uniter_encoder_debug_xcd_forward(int enable);
-/* Profiling hook of that launch: dev = device buffer of 256*32*8*2 uint64 that receives 100 MHz wall-clock stamps per
- * workgroup / layer / phase (work done, barrier passed); NULL (default) switches it off. */
-int uniter_encoder_debug_xcd_probe(void* dev);
+/* Overlapped kernel chains (ABI v7).  With a scratch buffer, uniter_encoder_forward and (in the deferred-weight-gradient flow)
+ * uniter_encoder_backward dispatch the dependent kernels of all their layers WITHOUT the queue barrier between them
+ * (hipExtLaunchKernel, hipExtAnyOrderLaunch) and order them through per-32-row flags in the scratch buffer instead: a consumer
+ * tile starts when the row block it reads is complete, not when the slowest tile of the producer has drained
+ * (csrc/common.cuh "Overlapped kernel chains").  Same kernels, same arithmetic: results are bit-identical
+ * to the in-order launches, which uniter_encoder_debug_chain(0) (or UNITER_AMD_CHAIN=0) selects.  A flag wait that does not
+ * complete within 50 ms gives up and sets a status word instead of hanging; uniter_encoder_chain_status reads it
+ * (synchronising the device): 0 = clean.  (model/model.py:282-292 has no counterpart.) */
+int uniter_encoder_debug_chain(int enable);
+int uniter_encoder_chain_status(const UniterEncoderShape* s, const void* scratch, int32_t* status_out);
 /* 0 = uniter_encoder_autotune keeps the isolated per-GEMM winners; 1 (default) = it then re-picks every GEMM's tile among
  * its fastest candidates by timing a short forward+backward stack (cold weights, wgrad side stream running). */
 int uniter_encoder_debug_tune_in_situ(int enable);

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../.."
 mkdir -p probe_bin /tmp/uniter_probe_build
-for f in capi gemm attention layernorm embed adamw encoder comm ot pool lmhead head xcd_forward; do
+for f in capi gemm attention layernorm embed adamw encoder comm ot pool lmhead head; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -DNDEBUG -DUNITER_GEMM_PROBE -DUNITER_ATTN_PROBE -c uniter_amd/csrc/$f.hip -o /tmp/uniter_probe_build/$f.o &
 done
 wait

@@ -1101,23 +1101,30 @@ static void bench_encoder(int B, int L, int H, int heads, int I, int layers) {
     const int nt = load_tuned_json(tj ? tj : "uniter_amd/tuned/gfx950.json");
     printf("  tile table: %d entries\n", nt);
     if (nt == 0) { UHCHK(uniter_encoder_autotune(&sh, 0)); }
-    if (!getenv("UNITER_BENCH_SKIP_XCD_CHECK")) {
-        // the persistent per-XCD forward against the kernel-per-operation forward: every saved activation, bit for bit
+    if (!getenv("UNITER_BENCH_SKIP_CHAIN_CHECK")) {
+        // the overlapped kernel chain (no queue barrier between dependent kernels, row-block flags) against the in-order launches:
+        // every saved activation of every layer, bit for bit — same kernels, same arithmetic, only the dispatch differs
         std::vector<unsigned char> ref(act * layers), got(act * layers);
-        UHCHK(uniter_encoder_debug_xcd_forward(0));
+        UHCHK(uniter_encoder_debug_chain(0));
         HIPCHK(hipMemset(acts, 0, act * layers));
         UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0));
         HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipMemcpy(ref.data(), acts, ref.size(), hipMemcpyDeviceToHost));
-        UHCHK(uniter_encoder_debug_xcd_forward(1));
-        HIPCHK(hipMemset(acts, 0, act * layers));
-        UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0));
-        HIPCHK(hipDeviceSynchronize());
-        HIPCHK(hipMemcpy(got.data(), acts, got.size(), hipMemcpyDeviceToHost));
+        UHCHK(uniter_encoder_debug_chain(1));
         size_t bad = 0, first = 0;
-        for (size_t k = 0; k < ref.size(); ++k) if (ref[k] != got[k]) { if (!bad) first = k; ++bad; }
-        printf("[%s] persistent per-XCD forward == per-operation forward: %zu of %zu bytes differ", bad ? "FAIL" : " OK ", bad, ref.size());
-        if (bad) { printf(" (first at layer %zu, offset %zu of %zu)", first / act, first % act, act); ++g_fail; }
+        int32_t st_word = 0;
+        for (int rep = 0; rep < 4; ++rep) {                 // (several launches: a race would not show every time)
+            HIPCHK(hipMemset(acts, 0, act * layers));
+            UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0));
+            int32_t w = 0;
+            UHCHK(uniter_encoder_chain_status(&sh, scratch, &w));
+            st_word |= w;
+            HIPCHK(hipMemcpy(got.data(), acts, got.size(), hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < ref.size(); ++k) if (ref[k] != got[k]) { if (!bad) first = k; ++bad; }
+        }
+        printf("[%s] overlapped-chain forward == in-order forward (4 launches): %zu of %zu bytes differ, status word %d", (bad || st_word) ? "FAIL" : " OK ", bad, 4 * ref.size(), st_word);
+        if (bad) printf(" (first at layer %zu, offset %zu of %zu)", first / act, first % act, act);
+        if (bad || st_word) ++g_fail;
         printf("\n");
         if (bad) {          // which saved tensor of which layer (the block layout of encoder.hip: 256-byte aligned fields in this order)
             static const char* names[] = {"qkv", "lse", "ctx", "z1", "mean1", "rstd1", "a", "u", "g", "z2", "mean2", "rstd2", "y"};
@@ -1135,53 +1142,14 @@ static void bench_encoder(int B, int L, int H, int heads, int I, int layers) {
         }
         double t0 = 1e30, t1 = 1e30;
         for (int rep = 0; rep < 3; ++rep) {
-            UHCHK(uniter_encoder_debug_xcd_forward(0));
+            UHCHK(uniter_encoder_debug_chain(0));
             t0 = std::min(t0, tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 20));
-            UHCHK(uniter_encoder_debug_xcd_forward(1));
+            UHCHK(uniter_encoder_debug_chain(1));
             t1 = std::min(t1, tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 20));
         }
-        printf("  forward: per-operation kernels %.1f us | one persistent launch %.1f us\n", t0, t1);
-        {   // where the persistent launch spends its time: per phase, work (previous barrier -> done) and wait at the barrier
-            const size_t nst = (size_t)256 * 32 * 8 * 2 + (size_t)256 * 4 * 8;
-            unsigned long long* dpr = dalloc<unsigned long long>(nst);
-            HIPCHK(hipMemset(dpr, 0, nst * 8));
-            UHCHK(uniter_encoder_debug_xcd_probe(dpr));
-            UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0));
-            HIPCHK(hipDeviceSynchronize());
-            UHCHK(uniter_encoder_debug_xcd_probe(nullptr));
-            std::vector<unsigned long long> h(nst);
-            HIPCHK(hipMemcpy(h.data(), dpr, nst * 8, hipMemcpyDeviceToHost));
-            static const char* ph[] = {"qkv gemm", "attention", "out-proj", "layernorm 1", "ffn1", "activation", "ffn2", "layernorm 2"};
-            auto at = [&](int wg, int l, int p, int w) { return h[(((size_t)wg * 32 + l) * 8 + p) * 2 + w]; };
-            for (int p = 0; p < 8; ++p) {
-                double work = 0, wait = 0, wmax = 0; long n = 0;
-                for (int wg = 0; wg < 256; ++wg)
-                    for (int l = 1; l + 1 < layers; ++l) {
-                        const unsigned long long start = p == 0 ? at(wg, l - 1, 7, 1) : at(wg, l, p - 1, 1);
-                        const unsigned long long done = at(wg, l, p, 0), passed = at(wg, l, p, 1);
-                        if (!start || !done || !passed) continue;
-                        work += (double)(done - start); wait += (double)(passed - done); wmax = std::max(wmax, (double)(done - start)); ++n;
-                    }
-                if (n) printf("    phase %-12s work avg %6.2f us (max %6.2f) | barrier wait avg %5.2f us\n", ph[p], work / n * 0.01, wmax * 0.01, wait / n * 0.01);
-            }
-            static const char* gn[] = {"qkv gemm", "out-proj", "ffn1", "ffn2"};
-            static const int gphase[] = {0, 2, 4, 6};
-            for (int k = 0; k < 4; ++k) {          // inside the GEMM phases of layer 5 (wave 0 = MFMA wave, wave 4 = loader wave)
-                double c[4] = {0, 0, 0, 0}, ld[4] = {0, 0, 0, 0}; long n = 0;
-                for (int wg = 0; wg < 256; ++wg) {
-                    const unsigned long long* r = &h[(size_t)256 * 32 * 8 * 2 + ((size_t)wg * 4 + k) * 8];
-                    const unsigned long long start = gphase[k] == 0 ? at(wg, 4, 7, 1) : at(wg, 5, gphase[k] - 1, 1);
-                    if (!r[0] || !r[3] || !r[4] || !r[7] || !start) continue;
-                    c[0] += (double)(r[0] - start); c[1] += (double)(r[1] - r[0]); c[2] += (double)(r[2] - r[1]); c[3] += (double)(r[3] - r[2]);
-                    ld[0] += (double)(r[4] - start); ld[1] += (double)(r[5] - r[4]); ld[2] += (double)(r[6] - r[5]); ld[3] += (double)(r[7] - r[6]);
-                    ++n;
-                }
-                if (n) printf("    %-10s MFMA wave: call %.2f | first tile ready %.2f | main loop %.2f | last epilogue %.2f us   loader: call %.2f | first issues %.2f | first step landed %.2f | rest %.2f us\n",
-                              gn[k], c[0] / n * 0.01, c[1] / n * 0.01, c[2] / n * 0.01, c[3] / n * 0.01, ld[0] / n * 0.01, ld[1] / n * 0.01, ld[2] / n * 0.01, ld[3] / n * 0.01);
-            }
-        }
+        printf("  forward: in-order launches %.1f us | overlapped chain %.1f us\n", t0, t1);
     }
-    if (getenv("UNITER_BENCH_XCD_ONLY")) return;
+    if (getenv("UNITER_BENCH_CHAIN_ONLY")) return;
     // deferred weight gradients (one launch for all layers of the call) against the per-layer grouped launches: every
     // parameter gradient of every layer, same inputs, gradients zeroed before each run
     const size_t stb = uniter_encoder_wgrad_stage_bytes(&sh, layers);
@@ -1212,13 +1180,43 @@ static void bench_encoder(int B, int L, int H, int heads, int I, int layers) {
             }
         }
         for (int l = 0; l < layers; ++l) HIPCHK(hipMemset(gbase[l], 0, per * 2));
+        // the backward data-gradient chain overlapped (row-block flags) against in-order launches, stage registered in both: dx and
+        // every parameter gradient of every layer, bit for bit
+        std::vector<std::vector<uint16_t>> gref(layers);
+        std::vector<uint16_t> dxref((size_t)T * H), dxgot((size_t)T * H), ggot(per);
+        size_t bad = 0;
+        int32_t st_word = 0;
+        for (int pass = 0; pass < 4; ++pass) {              // pass 0: in order; 1..3: chained
+            UHCHK(uniter_encoder_debug_chain(pass == 0 ? 0 : 1));
+            for (int l = 0; l < layers; ++l) HIPCHK(hipMemset(gbase[l], 0, per * 2));
+            HIPCHK(hipMemset(dDx, 0, (size_t)T * H * 2));
+            UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0));
+            HIPCHK(hipDeviceSynchronize());
+            if (pass > 0) { int32_t w = 0; UHCHK(uniter_encoder_chain_status(&sh, scratch, &w)); st_word |= w; }
+            HIPCHK(hipMemcpy(pass == 0 ? dxref.data() : dxgot.data(), dDx, (size_t)T * H * 2, hipMemcpyDeviceToHost));
+            if (pass > 0) for (size_t k = 0; k < dxref.size(); ++k) bad += dxref[k] != dxgot[k];
+            for (int l = 0; l < layers; ++l) {
+                if (pass == 0) { gref[l].resize(per); HIPCHK(hipMemcpy(gref[l].data(), gbase[l], per * 2, hipMemcpyDeviceToHost)); continue; }
+                HIPCHK(hipMemcpy(ggot.data(), gbase[l], per * 2, hipMemcpyDeviceToHost));
+                for (size_t k = 0; k < per; ++k) bad += gref[l][k] != ggot[k];
+            }
+        }
+        printf("[%s] overlapped-chain backward == in-order backward (3 launches): %zu elements of dx / parameter gradients differ, status word %d\n",
+               (bad || st_word) ? "FAIL" : " OK ", bad, st_word);
+        if (bad || st_word) ++g_fail;
+        for (int l = 0; l < layers; ++l) HIPCHK(hipMemset(gbase[l], 0, per * 2));
     }
     if (getenv("UNITER_BENCH_NO_STAGE")) UHCHK(uniter_encoder_set_wgrad_stage(nullptr, 0));
-    double tf = 1e30, tb = 1e30;
+    double tf = 1e30, tb = 1e30, tf0 = 1e30, tb0 = 1e30;
     for (int rep = 0; rep < 5; ++rep) {
+        UHCHK(uniter_encoder_debug_chain(0));
+        tf0 = std::min(tf0, tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 20));
+        tb0 = std::min(tb0, tm.run([&] { UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0)); }, 2, 20));
+        UHCHK(uniter_encoder_debug_chain(1));
         tf = std::min(tf, tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 20));
         tb = std::min(tb, tm.run([&] { UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0)); }, 2, 20));
     }
+    printf("  in-order launches: fwd %.1f us | bwd %.1f us ;  overlapped chains: fwd %.1f us | bwd %.1f us\n", tf0, tb0, tf, tb);
     {
         static const char* kinds[] = {"gemm fwd +bias", "gemm fwd +gelu", "gemm fwd +drop+res", "gemm dgrad", "gemm dgrad gelu'", "gemm wgrad",
                                       "attn fwd", "attn bwd", "ln fwd", "ln bwd rows", "colsum", "adamw", "ln bwd cols", "gemm wgrad group"};

@@ -307,43 +307,47 @@ def test_full_size_determinism_and_eval_equals_p0(full_model):
     assert torch.isfinite(y1.float()).all()
 
 
-@pytest.mark.parametrize("pack", [False, True])
-def test_persistent_per_xcd_forward_is_bit_identical(full_model, pack):
-    """csrc/xcd_forward.hip (one launch, one team of workgroups per XCD, L2-local barriers; opt-in) against the
-    kernel-per-operation forward at the benchmark shape: every layer's output with dropout on and a ragged batch, and the
-    gradients of a backward pass that runs off the activations each path saved."""
+@pytest.mark.parametrize("mode", ["dense96", "ragged", "packed"])
+def test_overlapped_kernel_chain_is_bit_identical_to_in_order_launches(full_model, mode):
+    """The encoder's forward and data-gradient chains dispatched WITHOUT the queue barrier between dependent kernels and ordered
+    by row-block flags (include/uniter_hip.h "Overlapped kernel chains", ABI v7) against the same kernels launched in order, at
+    the benchmark shape with dropout on: every layer's output and every gradient, bit for bit.  dense96 = 32 x 96 tokens, every
+    kernel of the call in the chain; ragged = a padded batch whose length is not a multiple of 32 (attention drops out of the
+    chain, the GEMMs / LayerNorms around it stay in); packed = padding-free rows (cu_seqlens)."""
     from uniter_amd import _lib, ops
     from uniter_amd.utils.misc import set_dropout
     lib = _lib.load()
-    b = _full_batch(seed=11, ragged=True)
+    b = _full_batch(seed=11, ragged=(mode != "dense96"))
     params = [p for p in full_model.uniter.parameters()]
     set_dropout(full_model, 0.1)
-    full_model.uniter.pack_padding = pack            # padding-free rows (cu_seqlens): team boundaries fall on ragged row counts
+    full_model.uniter.pack_padding = (mode == "packed")
 
     def run(enable):
-        lib.uniter_encoder_debug_xcd_forward(enable)
+        lib.uniter_encoder_debug_chain(enable)
         ops.manual_seed(1234)
         for p in params:
             p.grad = None
         ys = full_model.uniter(b['input_ids'], b['position_ids'], b['img_feat'], b['img_pos_feat'], b['attn_masks'],
                                b['gather_index'], output_all_encoded_layers=True)
         (ys[-1].float() * b['attn_masks'].unsqueeze(-1)).square().mean().backward()
+        torch.cuda.synchronize()
         return [y.detach().clone() for y in ys], [None if p.grad is None else p.grad.detach().clone() for p in params]
 
     try:
         y0, g0 = run(0)
-        y1, g1 = run(1)
+        runs = [run(1) for _ in range(3)]            # (a race would not show on every launch)
     finally:
-        lib.uniter_encoder_debug_xcd_forward(0)
+        lib.uniter_encoder_debug_chain(1)
         set_dropout(full_model, 0.0)
         full_model.uniter.pack_padding = False
-    assert len(y0) == len(y1) == 12
-    for a, c in zip(y0, y1):
-        assert torch.equal(a, c)
-    for a, c in zip(g0, g1):
-        assert (a is None) == (c is None)
-        if a is not None:
+    assert len(y0) == 12
+    for y1, g1 in runs:
+        for a, c in zip(y0, y1):
             assert torch.equal(a, c)
+        for a, c in zip(g0, g1):
+            assert (a is None) == (c is None)
+            if a is not None:
+                assert torch.equal(a, c)
 
 
 def test_full_size_padding_invariance(full_model):

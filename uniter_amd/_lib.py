@@ -11,7 +11,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "build", "libuniter_hip.so")
-ABI_VERSION = 6          # UNITER_HIP_ABI_VERSION of include/uniter_hip.h (struct layouts below must match it)
+ABI_VERSION = 7          # UNITER_HIP_ABI_VERSION of include/uniter_hip.h (struct layouts below must match it)
 
 
 class UniterHipError(RuntimeError):
@@ -132,8 +132,8 @@ SIGNATURES = {
     "uniter_encoder_defer_side_join": (c_int, [c_int]),
     "uniter_encoder_side_join": (c_int, [c_void_p]),
     "uniter_encoder_side_stream": (c_int, [POINTER(c_void_p)]),
-    "uniter_encoder_debug_xcd_forward": (c_int, [c_int]),
-    "uniter_encoder_debug_xcd_probe": (c_int, [c_void_p]),
+    "uniter_encoder_debug_chain": (c_int, [c_int]),
+    "uniter_encoder_chain_status": (c_int, [POINTER(UniterEncoderShape), c_void_p, POINTER(c_int32)]),
     "uniter_encoder_debug_tune_in_situ": (c_int, [c_int]),
     "uniter_gemm_bias_relu_dropout_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
     "uniter_relu_dropout_bwd": (c_int, [_P, _P, _P, _I, c_float, _P]),

@@ -441,6 +441,19 @@ int uniter_adamw_step_async(void* plan, const UniterAdamGroup* groups, int32_t n
     return 0;
 }
 
+}  // extern "C"
+namespace uh {
+// an asynchronous optimizer step has segments the forward pass still has to wait for (encoder.hip: such a forward keeps its
+// kernels in queue order — the per-layer stream waits must stay between them)
+bool params_pending() {
+    std::lock_guard<std::mutex> lk(g_pt_mu);
+    ParamTracker* ptp = nullptr;
+    if (tracker_get(&ptp)) return true;
+    return !ptp->pending.empty();
+}
+}  // namespace uh
+extern "C" {
+
 int uniter_params_wait(const void* addr, void* stream) {
     std::lock_guard<std::mutex> lk(g_pt_mu);
     ParamTracker* ptp = nullptr;

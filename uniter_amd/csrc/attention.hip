@@ -34,7 +34,9 @@ namespace {
 template <int MAXKT, int MAXT = 512>
 __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    attn_chain_wait<1>(p);
     attn_fwd_unit<MAXKT, false>(p, (int)blockIdx.x, smem_raw);
+    attn_chain_signal<1>(p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -76,6 +78,8 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const AttnArgs p) {
     const bf16_t* O = p.ctx + row0 * H + h * DH;
     unsigned long long* stamp = ((ATTN_DBG(p) & 8) && live) ? reinterpret_cast<unsigned long long*>(p.dsum) + ((size_t)bh * 8 + (tid >> 6)) * 8 : nullptr;
     if (stamp && (tid & 63) == 0) stamp[0] = __builtin_readcyclecounter();
+    attn_chain_wait<HP>(p);
+    const bool wt = p.chain.signal != nullptr;
 
     if (live)
     {
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const AttnArgs p) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const float v[4] = {dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]};
-                __builtin_nontemporal_store(pack4(v), reinterpret_cast<u32x2*>(dst + dt * 16));
+                out_store8c(dst + dt * 16, pack4(v), wt);
             }
         }
     }
@@ -253,13 +257,14 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const AttnArgs p) {
             for (int dt = 0; dt < 4; ++dt) {
                 const float kv[4] = {dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]};
                 const float vv[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
-                __builtin_nontemporal_store(pack4(kv), reinterpret_cast<u32x2*>(dst + H + dt * 16));
-                __builtin_nontemporal_store(pack4(vv), reinterpret_cast<u32x2*>(dst + 2 * H + dt * 16));
+                out_store8c(dst + H + dt * 16, pack4(kv), wt);
+                out_store8c(dst + 2 * H + dt * 16, pack4(vv), wt);
             }
         }
         if (stamp && lane == 0) { asm volatile("s_nop 0" ::: "memory"); stamp[5] = __builtin_readcyclecounter(); }
     }
     if (stamp && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[6] = __builtin_readcyclecounter(); }
+    attn_chain_signal<HP>(p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -312,6 +317,8 @@ __global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_share_kernel(con
     const bf16_t* O = p.ctx + row0 * H + h * DH;
     unsigned long long* stamp = ((ATTN_DBG(p) & 8) && live) ? reinterpret_cast<unsigned long long*>(p.dsum) + ((size_t)bh * 8 + (tid >> 6)) * 8 : nullptr;
     if (stamp && (tid & 63) == 0) stamp[0] = __builtin_readcyclecounter();
+    attn_chain_wait<HP>(p);
+    const bool wt = p.chain.signal != nullptr;
 
     if (live) {
         // prologue: Q, K, V, dO, O, the mask and lse all leave in one burst, then go to LDS (see tile_fetch)
@@ -441,7 +448,7 @@ __global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_share_kernel(con
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const float v[4] = {dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]};
-                __builtin_nontemporal_store(pack4(v), reinterpret_cast<u32x2*>(dst + dt * 16));
+                out_store8c(dst + dt * 16, pack4(v), wt);
             }
         }
     }
@@ -492,13 +499,14 @@ __global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_share_kernel(con
             for (int dt = 0; dt < 4; ++dt) {
                 const float kv[4] = {dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]};
                 const float vv[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
-                __builtin_nontemporal_store(pack4(kv), reinterpret_cast<u32x2*>(dst + H + dt * 16));
-                __builtin_nontemporal_store(pack4(vv), reinterpret_cast<u32x2*>(dst + 2 * H + dt * 16));
+                out_store8c(dst + H + dt * 16, pack4(kv), wt);
+                out_store8c(dst + 2 * H + dt * 16, pack4(vv), wt);
             }
         }
     }
     if (stamp && lane == 0) { asm volatile("s_nop 0" ::: "memory"); stamp[5] = __builtin_readcyclecounter(); }
     if (stamp && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[6] = __builtin_readcyclecounter(); }
+    attn_chain_signal<HP>(p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -768,8 +776,19 @@ static int check(int64_t B, int64_t L, int64_t heads) {
     return 0;
 }
 
+bool attention_chainable(int64_t L, const int32_t* cu) { return cu == nullptr && L % 32 == 0 && L <= LMAX; }
+
+// binds a chain step to a launch's arguments; steps this shape cannot honour are turned into plain in-order launches
+static void attn_bind(AttnArgs& a, ChainStep*& chain, int64_t L, const int32_t* cu, int64_t heads) {
+    a.chain = ChainLink{nullptr, nullptr, nullptr, 0, 0};
+    if (chain == nullptr) return;
+    if (!attention_chainable(L, cu)) { chain->anyorder = 0; chain->produced = 0; return; }
+    a.chain = chain->link;
+    chain->produced = (uint32_t)heads;
+}
+
 int attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse,
-                  int64_t B, int64_t L, int64_t heads, const DropoutCfg& drop, hipStream_t st, const int32_t* cu) {
+                  int64_t B, int64_t L, int64_t heads, const DropoutCfg& drop, hipStream_t st, const int32_t* cu, ChainStep* chain) {
     if (check(B, L, heads)) return -1;
     LaunchTimer lt(TIME_ATTN_FWD, B, L, heads, st);
     AttnArgs a{};
@@ -779,6 +798,7 @@ int attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse
     a.drop = drop;
     a.cu = cu;
     a.dbg = attn_dbg();
+    attn_bind(a, chain, L, cu, heads);
     if (cu == nullptr && mask_bias == nullptr) { uh_set_error("attention: dense mode needs mask_bias"); return -1; }
     const int nkt = a.Lp / 16;
     const int nqt_all = (int)((L + 15) / 16);
@@ -791,22 +811,22 @@ int attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse
     int rc;
     if (nkt > 16) {            // 256 < L <= 512: the whole score row of a query tile in registers (128 accumulators)
         if ((rc = set_lds(attn_fwd_kernel<32>, lds))) return rc;
-        hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, lds, st, a);
+        chain_launch(chain, attn_fwd_kernel<32>, grid, block, lds, st, a);
     } else if (nkt <= 6) {
         if ((rc = set_lds(attn_fwd_kernel<6>, lds))) return rc;
-        hipLaunchKernelGGL(attn_fwd_kernel<6>, grid, block, lds, st, a);
+        chain_launch(chain, attn_fwd_kernel<6>, grid, block, lds, st, a);
     } else if (nkt <= 8) {
         if ((rc = set_lds(attn_fwd_kernel<8>, lds))) return rc;
-        hipLaunchKernelGGL(attn_fwd_kernel<8>, grid, block, lds, st, a);
+        chain_launch(chain, attn_fwd_kernel<8>, grid, block, lds, st, a);
     } else if (nkt <= 12 && nw > 8) {
         if ((rc = set_lds(attn_fwd_kernel<12, 768>, lds))) return rc;
-        hipLaunchKernelGGL((attn_fwd_kernel<12, 768>), grid, block, lds, st, a);
+        chain_launch(chain, attn_fwd_kernel<12, 768>, grid, block, lds, st, a);
     } else if (nkt <= 12) {
         if ((rc = set_lds(attn_fwd_kernel<12>, lds))) return rc;
-        hipLaunchKernelGGL(attn_fwd_kernel<12>, grid, block, lds, st, a);
+        chain_launch(chain, attn_fwd_kernel<12>, grid, block, lds, st, a);
     } else {
         if ((rc = set_lds(attn_fwd_kernel<16>, lds))) return rc;
-        hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, block, lds, st, a);
+        chain_launch(chain, attn_fwd_kernel<16>, grid, block, lds, st, a);
     }
     UH_LAUNCH_CHECK();
     return 0;
@@ -818,7 +838,7 @@ size_t attention_bwd_workspace_bytes(int64_t B, int64_t L, int64_t heads) {
 
 int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, const float* lse,
                   const void* dctx, void* dqkv, int64_t B, int64_t L, int64_t heads,
-                  const DropoutCfg& drop, hipStream_t st, const int32_t* cu, void* workspace) {
+                  const DropoutCfg& drop, hipStream_t st, const int32_t* cu, void* workspace, ChainStep* chain) {
     if (check(B, L, heads)) return -1;
     LaunchTimer lt(TIME_ATTN_BWD, B, L, heads, st);
     AttnArgs a{};
@@ -828,6 +848,7 @@ int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, cons
     a.drop = drop;
     a.cu = cu;
     a.dbg = attn_dbg();
+    attn_bind(a, chain, L, cu, heads);
     if (cu == nullptr && mask_bias == nullptr) { uh_set_error("attention: dense mode needs mask_bias"); return -1; }
     if (L > LMAX) {            // two launches: dQ (+ D) with K, V in LDS, then dK / dV with Q, dO in LDS
         if (workspace == nullptr) { uh_set_error("attention_bwd: L > %d needs the workspace of uniter_attention_bwd_workspace_bytes", LMAX); return -1; }
@@ -862,10 +883,10 @@ int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, cons
         const size_t ub = ((size_t)a.Lp * 64 * 2 * (4 + npanel) + (size_t)a.Lp * 4 * 3 + 15) & ~(size_t)15;
         if (2 * nw <= 12 && 2 * ub <= 156 * 1024 && a.Lp <= 96) {   // two units per workgroup: 12 waves, three per SIMD (see attn_bwd_kernel)
             if ((rc = set_lds(attn_bwd_share_kernel<2, 6>, 2 * ub))) return rc;
-            hipLaunchKernelGGL((attn_bwd_share_kernel<2, 6>), dim3((unsigned)((units + 1) / 2)), dim3(2 * nw * 64), 2 * ub, st, a);
+            chain_launch(chain, attn_bwd_share_kernel<2, 6>, dim3((unsigned)((units + 1) / 2)), dim3(2 * nw * 64), 2 * ub, st, a);
         } else {
             if ((rc = set_lds(attn_bwd_share_kernel<1, 8>, ub))) return rc;
-            hipLaunchKernelGGL((attn_bwd_share_kernel<1, 8>), dim3((unsigned)units), dim3(nw * 64), ub, st, a);
+            chain_launch(chain, attn_bwd_share_kernel<1, 8>, dim3((unsigned)units), dim3(nw * 64), ub, st, a);
         }
         UH_LAUNCH_CHECK();
         return 0;
@@ -874,14 +895,14 @@ int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, cons
     const size_t unit_bytes = (lds + 15) & ~(size_t)15;
     if (2 * nw <= 12 && 2 * unit_bytes <= 156 * 1024) {     // (and both units' tiles fit the CU's 160 KiB of LDS)
         if ((rc = set_lds(attn_bwd_kernel<2>, 2 * unit_bytes))) return rc;
-        hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3((unsigned)((units + 1) / 2)), dim3(2 * nw * 64), 2 * unit_bytes, st, a);
+        chain_launch(chain, attn_bwd_kernel<2>, dim3((unsigned)((units + 1) / 2)), dim3(2 * nw * 64), 2 * unit_bytes, st, a);
     } else {
         if (nw > 8) {
             if ((rc = set_lds(attn_bwd_kernel<1, 768>, lds))) return rc;
-            hipLaunchKernelGGL((attn_bwd_kernel<1, 768>), dim3((unsigned)units), dim3(nw * 64), lds, st, a);
+            chain_launch(chain, attn_bwd_kernel<1, 768>, dim3((unsigned)units), dim3(nw * 64), lds, st, a);
         } else {
             if ((rc = set_lds(attn_bwd_kernel<1>, lds))) return rc;
-            hipLaunchKernelGGL(attn_bwd_kernel<1>, dim3((unsigned)units), dim3(nw * 64), lds, st, a);
+            chain_launch(chain, attn_bwd_kernel<1>, dim3((unsigned)units), dim3(nw * 64), lds, st, a);
         }
     }
     UH_LAUNCH_CHECK();

@@ -98,7 +98,33 @@ struct AttnArgs {
     const int32_t* cu;     // packed mode: example b owns rows cu[b] .. cu[b+1]-1 of qkv / ctx (NULL = dense [B, L])
     DropoutCfg drop;
     int dbg;               // profiling builds of the harness only (UNITER_AMD_ATTN_DBG): bit 0 = no output stores, 1 = no key sweep, 2 = no query sweep
+    ChainLink chain;       // overlapped kernel chain (common.cuh); only dense launches with L % 32 == 0 take part
 };
+
+// chain helpers for kernels that run HP (example, head) units per workgroup: the workgroup waits for the rows of the examples its
+// units belong to, and every live unit contributes 1 to each 32-row unit of its example (a consumer expects `heads`)
+template <int HP>
+__device__ __forceinline__ void attn_chain_wait(const AttnArgs& p) {
+    if (p.chain.wait == nullptr) return;
+    const int last = p.B * p.heads - 1;
+    const int bh0 = min((int)blockIdx.x * HP, last), bh1 = min((int)blockIdx.x * HP + HP - 1, last);
+    const int b0 = bh0 / p.heads, b1 = bh1 / p.heads;
+    chain_wait(p.chain, b0 * p.L, (b1 - b0 + 1) * p.L);
+}
+template <int HP>
+__device__ __forceinline__ void attn_chain_signal(const AttnArgs& p) {
+    if (p.chain.signal == nullptr) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // write-through stores acknowledged
+    __syncthreads();
+    const int nu = p.L >> 5;
+    const int t = (int)threadIdx.x;
+    if (t < HP * nu) {
+        const int slot = t / nu, u = t - slot * nu;
+        const int bh = (int)blockIdx.x * HP + slot;
+        if (bh < p.B * p.heads)
+            __hip_atomic_fetch_add(p.chain.signal + (bh / p.heads) * nu + u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // forward
@@ -242,7 +268,8 @@ __device__ __forceinline__ void attn_fwd_unit(const AttnArgs& p, const int bh, c
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const float v[4] = {o[dt][0], o[dt][1], o[dt][2], o[dt][3]};
-                stg8<COH>(dst + dt * 16, pack4(v));
+                if constexpr (COH) stg8<true>(dst + dt * 16, pack4(v));
+                else out_store8c(dst + dt * 16, pack4(v), p.chain.signal != nullptr);
             }
         }
     }

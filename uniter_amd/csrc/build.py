@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 BUILD = os.path.join(HERE, "build")
 LIB = os.path.join(BUILD, "libuniter_hip.so")
-SOURCES = ["capi.hip", "gemm.hip", "attention.hip", "layernorm.hip", "embed.hip", "adamw.hip", "encoder.hip", "comm.hip", "ot.hip", "pool.hip", "lmhead.hip", "head.hip", "xcd_forward.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "attention.hip", "layernorm.hip", "embed.hip", "adamw.hip", "encoder.hip", "comm.hip", "ot.hip", "pool.hip", "lmhead.hip", "head.hip"]
 HEADERS = [os.path.join(HERE, h) for h in ("common.cuh", "kernels.h", "gemm_lds.cuh", "gemm_args.cuh", "gemm8.cuh", "attention_fwd.cuh", "layernorm_fwd.cuh")] + \
     [os.path.join(ROOT, "include", "uniter_hip.h")]
 ARCH = "gfx950"

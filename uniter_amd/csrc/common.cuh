@@ -104,6 +104,72 @@ __device__ __forceinline__ void out_store8(void* p, const u32x2 v) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Overlapped kernel chains (feasibility: tests/native/anyorder_probe.cpp, profiles/r04_anyorder_probe.log)
+// ---------------------------------------------------------------------------------------------
+// The kernels of an encoder forward / backward call form a dependent chain in which every operation is local to a block of
+// rows (tokens) — attention to an example, which at L % 32 == 0 is a whole number of 32-row units.  Launched in order, each
+// kernel boundary costs ~1.5-2 us of idle chip (queue barrier, cache write-back / invalidate) plus the ramp of one kernel
+// that cannot overlap the drain of the previous one.  A chain kernel is therefore dispatched WITHOUT the barrier packet bit
+// (hipExtLaunchKernel + hipExtAnyOrderLaunch: it starts as soon as its predecessor has been dispatched, measured) and orders
+// itself by flags: one counter per 32-row unit and kernel; a producer tile adds 1 to each unit it covers when its output has
+// left the chip's caches, a consumer tile waits until the units under its rows have received `expect` contributions.
+// Deadlock-free by construction: packets of one queue are dispatched in order, so every workgroup a consumer can wait for is
+// already resident or done.  Coherence across XCDs without a kernel boundary (measured in the probe: 0 stale words of 3e8):
+// producers store write-through (`sc1`) and wait for the acknowledgement (`s_waitcnt vmcnt(0)`) before they signal; consumers
+// read with plain loads AFTER seeing the flag — and no buffer of a chain is written twice within a call (encoder.hip gives
+// every layer its own), so no cache on the chip can hold an older version of a line a consumer asks for.
+// A wait that does not complete within 50 ms sets *status and falls through: a broken chain fails a test, it never hangs the GPU.
+struct ChainLink {
+    const uint32_t* wait;      // the producer kernel's counters, one per 32-row unit (nullptr: inputs are complete at dispatch)
+    uint32_t* signal;          // this kernel's counters (nullptr: consumers are ordered by a normal kernel boundary)
+    uint32_t* status;          // device word, set to 1 by a wait that timed out
+    uint32_t expect;           // contributions a producer unit receives (the producer's column tiles / heads / row groups)
+    uint32_t pad;
+};
+
+// all threads of the workgroup; rows [row0, row0 + nrows) of the producer's output are about to be read (nrows <= 2048)
+__device__ __forceinline__ void chain_wait(const ChainLink& c, const int row0, const int nrows) {
+    if (c.wait == nullptr) return;                         // (uniform)
+    if (threadIdx.x < 64) {
+        const int u0 = row0 >> 5;
+        const int nu = ((row0 + nrows + 31) >> 5) - u0;
+        const int lane = (int)threadIdx.x;
+        bool ok = lane >= nu;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (unsigned spins = 0;; ++spins) {
+            if (!ok) ok = __hip_atomic_load(c.wait + u0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= c.expect;
+            if (__all(ok)) break;
+            if ((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > 5000000ull) {      // 50 ms at 100 MHz
+                if (lane == 0 && c.status != nullptr) __hip_atomic_store(c.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+}
+
+// all live threads of the workgroup, after their last output store; rows [row0, row0 + nrows) of this kernel's output are final
+__device__ __forceinline__ void chain_signal(const ChainLink& c, const int row0, const int nrows) {
+    if (c.signal == nullptr) return;                       // (uniform)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my write-through stores have been acknowledged
+    __syncthreads();
+    const int u0 = row0 >> 5;
+    const int nu = ((row0 + nrows + 31) >> 5) - u0;
+    if ((int)threadIdx.x < nu) __hip_atomic_fetch_add(c.signal + u0 + (int)threadIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// output stores of a kernel that may run inside a chain: write-through when it signals, the kernel's usual policy otherwise
+__device__ __forceinline__ void out_store16c(void* p, const u32x4 v, const bool wt) {
+    if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"((gmem_u32x4*)p), "v"(v) : "memory");
+    else out_store16(p, v);
+}
+__device__ __forceinline__ void out_store8c(void* p, const u32x2 v, const bool wt) {
+    if (wt) asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 0" ::"v"((gmem_u32x2*)p), "v"(v) : "memory");
+    else out_store8(p, v);
+}
+
+// ---------------------------------------------------------------------------------------------
 // wave64 reductions
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -46,8 +46,9 @@ ActLayout act_layout(const UniterEncoderShape& s) {
 }
 
 struct ScratchLayout {
-    size_t bufA, bufB, dd[2], dd1[2], dctx, dqkv[2], dpre[2], red, red2, red_bytes, wg, wg_bytes, attn_ws, total;
+    size_t bufA, bufB, dd[2], dd1[2], dctx, dqkv[2], dpre[2], red, red2, red_bytes, wg, wg_bytes, attn_ws, chain, chain_bytes, total;
 };
+constexpr int kChainSlots = 448;        // launches one call may chain (7 per layer forward, 7 backward: 64 layers)
 ScratchLayout scratch_layout(const UniterEncoderShape& s) {
     const size_t T = tokens(s), H = s.H, I = s.I;
     ScratchLayout l{};
@@ -78,9 +79,64 @@ ScratchLayout scratch_layout(const UniterEncoderShape& s) {
     l.wg_bytes = big * 8 * sizeof(float);
     l.wg = take(l.wg_bytes);
     l.attn_ws = take(uh::attention_bwd_workspace_bytes(s.B, s.L, s.heads) + 16);      // D = rowsum(dO*O) of the split backward (L > 256)
+    // row-block flags of an overlapped kernel chain: one counter per 32-row unit and launch, plus the status word (first 256 bytes)
+    l.chain_bytes = 256 + (size_t)kChainSlots * ((T + 31) / 32) * sizeof(uint32_t);
+    l.chain = take(l.chain_bytes);
     l.total = o;
     return l;
 }
+
+// ---- overlapped kernel chain (common.cuh) --------------------------------------------------------------
+// One per uniter_encoder_forward / _backward call.  next() hands the launcher of the following kernel its step (wait on the
+// previous launch's flags, signal a fresh slot, drop the queue barrier); done() records what that launcher reported.  A
+// launcher that cannot take part (packed attention, split-K) clears produced: it has then run as an ordinary in-order kernel
+// without flags, and so does the kernel after it.
+int g_chain = [] { const char* e = getenv("UNITER_AMD_CHAIN"); return e ? atoi(e) : 1; }();
+struct Chain {
+    bool on = false;
+    uint32_t* flags = nullptr;
+    uint32_t* status = nullptr;
+    int units = 0, slot = 0;
+    const uint32_t* prev_sig = nullptr;
+    uint32_t prev_produced = 0;
+    uh::ChainStep step;
+
+    // `scratch_chain` = the chain region of the caller's scratch buffer; zeroes the flags this call may use (in stream order)
+    int begin(void* scratch_chain, const UniterEncoderShape& s, int launches, hipStream_t st) {
+        on = false;
+        const size_t T = tokens(s);
+        if (!g_chain || scratch_chain == nullptr || uh::g_timing_on || T % 32 != 0 || launches > kChainSlots) return 0;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return 0;
+        status = (uint32_t*)scratch_chain;
+        flags = status + 64;
+        units = (int)(T / 32);
+        UH_CHECK_HIP(hipMemsetAsync(scratch_chain, 0, 256 + (size_t)launches * units * sizeof(uint32_t), st));
+        slot = 0;
+        prev_sig = nullptr;
+        prev_produced = 0;
+        on = true;
+        return 0;
+    }
+    uh::ChainStep* next() {
+        if (!on) return nullptr;
+        step = uh::ChainStep{};
+        step.link.wait = prev_sig;
+        step.link.expect = prev_produced;
+        step.link.signal = flags + (size_t)slot * units;
+        step.link.status = status;
+        step.anyorder = prev_sig != nullptr ? 1 : 0;        // the first kernel of a chain keeps its place in the queue
+        ++slot;
+        return &step;
+    }
+    void done() {
+        if (!on) return;
+        if (step.produced == 0) { prev_sig = nullptr; prev_produced = 0; }
+        else { prev_sig = step.link.signal; prev_produced = step.produced; }
+    }
+};
+// CH(call): `cs` inside the call expression is the step of this launch (nullptr when the call does not run as a chain)
+#define CH(expr) do { uh::ChainStep* cs = ch.next(); (void)cs; RC(expr); ch.done(); } while (0)
 
 // ---- second stream for the weight-gradient GEMMs ------------------------------------------------------
 // dgrad(l) and wgrad(l) both need only dY(l); nothing downstream of backward needs the weight gradients
@@ -164,7 +220,7 @@ struct WgradStage {
 };
 thread_local WgradStage g_stage;
 int g_wgrad_multi = [] { const char* e = getenv("UNITER_AMD_WGRAD_MULTI"); return e ? atoi(e) : 1; }();
-struct StageSet { size_t dd, dd1, dqkv, dpre, dy2, dy1, total; };
+struct StageSet { size_t dd, dd1, dqkv, dpre, dy2, dy1, dz2, dz1, dctx, total; };
 StageSet stage_set(const UniterEncoderShape& s) {
     const size_t T = tokens(s), H = s.H, I = s.I;
     StageSet l{};
@@ -178,6 +234,12 @@ StageSet stage_set(const UniterEncoderShape& s) {
     // write anyway: kept per layer, they let the LayerNorm parameter gradients (dgamma, dbeta) ride on the deferred launch too
     l.dy2 = take(T * H * 2);
     l.dy1 = take(T * H * 2);
+    // the LayerNorm-backward outputs the data-gradient epilogues add (dz2, dz1) and the attention backward's input (dctx): per
+    // layer instead of the recycled scratch buffers, so that no buffer of a backward call is written twice — what an
+    // overlapped kernel chain needs (common.cuh: consumers read with plain loads; there must be no older version to find)
+    l.dz2 = take(T * H * 2);
+    l.dz1 = take(T * H * 2);
+    l.dctx = take(T * H * 2);
     l.total = o;
     return l;
 }
@@ -234,18 +296,16 @@ int uniter_encoder_forward(const UniterEncoderShape* s, const UniterLayerParams*
     UH_CHECK_ARG(layers != nullptr && x_in != nullptr && acts != nullptr, "null pointer");
     UH_CHECK_ARG(mask_bias != nullptr || s->total_tokens > 0, "dense mode needs mask_bias");
     UH_CHECK_ARG(layer_begin >= 0 && layer_end >= layer_begin, "bad layer range");
-    (void)scratch;
     hipStream_t st = (hipStream_t)stream;
     const ActLayout al = act_layout(*s);
     const int64_t T = (int64_t)tokens(*s), H = s->H, I = s->I;
     const bool tr = s->training != 0;
     const DropoutCfg nodrop = make_dropout(0.f, 0, 0);
-    if (layer_end > layer_begin && uh::xcd_forward_eligible(*s, layer_end)) {
-        // one persistent launch, one team of workgroups per XCD (xcd_forward.hip); same results as the loop below
-        RC(uniter_params_wait_all(stream));
-        const uh::XcdActOffsets xo{al.qkv, al.lse, al.ctx, al.z1, al.mean1, al.rstd1, al.a, al.u, al.g, al.z2, al.mean2, al.rstd2, al.y};
-        return uh::xcd_forward(s, layers, layer_begin, layer_end, x_in, mask_bias, acts, al.total, xo, seed, offset, st);
-    }
+    // the seven kernels of every layer as one overlapped chain (row-block flags instead of queue barriers) when the caller
+    // provides the scratch buffer; every activation lives in its own per-layer slot of `acts`, nothing is written twice
+    Chain ch;
+    if (layer_end > layer_begin && !uh::params_pending())
+        RC(ch.begin(scratch != nullptr ? (char*)scratch + scratch_layout(*s).chain : nullptr, *s, 7 * (layer_end - layer_begin), st));
     const char* x = (const char*)x_in;
     for (int l = layer_begin; l < layer_end; ++l) {
         const UniterLayerParams& P = layers[l];
@@ -256,20 +316,20 @@ int uniter_encoder_forward(const UniterEncoderShape* s, const UniterLayerParams*
         const DropoutCfg d_h2 = tr ? make_dropout(s->p_hidden, seed, off + 2) : nodrop;
         RC(uniter_params_wait(P.wqkv, stream));        // an asynchronous optimizer step may still be writing this layer
         // model/layer.py:76-78  (three Linear(H,H) fused into one [3H,H] GEMM)
-        RC(uh::gemm_fwd(uh::GEMM_EPI_BIAS, x, P.wqkv, P.bqkv, nullptr, A + al.qkv, nullptr, T, 3 * H, H, nodrop, st));
+        CH(uh::gemm_fwd(uh::GEMM_EPI_BIAS, x, P.wqkv, P.bqkv, nullptr, A + al.qkv, nullptr, T, 3 * H, H, nodrop, st, 0, 0, 0, cs));
         // model/layer.py:80-100
-        RC(uh::attention_fwd(A + al.qkv, s->total_tokens > 0 ? nullptr : mask_bias, A + al.ctx, (float*)(A + al.lse), s->B, s->L, s->heads, d_attn, st,
-                             s->total_tokens > 0 ? s->cu_seqlens : nullptr));
+        CH(uh::attention_fwd(A + al.qkv, s->total_tokens > 0 ? nullptr : mask_bias, A + al.ctx, (float*)(A + al.lse), s->B, s->L, s->heads, d_attn, st,
+                             s->total_tokens > 0 ? s->cu_seqlens : nullptr, cs));
         // model/layer.py:112-114  dense + dropout + residual
-        RC(uh::gemm_fwd(uh::GEMM_EPI_BIAS_DROP_RES, A + al.ctx, P.wo, P.bo, x, A + al.z1, nullptr, T, H, H, d_h1, st));
-        RC(uh::layernorm_fwd(A + al.z1, P.ln1_g, P.ln1_b, A + al.a, (float*)(A + al.mean1), (float*)(A + al.rstd1),
-                             T, H, s->ln_eps, nodrop, st));
+        CH(uh::gemm_fwd(uh::GEMM_EPI_BIAS_DROP_RES, A + al.ctx, P.wo, P.bo, x, A + al.z1, nullptr, T, H, H, d_h1, st, 0, 0, 0, cs));
+        CH(uh::layernorm_fwd(A + al.z1, P.ln1_g, P.ln1_b, A + al.a, (float*)(A + al.mean1), (float*)(A + al.rstd1),
+                             T, H, s->ln_eps, nodrop, st, cs));
         // model/layer.py:140-141  dense + erf-GELU
-        RC(uh::gemm_fwd(uh::GEMM_EPI_BIAS_GELU, A + al.a, P.w1, P.b1, nullptr, A + al.u, A + al.g, T, I, H, nodrop, st, 0, 0, s->hidden_act));
+        CH(uh::gemm_fwd(uh::GEMM_EPI_BIAS_GELU, A + al.a, P.w1, P.b1, nullptr, A + al.u, A + al.g, T, I, H, nodrop, st, 0, 0, s->hidden_act, cs));
         // model/layer.py:153-155
-        RC(uh::gemm_fwd(uh::GEMM_EPI_BIAS_DROP_RES, A + al.g, P.w2, P.b2, A + al.a, A + al.z2, nullptr, T, H, I, d_h2, st));
-        RC(uh::layernorm_fwd(A + al.z2, P.ln2_g, P.ln2_b, A + al.y, (float*)(A + al.mean2), (float*)(A + al.rstd2),
-                             T, H, s->ln_eps, nodrop, st));
+        CH(uh::gemm_fwd(uh::GEMM_EPI_BIAS_DROP_RES, A + al.g, P.w2, P.b2, A + al.a, A + al.z2, nullptr, T, H, I, d_h2, st, 0, 0, 0, cs));
+        CH(uh::layernorm_fwd(A + al.z2, P.ln2_g, P.ln2_b, A + al.y, (float*)(A + al.mean2), (float*)(A + al.rstd2),
+                             T, H, s->ln_eps, nodrop, st, cs));
         x = A + al.y;
     }
     // everything after the stack (task heads, the backward pass that accumulates into .grad) sees a finished update
@@ -329,6 +389,10 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         g_stage.last_nl = nl;
     }
     auto stage_of = [&](int l) { return g_stage.buf + ((size_t)stage_half * (size_t)nl + (size_t)(l - layer_begin)) * sset.total; };
+    // the data-gradient chain as an overlapped kernel chain: only in the deferred flow, where every intermediate of every layer
+    // has its own buffer in the stage (nothing is written twice) and no side-stream kernel runs inside the chain
+    Chain ch;
+    if (defer_wg) RC(ch.begin(S + sl.chain, *s, 7 * nl, st));
     // Event slots (main_ev[k]: "inputs of side job k are ready", side_ev[k]: "side job k has read its inputs"):
     //   0 / 1  the weight-gradient work of even / odd layers (reads dd2, dpre, dd1, dqkv of that parity's buffer set)
     //   2 / 3  the early column sums of the current layer (bias gradients of FFN1 / QKV read dpre / dqkv)   [ungrouped: wgrads too]
@@ -400,6 +464,9 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         // deferred mode: da (input of the attention block's LayerNorm backward) and this layer's dx (input of the LayerNorm
         // backward of the layer below) go to their own per-layer buffers instead of the recycled bufB
         char* dab = defer_wg ? stage_of(l) + sset.dy1 : bufB;
+        char* dz2b = defer_wg ? stage_of(l) + sset.dz2 : bufA;      // LayerNorm-backward outputs added by the data-gradient epilogues
+        char* dz1b = defer_wg ? stage_of(l) + sset.dz1 : bufA;
+        char* dctxb = defer_wg ? stage_of(l) + sset.dctx : dctx;
 
         // ---- BertOutput backward (model/layer.py:152-156) ----
         // LayerNorm backward is split: the row half (dz, dd) stays on the critical path, the column sums
@@ -417,13 +484,13 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
             RC(uh::layernorm_bwd_fused_finalize(red, nbp, P.g_ln2_g, P.g_ln2_b, H, 1, ss));
             RC(joined(4));
         } else {
-        RC(uh::layernorm_bwd_rows(dyl, nullptr, A + al.z2, (const float*)(A + al.mean2), (const float*)(A + al.rstd2),
-                                  P.ln2_g, bufA, ddb2, T, H, d_h2, 0, st));
+        CH(uh::layernorm_bwd_rows(dyl, nullptr, A + al.z2, (const float*)(A + al.mean2), (const float*)(A + al.rstd2),
+                                  P.ln2_g, dz2b, ddb2, T, H, d_h2, 0, st, cs));
         RC(tick());
         if (!defer_wg) {                       // (deferred: dgamma / dbeta come out of the one launch at the end of the call)
         RC(fork(4));
         RC(uh::layernorm_bwd_cols(dyl, nullptr, A + al.z2, (const float*)(A + al.mean2), (const float*)(A + al.rstd2),
-                                  bufA, ddb2, P.g_ln2_g, P.g_ln2_b, grouped ? nullptr : P.g_b2, T, H, 1, d_h2, 0,
+                                  dz2b, ddb2, P.g_ln2_g, P.g_ln2_b, grouped ? nullptr : P.g_b2, T, H, 1, d_h2, 0,
                                   side ? red2 : red, sl.red_bytes, ss));
         RC(joined(4));                         // dyl (bufB below the top layer) has been read
         }
@@ -432,7 +499,7 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
             RC(uh::gemm_wgrad(ddb2, A + al.g, P.g_w2, T, H, I, 1, wg, sl.wg_bytes, ss));
             RC(joined(par));
         }
-        RC(uh::gemm_dgrad(uh::GEMM_EPI_GELU_BWD, ddb2, P.w2, A + al.u, dpre, T, H, I, st, 0, s->hidden_act));
+        CH(uh::gemm_dgrad(uh::GEMM_EPI_GELU_BWD, ddb2, P.w2, A + al.u, dpre, T, H, I, st, 0, s->hidden_act, cs));
         RC(tick());
         // ---- BertIntermediate backward (model/layer.py:139-142) ----
         if (!grouped) {
@@ -442,7 +509,7 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
             RC(joined(par));
         }
         RC(before_overwrite(4));               // bufB is about to receive da
-        RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dpre, P.w1, bufA, dab, T, I, H, st));           // da = dpre*W1 + dz2
+        CH(uh::gemm_dgrad(uh::GEMM_EPI_RES, dpre, P.w1, dz2b, dab, T, I, H, st, 0, 0, cs));           // da = dpre*W1 + dz2
         RC(tick());
         // ---- BertSelfOutput backward (model/layer.py:111-115) ----
         if (lnf) {
@@ -455,13 +522,13 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
             RC(uh::layernorm_bwd_fused_finalize(red2, nbp, P.g_ln1_g, P.g_ln1_b, H, 1, ss));
             RC(joined(5));
         } else {
-        RC(uh::layernorm_bwd_rows(dab, nullptr, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1),
-                                  P.ln1_g, bufA, ddb1, T, H, d_h1, 0, st));
+        CH(uh::layernorm_bwd_rows(dab, nullptr, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1),
+                                  P.ln1_g, dz1b, ddb1, T, H, d_h1, 0, st, cs));
         RC(tick());
         if (!defer_wg) {
         RC(fork(5));
         RC(uh::layernorm_bwd_cols(dab, nullptr, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1),
-                                  bufA, ddb1, P.g_ln1_g, P.g_ln1_b, grouped ? nullptr : P.g_bo, T, H, 1, d_h1, 0,
+                                  dz1b, ddb1, P.g_ln1_g, P.g_ln1_b, grouped ? nullptr : P.g_bo, T, H, 1, d_h1, 0,
                                   side ? red2 : red, sl.red_bytes, ss));
         RC(joined(5));                         // bufB (da) has been read
         }
@@ -470,11 +537,11 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
             RC(uh::gemm_wgrad(ddb1, A + al.ctx, P.g_wo, T, H, H, 1, wg, sl.wg_bytes, ss));
             RC(joined(par));
         }
-        RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, ddb1, P.wo, nullptr, dctx, T, H, H, st));
+        CH(uh::gemm_dgrad(uh::GEMM_EPI_RES, ddb1, P.wo, nullptr, dctxb, T, H, H, st, 0, 0, cs));
         RC(tick());
         // ---- BertSelfAttention backward (model/layer.py:75-101) ----
-        RC(uh::attention_bwd(A + al.qkv, s->total_tokens > 0 ? nullptr : mask_bias, A + al.ctx, (const float*)(A + al.lse), dctx, dqkv,
-                             s->B, s->L, s->heads, d_attn, st, s->total_tokens > 0 ? s->cu_seqlens : nullptr, S + sl.attn_ws));
+        CH(uh::attention_bwd(A + al.qkv, s->total_tokens > 0 ? nullptr : mask_bias, A + al.ctx, (const float*)(A + al.lse), dctxb, dqkv,
+                             s->B, s->L, s->heads, d_attn, st, s->total_tokens > 0 ? s->cu_seqlens : nullptr, S + sl.attn_ws, cs));
         if (grouped && defer_wg) {
             // nothing here: the weight gradients of the whole call go out below, in one launch
         } else if (grouped) {
@@ -491,7 +558,7 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         }
         char* dxl = (l == layer_begin) ? (char*)dx : (defer_wg ? stage_of(l - 1) + sset.dy2 : bufB);
         RC(before_overwrite(5));               // bufB is about to receive this layer's dx
-        RC(uh::gemm_dgrad(uh::GEMM_EPI_RES, dqkv, P.wqkv, bufA, dxl, T, 3 * H, H, st));     // dx = dqkv*Wqkv + dz1
+        CH(uh::gemm_dgrad(uh::GEMM_EPI_RES, dqkv, P.wqkv, dz1b, dxl, T, 3 * H, H, st, 0, 0, cs));     // dx = dqkv*Wqkv + dz1
         RC(tick());
         dyl = dxl;
     }
@@ -733,8 +800,19 @@ int uniter_encoder_debug_tune_in_situ(int enable) {
 }
 
 // test / tuning hook: 0 = run the weight-gradient GEMMs on the caller's stream, 1 = on the library's side stream
-int uniter_encoder_debug_xcd_forward(int enable) { uh::xcd_forward_enable(enable); return 0; }
-int uniter_encoder_debug_xcd_probe(void* dev) { uh::xcd_forward_probe(dev); return 0; }
+// test / measurement hook: 0 = every kernel of the encoder calls in queue order (barrier between dependent kernels), 1 = the
+// overlapped chains (the default; UNITER_AMD_CHAIN=0 in the environment is the same switch)
+int uniter_encoder_debug_chain(int enable) { g_chain = enable; return 0; }
+// the status word of the last chained call whose flags lived in `scratch`: 0 = no wait timed out.  Synchronises the device.
+int uniter_encoder_chain_status(const UniterEncoderShape* s, const void* scratch, int32_t* status_out) {
+    RC(check_shape(s));
+    UH_CHECK_ARG(scratch != nullptr && status_out != nullptr, "null pointer");
+    uint32_t v = 0;
+    UH_CHECK_HIP(hipDeviceSynchronize());
+    UH_CHECK_HIP(hipMemcpy(&v, (const char*)scratch + scratch_layout(*s).chain, sizeof(v), hipMemcpyDeviceToHost));
+    *status_out = (int32_t)v;
+    return 0;
+}
 int uniter_encoder_debug_side_stream(int enable) {
     g_use_side_stream = enable;
     return 0;

@@ -181,6 +181,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     const int k_end = min(p.K, k_begin + p.k_per_split);
     const int nk = (k_end - k_begin + 63) >> 6;
 
+    // overlapped chain: the M-side rows of this tile (activations of the previous kernel) are complete once their 32-row
+    // units carry every contribution of that kernel; the weights and the epilogue's operands need no flag (older than the
+    // producer by transitivity, see common.cuh)
+    if constexpr (!TRA) chain_wait(p.chain, m0, min(BM, p.M - m0));
+    const bool wt = p.chain.signal != nullptr;              // write-through output stores for a consumer that does not wait for a kernel boundary
+
     Stage<BM, TRA> sr;
     Stage<BN, TRB> sc;
 
@@ -460,7 +466,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 bf16_t* cptr = p.C + (int64_t)m * p.ldc + n;
                 if (EPI == EPI_BIAS_GELU) {
                     const u32x4 uq_bits = pack8(v);
-                    out_store16(cptr, uq_bits);   // u (pre-activation)
+                    out_store16c(cptr, uq_bits, wt);   // u (pre-activation)
                     // activation is applied to the bf16-rounded u so that backward (which only has u) is consistent
                     float uq[8], gq[8];
                     unpack8(uq_bits, uq);
@@ -469,7 +475,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                         const f32x2_t gp = act_fwd2(p.relu, f32x2_t{uq[e], uq[e + 1]});
                         gq[e] = gp.x; gq[e + 1] = gp.y;
                     }
-                    out_store16(p.C2 + (int64_t)m * p.ldc + n, pack8(gq));
+                    out_store16c(p.C2 + (int64_t)m * p.ldc + n, pack8(gq), wt);
                     continue;
                 }
                 if (EPI == EPI_BIAS_DROP_RES) {
@@ -507,10 +513,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += ov[e];
                 }
-                out_store16(cptr, pack8(v));    // consumed by a later kernel from MALL/HBM, never from this L2
+                out_store16c(cptr, pack8(v), wt);    // consumed by a later kernel from MALL/HBM, never from this L2
             }
         }
     }
+    if constexpr (!TRA) chain_signal(p.chain, m0, min(BM, p.M - m0));
 #ifdef UNITER_GEMM_PROBE
     if (life != nullptr && t == 0 && bx < 4096) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); life[1] = __builtin_readcyclecounter(); }
 #endif
@@ -634,6 +641,17 @@ bool g8_shape_ok(const GemmArgs& a, bool tra, bool trb) {
     return span_r * 2 < ((int64_t)1 << 32) && span_c * 2 < ((int64_t)1 << 32);
 }
 
+// The chain step of the launch in progress on this thread (set by gemm_fwd / gemm_dgrad around launch_gemm): the launchers
+// below copy its link into the kernel arguments, report the column-tile count and drop the queue barrier when asked to.
+thread_local uh::ChainStep* t_chain = nullptr;
+static inline void chain_bind(GemmArgs& a, int tiles_n, int splits) {
+    a.chain = ChainLink{nullptr, nullptr, nullptr, 0, 0};
+    if (t_chain == nullptr) return;
+    if (splits != 1) { t_chain->anyorder = 0; t_chain->produced = 0; return; }    // (split-K partials: in-order launch, nobody may wait on this step)
+    a.chain = t_chain->link;
+    t_chain->produced = (uint32_t)tiles_n;
+}
+
 template <bool TRA, bool TRB, int EPI>
 int launch_g8(const GemmArgs& a_in, int splits, hipStream_t st) {
     GemmArgs a = a_in;
@@ -656,7 +674,8 @@ int launch_g8(const GemmArgs& a_in, int splits, hipStream_t st) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS_BYTES));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm8_kernel<TRA, TRB, EPI>), dim3(tiles_m * tiles_n, splits, 1), dim3(G8_THREADS), G8_LDS_BYTES, st, a);
+    chain_bind(a, tiles_n, splits);
+    uh::chain_launch(t_chain, gemm8_kernel<TRA, TRB, EPI>, dim3(tiles_m * tiles_n, splits, 1), dim3(G8_THREADS), G8_LDS_BYTES, st, a);
     UH_LAUNCH_CHECK();
     return 0;
 }
@@ -687,7 +706,8 @@ int launch_g6(const GemmArgs& a_in, int splits, hipStream_t st) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS_BYTES));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm6_kernel<TRA, TRB, EPI>), dim3(tiles_m * tiles_n, splits, 1), dim3(G8_THREADS), G6_LDS_BYTES, st, a);
+    chain_bind(a, tiles_n, splits);
+    uh::chain_launch(t_chain, gemm6_kernel<TRA, TRB, EPI>, dim3(tiles_m * tiles_n, splits, 1), dim3(G8_THREADS), G6_LDS_BYTES, st, a);
     UH_LAUNCH_CHECK();
     return 0;
 }
@@ -717,7 +737,8 @@ int launch_cfg(const GemmArgs& a_in, int splits, hipStream_t st) {
         attr_done = true;
     }
     dim3 grid(tiles_m * tiles_n, splits, 1);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, TRA, TRB, EPI, NSTAGE, WS>), grid, dim3(WaveGrid<BM, BN, WS>::THREADS), lds, st, a);
+    chain_bind(a, tiles_n, splits);
+    uh::chain_launch(t_chain, gemm_kernel<BM, BN, TRA, TRB, EPI, NSTAGE, WS>, grid, dim3(WaveGrid<BM, BN, WS>::THREADS), lds, st, a);
     UH_LAUNCH_CHECK();
     return 0;
     }
@@ -994,8 +1015,10 @@ static int check_common(int64_t M, int64_t N, int64_t K) {
 }
 
 int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void* resid, void* y, void* y2,
-             int64_t M, int64_t N, int64_t K, const DropoutCfg& drop, hipStream_t st, int64_t ldx, int64_t ldy, int relu) {
+             int64_t M, int64_t N, int64_t K, const DropoutCfg& drop, hipStream_t st, int64_t ldx, int64_t ldy, int relu,
+             ChainStep* chain) {
     if (check_common(M, N, K)) return -1;
+    struct Bind { explicit Bind(ChainStep* c) { t_chain = c; } ~Bind() { t_chain = nullptr; } } bind(chain);
     if (ldx == 0) ldx = K;
     if (ldy == 0) ldy = N;
     if (ldx < K || ldy < N || ldx % 8 != 0 || ldy % 8 != 0) { uh_set_error("gemm_fwd: bad leading dimension"); return -1; }
@@ -1026,8 +1049,9 @@ int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void
 
 // dx[M,K] = dy[M,N] * w[N,K]  -> output dims (M, K), contraction N
 int gemm_dgrad(int epi, const void* dy, const void* w, const void* aux, void* dx,
-               int64_t M, int64_t N, int64_t K, hipStream_t st, int64_t lddy, int act) {
+               int64_t M, int64_t N, int64_t K, hipStream_t st, int64_t lddy, int act, ChainStep* chain) {
     if (check_common(M, N, K)) return -1;
+    struct Bind { explicit Bind(ChainStep* c) { t_chain = c; } ~Bind() { t_chain = nullptr; } } bind(chain);
     if (K % 64 != 0 || N % 8 != 0) { uh_set_error("gemm_dgrad: need K %% 64 == 0 and N %% 8 == 0"); return -1; }
     if (lddy == 0) lddy = N;
     if (lddy < N || lddy % 8 != 0) { uh_set_error("gemm_dgrad: bad leading dimension"); return -1; }

@@ -227,6 +227,7 @@ __device__ __forceinline__ void gemm8_tile(const GemmArgs& p, const int bx, cons
     const int k_begin = by * p.k_per_split;
     const int k_end = min(p.K, k_begin + p.k_per_split);
     const int nk = (k_end - k_begin) >> 6;                  // whole K tiles (the launcher guarantees it)
+    if constexpr (!TRA) chain_wait(p.chain, m0, min(256, p.M - m0));      // overlapped chain (common.cuh)
 
     // ---- LDS-DMA sources and destinations -------------------------------------------------------------------------------
     uint32_t offA[2][2], offB[2][2];                        // [half][instruction of this wave]: byte offsets from the K tile's origin
@@ -532,6 +533,7 @@ __device__ __forceinline__ void gemm8_tile(const GemmArgs& p, const int bx, cons
                 ep.template emit<8>(p, by, m0 + mq * 128 + wr * 64 + b * 16 + i, ncol + nq * 128, v, auxw[nq][b], biasw[nq]);
             }
     }
+    if constexpr (!TRA) chain_signal(p.chain, m0, min(256, p.M - m0));    // (the epilogue's stores are write-through already)
 }
 
 // ---- the 192 x 192 x 64 tile: three phases per K tile, three LDS buffers ----------------------------------------------------
@@ -584,6 +586,7 @@ __device__ __forceinline__ void gemm6_tile(const GemmArgs& p, const int bx, cons
     const int k_begin = by * p.k_per_split;
     const int k_end = min(p.K, k_begin + p.k_per_split);
     const int nk = (k_end - k_begin) >> 6;
+    if constexpr (!TRA) chain_wait(p.chain, m0, min(192, p.M - m0));      // overlapped chain (common.cuh)
 
     uint32_t offM[3], offN[3];
 #pragma unroll
@@ -772,6 +775,7 @@ __device__ __forceinline__ void gemm6_tile(const GemmArgs& p, const int bx, cons
             ep.template emit<4>(p, by, m, n4, v4, aux4[b], bias4);
         }
     }
+    if constexpr (!TRA) chain_signal(p.chain, m0, min(192, p.M - m0));    // (the epilogue's stores are write-through already)
 }
 
 template <bool TRA, bool TRB, int EPI>

@@ -33,6 +33,7 @@ struct GemmArgs {
     unsigned long long* probe;   // cycle stamps of wave 0 of every workgroup: [block][kt][5] (profiling builds only)
 #endif
     DropoutCfg drop;
+    ChainLink chain;      // overlapped kernel chain (common.cuh): wait for the M-side rows' producer, signal the output rows
 };
 
 // bijective XCD-aware block remap (cdna_hip_programming.md T1): consecutive hardware block ids go to

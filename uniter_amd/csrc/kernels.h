@@ -2,14 +2,32 @@
 // The public C ABI (include/uniter_hip.h) is implemented in capi.hip on top of these.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stddef.h>
 #include <stdint.h>
+#include "common.cuh"
 
 struct DropoutCfg;
 struct UniterEncoderShape;
 struct UniterLayerParams;
 
 namespace uh {
+
+// ---- overlapped kernel chains (common.cuh: ChainLink; encoder.hip builds the chain) ----
+// One launch of a chain.  A launcher that is handed a step puts `link` into its kernel's arguments, dispatches without the
+// queue barrier when `anyorder` is set, and reports in `produced` how many contributions each 32-row unit of link.signal
+// receives from this launch (its column tiles / heads / row groups) — the next step's link.expect.
+struct ChainStep {
+    ChainLink link{nullptr, nullptr, nullptr, 0, 0};
+    int anyorder = 0;
+    uint32_t produced = 0;
+};
+// launch with or without the barrier bit of the dispatch packet
+template <typename K, typename... Args>
+inline void chain_launch(const ChainStep* cs, K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+    if (cs != nullptr && cs->anyorder) hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, nullptr, nullptr, hipExtAnyOrderLaunch, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+}
 
 // ---- capi.hip: optional per-launch timing (uniter_hip_timing_begin / _end) ----
 // Kinds of timed launches; (kind, M, N, K) identifies one row of the report.
@@ -26,13 +44,16 @@ struct LaunchTimer {
     ~LaunchTimer() { if (on) timing_mark(kind, M, N, K, st, false); }
 };
 
+// ---- adamw.hip ----
+bool params_pending();      // segments of an asynchronous optimizer step are outstanding on this device
+
 // ---- gemm.hip ----
 enum { GEMM_EPI_BIAS = 0, GEMM_EPI_BIAS_GELU = 1, GEMM_EPI_BIAS_DROP_RES = 2, GEMM_EPI_RES = 3, GEMM_EPI_GELU_BWD = 4 };
 int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void* resid, void* y, void* y2,
              int64_t M, int64_t N, int64_t K, const DropoutCfg& drop, hipStream_t st, int64_t ldx = 0, int64_t ldy = 0,
-             int relu = 0);
+             int relu = 0, ChainStep* chain = nullptr);
 int gemm_dgrad(int epi, const void* dy, const void* w, const void* aux, void* dx,
-               int64_t M, int64_t N, int64_t K, hipStream_t st, int64_t lddy = 0, int act = 0);
+               int64_t M, int64_t N, int64_t K, hipStream_t st, int64_t lddy = 0, int act = 0, ChainStep* chain = nullptr);
 size_t gemm_dgrad_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int gemm_dgrad_splitk(const void* dy, const void* w, void* dx, int64_t M, int64_t N, int64_t K, void* workspace,
                       size_t ws_bytes, hipStream_t st, int64_t lddy = 0);
@@ -59,27 +80,21 @@ int gemm_autotune_candidates(int kind, int64_t M, int64_t N, int64_t K, int* cfg
 void gemm_set_num_cus(int n);
 int gemm_tile_count();
 
-// ---- xcd_forward.hip: the forward pass of a layer range as one persistent launch, one team of workgroups per XCD ----
-struct XcdActOffsets { size_t qkv, lse, ctx, z1, mean1, rstd1, a, u, g, z2, mean2, rstd2, y; };   // byte offsets inside a layer's block
-bool xcd_forward_eligible(const UniterEncoderShape& s, int n_layers);
-int xcd_forward(const UniterEncoderShape* s, const UniterLayerParams* layers, int layer_begin, int layer_end, const void* x_in,
-                const float* mask_bias, void* acts, size_t act_stride, const XcdActOffsets& o, uint64_t seed, uint64_t offset,
-                hipStream_t st);
-void xcd_forward_enable(int on);
-void xcd_forward_probe(void* dev);   // debug: 256 x 32 x 8 x 2 wall-clock stamps (100 MHz) per launch, null = off
-
 // ---- attention.hip ----
 int attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse,
                   int64_t B, int64_t L, int64_t heads, const DropoutCfg& drop, hipStream_t st,
-                  const int32_t* cu = nullptr);
+                  const int32_t* cu = nullptr, ChainStep* chain = nullptr);
+// whether attention can be a link of an overlapped chain at this shape (dense examples of whole 32-row units, one launch)
+bool attention_chainable(int64_t L, const int32_t* cu);
 size_t attention_bwd_workspace_bytes(int64_t B, int64_t L, int64_t heads);
 int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, const float* lse,
                   const void* dctx, void* dqkv, int64_t B, int64_t L, int64_t heads,
-                  const DropoutCfg& drop, hipStream_t st, const int32_t* cu = nullptr, void* workspace = nullptr);
+                  const DropoutCfg& drop, hipStream_t st, const int32_t* cu = nullptr, void* workspace = nullptr,
+                  ChainStep* chain = nullptr);
 
 // ---- layernorm.hip ----
 int layernorm_fwd(const void* z, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
-                  int64_t rows, int64_t H, float eps, const DropoutCfg& drop, hipStream_t st);
+                  int64_t rows, int64_t H, float eps, const DropoutCfg& drop, hipStream_t st, ChainStep* chain = nullptr);
 size_t layernorm_bwd_workspace_bytes(int64_t rows, int64_t H);
 int layernorm_bwd(const void* dy, const void* dy_extra, const void* z, const float* mean, const float* rstd,
                   const void* gamma, void* dz, void* dd, void* dgamma, void* dbeta, void* dbias,
@@ -91,7 +106,7 @@ int layernorm_bwd_fused_rows(const void* dy, const void* z, const float* mean, c
 int layernorm_bwd_fused_finalize(const void* workspace, int nb, void* dgamma, void* dbeta, int64_t H, int accumulate, hipStream_t st);
 int layernorm_bwd_rows(const void* dy, const void* dy_extra, const void* z, const float* mean, const float* rstd,
                        const void* gamma, void* dz, void* dd, int64_t rows, int64_t H, const DropoutCfg& drop,
-                       int post_drop, hipStream_t st);
+                       int post_drop, hipStream_t st, ChainStep* chain = nullptr);
 int layernorm_bwd_cols(const void* dy, const void* dy_extra, const void* z, const float* mean, const float* rstd,
                        const void* dz, const void* dd, void* dgamma, void* dbeta, void* dbias,
                        int64_t rows, int64_t H, int accumulate, const DropoutCfg& drop, int post_drop,

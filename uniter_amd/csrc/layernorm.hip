@@ -17,11 +17,12 @@ template <int NC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ z, const bf16_t* __restrict__ gamma,
                                                      const bf16_t* __restrict__ beta, bf16_t* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                     int rows, int H, float eps, const DropoutCfg drop) {
+                                                     int rows, int H, float eps, const DropoutCfg drop, const ChainLink chain) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int row = blockIdx.x * ROWS_PER_BLOCK + wid;
-    if (row >= rows) return;
-    ln_fwd_row<NC, false>(z, gamma, beta, y, mean_out, rstd_out, row, H, eps, drop, lane);
+    chain_wait(chain, blockIdx.x * ROWS_PER_BLOCK, ROWS_PER_BLOCK);      // overlapped chain (common.cuh): z rows of this block
+    if (row < rows) ln_fwd_row<NC, false>(z, gamma, beta, y, mean_out, rstd_out, row, H, eps, drop, lane, chain.signal != nullptr);
+    chain_signal(chain, blockIdx.x * ROWS_PER_BLOCK, ROWS_PER_BLOCK);
 }
 
 // Backward.  partial layout: [gridDim.x][3][H] fp32 = per-block column sums of (dgamma, dbeta, dbias).
@@ -153,9 +154,12 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ z, const float* __restrict__ mean_in,
                                                           const float* __restrict__ rstd_in, const bf16_t* __restrict__ gamma,
                                                           bf16_t* __restrict__ dz, bf16_t* __restrict__ dd, int rows, int H,
-                                                          int post_drop, const DropoutCfg drop) {
+                                                          int post_drop, const DropoutCfg drop, const ChainLink chain) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int nch = H >> 2;
+    // overlapped chain (common.cuh): such launches cover all rows in one pass of the grid, so a block owns rows 4b .. 4b+3
+    chain_wait(chain, blockIdx.x * 4, 4);
+    const bool wt = chain.signal != nullptr;
     float gv[NC][4];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const bf16_t* __restri
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rstd * (gy[c][e] - c1 - xh[c][e] * c2);
                 const u32x2 packed = pack4(o);
-                __builtin_nontemporal_store(packed, reinterpret_cast<u32x2*>(dz + ro + ch * 4));
+                out_store8c(dz + ro + ch * 4, packed, wt);
                 if (dd != nullptr) {            // dd = dropout-masked dz (a plain copy when there is no dropout)
                     u32x2 dpk = packed;
                     if (use_drop) {
@@ -222,11 +226,12 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const bf16_t* __restri
                         for (int e = 0; e < 4; ++e) oq[e] *= mult[e];
                         dpk = pack4(oq);
                     }
-                    __builtin_nontemporal_store(dpk, reinterpret_cast<u32x2*>(dd + ro + ch * 4));
+                    out_store8c(dd + ro + ch * 4, dpk, wt);
                 }
             }
         }
     }
+    chain_signal(chain, blockIdx.x * 4, 4);
 }
 
 // Column part: per-block partial sums over rows of (dy*xhat, dy, d) with d = `dsrc` (the bf16 dd / dz the row kernel
@@ -395,14 +400,20 @@ int colsum_blocks(int64_t rows, int64_t N) {
 namespace uh {
 
 int layernorm_fwd(const void* z, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
-                  int64_t rows, int64_t H, float eps, const DropoutCfg& drop, hipStream_t st) {
+                  int64_t rows, int64_t H, float eps, const DropoutCfg& drop, hipStream_t st, ChainStep* chain) {
     if (rows <= 0 || H <= 0 || H % 4 != 0 || H > 4096) { uh_set_error("layernorm_fwd: need H %% 4 == 0 and H <= 4096 (H=%lld)", (long long)H); return -1; }
     const int nc = (int)((H / 4 + 63) / 64);
     LaunchTimer lt(TIME_LN_FWD, rows, H, 0, st);
     dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+    // a chain step needs whole 32-row units (each receives 32 / ROWS_PER_BLOCK contributions)
+    ChainLink link{nullptr, nullptr, nullptr, 0, 0};
+    if (chain != nullptr) {
+        if (rows % 32 == 0) { link = chain->link; chain->produced = 32 / ROWS_PER_BLOCK; }
+        else { chain->anyorder = 0; chain->produced = 0; }
+    }
 #define LN_FWD(NCV)                                                                                         \
-    hipLaunchKernelGGL(ln_fwd_kernel<NCV>, grid, block, 0, st, (const bf16_t*)z, (const bf16_t*)gamma,      \
-                       (const bf16_t*)beta, (bf16_t*)y, mean, rstd, (int)rows, (int)H, eps, drop)
+    chain_launch(chain, ln_fwd_kernel<NCV>, grid, block, 0, st, (const bf16_t*)z, (const bf16_t*)gamma,     \
+                 (const bf16_t*)beta, (bf16_t*)y, mean, rstd, (int)rows, (int)H, eps, drop, link)
     if (nc <= 1) LN_FWD(1);
     else if (nc == 2) LN_FWD(2);
     else if (nc == 3) LN_FWD(3);
@@ -429,17 +440,23 @@ static int ln_bwd_check(int64_t rows, int64_t H) {
 // Row half of the split backward (H % 8 == 0): dz, and dd = dropout-masked dz when the dropout sat on the dense branch.
 int layernorm_bwd_rows(const void* dy, const void* dy_extra, const void* z, const float* mean, const float* rstd,
                        const void* gamma, void* dz, void* dd, int64_t rows, int64_t H, const DropoutCfg& drop,
-                       int post_drop, hipStream_t st) {
+                       int post_drop, hipStream_t st, ChainStep* chain) {
     if (ln_bwd_check(rows, H)) return -1;
     if (H % 8 != 0) { uh_set_error("layernorm_bwd_rows: need H %% 8 == 0"); return -1; }
     LaunchTimer lt(TIME_LN_BWD, rows, H, 0, st);
     const int nc = (int)((H / 4 + 63) / 64);
     int64_t nb = (rows + 3) / 4;
-    if (nb > 4096) nb = 4096;
+    // a chain step needs one pass of the grid over whole 32-row units (each receives 8 contributions)
+    ChainLink link{nullptr, nullptr, nullptr, 0, 0};
+    if (chain != nullptr) {
+        if (rows % 32 == 0 && nb <= 65536) { link = chain->link; chain->produced = 8; }
+        else { chain->anyorder = 0; chain->produced = 0; }
+    }
+    if (link.signal == nullptr && link.wait == nullptr && nb > 4096) nb = 4096;
 #define LN_ROWS(NCV)                                                                                                   \
-    hipLaunchKernelGGL(ln_bwd_rows_kernel<NCV>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)dy,              \
-                       (const bf16_t*)dy_extra, (const bf16_t*)z, mean, rstd, (const bf16_t*)gamma, (bf16_t*)dz,      \
-                       (bf16_t*)dd, (int)rows, (int)H, post_drop, drop)
+    chain_launch(chain, ln_bwd_rows_kernel<NCV>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)dy,             \
+                 (const bf16_t*)dy_extra, (const bf16_t*)z, mean, rstd, (const bf16_t*)gamma, (bf16_t*)dz,             \
+                 (bf16_t*)dd, (int)rows, (int)H, post_drop, drop, link)
     if (nc <= 1) LN_ROWS(1);
     else if (nc == 2) LN_ROWS(2);
     else if (nc == 3) LN_ROWS(3);

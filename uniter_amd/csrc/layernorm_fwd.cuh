@@ -11,7 +11,8 @@ template <int NC, bool COH>
 __device__ __forceinline__ void ln_fwd_row(const bf16_t* __restrict__ z, const bf16_t* __restrict__ gamma,
                                            const bf16_t* __restrict__ beta, bf16_t* __restrict__ y,
                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                           const int row, const int H, const float eps, const DropoutCfg& drop, const int lane) {
+                                           const int row, const int H, const float eps, const DropoutCfg& drop, const int lane,
+                                           const bool wt = false) {
 #pragma clang fp contract(off)          // the same bits from every kernel this is inlined into
     const int nch = H >> 2;
     const bf16_t* zr = z + (int64_t)row * H;
@@ -60,7 +61,8 @@ __device__ __forceinline__ void ln_fwd_row(const bf16_t* __restrict__ z, const b
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = oq[e] * mult[e];
             }
-            stg8<COH>(yr + ch * 4, pack4(o));
+            if constexpr (COH) stg8<true>(yr + ch * 4, pack4(o));
+            else out_store8c(yr + ch * 4, pack4(o), wt);       // (wt: write-through for a consumer inside an overlapped chain)
         }
     }
 }

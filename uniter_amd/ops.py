@@ -407,8 +407,10 @@ class _EncoderFn(torch.autograd.Function):
         table, keep = _layer_table(layers, with_grads=False)
         seed, off = _next_offsets(n * 8) if training else (0, 0)
         xc = x.contiguous()
+        # the shared scratch buffer also holds the row-block flags of the overlapped kernel chain (include/uniter_hip.h, ABI v7)
+        scratch = _scratch(("enc", x.device.index), C.uniter_encoder_scratch_bytes(ctypes.byref(s)), x.device)
         C.uniter_encoder_forward(ctypes.byref(s), table, 0, n, ptr(xc), None if packed is not None else ptr(mask_bias),
-                                 ptr(acts), None, seed, off, _lib.stream_ptr())
+                                 ptr(acts), ptr(scratch), seed, off, _lib.stream_ptr())
         _lib.set_async_pending(False)          # the call ends with uniter_params_wait_all on this stream
 
         n_rows = out_shape[0] if packed is not None else B * L
