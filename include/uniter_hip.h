@@ -426,6 +426,19 @@ int uniter_encoder_side_join(void* stream);
  * A training loop that defers the join of its one backward call lets the embedding backward overlap the deferred weight-gradient
  * launch, and calls this before anything reads a weight gradient (clip_grad_norm_, optimizer.step, zero_grad). */
 int uniter_encoder_side_join_all(void* stream);
+/* Gradient buckets of a data-parallel step (ABI v7; utils/distributed.py:16-43 and pretrain.py:298-312 allreduce all gradients
+ * after backward; this lets the reduction of the top layers' gradients start while the rest are still being computed WITHOUT
+ * cutting the backward call into per-bucket ranges).  uniter_encoder_set_grad_buckets(L) — per thread, 0 = off — groups the
+ * layers of the following uniter_encoder_backward calls into buckets of L layers, top layers first; the deferred launch then
+ * completes the buckets in that order and raises one flag per bucket.  uniter_encoder_grad_bucket_count reports how many buckets
+ * the thread's last backward call completed that way (0: it ran without a stage / without buckets — use
+ * uniter_encoder_side_join instead), and uniter_encoder_bucket_wait(k, stream) makes `stream` (a communication stream) wait
+ * for bucket k of that call (hipStreamWaitValue32 on a word of signal memory): everything enqueued on `stream` afterwards
+ * sees the weight, bias and LayerNorm-parameter gradients of the bucket's layers complete.  Epoch counter wraps at 2^32 calls. */
+int uniter_encoder_set_grad_buckets(int32_t layers_per_bucket);
+int uniter_encoder_grad_bucket_count(int32_t* n_out);
+int uniter_encoder_bucket_wait(int32_t bucket, void* stream);
+
 /* The calling thread's weight-gradient stream (created on first use), as a raw hipStream_t.  A deferred launch reads the
  * call's activations / input / dy after uniter_encoder_backward has returned; a caller whose allocator recycles memory per
  * stream (PyTorch: Tensor.record_stream on an ExternalStream of this handle) uses it to keep those buffers from being handed

@@ -38,13 +38,32 @@ def main():
     g = load_golden()
     batch = to_device(g.batch('nlvr2'), dev)
     opts = Struct(dict(optim='adamw', learning_rate=1e-3, betas=(0.9, 0.98), weight_decay=0.01))
+    # UNITER_W1_WIDE=1: a configuration the deferred weight-gradient launch accepts (hidden / intermediate sizes multiples of 256,
+    # a multiple of 64 tokens): the reducer then keeps the backward ONE call and waits for per-bucket flags (hipStreamWaitValue32)
+    wide = os.environ.get("UNITER_W1_WIDE") == "1"
+    lpb = int(os.environ.get("UNITER_W1_LAYERS_PER_BUCKET", "1"))
+    if wide:
+        import json as _json
+        import tempfile
+        from uniter_amd.utils.synthetic import make_batch
+        cfg = dict(vocab_size=512, hidden_size=256, num_hidden_layers=4, num_attention_heads=4, intermediate_size=512,
+                   hidden_act="gelu", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, max_position_embeddings=64,
+                   type_vocab_size=2, initializer_range=0.02)
+        cfg_path = os.path.join(tempfile.mkdtemp(), "wide.json")
+        open(cfg_path, "w").write(_json.dumps(cfg))
+        batch = to_device(make_batch('nlvr2', 8, max_txt_len=20, num_bb=12, img_dim=IMG_DIM, vocab_size=512, seed=5), dev)   # 8 x 32 tokens
     results = []
     for use_reducer in (False, True):
-        w, nl = g.weights('pre'), g.weights('nlvr2')
-        table3 = nl.pop('uniter.embeddings.token_type_embeddings.weight')
-        model = UniterForNlvr2PairedAttn.from_pretrained(TINY_CONFIG, {**w, **nl}, img_dim=IMG_DIM)
-        model.init_type_embedding()
-        model.uniter.embeddings.token_type_embeddings.weight.data.copy_(table3)
+        if wide:
+            torch.manual_seed(3)
+            model = UniterForNlvr2PairedAttn.from_pretrained(cfg_path, {}, img_dim=IMG_DIM)
+            model.init_type_embedding()
+        else:
+            w, nl = g.weights('pre'), g.weights('nlvr2')
+            table3 = nl.pop('uniter.embeddings.token_type_embeddings.weight')
+            model = UniterForNlvr2PairedAttn.from_pretrained(TINY_CONFIG, {**w, **nl}, img_dim=IMG_DIM)
+            model.init_type_embedding()
+            model.uniter.embeddings.token_type_embeddings.weight.data.copy_(table3)
         model.to(dev).bfloat16()
         set_dropout(model, 0.0)
         for m in model.modules():
@@ -54,13 +73,22 @@ def main():
         arena = flatten_model(model)
         D.broadcast_tensors([p.data for p in model.parameters()], 0)
         opt = build_optimizer(model, opts)
-        reducer = D.GradientReducer(arena, model.uniter.encoder, layers_per_bucket=1) if use_reducer else None
+        reducer = D.GradientReducer(arena, model.uniter.encoder, layers_per_bucket=lpb,
+                                    word_embeddings=model.uniter.embeddings.word_embeddings.weight) if use_reducer else None
+        if not use_reducer:
+            from uniter_amd import ops as _ops
+            model.uniter.encoder.grad_ready_hook = _ops.DeferWgradJoin()      # the single-process training loop's hook
         before = calls["n"]
+        buckets_seen = 0
         for step in range(2):
             if reducer is not None:
                 reducer.begin()
             model(batch, compute_loss=True).mean().backward()
-            scale = reducer.finish() if reducer is not None else 1.0
+            if reducer is not None and reducer.single_launch:
+                # (the hooks ran on the autograd thread; what they saw there is what this records)
+                buckets_seen = max(buckets_seen, getattr(reducer, "last_flag_waits", 0))
+            # NLVR2 has no MLM head: the word-embedding gradient travels as rows
+            scale = reducer.finish(word_ids=batch['input_ids'] if wide else None) if reducer is not None else 1.0
             clip_grad_norm_(opt, 1.0, grad_scale=scale)
             opt.step()
             opt.zero_grad()
@@ -69,7 +97,8 @@ def main():
     (plain, _, _), (reduced, n_calls, numel) = results
     same = all(torch.equal(plain[n], reduced[n]) for n in plain)
     n_layers = len(model.uniter.encoder.layer)
-    print(json.dumps({"identical": bool(same), "allreduce_calls": n_calls, "encoder_layers": n_layers,
+    print(json.dumps({"identical": bool(same), "allreduce_calls": n_calls, "encoder_layers": n_layers, "flag_waits": buckets_seen,
+                      "single_launch": bool(reducer.single_launch),
                       "elements_reduced_per_step": calls["elems"] // 2 if n_calls else 0, "arena_elements": numel,
                       "backend": dist.get_backend()}))
     dist.destroy_process_group()

@@ -110,6 +110,50 @@ def _case_gradient_reducer(rank, world, D):
     assert torch.equal(arena.grad, before)
 
 
+def _case_sparse_word_rows(rank, world, D):
+    """finish(word_ids=...): the word-embedding gradient exchanged as touched rows (all-gather of ids + rows) equals the dense
+    sum-allreduce of the same gradients — both forms of the row sum (vocabulary-sized fp32 buffer / compact segment sums), bf16
+    and fp32 arenas, duplicate tokens inside a rank and tokens shared between ranks."""
+    from tests.common import IMG_DIM, LABEL_DIM, TINY_CONFIG
+    from uniter_amd.model.pretrain import UniterForPretraining
+    from uniter_amd.utils.arena import flatten_model
+    for dtype, big_vocab in ((torch.float32, False), (torch.bfloat16, False), (torch.bfloat16, True)):
+        torch.manual_seed(0)
+        model = UniterForPretraining.from_pretrained(TINY_CONFIG, {}, img_dim=IMG_DIM, img_label_dim=LABEL_DIM).to(dtype)
+        arena = flatten_model(model)
+        word = model.uniter.embeddings.word_embeddings.weight
+        V, H = word.shape
+        g = torch.Generator().manual_seed(60 + rank)
+        ids = torch.randint(0, V, (3, 7), generator=g)
+        ids[0, :3] = 5                                            # duplicates inside the rank, and id 5 on every rank
+        ids[1, 0] = 7 + rank                                      # an id only this rank has
+
+        def fill():
+            arena.grad.copy_(torch.randn(arena.numel, generator=torch.Generator().manual_seed(70 + rank)).to(dtype))
+            lo, hi = arena.span([word])
+            wg = arena.grad[lo:hi].view(V, H)
+            keep = torch.zeros(V, dtype=torch.bool)
+            keep[ids.reshape(-1)] = True
+            wg[~keep] = 0                                         # a lookup-only table: gradient rows of absent tokens are zero
+        results = []
+        for sparse in (False, True):
+            reducer = D.GradientReducer(arena, model.uniter.encoder, layers_per_bucket=1, word_embeddings=word)
+            assert reducer.word_span is not None
+            if big_vocab:
+                reducer.word_span = reducer.word_span[:2] + (V, H)
+            fill()
+            reducer.begin()
+            for l in reversed(range(len(model.uniter.encoder.layer))):
+                model.uniter.encoder.grad_ready_hook(l)
+            if sparse and big_vocab:
+                os.environ["UNITER_AMD_DP_WORD_COMPACT"] = "1"
+            scale = reducer.finish(word_ids=ids if sparse else None)
+            os.environ.pop("UNITER_AMD_DP_WORD_COMPACT", None)
+            assert scale == 1.0 / world
+            results.append(arena.grad.clone())
+        assert torch.equal(results[0], results[1]), (dtype, big_vocab, float((results[0].float() - results[1].float()).abs().max()))
+
+
 def _case_task_mix_and_retrieval_gather(rank, world, D):
     """MetaLoader: every rank trains the task rank 0 drew.  itm_eval.evaluate: ranks own different numbers of texts, the
     score rows are gathered in rank order and only rank 0 reports (reference utils/itm_eval.py:68-90)."""
@@ -196,7 +240,7 @@ def _case_bf16_sum_over_8_ranks(rank, world, D):
     torch.testing.assert_close(a.grad.float() * scale, got, rtol=0, atol=0)
 
 
-@pytest.mark.parametrize("case", ["_case_allreduce", "_case_broadcast_and_objects", "_case_gradient_reducer",
+@pytest.mark.parametrize("case", ["_case_allreduce", "_case_broadcast_and_objects", "_case_gradient_reducer", "_case_sparse_word_rows",
                                   "_case_task_mix_and_retrieval_gather"])
 def test_world_size_2(case, tmp_path):
     _spawn(case, tmp_path)

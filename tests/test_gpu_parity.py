@@ -337,7 +337,7 @@ def test_overlapped_kernel_chain_is_bit_identical_to_in_order_launches(full_mode
         y0, g0 = run(0)
         runs = [run(1) for _ in range(3)]            # (a race would not show on every launch)
     finally:
-        lib.uniter_encoder_debug_chain(1)
+        lib.uniter_encoder_debug_chain(0)            # (the library's default: chains are opt-in)
         set_dropout(full_model, 0.0)
         full_model.uniter.pack_padding = False
     assert len(y0) == 12

@@ -30,6 +30,24 @@ def test_gradient_reducer_over_one_rank_rccl_matches_plain_step():
     assert out["elements_reduced_per_step"] == out["arena_elements"], out     # every gradient element exactly once
 
 
+@pytest.mark.parametrize("lpb", [1, 2])
+def test_single_launch_reducer_with_bucket_flags_over_one_rank_rccl(lpb):
+    """The round-4 data-parallel path on a shape the deferred weight-gradient launch accepts: ONE backward call, the launch
+    completes the gradient buckets in order and raises a flag per bucket, each bucket's RCCL allreduce is enqueued behind a
+    hipStreamWaitValue32 on that flag; the word-embedding gradient travels as rows.  Two optimizer steps must end bit-identical
+    to the collective-free training loop, with every encoder bucket reduced behind a flag wait."""
+    env = dict(os.environ, UNITER_DIST_FORCE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29551 + lpb), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", UNITER_W1_WIDE="1", UNITER_W1_LAYERS_PER_BUCKET=str(lpb))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_world1_script.py")], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads(lines[-1])
+    assert out["backend"] == "nccl" and out["single_launch"]
+    assert out["identical"], out
+    assert out["flag_waits"] == (out["encoder_layers"] + lpb - 1) // lpb, out        # every bucket of a step went behind its flag
+
+
 def test_raw_rccl_communicator_one_rank():
     code = r'''
 import ctypes, sys, torch

@@ -132,6 +132,9 @@ SIGNATURES = {
     "uniter_encoder_defer_side_join": (c_int, [c_int]),
     "uniter_encoder_side_join": (c_int, [c_void_p]),
     "uniter_encoder_side_stream": (c_int, [POINTER(c_void_p)]),
+    "uniter_encoder_set_grad_buckets": (c_int, [c_int32]),
+    "uniter_encoder_grad_bucket_count": (c_int, [POINTER(c_int32)]),
+    "uniter_encoder_bucket_wait": (c_int, [c_int32, c_void_p]),
     "uniter_encoder_debug_chain": (c_int, [c_int]),
     "uniter_encoder_chain_status": (c_int, [POINTER(UniterEncoderShape), c_void_p, POINTER(c_int32)]),
     "uniter_encoder_debug_tune_in_situ": (c_int, [c_int]),

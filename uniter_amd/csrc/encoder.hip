@@ -91,7 +91,7 @@ ScratchLayout scratch_layout(const UniterEncoderShape& s) {
 // previous launch's flags, signal a fresh slot, drop the queue barrier); done() records what that launcher reported.  A
 // launcher that cannot take part (packed attention, split-K) clears produced: it has then run as an ordinary in-order kernel
 // without flags, and so does the kernel after it.
-int g_chain = [] { const char* e = getenv("UNITER_AMD_CHAIN"); return e ? atoi(e) : 1; }();
+int g_chain = [] { const char* e = getenv("UNITER_AMD_CHAIN"); return e ? atoi(e) : 0; }();     // (opt-in: measured neutral to -1 % at 32 x 96 tokens)
 struct Chain {
     bool on = false;
     uint32_t* flags = nullptr;
@@ -244,6 +244,37 @@ StageSet stage_set(const UniterEncoderShape& s) {
     return l;
 }
 
+// ---- gradient buckets of a data-parallel step ---------------------------------------------------------------------------------
+// uniter_encoder_set_grad_buckets(L) groups the layers of the following backward calls of this thread into buckets of L layers
+// (top layers first — the order in which allreduces want them) and makes the deferred launch complete them in that order,
+// raising one flag (a word of signal memory) per bucket; uniter_encoder_bucket_wait(k, stream) enqueues a wait for bucket k of
+// the thread's last backward call on a communication stream (hipStreamWaitValue32) — the bucket's allreduce goes behind it.
+struct GradBuckets {
+    int layers_per_bucket = 0;
+    unsigned* flag[24] = {nullptr};       // hipExtMallocWithFlags(hipMallocSignalMemory): created on first use
+    unsigned* count = nullptr;            // 24 zeroed device words
+    unsigned epoch = 0;
+    int last_nb = 0;                      // buckets of this thread's last bucketed launch (0: the last call ran without buckets)
+    int device = -1;
+};
+thread_local GradBuckets g_buckets;
+int buckets_init() {
+    int dev = 0;
+    UH_CHECK_HIP(hipGetDevice(&dev));
+    if (g_buckets.count != nullptr && g_buckets.device == dev) return 0;
+    for (int k = 0; k < 24; ++k) {
+        void* p = nullptr;
+        UH_CHECK_HIP(hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory));
+        UH_CHECK_HIP(hipMemset(p, 0, 8));
+        g_buckets.flag[k] = (unsigned*)p;
+    }
+    UH_CHECK_HIP(hipMalloc((void**)&g_buckets.count, 24 * sizeof(unsigned)));
+    UH_CHECK_HIP(hipMemset(g_buckets.count, 0, 24 * sizeof(unsigned)));
+    g_buckets.device = dev;
+    g_buckets.epoch = 0;
+    return 0;
+}
+
 int g_use_side_stream = 1;
 int g_tune_in_situ = 1;
 int g_group_wgrad = 1;      // 1: the four weight gradients of a layer go out as one grouped launch
@@ -376,6 +407,7 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         RC(side_init());
         ss = g_side.stream;
     }
+    g_buckets.last_nb = 0;                      // (set again below when this call's deferred launch runs with buckets)
     if (defer_wg) {
         for (int k = 0; k < 2; ++k)
             if (g_stage.busy[k] == nullptr) UH_CHECK_HIP(hipEventCreateWithFlags(&g_stage.busy[k], hipEventDisableTiming));
@@ -593,9 +625,31 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
             ln.push_back(uh::LnColsJob{stage_of(l) + sset.dy1, Ag + al.z1, (const float*)(Ag + al.mean1), (const float*)(Ag + al.rstd1), Pg.g_ln1_g,
                                        Pg.g_ln1_b, T, H});
         }
+        // data-parallel steps: buckets of layers complete in order inside the launch, one flag each
+        uh::MultiBuckets mb{};
+        std::vector<int> pbk, lbk;
+        const uh::MultiBuckets* mbp = nullptr;
+        g_buckets.last_nb = 0;
+        if (g_buckets.layers_per_bucket > 0) {
+            const int lpb = g_buckets.layers_per_bucket;
+            const int nb = (nl + lpb - 1) / lpb;
+            if (nb <= 24) {
+                RC(buckets_init());
+                for (int l = layer_end - 1; l >= layer_begin; --l) {
+                    const int k = (layer_end - 1 - l) / lpb;
+                    for (int q = 0; q < 4; ++q) pbk.push_back(k);
+                    lbk.push_back(k); lbk.push_back(k);
+                }
+                ++g_buckets.epoch;
+                if (g_buckets.epoch == 0) ++g_buckets.epoch;
+                mb = uh::MultiBuckets{nb, pbk.data(), lbk.data(), g_buckets.flag, g_buckets.count, g_buckets.epoch};
+                mbp = &mb;
+                g_buckets.last_nb = nb;
+            }
+        }
         RC(fork(3));
         const int mrc = uh::gemm_wgrad_multi((int)vdy.size(), vdy.data(), vx.data(), vdw.data(), vdb.data(), T, vN.data(), vK.data(), 1, ss,
-                                             (int)ln.size(), ln.data());
+                                             (int)ln.size(), ln.data(), mbp);
         if (mrc != 0) {
             if (mrc == 1) uh_set_error("encoder backward: the deferred weight-gradient launch does not fit these shapes");
             return mrc == 1 ? -1 : mrc;
@@ -643,6 +697,27 @@ int uniter_encoder_side_join_all(void* stream) {
         UH_CHECK_HIP(hipEventRecord(p->done, p->stream));
         UH_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, p->done, 0));
     }
+    return 0;
+}
+
+int uniter_encoder_set_grad_buckets(int32_t layers_per_bucket) {
+    if (layers_per_bucket < 0) { uh_set_error("encoder_set_grad_buckets: negative bucket size"); return -1; }
+    g_buckets.layers_per_bucket = layers_per_bucket;
+    return 0;
+}
+
+int uniter_encoder_grad_bucket_count(int32_t* n_out) {
+    if (n_out == nullptr) { uh_set_error("encoder_grad_bucket_count: null pointer"); return -1; }
+    *n_out = g_buckets.last_nb;
+    return 0;
+}
+
+int uniter_encoder_bucket_wait(int32_t bucket, void* stream) {
+    if (bucket < 0 || bucket >= g_buckets.last_nb) {
+        uh_set_error("encoder_bucket_wait: bucket %d, the last backward call of this thread completed %d buckets", (int)bucket, g_buckets.last_nb);
+        return -1;
+    }
+    UH_CHECK_HIP(hipStreamWaitValue32((hipStream_t)stream, g_buckets.flag[bucket], g_buckets.epoch, hipStreamWaitValueGte, 0xFFFFFFFFu));
     return 0;
 }
 

@@ -1318,8 +1318,14 @@ constexpr int kMultiTailMax = 8;                             // tiles per XCD be
 }  // namespace
 
 int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* const* dw, void* const* db, int64_t M,
-                     const int64_t* N, const int64_t* K, int accumulate, hipStream_t st, int n_ln, const LnColsJob* ln) {
+                     const int64_t* N, const int64_t* K, int accumulate, hipStream_t st, int n_ln, const LnColsJob* ln,
+                     const MultiBuckets* buckets) {
     if (n < 1 || n > 128) { uh_set_error("gemm_wgrad_multi: 1..128 problems"); return -1; }
+    if (buckets != nullptr && (buckets->nb < 1 || buckets->nb > G8_MAX_BUCKETS || buckets->prob_bucket == nullptr || buckets->flag == nullptr ||
+                               buckets->count == nullptr || (n_ln > 0 && buckets->ln_bucket == nullptr))) {
+        uh_set_error("gemm_wgrad_multi: bad bucket description");
+        return -1;
+    }
     if (M % 64 != 0 || M < 64) return 1;
     for (int q = 0; q < n; ++q)
         if (N[q] % 256 != 0 || K[q] % 256 != 0 || dy[q] == nullptr || x[q] == nullptr || dw[q] == nullptr) return 1;
@@ -1360,11 +1366,48 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
     }
     const size_t tbl_bytes = tbl.size() * sizeof(GemmArgs), meta_off = (tbl_bytes + 255) & ~(size_t)255;
     const size_t ln_off = (meta_off + meta.size() * sizeof(int) + 255) & ~(size_t)255;
-    const size_t bytes = ln_off + jobs.size() * sizeof(G8LnJob);
+    const size_t bk_off = (ln_off + jobs.size() * sizeof(G8LnJob) + 255) & ~(size_t)255;      // bucket ids: [n] problems, [n_ln] jobs
+    const size_t bytes = bk_off + (buckets != nullptr ? (size_t)(n + n_ln) * sizeof(int) : 0);
     std::vector<char> img(bytes, 0);
     memcpy(img.data(), tbl.data(), tbl_bytes);
     memcpy(img.data() + meta_off, meta.data(), meta.size() * sizeof(int));
     if (n_ln > 0) memcpy(img.data() + ln_off, jobs.data(), jobs.size() * sizeof(G8LnJob));
+    G8Buckets bk{};
+    bk.nb = 0;
+    int per_bucketed = 0;
+    if (buckets != nullptr) {
+        memcpy(img.data() + bk_off, buckets->prob_bucket, (size_t)n * sizeof(int));
+        if (n_ln > 0) memcpy(img.data() + bk_off + (size_t)n * sizeof(int), buckets->ln_bucket, (size_t)n_ln * sizeof(int));
+        bk.nb = buckets->nb;
+        // tiles of a bucket are contiguous in the linear order (the ids do not decrease along the problem list)
+        for (int k = 0; k < bk.nb; ++k) { bk.tile_start[k] = -1; bk.total[k] = 0; }
+        bk.tile_start[bk.nb] = tiles;
+        int prev = 0;
+        for (int q = 0; q < n; ++q) {
+            const int k = buckets->prob_bucket[q];
+            if (k < prev || k >= bk.nb) { uh_set_error("gemm_wgrad_multi: bucket ids must be non-decreasing and < nb"); return -1; }
+            if (bk.tile_start[k] < 0) bk.tile_start[k] = meta[(size_t)q];
+            prev = k;
+            bk.total[k] += (unsigned)(meta[(size_t)q + 1] - meta[(size_t)q]);
+        }
+        for (int k = 0; k < bk.nb; ++k)
+            if (bk.tile_start[k] < 0) { uh_set_error("gemm_wgrad_multi: bucket %d has no problem", k); return -1; }
+        bk.slot_start[0] = 0;
+        for (int k = 0; k < bk.nb; ++k) bk.slot_start[k + 1] = bk.slot_start[k] + (bk.tile_start[k + 1] - bk.tile_start[k] + 7) / 8;
+        per_bucketed = bk.slot_start[bk.nb];
+        for (int j = 0; j < n_ln; ++j) {
+            const int k = buckets->ln_bucket[j];
+            if (k < 0 || k >= bk.nb) { uh_set_error("gemm_wgrad_multi: LayerNorm job bucket out of range"); return -1; }
+            bk.total[k] += (unsigned)ln_strips_per_job;
+        }
+        for (int k = 0; k < bk.nb; ++k) {
+            if (bk.total[k] == 0) { uh_set_error("gemm_wgrad_multi: empty bucket %d", k); return -1; }
+            bk.flag[k] = buckets->flag[k];
+        }
+        bk.count = buckets->count;
+        bk.epoch = buckets->epoch;
+        if (strips != 0) { uh_set_error("gemm_wgrad_multi: bucketed launches have no bias strips"); return -1; }
+    }
     int dev = 0;
     UH_CHECK_HIP(hipGetDevice(&dev));
     MultiTable& T = g_multi.tables[std::make_pair(dev, (uint64_t)(uintptr_t)dw[0])];
@@ -1391,7 +1434,11 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
         UH_CHECK_HIP(hipEventRecord(g_multi.pinned_ev[slot], st));
         T.last = img;
     }
-    const int per = (tiles + 7) / 8;
+    const int per = buckets != nullptr ? per_bucketed : (tiles + 7) / 8;
+    if (buckets != nullptr) {
+        bk.prob_bucket = (const int*)((const char*)T.dev + bk_off);
+        bk.ln_bucket = bk.prob_bucket + n;
+    }
     // tiles of an XCD's segment beyond whole rounds of its 32 CUs: when they are few they run as two K slices each (see the kernel)
     int full = per;
     unsigned* tail_pairs = nullptr;
@@ -1399,7 +1446,7 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
     {
         static const bool split_tail = [] { const char* e = getenv("UNITER_AMD_MULTI_TAIL_SPLIT"); return e == nullptr || atoi(e) != 0; }();
         const int tail = per % 32;
-        if (split_tail && per > 32 && tail > 0 && tail <= kMultiTailMax && M >= 256 && dev >= 0 && dev < 16) {
+        if (split_tail && buckets == nullptr && per > 32 && tail > 0 && tail <= kMultiTailMax && M >= 256 && dev >= 0 && dev < 16) {
             if (g_multi.tail_slabs[dev] == nullptr &&
                 hipMalloc(&g_multi.tail_slabs[dev], (size_t)8 * kMultiTailMax * 256 * 256 * sizeof(float)) != hipSuccess)
                 g_multi.tail_slabs[dev] = nullptr;
@@ -1434,7 +1481,7 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
     hipLaunchKernelGGL(gemm8_multi_kernel, dim3(gemm_blocks + strips + n_ln * ln_strips_per_job), dim3(G8_THREADS), G8_LDS_BYTES, st,
                        (const GemmArgs*)T.dev, (const int*)((const char*)T.dev + meta_off), n, per, full, gemm_blocks,
                        (const G8LnJob*)((const char*)T.dev + ln_off), ln_strips_per_job, strips, tail_pairs, tail_slabs, stamp_dev,
-                       lead_strips);
+                       lead_strips, bk);
     UH_LAUNCH_CHECK();
     if (stamp_dev != nullptr) {                              // harness profiling: synchronous, prints the launch's schedule
         const int nb = gemm_blocks + strips + n_ln * ln_strips_per_job;

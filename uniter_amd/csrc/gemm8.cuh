@@ -949,12 +949,42 @@ __device__ __forceinline__ void g8_ln_cols_strip(const G8LnJob& j, const int str
     }
 }
 
+// Gradient buckets of a data-parallel step (round 4): the problems of a multi launch are grouped into up to 24 buckets (the layers
+// of one allreduce); every XCD walks bucket 0's share of tiles first, then bucket 1's, ..., so the buckets complete one after the
+// other INSIDE the launch, and the last work item of a bucket raises that bucket's flag — a word of signal memory a communication
+// stream waits on with hipStreamWaitValue32 before the bucket's allreduce (utils/distributed.py: no per-bucket launches, no host
+// hand-back).  nb == 0: the plain single-segment order.
+constexpr int G8_MAX_BUCKETS = 24;
+struct G8Buckets {
+    int nb;
+    int tile_start[G8_MAX_BUCKETS + 1];      // first tile (linear order) of every bucket
+    int slot_start[G8_MAX_BUCKETS + 1];      // first slot of every bucket inside an XCD's walk (cumulative per-XCD shares)
+    unsigned total[G8_MAX_BUCKETS];          // work items (tiles + LayerNorm strips) of every bucket
+    unsigned* count;                         // [nb] arrivals, left at zero by the last arrival
+    unsigned* flag[G8_MAX_BUCKETS];          // signal memory, one word per bucket
+    unsigned epoch;                          // value written to a completed bucket's flag
+    const int* prob_bucket;                  // [n] bucket of every problem
+    const int* ln_bucket;                    // [LayerNorm jobs]
+};
+__device__ __forceinline__ void g8_bucket_arrive(const G8Buckets& bk, const int k) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();                                    // (strip results are plain stores: write them back before counting)
+        const unsigned seen = __hip_atomic_fetch_add(bk.count + k, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen + 1u == bk.total[k]) {
+            __hip_atomic_store(bk.count + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(bk.flag[k], bk.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_multi_kernel(const GemmArgs* __restrict__ tbl, const int* __restrict__ meta,
                                                                     const int n, const int per, const int full, const int gemm_blocks,
                                                                     const G8LnJob* __restrict__ ln_jobs, const int ln_strips_per_job,
                                                                     const int bias_strips, unsigned* __restrict__ tail_pairs,
                                                                     float* __restrict__ tail_slabs, unsigned long long* __restrict__ stamps,
-                                                                    const int lead_strips) {
+                                                                    const int lead_strips, const G8Buckets bk) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // Block order: `lead_strips` LayerNorm strips FIRST (a multiple of 8, at most half the chip), then the tiles, then the other
     // strips.  The CUs that start with a 28 us strip run their 83 us tiles that much later than the rest for the whole launch, so
@@ -986,6 +1016,7 @@ __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_multi_kernel(const GemmAr
         const int s = b - gemm_blocks - bias_strips;
         const G8LnJob j = ln_jobs[s / ln_strips_per_job];
         g8_ln_cols_strip(j, s % ln_strips_per_job, smem_raw);
+        if (bk.nb > 0) g8_bucket_arrive(bk, bk.ln_bucket[s / ln_strips_per_job]);
         return;
     }
     if (b >= gemm_blocks) {
@@ -1000,6 +1031,23 @@ __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_multi_kernel(const GemmAr
     // round) would be a round of their own at one tile per handful of CUs — they run as TWO K slices combined in the launch
     // (gemm8_tile's pair path: half the K tiles each, one fp32 slab per tile), twice as many workgroups for half as long.
     const int xcd = b & 7, loc = b >> 3;
+    if (bk.nb > 0) {
+        // bucketed walk: slot `loc` of this XCD lies in bucket k = the last one with slot_start[k] <= loc
+        int k = 0;
+        for (int c = 1; c < bk.nb; ++c) k = (bk.slot_start[c] <= loc) ? c : k;
+        const int share = bk.slot_start[k + 1] - bk.slot_start[k];
+        const int bpos = bk.tile_start[k] + xcd * share + (loc - bk.slot_start[k]);
+        if (bpos >= bk.tile_start[k + 1]) return;           // (an XCD's share of a bucket rounds up: a few idle workgroups)
+        const int q = find(tile_start, bpos);
+        const GemmArgs p = tbl[q];
+        const int bx = bpos - tile_start[q];
+        const int tiles_m = p.M >> 8, tiles_n = p.N >> 8;
+        const int tm = tiles_n >= tiles_m ? bx % tiles_m : bx / tiles_n;
+        const int tn = tiles_n >= tiles_m ? bx / tiles_m : bx % tiles_n;
+        gemm8_tile<true, true, EPI_WGRAD, true>(p, tm * tiles_n + tn, 0, smem_raw);
+        g8_bucket_arrive(bk, k);
+        return;
+    }
     int pos = xcd * per + loc, slice = 0, slot = -1;
     if (loc >= full) {
         const int t = loc - full;

@@ -69,8 +69,13 @@ size_t gemm_wgrad_group_workspace_bytes(int n, const int64_t* N, const int64_t* 
 // n problems (the weight gradients of several layers) in ONE launch on the 256 x 256 tile; 1 = not applicable (shape, capture).
 // n_ln LayerNorm parameter-gradient jobs (dgamma, dbeta: column sums over `rows` tokens) ride along as extra workgroups.
 struct LnColsJob { const void* dy; const void* z; const float* mean; const float* rstd; void* dgamma; void* dbeta; int64_t rows, H; };
+// Gradient buckets of a multi launch (data-parallel steps): problems / LayerNorm jobs carry a bucket id (non-decreasing along
+// the problem list, < 24); the launch finishes the buckets in order and writes `epoch` to flag[k] (signal memory, one word per
+// bucket: hipExtMallocWithFlags(hipMallocSignalMemory)) when bucket k is complete.  count: nb zeroed device words.
+struct MultiBuckets { int nb; const int* prob_bucket; const int* ln_bucket; unsigned* const* flag; unsigned* count; unsigned epoch; };
 int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* const* dw, void* const* db, int64_t M,
-                     const int64_t* N, const int64_t* K, int accumulate, hipStream_t st, int n_ln = 0, const LnColsJob* ln = nullptr);
+                     const int64_t* N, const int64_t* K, int accumulate, hipStream_t st, int n_ln = 0, const LnColsJob* ln = nullptr,
+                     const MultiBuckets* buckets = nullptr);
 int gemm_group_autotune(int n, int64_t M, const int64_t* N, const int64_t* K, hipStream_t st);
 void gemm_debug_force(int cfg, int splits);
 int gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, hipStream_t st);

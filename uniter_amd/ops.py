@@ -484,6 +484,9 @@ class _EncoderFn(torch.autograd.Function):
                 defer_only = bool(getattr(hook, "defer_wgrad_join", False)) and os.environ.get("UNITER_AMD_DEFER_WGRAD_JOIN", "1") != "0"
                 want_defer = defer_only
             C.uniter_encoder_defer_side_join(1 if want_defer else 0)
+            # gradient buckets of a data-parallel reducer (one call, flags per bucket): per thread and sticky, so stated every time
+            gb = getattr(hook, "grad_buckets", None)
+            C.uniter_encoder_set_grad_buckets(int(gb()) if callable(gb) and begin == 0 and end == n else 0)
             if defer or defer_only:
                 # the call returns before the deferred launch (which reads the saved activations, the range's input and this
                 # call's dy) has run: keep them alive until the weight-gradient stream is joined (_lib.join_wgrads)

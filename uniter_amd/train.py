@@ -118,7 +118,8 @@ class StepRunner(object):
             # 4-layer buckets: a backward range's deferred weight-gradient launch is 432 tiles (1.7 rounds of 256 CUs); with 3
             # layers it is 324 (1.3 rounds) and the one-rank RCCL step measures 5.49 ms against 5.26
             reducer_layers_per_bucket = int(os.environ.get("UNITER_AMD_LAYERS_PER_BUCKET", "4"))
-        self.reducer = (D.GradientReducer(self.arena, self.model.uniter.encoder, layers_per_bucket=reducer_layers_per_bucket)
+        self.reducer = (D.GradientReducer(self.arena, self.model.uniter.encoder, layers_per_bucket=reducer_layers_per_bucket,
+                                          word_embeddings=self.model.uniter.embeddings.word_embeddings.weight)
                         if (world > 1 or D._on()) else None)
         self.model.uniter.pack_padding = bool(pack)
         # each rank trains on its own shard (data/data.py:222): different synthetic batches per rank, resident in HBM
@@ -228,7 +229,8 @@ class StepRunner(object):
                 _l.join_wgrads()                                      # the backward segment ends when every weight gradient is written
                 e2.record()
                 seg.append((e0, e1, e2))
-        scale = self.reducer.finish() if self.reducer is not None else 1.0
+        # (every task but MLM reaches the word-embedding table only through the input lookup: its gradient is exchanged as rows)
+        scale = self.reducer.finish(word_ids=None if task == 'mlm' else batch['input_ids']) if self.reducer is not None else 1.0
         clip_grad_norm_(self.optimizer, self.opts.grad_norm, grad_scale=scale)
         self.optimizer.step()
         self.optimizer.zero_grad()

@@ -213,10 +213,12 @@ def any_broadcast(data, root_rank):
 class _LayerHook(object):
     """callable(layer_index) + the set of layers at which it actually has work to do."""
 
-    def __init__(self, fn, ready_layers, joins_side_stream=False):
+    def __init__(self, fn, ready_layers, joins_side_stream=False, defer_wgrad_join=False, grad_buckets=None):
         self.fn = fn
         self.ready_layers = ready_layers
         self.joins_side_stream = joins_side_stream      # ops._EncoderFn.backward: see uniter_encoder_defer_side_join
+        self.defer_wgrad_join = defer_wgrad_join        # one backward call, returns without joining the weight-gradient stream
+        self.grad_buckets = grad_buckets                # callable -> layers per bucket for uniter_encoder_set_grad_buckets (0 = off)
 
     def __call__(self, layer_index):
         return self.fn(layer_index)
@@ -236,9 +238,19 @@ class GradientReducer(object):
     Buckets are contiguous arena ranges: one per `layers_per_bucket` encoder layers (reverse order, as backward
     produces them) plus one for everything outside the encoder (embeddings, pooler, heads), reduced at finish()
     (heads finish first in backward, embeddings last: both are small next to the encoder).
+
+    On the GPU the encoder's backward stays ONE call with ONE deferred weight-gradient launch (round 4; include/uniter_hip.h
+    "Gradient buckets"): the launch completes the buckets in order and raises a flag per bucket, and a bucket's allreduce is
+    enqueued on the communication stream behind a wait for that flag — rounds 1-3 cut the backward into one call per bucket,
+    whose shorter launches filled the chip less well (+12 % per step before a byte crossed xGMI).  UNITER_AMD_DP_SINGLE_LAUNCH=0
+    keeps the per-bucket calls.
+
+    finish(word_ids=...) exchanges the word-embedding gradient as touched rows when the step's loss reaches that table only
+    through the input lookup (every task but MLM, whose tied decoder makes the gradient dense): each rank contributes the rows of
+    the tokens in its batch (all-gather of ids and rows, <= B*Lt x H per rank instead of a vocab x H allreduce).
     """
 
-    def __init__(self, arena, encoder=None, layers_per_bucket=3):
+    def __init__(self, arena, encoder=None, layers_per_bucket=3, word_embeddings=None):
         self.arena = arena
         self.encoder = encoder
         self.buckets = []          # (lo, hi) element ranges
@@ -247,6 +259,10 @@ class GradientReducer(object):
         self._armed = False
         self._stream = None
         self._pending = []
+        self.layers_per_bucket = int(layers_per_bucket)
+        self.single_launch = (encoder is not None and bool(arena.grad.is_cuda)
+                              and os.environ.get("UNITER_AMD_DP_SINGLE_LAUNCH", "1") != "0"
+                              and (len(list(encoder.layer)) + self.layers_per_bucket - 1) // self.layers_per_bucket <= 24)
         covered = []
         if encoder is not None:
             layers = list(encoder.layer)
@@ -258,10 +274,15 @@ class GradientReducer(object):
                 self.layer_bucket[lo_l] = len(self.buckets)     # ready once layer lo_l's backward is enqueued
                 self.buckets.append(span)
                 covered.append(span)
-            # backward only has to hand control back at the layers that complete a bucket (ops._EncoderFn.backward cuts
-            # the stack there instead of after every layer)
-            encoder.grad_ready_hook = _LayerHook(self._on_layer, set(self.layer_bucket.keys()),
-                                                 joins_side_stream=bool(arena.grad.is_cuda) and os.environ.get("UNITER_AMD_DEFER_JOIN", "1") != "0")
+            if self.single_launch:
+                # no cut points: the whole stack is one backward call; the hook still fires per layer (after the call)
+                encoder.grad_ready_hook = _LayerHook(self._on_layer, set(), joins_side_stream=False, defer_wgrad_join=True,
+                                                     grad_buckets=lambda: self.layers_per_bucket if self._armed and _on() else 0)
+            else:
+                # backward only has to hand control back at the layers that complete a bucket (ops._EncoderFn.backward cuts
+                # the stack there instead of after every layer)
+                encoder.grad_ready_hook = _LayerHook(self._on_layer, set(self.layer_bucket.keys()),
+                                                     joins_side_stream=bool(arena.grad.is_cuda) and os.environ.get("UNITER_AMD_DEFER_JOIN", "1") != "0")
         covered.sort()
         pos = 0
         for lo, hi in covered:
@@ -277,30 +298,89 @@ class GradientReducer(object):
         self.rest_early = [r for r in self.rest if covered and r[0] >= enc_hi]
         self.rest = [r for r in self.rest if r not in self.rest_early]
         self._early_done = False
+        # the word-embedding table's range (sparse exchange in finish): must lie inside one `rest` range
+        self.word_span = None
+        if word_embeddings is not None:
+            lo, hi = arena.span([word_embeddings])
+            if any(r[0] <= lo and hi <= r[1] for r in self.rest):
+                self.word_span = (lo, hi, int(word_embeddings.shape[0]), int(word_embeddings.shape[1]))
 
     def begin(self):
         self._armed = True
+        self.last_flag_waits = 0        # buckets of this step whose allreduce went behind a flag wait (tests)
         self._pending = []
         self._early_done = False
         if _on() and self.arena.grad.is_cuda and self._stream is None:
             self._stream = torch.cuda.Stream()
 
-    def _reduce_range(self, lo, hi):
+    def _reduce_range(self, lo, hi, bucket=None):
         if not _on() or hi <= lo:
             return
         g = self.arena.grad[lo:hi]
         if g.is_cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self._stream.wait_event(ev)
-            # the weight gradients of the bucket come from the library's side stream, which the current stream has not
-            # been made to wait for between layer ranges (uniter_encoder_defer_side_join)
             from .. import _lib
-            _lib.load().uniter_encoder_side_join(ctypes.c_void_p(self._stream.cuda_stream))
+            lib = _lib.load()
+            waited = False
+            if bucket is not None and self.single_launch:
+                # the bucket's gradients all come out of the one deferred launch of the backward call that just returned on
+                # THIS thread: wait for the bucket's flag, not for a stream
+                n = ctypes.c_int32(0)
+                lib.uniter_encoder_grad_bucket_count(ctypes.byref(n))
+                if bucket < n.value:
+                    lib.uniter_encoder_bucket_wait(ctypes.c_int32(bucket), ctypes.c_void_p(self._stream.cuda_stream))
+                    waited = True
+                    self.last_flag_waits += 1
+            if not waited:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self._stream.wait_event(ev)
+                # the weight gradients of the bucket come from the library's side stream, which the current stream has not
+                # been made to wait for between layer ranges (uniter_encoder_defer_side_join)
+                lib.uniter_encoder_side_join(ctypes.c_void_p(self._stream.cuda_stream))
             with torch.cuda.stream(self._stream):
                 self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
         else:
             self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+
+    def _exchange_word_rows(self, word_ids):
+        """Sum of the ranks' word-embedding gradients when each is non-zero only in the rows of its own tokens: all-gather of
+        (ids, rows of first occurrences) and a local fp32 row sum, written back in place.  Same result as the dense sum-allreduce
+        up to the summation order (exactly the same for two ranks); no host synchronisation, fixed shapes."""
+        lo, hi, V, H = self.word_span
+        g = self.arena.grad[lo:hi].view(V, H)
+        ids = word_ids.reshape(-1).to(g.device, torch.int64)
+        n = ids.numel()
+        # first occurrence of every id in this rank's batch (the others contribute a zero row): sort, compare neighbours
+        sid, order = torch.sort(ids, stable=True)
+        first = torch.ones(n, dtype=torch.bool, device=g.device)
+        first[1:] = sid[1:] != sid[:-1]
+        rows = g.index_select(0, sid) * first.unsqueeze(1).to(g.dtype)
+        world = size()
+        all_ids = torch.empty(world * n, dtype=torch.int64, device=g.device)
+        all_rows = torch.empty(world * n, H, dtype=g.dtype, device=g.device)
+        dist.all_gather_into_tensor(all_ids, sid)
+        dist.all_gather_into_tensor(all_rows, rows)
+        # rows of the union, summed over ranks in fp32 and rounded once; every touched row is rewritten by every rank alike
+        uniq_ids = all_ids                       # (duplicates carry zero rows or the same id from another rank: index_add sums them)
+        compact = V * H > (1 << 22) or os.environ.get("UNITER_AMD_DP_WORD_COMPACT") == "1"
+        acc = None if compact else torch.zeros(V, H, dtype=torch.float32, device=g.device)
+        if acc is not None:
+            acc.index_add_(0, uniq_ids, all_rows.float())
+            touched = torch.zeros(V, dtype=torch.bool, device=g.device)
+            touched[uniq_ids] = True
+            g.copy_(torch.where(touched.unsqueeze(1), acc.to(g.dtype), g))
+        else:
+            # large vocabulary: accumulate on the compact list instead of a vocab-sized fp32 buffer.  Sort the gathered ids,
+            # segment-sum equal ids, scatter the segment sums back.
+            s2, o2 = torch.sort(uniq_ids, stable=True)
+            r2 = all_rows.index_select(0, o2).float()
+            head = torch.ones(s2.numel(), dtype=torch.bool, device=g.device)
+            head[1:] = s2[1:] != s2[:-1]
+            seg = torch.cumsum(head.to(torch.int64), 0) - 1                   # segment index of every gathered row
+            sums = torch.zeros(s2.numel(), H, dtype=torch.float32, device=g.device)
+            sums.index_add_(0, seg, r2)
+            # every row of a segment receives the segment's sum (same id -> same value: the scatter below is race-free in value)
+            g.index_copy_(0, s2, sums.index_select(0, seg).to(g.dtype))
 
     def _on_layer(self, layer_index):
         if not self._armed:
@@ -311,10 +391,13 @@ class GradientReducer(object):
                 self._early_done = True
                 for lo, hi in self.rest_early:
                     self._reduce_range(lo, hi)
-            self._reduce_range(*self.buckets[b])
+            self._reduce_range(*self.buckets[b], bucket=b)
 
-    def finish(self):
-        """Reduce what is left (non-encoder parameters), wait for every bucket, return the averaging factor."""
+    def finish(self, word_ids=None):
+        """Reduce what is left (non-encoder parameters), wait for every bucket, return the averaging factor.
+        word_ids: the step's input_ids when the word-embedding gradient is non-zero only in those rows (see the class docstring)."""
+        sparse = self._armed and _on() and word_ids is not None and self.word_span is not None \
+            and os.environ.get("UNITER_AMD_DP_SPARSE_WORD", "1") != "0"
         if self._armed:
             if self.encoder is None:
                 self._reduce_range(0, self.arena.numel)
@@ -323,7 +406,21 @@ class GradientReducer(object):
                     for lo, hi in self.rest_early:
                         self._reduce_range(lo, hi)
                 for lo, hi in self.rest:
-                    self._reduce_range(lo, hi)
+                    if sparse and lo <= self.word_span[0] and self.word_span[1] <= hi:
+                        # dense around the word table, rows inside it
+                        self._reduce_range(lo, self.word_span[0])
+                        self._reduce_range(self.word_span[1], hi)
+                    else:
+                        self._reduce_range(lo, hi)
+        if sparse:
+            if self.arena.grad.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self._stream.wait_event(ev)
+                with torch.cuda.stream(self._stream):
+                    self._exchange_word_rows(word_ids)
+            else:
+                self._exchange_word_rows(word_ids)
         for w in self._pending:
             w.wait()
         if self._stream is not None:
