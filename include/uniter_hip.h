@@ -438,6 +438,13 @@ int uniter_encoder_side_join_all(void* stream);
 int uniter_encoder_set_grad_buckets(int32_t layers_per_bucket);
 int uniter_encoder_grad_bucket_count(int32_t* n_out);
 int uniter_encoder_bucket_wait(int32_t bucket, void* stream);
+/* The same wait in two halves, for a caller that learns about the buckets on one thread (autograd's, inside backward) and
+ * enqueues the collectives later from another: _token returns the flag's address and the value bucket k of the thread's last
+ * backward call will write; uniter_hip_stream_wait_value32 — callable from any thread — makes `stream` wait until the word at
+ * `flag` (signal memory) is >= value.  (Issuing the waits and collectives only after backward() has returned keeps the host
+ * from delaying the embedding backward, which should start while the deferred launch is young.) */
+int uniter_encoder_bucket_token(int32_t bucket, void** flag_out, uint32_t* value_out);
+int uniter_hip_stream_wait_value32(void* stream, void* flag, uint32_t value);
 
 /* The calling thread's weight-gradient stream (created on first use), as a raw hipStream_t.  A deferred launch reads the
  * call's activations / input / dy after uniter_encoder_backward has returned; a caller whose allocator recycles memory per

@@ -84,11 +84,10 @@ def main():
             if reducer is not None:
                 reducer.begin()
             model(batch, compute_loss=True).mean().backward()
-            if reducer is not None and reducer.single_launch:
-                # (the hooks ran on the autograd thread; what they saw there is what this records)
-                buckets_seen = max(buckets_seen, getattr(reducer, "last_flag_waits", 0))
             # NLVR2 has no MLM head: the word-embedding gradient travels as rows
             scale = reducer.finish(word_ids=batch['input_ids'] if wide else None) if reducer is not None else 1.0
+            if reducer is not None and reducer.single_launch:
+                buckets_seen = max(buckets_seen, getattr(reducer, "last_flag_waits", 0))      # collectives enqueued behind a flag wait
             clip_grad_norm_(opt, 1.0, grad_scale=scale)
             opt.step()
             opt.zero_grad()

@@ -147,8 +147,10 @@ def _case_sparse_word_rows(rank, world, D):
                 model.uniter.encoder.grad_ready_hook(l)
             if sparse and big_vocab:
                 os.environ["UNITER_AMD_DP_WORD_COMPACT"] = "1"
+            os.environ["UNITER_AMD_DP_SPARSE_WORD"] = "1"         # (two ranks: below the automatic threshold)
             scale = reducer.finish(word_ids=ids if sparse else None)
             os.environ.pop("UNITER_AMD_DP_WORD_COMPACT", None)
+            os.environ.pop("UNITER_AMD_DP_SPARSE_WORD", None)
             assert scale == 1.0 / world
             results.append(arena.grad.clone())
         assert torch.equal(results[0], results[1]), (dtype, big_vocab, float((results[0].float() - results[1].float()).abs().max()))

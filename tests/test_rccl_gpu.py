@@ -37,7 +37,8 @@ def test_single_launch_reducer_with_bucket_flags_over_one_rank_rccl(lpb):
     hipStreamWaitValue32 on that flag; the word-embedding gradient travels as rows.  Two optimizer steps must end bit-identical
     to the collective-free training loop, with every encoder bucket reduced behind a flag wait."""
     env = dict(os.environ, UNITER_DIST_FORCE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29551 + lpb), RANK="0", WORLD_SIZE="1",
-               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", UNITER_W1_WIDE="1", UNITER_W1_LAYERS_PER_BUCKET=str(lpb))
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", UNITER_W1_WIDE="1", UNITER_W1_LAYERS_PER_BUCKET=str(lpb),
+               UNITER_AMD_DP_SPARSE_WORD="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_world1_script.py")], capture_output=True, text=True,
                        timeout=300, env=env, cwd=ROOT)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -135,6 +135,8 @@ SIGNATURES = {
     "uniter_encoder_set_grad_buckets": (c_int, [c_int32]),
     "uniter_encoder_grad_bucket_count": (c_int, [POINTER(c_int32)]),
     "uniter_encoder_bucket_wait": (c_int, [c_int32, c_void_p]),
+    "uniter_encoder_bucket_token": (c_int, [c_int32, POINTER(c_void_p), POINTER(ctypes.c_uint32)]),
+    "uniter_hip_stream_wait_value32": (c_int, [c_void_p, c_void_p, ctypes.c_uint32]),
     "uniter_encoder_debug_chain": (c_int, [c_int]),
     "uniter_encoder_chain_status": (c_int, [POINTER(UniterEncoderShape), c_void_p, POINTER(c_int32)]),
     "uniter_encoder_debug_tune_in_situ": (c_int, [c_int]),

@@ -712,6 +712,23 @@ int uniter_encoder_grad_bucket_count(int32_t* n_out) {
     return 0;
 }
 
+int uniter_encoder_bucket_token(int32_t bucket, void** flag_out, uint32_t* value_out) {
+    if (flag_out == nullptr || value_out == nullptr) { uh_set_error("encoder_bucket_token: null pointer"); return -1; }
+    if (bucket < 0 || bucket >= g_buckets.last_nb) {
+        uh_set_error("encoder_bucket_token: bucket %d, the last backward call of this thread completed %d buckets", (int)bucket, g_buckets.last_nb);
+        return -1;
+    }
+    *flag_out = (void*)g_buckets.flag[bucket];
+    *value_out = g_buckets.epoch;
+    return 0;
+}
+
+int uniter_hip_stream_wait_value32(void* stream, void* flag, uint32_t value) {
+    if (flag == nullptr) { uh_set_error("stream_wait_value32: null flag"); return -1; }
+    UH_CHECK_HIP(hipStreamWaitValue32((hipStream_t)stream, flag, value, hipStreamWaitValueGte, 0xFFFFFFFFu));
+    return 0;
+}
+
 int uniter_encoder_bucket_wait(int32_t bucket, void* stream) {
     if (bucket < 0 || bucket >= g_buckets.last_nb) {
         uh_set_error("encoder_bucket_wait: bucket %d, the last backward call of this thread completed %d buckets", (int)bucket, g_buckets.last_nb);

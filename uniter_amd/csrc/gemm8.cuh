@@ -966,15 +966,21 @@ struct G8Buckets {
     const int* prob_bucket;                  // [n] bucket of every problem
     const int* ln_bucket;                    // [LayerNorm jobs]
 };
-__device__ __forceinline__ void g8_bucket_arrive(const G8Buckets& bk, const int k) {
+// plain_stores: this work item also wrote results with ordinary (write-back) stores — a bias gradient, LayerNorm parameter
+// gradients — which have to be written back from this XCD's L2 before the item is counted; tile outputs are write-through
+// (sc1) and acknowledged by the s_waitcnt, so most items need no cache operation at all (a release fence per tile cost the
+// bucketed launch ~100 us: buffer_wbl2 walks the L2).
+__device__ __forceinline__ void g8_bucket_arrive(const G8Buckets& bk, const int k, const bool plain_stores) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();                                    // (strip results are plain stores: write them back before counting)
-        const unsigned seen = __hip_atomic_fetch_add(bk.count + k, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned seen;
+        if (plain_stores) seen = __hip_atomic_fetch_add(bk.count + k, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        else seen = __hip_atomic_fetch_add(bk.count + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (seen + 1u == bk.total[k]) {
+            // every other item of the bucket had its results in memory before it was counted
             __hip_atomic_store(bk.count + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(bk.flag[k], bk.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(bk.flag[k], bk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -1016,7 +1022,7 @@ __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_multi_kernel(const GemmAr
         const int s = b - gemm_blocks - bias_strips;
         const G8LnJob j = ln_jobs[s / ln_strips_per_job];
         g8_ln_cols_strip(j, s % ln_strips_per_job, smem_raw);
-        if (bk.nb > 0) g8_bucket_arrive(bk, bk.ln_bucket[s / ln_strips_per_job]);
+        if (bk.nb > 0) g8_bucket_arrive(bk, bk.ln_bucket[s / ln_strips_per_job], true);
         return;
     }
     if (b >= gemm_blocks) {
@@ -1045,7 +1051,7 @@ __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_multi_kernel(const GemmAr
         const int tm = tiles_n >= tiles_m ? bx % tiles_m : bx / tiles_n;
         const int tn = tiles_n >= tiles_m ? bx / tiles_m : bx % tiles_n;
         gemm8_tile<true, true, EPI_WGRAD, true>(p, tm * tiles_n + tn, 0, smem_raw);
-        g8_bucket_arrive(bk, k);
+        g8_bucket_arrive(bk, k, tn == 0 && p.C2 != nullptr);         // (the first tile column also stored the bias gradient)
         return;
     }
     int pos = xcd * per + loc, slice = 0, slot = -1;

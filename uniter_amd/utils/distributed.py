@@ -308,35 +308,34 @@ class GradientReducer(object):
     def begin(self):
         self._armed = True
         self.last_flag_waits = 0        # buckets of this step whose allreduce went behind a flag wait (tests)
+        self._tokens = {}               # single-launch mode: bucket -> (flag address, value) noted by the backward hook
         self._pending = []
         self._early_done = False
         if _on() and self.arena.grad.is_cuda and self._stream is None:
             self._stream = torch.cuda.Stream()
 
-    def _reduce_range(self, lo, hi, bucket=None):
+    def _reduce_range(self, lo, hi, token=None):
+        """Sum-allreduce of arena.grad[lo:hi] on the communication stream.  token = (flag address, value) of a gradient bucket
+        of the single deferred launch: the collective goes behind a wait for that flag; else behind the current stream (and,
+        for encoder ranges of the per-bucket path, the library's weight-gradient stream)."""
         if not _on() or hi <= lo:
             return
         g = self.arena.grad[lo:hi]
         if g.is_cuda:
             from .. import _lib
             lib = _lib.load()
-            waited = False
-            if bucket is not None and self.single_launch:
-                # the bucket's gradients all come out of the one deferred launch of the backward call that just returned on
-                # THIS thread: wait for the bucket's flag, not for a stream
-                n = ctypes.c_int32(0)
-                lib.uniter_encoder_grad_bucket_count(ctypes.byref(n))
-                if bucket < n.value:
-                    lib.uniter_encoder_bucket_wait(ctypes.c_int32(bucket), ctypes.c_void_p(self._stream.cuda_stream))
-                    waited = True
-                    self.last_flag_waits += 1
-            if not waited:
+            if token is not None:
+                lib.uniter_hip_stream_wait_value32(ctypes.c_void_p(self._stream.cuda_stream), ctypes.c_void_p(token[0]),
+                                                   ctypes.c_uint32(token[1]))
+                self.last_flag_waits += 1
+            else:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
                 self._stream.wait_event(ev)
-                # the weight gradients of the bucket come from the library's side stream, which the current stream has not
-                # been made to wait for between layer ranges (uniter_encoder_defer_side_join)
-                lib.uniter_encoder_side_join(ctypes.c_void_p(self._stream.cuda_stream))
+                if not self.single_launch:
+                    # the weight gradients of the bucket come from the library's side stream, which the current stream has not
+                    # been made to wait for between layer ranges (uniter_encoder_defer_side_join)
+                    lib.uniter_encoder_side_join(ctypes.c_void_p(self._stream.cuda_stream))
             with torch.cuda.stream(self._stream):
                 self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
         else:
@@ -386,18 +385,39 @@ class GradientReducer(object):
         if not self._armed:
             return
         b = self.layer_bucket.get(layer_index)
-        if b is not None:
-            if not self._early_done:
-                self._early_done = True
-                for lo, hi in self.rest_early:
-                    self._reduce_range(lo, hi)
-            self._reduce_range(*self.buckets[b], bucket=b)
+        if b is None:
+            return
+        if self.single_launch and self.arena.grad.is_cuda and _on():
+            # Called on autograd's thread right after the one backward call of the stack.  Only note the bucket's flag here; the
+            # waits and collectives are enqueued by finish(), after backward() has returned: the ~0.3 ms of host work they cost
+            # would otherwise sit between the encoder's backward and the embedding backward, whose kernels then reach the GPU
+            # when the deferred launch already owns every CU and do not run until it ends (rocprofv3 trace).
+            from .. import _lib
+            lib = _lib.load()
+            n = ctypes.c_int32(0)
+            lib.uniter_encoder_grad_bucket_count(ctypes.byref(n))
+            if b < n.value:
+                flag, val = ctypes.c_void_p(), ctypes.c_uint32(0)
+                lib.uniter_encoder_bucket_token(ctypes.c_int32(b), ctypes.byref(flag), ctypes.byref(val))
+                self._tokens[b] = (flag.value, val.value)
+            else:
+                self._tokens[b] = None                   # the call ran without buckets: finish() joins the weight-gradient stream
+            return
+        if not self._early_done:
+            self._early_done = True
+            for lo, hi in self.rest_early:
+                self._reduce_range(lo, hi)
+        self._reduce_range(*self.buckets[b])
 
     def finish(self, word_ids=None):
         """Reduce what is left (non-encoder parameters), wait for every bucket, return the averaging factor.
         word_ids: the step's input_ids when the word-embedding gradient is non-zero only in those rows (see the class docstring)."""
+        # rows instead of the dense table from 4 ranks up (UNITER_AMD_DP_SPARSE_WORD=1 / 0 forces it): the exchange costs ~0.2 ms
+        # of small kernels on the communication stream (measured on one rank) against the ~0.26 ms a 44.5 MB ring allreduce is
+        # modelled to take at 8 ranks — a wash below that, and unmeasured on real links (DESIGN section 5)
+        want = os.environ.get("UNITER_AMD_DP_SPARSE_WORD")
         sparse = self._armed and _on() and word_ids is not None and self.word_span is not None \
-            and os.environ.get("UNITER_AMD_DP_SPARSE_WORD", "1") != "0"
+            and (want == "1" or (want is None and size() >= 4))
         if self._armed:
             if self.encoder is None:
                 self._reduce_range(0, self.arena.numel)
@@ -405,6 +425,14 @@ class GradientReducer(object):
                 if not self._early_done:
                     for lo, hi in self.rest_early:
                         self._reduce_range(lo, hi)
+                if self.single_launch and self._tokens:
+                    # the buckets the backward hook noted, in the order the deferred launch completes them
+                    if any(t is None for t in self._tokens.values()):
+                        from .. import _lib
+                        _lib.load().uniter_encoder_side_join_all(ctypes.c_void_p(self._stream.cuda_stream))
+                    for b in sorted(self._tokens):
+                        self._reduce_range(*self.buckets[b], token=self._tokens[b])
+                    self._tokens = {}
                 for lo, hi in self.rest:
                     if sparse and lo <= self.word_span[0] and self.word_span[1] <= hi:
                         # dense around the word table, rows inside it
