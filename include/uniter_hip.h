@@ -541,6 +541,10 @@ int uniter_adamw_step_dev(void* plan, const float* dev_hyper, int32_t n_groups, 
  *   uniter_cls_ce_fwd / _bwd            Linear(D, C <= 8) + F.cross_entropy(reduction='none') over n rows; logits are
  *                                       rounded to bf16 like the module's; probs [n,C] fp32 saved for backward; bwd writes
  *                                       dx [n,D] and ACCUMULATES into gw [C,D] / gb [C] (bf16).  targets int64 [n]. */
+/* uniter_nlvr2_pair_masks: the masks of the paired head from attn_masks [2 n_pairs rows in (pair, side) order, L] in one launch
+ * (model/nlvr2.py:172-176,183-186): pad [2n, L] uint8 = (mask == 0) with rows regrouped [left block; right block], and
+ * partner_bias [2n, L] fp32 = (1 - m) * -10000 of the OTHER image of the row's pair (the key mask of the cross attention). */
+int uniter_nlvr2_pair_masks(const int64_t* attn_masks, uint8_t* pad, float* partner_bias, int64_t n_pairs, int64_t L, void* stream);
 int uniter_gemm_bias_relu_dropout_fwd(const void* x, const void* w, const void* bias, void* y, int64_t M, int64_t N, int64_t K,
                                       float p_drop, uint64_t seed, uint64_t offset, void* stream);
 int uniter_relu_dropout_bwd(const void* dy, const void* out, void* dpre, int64_t numel, float p_drop, void* stream);

@@ -1456,12 +1456,22 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
         }
     }
     const int gemm_blocks = (full + 2 * (per - full)) * 8;
-    // LayerNorm strips that go first (see the kernel): half the chip's CUs, when the launch is long enough for it to matter
-    int lead_strips = 0;
+    // The staggered start (see the kernel): some CUs begin with a tile, the others with one or two LayerNorm strips, when the
+    // launch is long enough for it to matter.  UNITER_AMD_MULTI_STAGGER="tiles,strips,strips2" overrides (0,128,0 = round 3).
+    int lead_strips = 0, lead_tiles = 0, lead_strips2 = 0;
     {
-        static const int lead_cfg = [] { const char* e = getenv("UNITER_AMD_MULTI_LEAD_STRIPS"); return e ? atoi(e) : 128; }();
+        static int cfg[3] = {-1, -1, -1};
+        if (cfg[0] < 0) {
+            cfg[0] = 64; cfg[1] = 192; cfg[2] = 64;
+            const char* e = getenv("UNITER_AMD_MULTI_STAGGER");
+            if (e != nullptr) { int a = 0, b2 = 0, c = 0; if (sscanf(e, "%d,%d,%d", &a, &b2, &c) == 3 && a >= 0 && b2 >= 0 && c >= 0) { cfg[0] = a; cfg[1] = b2; cfg[2] = c; } }
+        }
         const int n_ln_strips = n_ln * ln_strips_per_job;
-        if (per > 64) lead_strips = std::min(lead_cfg, n_ln_strips) & ~7;
+        if (per > 64) {
+            lead_strips = std::min(cfg[1], n_ln_strips) & ~7;
+            lead_strips2 = std::min(cfg[2], n_ln_strips - lead_strips) & ~7;
+            lead_tiles = (lead_strips + lead_strips2 > 0) ? (std::min(cfg[0], gemm_blocks) & ~7) : 0;
+        }
     }
     unsigned long long* stamp_dev = nullptr;
     {
@@ -1481,7 +1491,7 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
     hipLaunchKernelGGL(gemm8_multi_kernel, dim3(gemm_blocks + strips + n_ln * ln_strips_per_job), dim3(G8_THREADS), G8_LDS_BYTES, st,
                        (const GemmArgs*)T.dev, (const int*)((const char*)T.dev + meta_off), n, per, full, gemm_blocks,
                        (const G8LnJob*)((const char*)T.dev + ln_off), ln_strips_per_job, strips, tail_pairs, tail_slabs, stamp_dev,
-                       lead_strips, bk);
+                       lead_strips, bk, lead_tiles, lead_strips2);
     UH_LAUNCH_CHECK();
     if (stamp_dev != nullptr) {                              // harness profiling: synchronous, prints the launch's schedule
         const int nb = gemm_blocks + strips + n_ln * ln_strips_per_job;

@@ -990,18 +990,24 @@ __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_multi_kernel(const GemmAr
                                                                     const G8LnJob* __restrict__ ln_jobs, const int ln_strips_per_job,
                                                                     const int bias_strips, unsigned* __restrict__ tail_pairs,
                                                                     float* __restrict__ tail_slabs, unsigned long long* __restrict__ stamps,
-                                                                    const int lead_strips, const G8Buckets bk) {
+                                                                    const int lead_strips, const G8Buckets bk, const int lead_tiles,
+                                                                    const int lead_strips2) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    // Block order: `lead_strips` LayerNorm strips FIRST (a multiple of 8, at most half the chip), then the tiles, then the other
-    // strips.  The CUs that start with a 28 us strip run their 83 us tiles that much later than the rest for the whole launch, so
-    // CUs come free in two phases per tile time instead of one — which is when the small kernels of the caller's stream (the
-    // embedding backward runs beside this launch) get to run at all: nothing can share a CU with a tile.
+    // Block order (all four counts multiples of 8, so a tile keeps the XCD its index implies): `lead_tiles` tiles, `lead_strips`
+    // LayerNorm strips, `lead_strips2` more strips, the remaining tiles, the remaining strips.  The CUs that start with one 28 us
+    // strip (or two: the second group lands on the CUs whose first strip ends first) run their 83 us tiles 28 / 56 us behind the
+    // CUs that started with a tile, for the whole launch — so CUs come free three times per tile time instead of once, which is
+    // when the small kernels of the caller's stream (the embedding backward runs beside this launch) get to run at all: nothing
+    // can share a CU with a tile, and a kernel launched beside this one waits for the next turnover.
     int b = (int)blockIdx.x;
-    const int n_ln_strips = (int)gridDim.x - gemm_blocks - bias_strips;
-    if (b < lead_strips) b = gemm_blocks + bias_strips + b;                                  // a leading LayerNorm strip
-    else if (b < lead_strips + gemm_blocks + bias_strips) b -= lead_strips;                 // tile / bias strip
-    // (else: one of the remaining LayerNorm strips, already at its index)
-    (void)n_ln_strips;
+    {
+        const int work = gemm_blocks + bias_strips;          // tiles (+ bias strips) in the logical order; LayerNorm strips follow
+        const int s12 = lead_strips + lead_strips2;
+        if (b < lead_tiles) { /* a leading tile: already at its index */ }
+        else if (b < lead_tiles + s12) b = work + (b - lead_tiles);                 // a leading LayerNorm strip
+        else if (b < s12 + work) b -= s12;                                          // the other tiles / bias strips
+        // (else: one of the remaining LayerNorm strips, already at its index)
+    }
     // profiling (UNITER_AMD_MULTI_STAMPS, harness only): start / end of every workgroup on the chip-wide 100 MHz clock
     struct Stamp {
         unsigned long long* p;

@@ -1,6 +1,7 @@
 // head.hip — the small dense pieces of the NLVR2 paired-attention head (model/nlvr2.py:150-204) that PyTorch would run
 // as ~40 tiny launches per step: the backward mask of Linear + ReLU + Dropout, and the 2-way classifier with its cross
 // entropy (Linear(2H, 2) + F.cross_entropy(reduction='none'), n = pairs per batch).
+#include <algorithm>
 #include "common.cuh"
 #include "kernels.h"
 #include "../../include/uniter_hip.h"
@@ -18,6 +19,24 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const bf16_t* __r
 #pragma unroll
         for (int e = 0; e < 8; ++e) r[e] = o[e] > 0.f ? g[e] * scale : 0.f;
         *reinterpret_cast<u32x4*>(dpre + i * 8) = pack8(r);
+    }
+}
+
+// The masks of the paired head in one pass over attn_masks [2n rows in (pair, side) order][L] (model/nlvr2.py:172-176,183-186):
+// rows regrouped as [left block; right block] (row o = side * n + pair), pad[o][t] = (mask == 0) for the attention pool, and
+// partner_bias[o][t] = the additive key mask ((1 - m) * -10000, model/model.py:342-345 form) of the sequence row o attends TO,
+// i.e. of the other image of its pair.  (PyTorch: view / transpose / == 0 / flip / reshape + the mask kernel = six launches.)
+__global__ __launch_bounds__(256) void pair_masks_kernel(const int64_t* __restrict__ m, uint8_t* __restrict__ pad, float* __restrict__ partner_bias,
+                                                         int n, int L) {
+    const int64_t total = (int64_t)2 * n * L;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int t = (int)(idx % L);
+        const int o = (int)(idx / L);
+        const int side = o / n, pair = o - side * n;
+        const int64_t own = m[((int64_t)2 * pair + side) * L + t];
+        const int64_t other = m[((int64_t)2 * pair + (1 - side)) * L + t];
+        pad[idx] = own == 0 ? 1 : 0;
+        partner_bias[idx] = (1.0f - (float)other) * -10000.0f;
     }
 }
 
@@ -159,6 +178,16 @@ int uniter_cls_ce_bwd(const void* x, const void* w, const float* probs, const in
     hipLaunchKernelGGL(cls_ce_bwd_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), (size_t)(n * C) * sizeof(float),
                        (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, probs, target, gloss, (bf16_t*)dx, (bf16_t*)gw,
                        (bf16_t*)gb, (int)n, (int)D, (int)C);
+    UH_LAUNCH_CHECK();
+    return 0;
+}
+
+int uniter_nlvr2_pair_masks(const int64_t* attn_masks, uint8_t* pad, float* partner_bias, int64_t n_pairs, int64_t L, void* stream) {
+    UH_CHECK_ARG(attn_masks && pad && partner_bias, "null pointer");
+    UH_CHECK_ARG(n_pairs > 0 && L > 0, "bad shape");
+    const int64_t total = 2 * n_pairs * L;
+    hipLaunchKernelGGL(pair_masks_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1024)), dim3(256), 0, (hipStream_t)stream,
+                       attn_masks, pad, partner_bias, (int)n_pairs, (int)L);
     UH_LAUNCH_CHECK();
     return 0;
 }

@@ -120,14 +120,22 @@ class UniterForNlvr2PairedAttn(_Nlvr2Base):
         n = bs // 2
         # rows 2i / 2i+1 are the left / right image of pair i (model/nlvr2.py:172-176): regroup as [side, pair, L, H]
         xs = seq.contiguous().view(n, 2, tl, d).transpose(0, 1).contiguous()
-        valid = batch['attn_masks'].contiguous().view(n, 2, tl).transpose(0, 1)         # [2, n, L]
-        pad = (valid == 0).reshape(bs, tl)                                              # left block, then right block
-        if self._fused_pair_attention(seq):
+        if self._fused_pair_attention(seq) and batch['attn_masks'].dtype == torch.int64:
             from .. import ops
-            # instance block 0 (left queries) attends to the right sequences and vice versa -> partner's key mask
+            # padding mask (left block, then right block) and the partner's key mask — instance block 0 (left queries) attends
+            # to the right sequences and vice versa — from one kernel instead of six small PyTorch launches
+            pad, partner_bias = ops.nlvr2_pair_masks(batch['attn_masks'])
+            att = ops.paired_cross_attention(xs, None, self.attn1, self.attn2, self.attn1.dropout, self.training,
+                                             partner_bias=partner_bias)
+        elif self._fused_pair_attention(seq):
+            from .. import ops
+            valid = batch['attn_masks'].contiguous().view(n, 2, tl).transpose(0, 1)     # [2, n, L]
+            pad = (valid == 0).reshape(bs, tl)                                          # left block, then right block
             att = ops.paired_cross_attention(xs, valid.flip(0).reshape(bs, tl), self.attn1, self.attn2,
                                              self.attn1.dropout, self.training)
         else:
+            valid = batch['attn_masks'].contiguous().view(n, 2, tl).transpose(0, 1)     # [2, n, L]
+            pad = (valid == 0).reshape(bs, tl)
             left, right = xs[0].transpose(0, 1), xs[1].transpose(0, 1)                  # (L, N, E) module layout
             l2r, _ = self.attn1(left, right, right, key_padding_mask=pad[n:], need_weights=False)
             r2l, _ = self.attn2(right, left, left, key_padding_mask=pad[:n], need_weights=False)

@@ -911,9 +911,22 @@ class _PairedCrossAttnFn(torch.autograd.Function):
         return (dxs if ctx.needs_input_grad[0] else None, None, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 6)
 
 
-def paired_cross_attention(xs, key_valid_partner, attn1, attn2, p_drop, training):
+def nlvr2_pair_masks(attn_masks):
+    """attn_masks [2n, L] int64, rows in (pair, side) order -> (pad [2n, L] uint8, rows regrouped [left block; right block];
+    partner key-mask bias [2n, L] fp32) in one launch (uniter_nlvr2_pair_masks)."""
+    _check_dev(attn_masks, "attn_masks", torch.int64)
+    bs, L = attn_masks.shape
+    m = attn_masks.contiguous()
+    pad = torch.empty(bs, L, dtype=torch.uint8, device=m.device)
+    bias = torch.empty(bs, L, dtype=torch.float32, device=m.device)
+    C.uniter_nlvr2_pair_masks(ptr(m), ptr(pad), ptr(bias), bs // 2, L, _lib.stream_ptr())
+    return pad, bias
+
+
+def paired_cross_attention(xs, key_valid_partner, attn1, attn2, p_drop, training, partner_bias=None):
     """xs [2, n, L, H] bf16 (left block, right block); key_valid_partner [2n, L] = attention mask (1 = real token) of
-    the sequence each instance attends TO.  Returns [2, n, L, H]: attn1(left->right) block, attn2(right->left) block."""
+    the sequence each instance attends TO (or partner_bias: its additive fp32 form, already computed).
+    Returns [2, n, L, H]: attn1(left->right) block, attn2(right->left) block."""
     _check_dev(xs, "paired sequences")
     if xs.dim() != 4 or xs.size(0) != 2:
         raise _lib.UniterHipError("paired sequences must be [2, n, L, H]")
@@ -925,7 +938,7 @@ def paired_cross_attention(xs, key_valid_partner, attn1, attn2, p_drop, training
             if prm is not None:
                 _check_dev(prm, "attention parameter")
     xs = xs.contiguous()
-    mb = mask_bias(key_valid_partner)
+    mb = partner_bias if partner_bias is not None else mask_bias(key_valid_partner)
     track = torch.is_grad_enabled()
     if not track:
         with torch.no_grad():
