@@ -258,6 +258,11 @@ struct GradBuckets {
     int device = -1;
 };
 thread_local GradBuckets g_buckets;
+// whether this device can make a stream wait on a memory value (hipStreamWaitValue32); else callers keep the stream-join path
+bool buckets_supported() {
+    int dev = 0, can = 0;
+    return hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can != 0;
+}
 int buckets_init() {
     int dev = 0;
     UH_CHECK_HIP(hipGetDevice(&dev));
@@ -633,7 +638,7 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         if (g_buckets.layers_per_bucket > 0) {
             const int lpb = g_buckets.layers_per_bucket;
             const int nb = (nl + lpb - 1) / lpb;
-            if (nb <= 24) {
+            if (nb <= 24 && buckets_supported()) {
                 RC(buckets_init());
                 for (int l = layer_end - 1; l >= layer_begin; --l) {
                     const int k = (layer_end - 1 - l) / lpb;
@@ -892,8 +897,8 @@ int uniter_encoder_debug_tune_in_situ(int enable) {
 }
 
 // test / tuning hook: 0 = run the weight-gradient GEMMs on the caller's stream, 1 = on the library's side stream
-// test / measurement hook: 0 = every kernel of the encoder calls in queue order (barrier between dependent kernels), 1 = the
-// overlapped chains (the default; UNITER_AMD_CHAIN=0 in the environment is the same switch)
+// test / measurement hook: 0 = every kernel of the encoder calls in queue order (barrier between dependent kernels; the default),
+// 1 = the overlapped chains (UNITER_AMD_CHAIN=1 in the environment is the same switch)
 int uniter_encoder_debug_chain(int enable) { g_chain = enable; return 0; }
 // the status word of the last chained call whose flags lived in `scratch`: 0 = no wait timed out.  Synchronises the device.
 int uniter_encoder_chain_status(const UniterEncoderShape* s, const void* scratch, int32_t* status_out) {
