@@ -94,6 +94,16 @@ int uniter_gemm_tuned_choice(int kind, int64_t M, int64_t N, int64_t K, int32_t 
 int uniter_gemm_bias_fwd(const void* x, const void* w, const void* bias, void* y,
                          int64_t M, int64_t N, int64_t K, void* stream);
 
+/* Up to four such GEMMs over the same M rows and contraction K in ONE launch (ABI v7): y_q[M, N_q] = x_q w_q^T + bias_q with
+ * per-problem row strides (0 = dense).  The two MultiheadAttention modules of the NLVR2 paired-attention head (model/nlvr2.py:
+ * 170-189, model/attention.py:103-127) are four input projections and two output projections of 1 536 rows each.  Shapes no
+ * grouped tile divides fall back to one launch per problem inside the call. */
+int uniter_gemm_bias_fwd_group(int32_t n, const void* const* x, const int64_t* ldx, const void* const* w, const void* const* bias,
+                               void* const* y, const int64_t* ldy, int64_t M, const int64_t* N, int64_t K, void* stream);
+/* ... and their data gradients: dx_q[M, K] = dy_q[M, N_q] w_q[N_q, K] (+ resid_q[M, K]), row stride lddy_q on dy (0 = dense). */
+int uniter_gemm_dgrad_group(int32_t n, const void* const* dy, const int64_t* lddy, const void* const* w, const void* const* resid,
+                            void* const* dx, int64_t M, const int64_t* N, int64_t K, void* stream);
+
 /* u = x*w^T + bias ; g = u*0.5*(1+erf(u/sqrt2))   writes both u (pre-activation, kept for backward)
  * and g.                                                                    layer.py:31-37,139-142 */
 int uniter_gemm_bias_gelu_fwd(const void* x, const void* w, const void* bias, void* u, void* g,

@@ -159,6 +159,8 @@ SIGNATURES = {
     "uniter_ot_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, c_float, c_int32, c_int32, _P]),
     "uniter_ot_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "uniter_nlvr2_pair_masks": (c_int, [_P, _P, _P, _I, _I, _P]),
+    "uniter_gemm_bias_fwd_group": (c_int, [c_int32, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
+    "uniter_gemm_dgrad_group": (c_int, [c_int32, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     "uniter_comm_unique_id": (c_int, [POINTER(c_uint8)]),
     "uniter_comm_init": (c_int, [POINTER(c_uint8), c_int32, c_int32, POINTER(c_void_p)]),
     "uniter_comm_destroy": (c_int, [_P]),

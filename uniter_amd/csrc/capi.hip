@@ -176,6 +176,33 @@ int uniter_gemm_bias_fwd_ld(const void* x, int64_t ldx, const void* w, const voi
     return uh::gemm_fwd(uh::GEMM_EPI_BIAS, x, w, bias, nullptr, y, nullptr, M, N, K, make_dropout(0.f, 0, 0), (hipStream_t)stream, ldx, ldy);
 }
 
+int uniter_gemm_bias_fwd_group(int32_t n, const void* const* x, const int64_t* ldx, const void* const* w, const void* const* bias,
+                               void* const* y, const int64_t* ldy, int64_t M, const int64_t* N, int64_t K, void* stream) {
+    UH_CHECK_ARG(x && w && y && N, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = uh::gemm_fwd_group(n, x, ldx, w, bias, y, ldy, M, N, K, st);
+    if (rc != 1) return rc;
+    for (int q = 0; q < n; ++q) {                            // no grouped tile for these shapes: one launch per problem
+        const int r = uh::gemm_fwd(uh::GEMM_EPI_BIAS, x[q], w[q], bias ? bias[q] : nullptr, nullptr, y[q], nullptr, M, N[q], K, make_dropout(0.f, 0, 0), st,
+                                   ldx ? ldx[q] : 0, ldy ? ldy[q] : 0);
+        if (r) return r;
+    }
+    return 0;
+}
+
+int uniter_gemm_dgrad_group(int32_t n, const void* const* dy, const int64_t* lddy, const void* const* w, const void* const* resid,
+                            void* const* dx, int64_t M, const int64_t* N, int64_t K, void* stream) {
+    UH_CHECK_ARG(dy && w && dx && N, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = uh::gemm_dgrad_group(n, dy, lddy, w, resid, dx, M, N, K, st);
+    if (rc != 1) return rc;
+    for (int q = 0; q < n; ++q) {
+        const int r = uh::gemm_dgrad(uh::GEMM_EPI_RES, dy[q], w[q], resid ? resid[q] : nullptr, dx[q], M, N[q], K, st, lddy ? lddy[q] : 0);
+        if (r) return r;
+    }
+    return 0;
+}
+
 int uniter_gemm_bias_gelu_fwd(const void* x, const void* w, const void* bias, void* u, void* g,
                               int64_t M, int64_t N, int64_t K, void* stream) {
     UH_CHECK_ARG(x && w && u && g, "null pointer");

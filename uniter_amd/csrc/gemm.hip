@@ -916,6 +916,40 @@ int launch_group(GemmGroupArgs& ga, int cfg, hipStream_t st) {
     }
 }
 
+// Grouped launch of up to four problems in the forward (TRA = TRB = false) or data-gradient (TRB) layout on ONE fixed tile: the
+// small GEMMs of the NLVR2 paired-attention head (model/nlvr2.py:170-189: two MultiheadAttention modules = four input
+// projections, two output projections, and their data gradients) are 1 536-row problems that fill a third of the chip each and
+// cost a launch + ramp + drain apiece; as one grid they share those.  Compact per-XCD segments as the weight-gradient groups.
+template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, int WS>
+int launch_group_layout(GemmGroupArgs& ga, hipStream_t st) {
+    int total = 0;
+    for (int q = 0; q < ga.n; ++q) {
+        GemmArgs& a = ga.g[q];
+        if (a.N % BN != 0 || (WS && a.K % 64 != 0) || (TRA && a.M % BM != 0)) return 1;      // 1 = this tile does not fit: caller falls back
+        const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
+        a.xr = -1;
+        a.k_per_split = (a.K + 63) / 64 * 64;
+        a.partial = nullptr;
+        a.chain = ChainLink{nullptr, nullptr, nullptr, 0, 0};
+        ga.start[q] = total;
+        total += tiles_m * tiles_n;
+    }
+    ga.start[ga.n] = total;
+    ga.compact = 1;
+    ga.per = (total + 7) / 8;
+    total = ga.per * 8;
+    constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * 64 * sizeof(bf16_t);
+    static bool attr_done = false;
+    if (lds > 64 * 1024 && !attr_done) {
+        UH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_group_kernel<BM, BN, TRA, TRB, EPI, NSTAGE, WS>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_group_kernel<BM, BN, TRA, TRB, EPI, NSTAGE, WS>), dim3(total), dim3(WaveGrid<BM, BN, WS>::THREADS), lds, st, ga);
+    UH_LAUNCH_CHECK();
+    return 0;
+}
+
 // Is tile `cfg` (with `splits` K slices) legal for the public call (kind, M, N, K)?  kind 0: fwd, out M x N, contraction K;
 // 1: dgrad, out M x K, contraction N; 2: wgrad, out N x K, contraction M.
 bool cfg_legal(int kind, int cfg, int64_t M, int64_t N, int64_t K, int splits) {
@@ -1075,6 +1109,66 @@ int gemm_dgrad(int epi, const void* dy, const void* w, const void* aux, void* dx
     if (epi == EPI_GELU_BWD) return launch_gemm<false, true, EPI_GELU_BWD>(a, cfg, 1, st);
     uh_set_error("gemm_dgrad: bad epilogue");
     return -1;
+}
+
+// y_q[M, N_q] = x_q[M, K] w_q[N_q, K]^T + bias_q for q < n <= 4, one launch; 1 = no grouped tile fits these shapes (nothing launched)
+int gemm_fwd_group(int n, const void* const* x, const int64_t* ldx, const void* const* w, const void* const* bias, void* const* y,
+                   const int64_t* ldy, int64_t M, const int64_t* N, int64_t K, hipStream_t st) {
+    if (n < 1 || n > 4) { uh_set_error("gemm_fwd_group: 1..4 problems"); return -1; }
+    if (M <= 0 || K <= 0 || K % 8 != 0 || M > INT32_MAX || K > INT32_MAX) { uh_set_error("gemm_fwd_group: bad M / K"); return -1; }
+    GemmGroupArgs ga{};
+    ga.n = n;
+    int64_t flops_n = 0;
+    for (int q = 0; q < n; ++q) {
+        if (x[q] == nullptr || w[q] == nullptr || y[q] == nullptr || N[q] <= 0 || N[q] % 64 != 0) { uh_set_error("gemm_fwd_group: bad problem %d", q); return -1; }
+        const int64_t lx = ldx != nullptr && ldx[q] ? ldx[q] : K, ly = ldy != nullptr && ldy[q] ? ldy[q] : N[q];
+        if (lx < K || ly < N[q] || lx % 8 != 0 || ly % 8 != 0) { uh_set_error("gemm_fwd_group: bad leading dimension"); return -1; }
+        GemmArgs a{};
+        a.R = (const bf16_t*)x[q]; a.ldr = lx;
+        a.Cc = (const bf16_t*)w[q]; a.ldcc = K;
+        a.C = (bf16_t*)y[q]; a.C2 = nullptr; a.ldc = ly;
+        a.bias = bias != nullptr ? (const bf16_t*)bias[q] : nullptr;
+        a.aux = nullptr; a.ldaux = N[q];
+        a.M = (int)M; a.N = (int)N[q]; a.K = (int)K;
+        a.accumulate = 0; a.relu = 0;
+        a.drop = make_dropout(0.f, 0, 0);
+        ga.g[q] = a;
+        flops_n += N[q];
+    }
+    LaunchTimer lt(TIME_GEMM_FWD_BIAS, M, flops_n, K, st);
+    int rc = launch_group_layout<96, 96, false, false, EPI_BIAS, 4, 1>(ga, st);
+    if (rc == 1) rc = launch_group_layout<128, 128, false, false, EPI_BIAS, 2, 0>(ga, st);
+    return rc;
+}
+
+// dx_q[M, K] = dy_q[M, N_q] w_q[N_q, K] (+ resid_q[M, K]) for q < n <= 4, one launch; 1 = no grouped tile fits (nothing launched)
+int gemm_dgrad_group(int n, const void* const* dy, const int64_t* lddy, const void* const* w, const void* const* resid, void* const* dx,
+                     int64_t M, const int64_t* N, int64_t K, hipStream_t st) {
+    if (n < 1 || n > 4) { uh_set_error("gemm_dgrad_group: 1..4 problems"); return -1; }
+    if (M <= 0 || K <= 0 || K % 64 != 0 || M > INT32_MAX || K > INT32_MAX) { uh_set_error("gemm_dgrad_group: bad M / K"); return -1; }
+    GemmGroupArgs ga{};
+    ga.n = n;
+    int64_t contraction = 0;
+    for (int q = 0; q < n; ++q) {
+        if (dy[q] == nullptr || w[q] == nullptr || dx[q] == nullptr || N[q] <= 0 || N[q] % 8 != 0) { uh_set_error("gemm_dgrad_group: bad problem %d", q); return -1; }
+        const int64_t ld = lddy != nullptr && lddy[q] ? lddy[q] : N[q];
+        if (ld < N[q] || ld % 8 != 0) { uh_set_error("gemm_dgrad_group: bad leading dimension"); return -1; }
+        GemmArgs a{};
+        a.R = (const bf16_t*)dy[q]; a.ldr = ld;
+        a.Cc = (const bf16_t*)w[q]; a.ldcc = K;           // stored [contraction = N][out cols = K]
+        a.C = (bf16_t*)dx[q]; a.C2 = nullptr; a.ldc = K;
+        a.bias = nullptr;
+        a.aux = resid != nullptr ? (const bf16_t*)resid[q] : nullptr; a.ldaux = K;
+        a.M = (int)M; a.N = (int)K; a.K = (int)N[q];
+        a.accumulate = 0; a.relu = 0;
+        a.drop = make_dropout(0.f, 0, 0);
+        ga.g[q] = a;
+        contraction += N[q];
+    }
+    LaunchTimer lt(TIME_GEMM_DGRAD, M, contraction, K, st);
+    int rc = launch_group_layout<96, 128, false, true, EPI_RES, 3, 2>(ga, st);
+    if (rc == 1) rc = launch_group_layout<64, 64, false, true, EPI_RES, 3, 1>(ga, st);
+    return rc;
 }
 
 // Split-K form of dx[M,K] = dy[M,N] * w[N,K] for a short M against a long contraction N (the MLM decoder's input
@@ -1462,7 +1556,7 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
     {
         static int cfg[3] = {-1, -1, -1};
         if (cfg[0] < 0) {
-            cfg[0] = 64; cfg[1] = 192; cfg[2] = 64;
+            cfg[0] = 0; cfg[1] = 128; cfg[2] = 0;         // (64,192,64 = three phases: the step -15 us, this launch +17 us and +18 % HBM-side reads — DESIGN 10.5)
             const char* e = getenv("UNITER_AMD_MULTI_STAGGER");
             if (e != nullptr) { int a = 0, b2 = 0, c = 0; if (sscanf(e, "%d,%d,%d", &a, &b2, &c) == 3 && a >= 0 && b2 >= 0 && c >= 0) { cfg[0] = a; cfg[1] = b2; cfg[2] = c; } }
         }

@@ -54,6 +54,11 @@ int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void
              int relu = 0, ChainStep* chain = nullptr);
 int gemm_dgrad(int epi, const void* dy, const void* w, const void* aux, void* dx,
                int64_t M, int64_t N, int64_t K, hipStream_t st, int64_t lddy = 0, int act = 0, ChainStep* chain = nullptr);
+// up to four forward / data-gradient problems over the same rows in one launch; 1 = no grouped tile fits (nothing was launched)
+int gemm_fwd_group(int n, const void* const* x, const int64_t* ldx, const void* const* w, const void* const* bias, void* const* y,
+                   const int64_t* ldy, int64_t M, const int64_t* N, int64_t K, hipStream_t st);
+int gemm_dgrad_group(int n, const void* const* dy, const int64_t* lddy, const void* const* w, const void* const* resid, void* const* dx,
+                     int64_t M, const int64_t* N, int64_t K, hipStream_t st);
 size_t gemm_dgrad_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int gemm_dgrad_splitk(const void* dy, const void* w, void* dx, int64_t M, int64_t N, int64_t K, void* workspace,
                       size_t ws_bytes, hipStream_t st, int64_t lddy = 0);

@@ -592,6 +592,32 @@ def wgrad_group(dys, lddys, xs_, ldxs, dws, dbs, M, Ns, Ks, training=True):
     C.uniter_gemm_wgrad_group(n, PA(*dys), IA(*lddys), PA(*xs_), IA(*ldxs), PA(*dws), PA(*dbs), M, Na, Ka, 1, st)
 
 
+_HEAD_GROUP = os.environ.get("UNITER_AMD_HEAD_GROUP", "1") != "0"
+
+
+def fwd_group(xs_, ldxs, ws, biases, ys, ldys, M, Ns, K):
+    """Up to four y_q[M, N_q] = x_q[M, K] w_q^T + b_q over the same rows in one launch (uniter_gemm_bias_fwd_group).  Raw device
+    addresses / row strides (0 = dense)."""
+    n = len(xs_)
+    if not _HEAD_GROUP:                                    # (A/B switch: one launch per problem)
+        for q in range(n):
+            C.uniter_gemm_bias_fwd_ld(xs_[q], ldxs[q] or K, ws[q], biases[q], ys[q], ldys[q] or Ns[q], M, Ns[q], K, _lib.stream_ptr())
+        return
+    PA, IA = ctypes.c_void_p * n, ctypes.c_int64 * n
+    C.uniter_gemm_bias_fwd_group(n, PA(*xs_), IA(*ldxs), PA(*ws), PA(*biases), PA(*ys), IA(*ldys), M, IA(*Ns), K, _lib.stream_ptr())
+
+
+def dgrad_group(dys, lddys, ws, resids, dxs, M, Ns, K):
+    """Up to four dx_q[M, K] = dy_q[M, N_q] w_q[N_q, K] (+ resid_q) in one launch (uniter_gemm_dgrad_group)."""
+    n = len(dys)
+    if not _HEAD_GROUP:
+        for q in range(n):
+            C.uniter_gemm_dgrad_ld(dys[q], lddys[q] or Ns[q], ws[q], resids[q], dxs[q], M, Ns[q], K, _lib.stream_ptr())
+        return
+    PA, IA = ctypes.c_void_p * n, ctypes.c_int64 * n
+    C.uniter_gemm_dgrad_group(n, PA(*dys), IA(*lddys), PA(*ws), PA(*resids), PA(*dxs), M, IA(*Ns), K, _lib.stream_ptr())
+
+
 # ----------------------------------------------------------------------------------------------------
 # LayerNorm (+ dropout on the output) as used by the embedding blocks
 # ----------------------------------------------------------------------------------------------------
@@ -832,18 +858,19 @@ class _PairedCrossAttnFn(torch.autograd.Function):
         b1, b2 = attn1.in_proj_bias, attn2.in_proj_bias
         bp = lambda b, o: None if b is None else b.data_ptr() + o * es
         p0, p1 = P.data_ptr(), P.data_ptr() + T2 * 3 * H * es
-        # rows 0..T2: attn1 — q from left, k|v from right;  rows T2..T: attn2 — q from right, k|v from left
-        C.uniter_gemm_bias_fwd_ld(x_l, H, w1.data_ptr(), bp(b1, 0), p0, 3 * H, T2, H, H, st)
-        C.uniter_gemm_bias_fwd_ld(x_r, H, w1.data_ptr() + H * H * es, bp(b1, H), p0 + H * es, 3 * H, T2, 2 * H, H, st)
-        C.uniter_gemm_bias_fwd_ld(x_r, H, w2.data_ptr(), bp(b2, 0), p1, 3 * H, T2, H, H, st)
-        C.uniter_gemm_bias_fwd_ld(x_l, H, w2.data_ptr() + H * H * es, bp(b2, H), p1 + H * es, 3 * H, T2, 2 * H, H, st)
+        # rows 0..T2: attn1 — q from left, k|v from right;  rows T2..T: attn2 — q from right, k|v from left.
+        # The four projections are ONE grouped launch (1 536-row problems: a launch each filled a third of the chip)
+        fwd_group([x_l, x_r, x_r, x_l], [H] * 4,
+                  [w1.data_ptr(), w1.data_ptr() + H * H * es, w2.data_ptr(), w2.data_ptr() + H * H * es],
+                  [bp(b1, 0), bp(b1, H), bp(b2, 0), bp(b2, H)],
+                  [p0, p0 + H * es, p1, p1 + H * es], [3 * H] * 4, T2, [H, 2 * H, H, 2 * H], H)
         p = float(p_drop) if training else 0.0
         seed, off = _next_offsets(1) if p > 0.0 else (0, 0)
         C.uniter_attention_fwd(ptr(P), ptr(mask_bias_p), ptr(cx), ptr(lse), 2 * n, L, heads, p, seed, off, st)
         o0, o1 = out.data_ptr(), out.data_ptr() + T2 * H * es
         c0, c1 = cx.data_ptr(), cx.data_ptr() + T2 * H * es
-        C.uniter_gemm_bias_fwd(c0, ptr(attn1.out_proj.weight), ptr(attn1.out_proj.bias), o0, T2, H, H, st)
-        C.uniter_gemm_bias_fwd(c1, ptr(attn2.out_proj.weight), ptr(attn2.out_proj.bias), o1, T2, H, H, st)
+        fwd_group([c0, c1], [0, 0], [ptr(attn1.out_proj.weight), ptr(attn2.out_proj.weight)],
+                  [ptr(attn1.out_proj.bias), ptr(attn2.out_proj.bias)], [o0, o1], [0, 0], T2, [H, H], H)
         ctx.mods = (attn1, attn2)
         ctx.p, ctx.seed, ctx.off = p, seed, off
         ctx.save_for_backward(xs, mask_bias_p, P, cx, lse)
@@ -875,9 +902,8 @@ class _PairedCrossAttnFn(torch.autograd.Function):
 
         half = T2 * H * es
         # ---- out_proj (model/attention.py:257) ----
-        for i, mod in enumerate((attn1, attn2)):
-            d_o, dc_i = dout.data_ptr() + i * half, dcx.data_ptr() + i * half
-            C.uniter_gemm_dgrad(d_o, ptr(mod.out_proj.weight), None, dc_i, T2, H, H, st)
+        dgrad_group([dout.data_ptr(), dout.data_ptr() + half], [0, 0], [ptr(attn1.out_proj.weight), ptr(attn2.out_proj.weight)],
+                    [None, None], [dcx.data_ptr(), dcx.data_ptr() + half], T2, [H, H], H)
         # both out_proj weight + bias gradients in one launch
         wgrad_group([dout.data_ptr(), dout.data_ptr() + half], [0, 0], [cx.data_ptr(), cx.data_ptr() + half], [0, 0],
                     [ptr(grad_of(attn1.out_proj.weight)), ptr(grad_of(attn2.out_proj.weight))],
@@ -896,10 +922,9 @@ class _PairedCrossAttnFn(torch.autograd.Function):
         wq1, wkv1 = w1.data_ptr(), w1.data_ptr() + H * H * es
         wq2, wkv2 = w2.data_ptr(), w2.data_ptr() + H * H * es
         # d_left = dq(attn1) Wq1 + dkv(attn2) Wkv2 ; d_right = dq(attn2) Wq2 + dkv(attn1) Wkv1
-        C.uniter_gemm_dgrad_ld(d0, 3 * H, wq1, None, dx_l, T2, H, H, st)
-        C.uniter_gemm_dgrad_ld(d1 + H * es, 3 * H, wkv2, dx_l, dx_l, T2, 2 * H, H, st)
-        C.uniter_gemm_dgrad_ld(d1, 3 * H, wq2, None, dx_r, T2, H, H, st)
-        C.uniter_gemm_dgrad_ld(d0 + H * es, 3 * H, wkv1, dx_r, dx_r, T2, 2 * H, H, st)
+        # (two grouped launches: the q halves of both sides, then the k|v halves added on top)
+        dgrad_group([d0, d1], [3 * H, 3 * H], [wq1, wq2], [None, None], [dx_l, dx_r], T2, [H, H], H)
+        dgrad_group([d1 + H * es, d0 + H * es], [3 * H, 3 * H], [wkv2, wkv1], [dx_l, dx_r], [dx_l, dx_r], T2, [2 * H, 2 * H], H)
         # the four in_proj weight gradients (q and k|v blocks of both modules) and their bias gradients in one launch
         g1, g2 = grad_of(w1), grad_of(w2)
         gb1, gb2 = grad_of(attn1.in_proj_bias), grad_of(attn2.in_proj_bias)
