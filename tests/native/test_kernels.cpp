@@ -1216,7 +1216,9 @@ static void bench_encoder(int B, int L, int H, int heads, int I, int layers) {
         tf = std::min(tf, tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 20));
         tb = std::min(tb, tm.run([&] { UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0)); }, 2, 20));
     }
-    printf("  in-order launches: fwd %.1f us | bwd %.1f us ;  overlapped chains: fwd %.1f us | bwd %.1f us\n", tf0, tb0, tf, tb);
+    printf("  in-order launches: fwd %.1f us | bwd %.1f us ;  overlapped chains (opt-in): fwd %.1f us | bwd %.1f us\n", tf0, tb0, tf, tb);
+    UHCHK(uniter_encoder_debug_chain(0));                  // the library's default from here on
+    tf = tf0; tb = tb0;                                     // the ENCODER line below is the default path
     {
         static const char* kinds[] = {"gemm fwd +bias", "gemm fwd +gelu", "gemm fwd +drop+res", "gemm dgrad", "gemm dgrad gelu'", "gemm wgrad",
                                       "attn fwd", "attn bwd", "ln fwd", "ln bwd rows", "colsum", "adamw", "ln bwd cols", "gemm wgrad group"};
