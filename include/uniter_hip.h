@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UNITER_HIP_ABI_VERSION 8
+#define UNITER_HIP_ABI_VERSION 7
 
 /* ------------------------------------------------------------------------------------------------
  * Library
@@ -479,15 +479,6 @@ int uniter_encoder_debug_side_stream(int enable);
  * (synchronising the device): 0 = clean.  (model/model.py:282-292 has no counterpart.) */
 int uniter_encoder_debug_chain(int enable);
 int uniter_encoder_chain_status(const UniterEncoderShape* s, const void* scratch, int32_t* status_out);
-/* LayerNorm fused with the GEMM that produces its input (ABI v8; model/layer.py:111-115,152-156: `LayerNorm(dropout(dense(h)) + x)`).
- * With a scratch buffer, uniter_encoder_forward runs both LayerNorms of a layer — and uniter_encoder_backward, in the
- * deferred-weight-gradient flow, the row halves of their backward — BEHIND the tiles of the preceding GEMM instead of as
- * launches of their own: the column tiles of a row block store write-through, meet at a counter in the scratch buffer and
- * share the block's rows (csrc/row_tail.cuh).  Same row arithmetic: bit-identical to the separate
- * launches, which uniter_encoder_debug_ln_tail(0) (or UNITER_AMD_LN_TAIL=0) selects; a launch whose tiles are not all resident at
- * once (or that runs on the deep-pipelined tile family) keeps the separate LayerNorm on its own.  A wait that does not complete
- * within 50 ms gives up and sets the status word uniter_encoder_chain_status reads. */
-int uniter_encoder_debug_ln_tail(int enable);
 /* 0 = uniter_encoder_autotune keeps the isolated per-GEMM winners; 1 (default) = it then re-picks every GEMM's tile among
  * its fastest candidates by timing a short forward+backward stack (cold weights, wgrad side stream running). */
 int uniter_encoder_debug_tune_in_situ(int enable);

@@ -1104,21 +1104,15 @@ static void bench_encoder(int B, int L, int H, int heads, int I, int layers) {
     if (!getenv("UNITER_BENCH_SKIP_CHAIN_CHECK")) {
         // the overlapped kernel chain (no queue barrier between dependent kernels, row-block flags) against the in-order launches:
         // every saved activation of every layer, bit for bit — same kernels, same arithmetic, only the dispatch differs
-        // ... and the LayerNorms run behind the tiles of the GEMM before them (row_tail.cuh) against LayerNorm launches of their own.
-        // Reference = in-order launches, separate LayerNorms.
         std::vector<unsigned char> ref(act * layers), got(act * layers);
         UHCHK(uniter_encoder_debug_chain(0));
-        UHCHK(uniter_encoder_debug_ln_tail(0));
         HIPCHK(hipMemset(acts, 0, act * layers));
         UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0));
         HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipMemcpy(ref.data(), acts, ref.size(), hipMemcpyDeviceToHost));
+        UHCHK(uniter_encoder_debug_chain(1));
         size_t bad = 0, first = 0;
         int32_t st_word = 0;
-        for (int mode = 1; mode <= 2; ++mode) {             // 1: LayerNorm tails (the default), 2: overlapped chain
-        UHCHK(uniter_encoder_debug_ln_tail(1));
-        UHCHK(uniter_encoder_debug_chain(mode == 2 ? 1 : 0));
-        bad = 0; first = 0; st_word = 0;
         for (int rep = 0; rep < 4; ++rep) {                 // (several launches: a race would not show every time)
             HIPCHK(hipMemset(acts, 0, act * layers));
             UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0));
@@ -1128,13 +1122,10 @@ static void bench_encoder(int B, int L, int H, int heads, int I, int layers) {
             HIPCHK(hipMemcpy(got.data(), acts, got.size(), hipMemcpyDeviceToHost));
             for (size_t k = 0; k < ref.size(); ++k) if (ref[k] != got[k]) { if (!bad) first = k; ++bad; }
         }
-        printf("[%s] %s forward == in-order forward with separate LayerNorm launches (4 launches): %zu of %zu bytes differ, status word %d", (bad || st_word) ? "FAIL" : " OK ",
-               mode == 1 ? "LayerNorm-tail" : "overlapped-chain", bad, 4 * ref.size(), st_word);
+        printf("[%s] overlapped-chain forward == in-order forward (4 launches): %zu of %zu bytes differ, status word %d", (bad || st_word) ? "FAIL" : " OK ", bad, 4 * ref.size(), st_word);
         if (bad) printf(" (first at layer %zu, offset %zu of %zu)", first / act, first % act, act);
         if (bad || st_word) ++g_fail;
         printf("\n");
-        if (bad) break;
-        }
         if (bad) {          // which saved tensor of which layer (the block layout of encoder.hip: 256-byte aligned fields in this order)
             static const char* names[] = {"qkv", "lse", "ctx", "z1", "mean1", "rstd1", "a", "u", "g", "z2", "mean2", "rstd2", "y"};
             const size_t sizes[] = {(size_t)T * 3 * H * 2, (size_t)B * heads * L * 4, (size_t)T * H * 2, (size_t)T * H * 2, (size_t)T * 4, (size_t)T * 4, (size_t)T * H * 2,
@@ -1149,18 +1140,14 @@ static void bench_encoder(int B, int L, int H, int heads, int I, int layers) {
                 }
             }
         }
-        double t0 = 1e30, t1 = 1e30, t2 = 1e30;
+        double t0 = 1e30, t1 = 1e30;
         for (int rep = 0; rep < 3; ++rep) {
             UHCHK(uniter_encoder_debug_chain(0));
-            UHCHK(uniter_encoder_debug_ln_tail(0));
             t0 = std::min(t0, tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 20));
-            UHCHK(uniter_encoder_debug_ln_tail(1));
-            t2 = std::min(t2, tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 20));
             UHCHK(uniter_encoder_debug_chain(1));
             t1 = std::min(t1, tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 20));
         }
-        UHCHK(uniter_encoder_debug_chain(0));
-        printf("  forward: separate LayerNorm launches %.1f us | LayerNorm tails %.1f us | overlapped chain %.1f us\n", t0, t2, t1);
+        printf("  forward: in-order launches %.1f us | overlapped chain %.1f us\n", t0, t1);
     }
     if (getenv("UNITER_BENCH_CHAIN_ONLY")) return;
     // deferred weight gradients (one launch for all layers of the call) against the per-layer grouped launches: every
@@ -1199,15 +1186,8 @@ static void bench_encoder(int B, int L, int H, int heads, int I, int layers) {
         std::vector<uint16_t> dxref((size_t)T * H), dxgot((size_t)T * H), ggot(per);
         size_t bad = 0;
         int32_t st_word = 0;
-        for (int pass = 0; pass < 7; ++pass) {              // pass 0: in order, separate LayerNorm launches; 1..3: LayerNorm tails; 4..6: chained
-            UHCHK(uniter_encoder_debug_chain(pass >= 4 ? 1 : 0));
-            UHCHK(uniter_encoder_debug_ln_tail(pass == 0 ? 0 : 1));
-            if (pass == 4) {
-                printf("[%s] LayerNorm-tail backward == in-order backward with separate LayerNorm launches (3 launches): %zu elements of dx / parameter gradients differ, status word %d\n",
-                       (bad || st_word) ? "FAIL" : " OK ", bad, st_word);
-                if (bad || st_word) ++g_fail;
-                bad = 0; st_word = 0;
-            }
+        for (int pass = 0; pass < 4; ++pass) {              // pass 0: in order; 1..3: chained
+            UHCHK(uniter_encoder_debug_chain(pass == 0 ? 0 : 1));
             for (int l = 0; l < layers; ++l) HIPCHK(hipMemset(gbase[l], 0, per * 2));
             HIPCHK(hipMemset(dDx, 0, (size_t)T * H * 2));
             UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0));
@@ -1227,21 +1207,16 @@ static void bench_encoder(int B, int L, int H, int heads, int I, int layers) {
         for (int l = 0; l < layers; ++l) HIPCHK(hipMemset(gbase[l], 0, per * 2));
     }
     if (getenv("UNITER_BENCH_NO_STAGE")) UHCHK(uniter_encoder_set_wgrad_stage(nullptr, 0));
-    double tf = 1e30, tb = 1e30, tf0 = 1e30, tb0 = 1e30, tfs = 1e30, tbs = 1e30;
+    double tf = 1e30, tb = 1e30, tf0 = 1e30, tb0 = 1e30;
     for (int rep = 0; rep < 5; ++rep) {
         UHCHK(uniter_encoder_debug_chain(0));
-        UHCHK(uniter_encoder_debug_ln_tail(0));
-        tfs = std::min(tfs, tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 20));
-        tbs = std::min(tbs, tm.run([&] { UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0)); }, 2, 20));
-        UHCHK(uniter_encoder_debug_ln_tail(1));
         tf0 = std::min(tf0, tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 20));
         tb0 = std::min(tb0, tm.run([&] { UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0)); }, 2, 20));
         UHCHK(uniter_encoder_debug_chain(1));
         tf = std::min(tf, tm.run([&] { UHCHK(uniter_encoder_forward(&sh, lp.data(), 0, layers, dX, dMask, acts, scratch, 1, 0, 0)); }, 2, 20));
         tb = std::min(tb, tm.run([&] { UHCHK(uniter_encoder_backward(&sh, lp.data(), 0, layers, dX, dMask, dY, dDx, acts, scratch, 1, 0, 0)); }, 2, 20));
     }
-    printf("  separate LayerNorm launches: fwd %.1f us | bwd %.1f us ;  LayerNorm tails (default): fwd %.1f us | bwd %.1f us ;  overlapped chains (opt-in): fwd %.1f us | bwd %.1f us\n",
-           tfs, tbs, tf0, tb0, tf, tb);
+    printf("  in-order launches: fwd %.1f us | bwd %.1f us ;  overlapped chains (opt-in): fwd %.1f us | bwd %.1f us\n", tf0, tb0, tf, tb);
     UHCHK(uniter_encoder_debug_chain(0));                  // the library's default from here on
     tf = tf0; tb = tb0;                                     // the ENCODER line below is the default path
     {

@@ -11,7 +11,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "build", "libuniter_hip.so")
-ABI_VERSION = 8          # UNITER_HIP_ABI_VERSION of include/uniter_hip.h (struct layouts below must match it)
+ABI_VERSION = 7          # UNITER_HIP_ABI_VERSION of include/uniter_hip.h (struct layouts below must match it)
 
 
 class UniterHipError(RuntimeError):
@@ -138,7 +138,6 @@ SIGNATURES = {
     "uniter_encoder_bucket_token": (c_int, [c_int32, POINTER(c_void_p), POINTER(ctypes.c_uint32)]),
     "uniter_hip_stream_wait_value32": (c_int, [c_void_p, c_void_p, ctypes.c_uint32]),
     "uniter_encoder_debug_chain": (c_int, [c_int]),
-    "uniter_encoder_debug_ln_tail": (c_int, [c_int]),
     "uniter_encoder_chain_status": (c_int, [POINTER(UniterEncoderShape), c_void_p, POINTER(c_int32)]),
     "uniter_encoder_debug_tune_in_situ": (c_int, [c_int]),
     "uniter_gemm_bias_relu_dropout_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),

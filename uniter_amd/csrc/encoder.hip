@@ -138,42 +138,6 @@ struct Chain {
 // CH(call): `cs` inside the call expression is the step of this launch (nullptr when the call does not run as a chain)
 #define CH(expr) do { uh::ChainStep* cs = ch.next(); (void)cs; RC(expr); ch.done(); } while (0)
 
-// ---- LayerNorms behind the GEMMs that produce their inputs (row_tail.cuh) -----------------------------
-// One per uniter_encoder_forward / _backward call: the counters live where the flags of an overlapped chain would (the two
-// are not combined), are zeroed in stream order at the start of the call and only ever grow inside it.
-int g_ln_tail = [] { const char* e = getenv("UNITER_AMD_LN_TAIL"); return e ? atoi(e) : 1; }();
-struct Tail {
-    bool on = false;
-    uint32_t* count = nullptr;
-    uint32_t* status = nullptr;
-    uint32_t sum = 0;
-    int begin(void* scratch_chain, const UniterEncoderShape& s, bool chained, hipStream_t st) {
-        on = false;
-        if (!g_ln_tail || chained || scratch_chain == nullptr || s.H > 1024 || s.H % 8 != 0) return 0;
-        const size_t units = (tokens(s) + 31) / 32;
-        status = (uint32_t*)scratch_chain;
-        count = status + 64;
-        UH_CHECK_HIP(hipMemsetAsync(scratch_chain, 0, 256 + units * sizeof(uint32_t), st));
-        sum = 0;
-        on = true;
-        return 0;
-    }
-    uh::RowTailReq fwd(const void* gamma, const void* beta, void* y, float* mean, float* rstd, float eps) {
-        uh::RowTailReq r{};
-        r.kind = 1; r.gamma = gamma; r.beta = beta; r.out = y; r.mean = mean; r.rstd = rstd; r.eps = eps;
-        r.drop = make_dropout(0.f, 0, 0);
-        r.count = count; r.status = status; r.sum = &sum;
-        return r;
-    }
-    uh::RowTailReq bwd(const void* z, const float* mean, const float* rstd, const void* gamma, void* dz, void* dd, const DropoutCfg& drop) {
-        uh::RowTailReq r{};
-        r.kind = 2; r.gamma = gamma; r.z = z; r.out = dz; r.out2 = dd; r.mean = const_cast<float*>(mean); r.rstd = const_cast<float*>(rstd);
-        r.drop = drop;
-        r.count = count; r.status = status; r.sum = &sum;
-        return r;
-    }
-};
-
 // ---- second stream for the weight-gradient GEMMs ------------------------------------------------------
 // dgrad(l) and wgrad(l) both need only dY(l); nothing downstream of backward needs the weight gradients
 // until the optimizer.  Running every wgrad / bias column-sum on a side stream lets them fill the CUs the
@@ -378,8 +342,6 @@ int uniter_encoder_forward(const UniterEncoderShape* s, const UniterLayerParams*
     Chain ch;
     if (layer_end > layer_begin && !uh::params_pending())
         RC(ch.begin(scratch != nullptr ? (char*)scratch + scratch_layout(*s).chain : nullptr, *s, 7 * (layer_end - layer_begin), st));
-    Tail tail;
-    if (layer_end > layer_begin) RC(tail.begin(scratch != nullptr ? (char*)scratch + scratch_layout(*s).chain : nullptr, *s, ch.on, st));
     const char* x = (const char*)x_in;
     for (int l = layer_begin; l < layer_end; ++l) {
         const UniterLayerParams& P = layers[l];
@@ -395,20 +357,13 @@ int uniter_encoder_forward(const UniterEncoderShape* s, const UniterLayerParams*
         CH(uh::attention_fwd(A + al.qkv, s->total_tokens > 0 ? nullptr : mask_bias, A + al.ctx, (float*)(A + al.lse), s->B, s->L, s->heads, d_attn, st,
                              s->total_tokens > 0 ? s->cu_seqlens : nullptr, cs));
         // model/layer.py:112-114  dense + dropout + residual
-        // (the LayerNorm runs behind the tiles of the GEMM where the launcher can arrange that: row_tail.cuh)
-        uh::RowTailReq t1 = tail.fwd(P.ln1_g, P.ln1_b, A + al.a, (float*)(A + al.mean1), (float*)(A + al.rstd1), s->ln_eps);
-        CH(uh::gemm_fwd(uh::GEMM_EPI_BIAS_DROP_RES, A + al.ctx, P.wo, P.bo, x, A + al.z1, nullptr, T, H, H, d_h1, st, 0, 0, 0, cs,
-                        tail.on ? &t1 : nullptr));
-        if (!t1.fused)
+        CH(uh::gemm_fwd(uh::GEMM_EPI_BIAS_DROP_RES, A + al.ctx, P.wo, P.bo, x, A + al.z1, nullptr, T, H, H, d_h1, st, 0, 0, 0, cs));
         CH(uh::layernorm_fwd(A + al.z1, P.ln1_g, P.ln1_b, A + al.a, (float*)(A + al.mean1), (float*)(A + al.rstd1),
                              T, H, s->ln_eps, nodrop, st, cs));
         // model/layer.py:140-141  dense + erf-GELU
         CH(uh::gemm_fwd(uh::GEMM_EPI_BIAS_GELU, A + al.a, P.w1, P.b1, nullptr, A + al.u, A + al.g, T, I, H, nodrop, st, 0, 0, s->hidden_act, cs));
         // model/layer.py:153-155
-        uh::RowTailReq t2 = tail.fwd(P.ln2_g, P.ln2_b, A + al.y, (float*)(A + al.mean2), (float*)(A + al.rstd2), s->ln_eps);
-        CH(uh::gemm_fwd(uh::GEMM_EPI_BIAS_DROP_RES, A + al.g, P.w2, P.b2, A + al.a, A + al.z2, nullptr, T, H, I, d_h2, st, 0, 0, 0, cs,
-                        tail.on ? &t2 : nullptr));
-        if (!t2.fused)
+        CH(uh::gemm_fwd(uh::GEMM_EPI_BIAS_DROP_RES, A + al.g, P.w2, P.b2, A + al.a, A + al.z2, nullptr, T, H, I, d_h2, st, 0, 0, 0, cs));
         CH(uh::layernorm_fwd(A + al.z2, P.ln2_g, P.ln2_b, A + al.y, (float*)(A + al.mean2), (float*)(A + al.rstd2),
                              T, H, s->ln_eps, nodrop, st, cs));
         x = A + al.y;
@@ -475,9 +430,6 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
     // has its own buffer in the stage (nothing is written twice) and no side-stream kernel runs inside the chain
     Chain ch;
     if (defer_wg) RC(ch.begin(S + sl.chain, *s, 7 * nl, st));
-    Tail tail;                                  // LayerNorm row halves behind the data-gradient GEMMs (deferred flow only)
-    if (defer_wg) RC(tail.begin(S + sl.chain, *s, ch.on, st));
-    bool ln2_done = false;                      // the row half of this layer's BertOutput LayerNorm ran behind the dx GEMM of the layer above
     // Event slots (main_ev[k]: "inputs of side job k are ready", side_ev[k]: "side job k has read its inputs"):
     //   0 / 1  the weight-gradient work of even / odd layers (reads dd2, dpre, dd1, dqkv of that parity's buffer set)
     //   2 / 3  the early column sums of the current layer (bias gradients of FFN1 / QKV read dpre / dqkv)   [ungrouped: wgrads too]
@@ -569,10 +521,8 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
             RC(uh::layernorm_bwd_fused_finalize(red, nbp, P.g_ln2_g, P.g_ln2_b, H, 1, ss));
             RC(joined(4));
         } else {
-        if (!ln2_done)
         CH(uh::layernorm_bwd_rows(dyl, nullptr, A + al.z2, (const float*)(A + al.mean2), (const float*)(A + al.rstd2),
                                   P.ln2_g, dz2b, ddb2, T, H, d_h2, 0, st, cs));
-        ln2_done = false;
         RC(tick());
         if (!defer_wg) {                       // (deferred: dgamma / dbeta come out of the one launch at the end of the call)
         RC(fork(4));
@@ -596,8 +546,7 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
             RC(joined(par));
         }
         RC(before_overwrite(4));               // bufB is about to receive da
-        uh::RowTailReq tb1 = tail.bwd(A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1), P.ln1_g, dz1b, ddb1, d_h1);
-        CH(uh::gemm_dgrad(uh::GEMM_EPI_RES, dpre, P.w1, dz2b, dab, T, I, H, st, 0, 0, cs, tail.on && !lnf ? &tb1 : nullptr));   // da = dpre*W1 + dz2
+        CH(uh::gemm_dgrad(uh::GEMM_EPI_RES, dpre, P.w1, dz2b, dab, T, I, H, st, 0, 0, cs));           // da = dpre*W1 + dz2
         RC(tick());
         // ---- BertSelfOutput backward (model/layer.py:111-115) ----
         if (lnf) {
@@ -610,7 +559,6 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
             RC(uh::layernorm_bwd_fused_finalize(red2, nbp, P.g_ln1_g, P.g_ln1_b, H, 1, ss));
             RC(joined(5));
         } else {
-        if (!tb1.fused)
         CH(uh::layernorm_bwd_rows(dab, nullptr, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1),
                                   P.ln1_g, dz1b, ddb1, T, H, d_h1, 0, st, cs));
         RC(tick());
@@ -647,17 +595,7 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         }
         char* dxl = (l == layer_begin) ? (char*)dx : (defer_wg ? stage_of(l - 1) + sset.dy2 : bufB);
         RC(before_overwrite(5));               // bufB is about to receive this layer's dx
-        // ... followed, inside the same launch, by the row half of the LayerNorm backward of the layer below (its dy is this dx)
-        uh::RowTailReq tb2{};
-        const bool below = tail.on && l > layer_begin;
-        if (below) {
-            const UniterLayerParams& Pb = layers[l - 1];
-            char* Ab = (char*)acts + (size_t)(l - 1) * al.total;
-            tb2 = tail.bwd(Ab + al.z2, (const float*)(Ab + al.mean2), (const float*)(Ab + al.rstd2), Pb.ln2_g, stage_of(l - 1) + sset.dz2,
-                           stage_of(l - 1) + sset.dd, make_dropout(s->p_hidden, seed, offset + (uint64_t)(l - 1) * 8 + 2));
-        }
-        CH(uh::gemm_dgrad(uh::GEMM_EPI_RES, dqkv, P.wqkv, dz1b, dxl, T, 3 * H, H, st, 0, 0, cs, below ? &tb2 : nullptr));     // dx = dqkv*Wqkv + dz1
-        ln2_done = below && tb2.fused != 0;
+        CH(uh::gemm_dgrad(uh::GEMM_EPI_RES, dqkv, P.wqkv, dz1b, dxl, T, 3 * H, H, st, 0, 0, cs));     // dx = dqkv*Wqkv + dz1
         RC(tick());
         dyl = dxl;
     }
@@ -962,8 +900,6 @@ int uniter_encoder_debug_tune_in_situ(int enable) {
 // test / measurement hook: 0 = every kernel of the encoder calls in queue order (barrier between dependent kernels; the default),
 // 1 = the overlapped chains (UNITER_AMD_CHAIN=1 in the environment is the same switch)
 int uniter_encoder_debug_chain(int enable) { g_chain = enable; return 0; }
-// 1 = LayerNorms behind the GEMMs that produce their inputs (row_tail.cuh; the default), 0 = LayerNorm launches of their own
-int uniter_encoder_debug_ln_tail(int enable) { g_ln_tail = enable; return 0; }
 // the status word of the last chained call whose flags lived in `scratch`: 0 = no wait timed out.  Synchronises the device.
 int uniter_encoder_chain_status(const UniterEncoderShape* s, const void* scratch, int32_t* status_out) {
     RC(check_shape(s));

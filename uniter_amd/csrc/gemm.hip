@@ -185,7 +185,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     // units carry every contribution of that kernel; the weights and the epilogue's operands need no flag (older than the
     // producer by transitivity, see common.cuh)
     if constexpr (!TRA) chain_wait(p.chain, m0, min(BM, p.M - m0));
-    const bool wt = p.chain.signal != nullptr || (p.tail.kind != 0 && !p.tail.local);   // write-through output stores for a consumer that does not wait for a kernel boundary
+    const bool wt = p.chain.signal != nullptr;              // write-through output stores for a consumer that does not wait for a kernel boundary
 
     Stage<BM, TRA> sr;
     Stage<BN, TRB> sc;
@@ -517,12 +517,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
             }
         }
     }
-    if constexpr (!TRA && (EPI == EPI_BIAS_DROP_RES || EPI == EPI_RES)) {
-        // LayerNorm (forward after the dense + dropout + residual epilogue, backward rows after a data gradient) of this row
-        // block, shared by its column tiles (row_tail.cuh)
-        if (p.tail.kind != 0)
-            row_tail_run<WG::NCW, EPI == EPI_BIAS_DROP_RES ? 1 : 2, (EPI == EPI_RES && WS == 1) ? 2 : 3>(p.tail, p.C, p.N, m0, min(BM, p.M - m0), tn, tiles_n, t);
-    }
     if constexpr (!TRA) chain_signal(p.chain, m0, min(BM, p.M - m0));
 #ifdef UNITER_GEMM_PROBE
     if (life != nullptr && t == 0 && bx < 4096) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); life[1] = __builtin_readcyclecounter(); }
@@ -658,36 +652,6 @@ static inline void chain_bind(GemmArgs& a, int tiles_n, int splits) {
     t_chain->produced = (uint32_t)tiles_n;
 }
 
-// The LayerNorm a caller wants behind this launch (gemm_fwd / gemm_dgrad set it around launch_gemm).  Only the LDS-ring family
-// runs tails, and only when every workgroup of the grid is resident at once (`capacity`: the tiles of a row block wait for
-// each other) — otherwise `fused` stays 0 and the caller launches the LayerNorm kernel.
-thread_local uh::RowTailReq* t_tail = nullptr;
-int g_tail_local = [] { const char* e = getenv("UNITER_AMD_LN_TAIL_LOCAL"); return e ? atoi(e) : 1; }();
-int g_num_cus = 256;
-static inline void tail_bind(GemmArgs& a, int tiles_m, int tiles_n, int splits, int64_t capacity) {
-    a.tail = RowTail{};
-    uh::RowTailReq* r = t_tail;
-    if (r == nullptr) return;
-    r->fused = 0;
-    if (splits != 1 || a.partial != nullptr || a.ldc != a.N || a.N > 1024 || a.N % 8 != 0 || a.chain.signal != nullptr || a.chain.wait != nullptr) return;
-    if ((int64_t)tiles_m * tiles_n > capacity || r->count == nullptr) return;
-    a.tail.count = r->count;
-    a.tail.status = r->status;
-    a.tail.expect = *r->sum + (uint32_t)tiles_n;
-    *r->sum += (uint32_t)tiles_n;
-    a.tail.kind = r->kind;
-    a.tail.gamma = (const bf16_t*)r->gamma;
-    a.tail.beta = (const bf16_t*)r->beta;
-    a.tail.z = (const bf16_t*)r->z;
-    a.tail.out = (bf16_t*)r->out;
-    a.tail.out2 = (bf16_t*)r->out2;
-    a.tail.mean = r->mean;
-    a.tail.rstd = r->rstd;
-    a.tail.eps = r->eps;
-    a.tail.drop = r->drop;
-    r->fused = 1;
-}
-
 template <bool TRA, bool TRB, int EPI>
 int launch_g8(const GemmArgs& a_in, int splits, hipStream_t st) {
     GemmArgs a = a_in;
@@ -711,7 +675,6 @@ int launch_g8(const GemmArgs& a_in, int splits, hipStream_t st) {
         attr_done = true;
     }
     chain_bind(a, tiles_n, splits);
-    tail_bind(a, tiles_m, tiles_n, splits, 0);
     uh::chain_launch(t_chain, gemm8_kernel<TRA, TRB, EPI>, dim3(tiles_m * tiles_n, splits, 1), dim3(G8_THREADS), G8_LDS_BYTES, st, a);
     UH_LAUNCH_CHECK();
     return 0;
@@ -744,7 +707,6 @@ int launch_g6(const GemmArgs& a_in, int splits, hipStream_t st) {
         attr_done = true;
     }
     chain_bind(a, tiles_n, splits);
-    tail_bind(a, tiles_m, tiles_n, splits, 0);
     uh::chain_launch(t_chain, gemm6_kernel<TRA, TRB, EPI>, dim3(tiles_m * tiles_n, splits, 1), dim3(G8_THREADS), G6_LDS_BYTES, st, a);
     UH_LAUNCH_CHECK();
     return 0;
@@ -776,20 +738,6 @@ int launch_cfg(const GemmArgs& a_in, int splits, hipStream_t st) {
     }
     dim3 grid(tiles_m * tiles_n, splits, 1);
     chain_bind(a, tiles_n, splits);
-    if constexpr (!TRA && (EPI == EPI_BIAS_DROP_RES || EPI == EPI_RES)) {
-        static int64_t capacity = -1;                       // workgroups of this kernel the chip holds at once
-        if (t_tail != nullptr && capacity < 0) {
-            int per_cu = 0;
-            UH_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_kernel<BM, BN, TRA, TRB, EPI, NSTAGE, WS>,
-                                                                      WaveGrid<BM, BN, WS>::THREADS, lds));
-            capacity = (int64_t)per_cu * g_num_cus;
-        }
-        tail_bind(a, tiles_m, tiles_n, splits, capacity);
-        if (a.tail.kind != 0 && g_tail_local && tiles_m % 8 == 0 && a.M % BM == 0) {   // whole row blocks per XCD: they meet in its L2
-            a.xr = 8;
-            a.tail.local = 1;
-        }
-    }
     uh::chain_launch(t_chain, gemm_kernel<BM, BN, TRA, TRB, EPI, NSTAGE, WS>, grid, dim3(WaveGrid<BM, BN, WS>::THREADS), lds, st, a);
     UH_LAUNCH_CHECK();
     return 0;
@@ -1022,6 +970,7 @@ bool cfg_legal(int kind, int cfg, int64_t M, int64_t N, int64_t K, int splits) {
 
 int g_force_cfg = -1;      // test / tuning hook (uniter_gemm_debug_force)
 int g_force_splits = -1;
+int g_num_cus = 256;
 
 // Cost model: a launch proceeds in rounds of (CUs x resident workgroups per CU) tiles; every round costs about one
 // tile's work (BM*BN per K step), scaled by how well the tile amortises its operand traffic (BM*BN/(BM+BN) ~ FLOP per
@@ -1101,11 +1050,9 @@ static int check_common(int64_t M, int64_t N, int64_t K) {
 
 int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void* resid, void* y, void* y2,
              int64_t M, int64_t N, int64_t K, const DropoutCfg& drop, hipStream_t st, int64_t ldx, int64_t ldy, int relu,
-             ChainStep* chain, RowTailReq* tail) {
-    if (tail != nullptr) tail->fused = 0;
+             ChainStep* chain) {
     if (check_common(M, N, K)) return -1;
     struct Bind { explicit Bind(ChainStep* c) { t_chain = c; } ~Bind() { t_chain = nullptr; } } bind(chain);
-    struct BindT { explicit BindT(RowTailReq* r) { t_tail = r; } ~BindT() { t_tail = nullptr; } } bind_tail(epi == GEMM_EPI_BIAS_DROP_RES ? tail : nullptr);
     if (ldx == 0) ldx = K;
     if (ldy == 0) ldy = N;
     if (ldx < K || ldy < N || ldx % 8 != 0 || ldy % 8 != 0) { uh_set_error("gemm_fwd: bad leading dimension"); return -1; }
@@ -1136,11 +1083,9 @@ int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void
 
 // dx[M,K] = dy[M,N] * w[N,K]  -> output dims (M, K), contraction N
 int gemm_dgrad(int epi, const void* dy, const void* w, const void* aux, void* dx,
-               int64_t M, int64_t N, int64_t K, hipStream_t st, int64_t lddy, int act, ChainStep* chain, RowTailReq* tail) {
-    if (tail != nullptr) tail->fused = 0;
+               int64_t M, int64_t N, int64_t K, hipStream_t st, int64_t lddy, int act, ChainStep* chain) {
     if (check_common(M, N, K)) return -1;
     struct Bind { explicit Bind(ChainStep* c) { t_chain = c; } ~Bind() { t_chain = nullptr; } } bind(chain);
-    struct BindT { explicit BindT(RowTailReq* r) { t_tail = r; } ~BindT() { t_tail = nullptr; } } bind_tail(epi == GEMM_EPI_RES ? tail : nullptr);
     if (K % 64 != 0 || N % 8 != 0) { uh_set_error("gemm_dgrad: need K %% 64 == 0 and N %% 8 == 0"); return -1; }
     if (lddy == 0) lddy = N;
     if (lddy < N || lddy % 8 != 0) { uh_set_error("gemm_dgrad: bad leading dimension"); return -1; }

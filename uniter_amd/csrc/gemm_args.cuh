@@ -1,7 +1,6 @@
 // gemm_args.cuh — argument block and epilogue kinds shared by the GEMM tile families (gemm.hip, gemm8.cuh).
 #pragma once
 #include "common.cuh"
-#include "row_tail.cuh"
 
 namespace {
 
@@ -35,7 +34,6 @@ struct GemmArgs {
 #endif
     DropoutCfg drop;
     ChainLink chain;      // overlapped kernel chain (common.cuh): wait for the M-side rows' producer, signal the output rows
-    RowTail tail;         // LayerNorm of the output rows behind the tiles of a row block (row_tail.cuh; kind 0 = none)
 };
 
 // bijective XCD-aware block remap (cdna_hip_programming.md T1): consecutive hardware block ids go to

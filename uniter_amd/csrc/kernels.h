@@ -48,27 +48,12 @@ struct LaunchTimer {
 bool params_pending();      // segments of an asynchronous optimizer step are outstanding on this device
 
 // ---- gemm.hip ----
-// A LayerNorm the caller wants done behind a GEMM, by the tiles of each row block (row_tail.cuh): kind 1 = forward of the
-// launch's output (dense + dropout + residual epilogue), kind 2 = row half of the backward with the launch's output as dy.
-// The launcher sets `fused` when the kernel it picked runs the tail; when it stays 0 the caller launches the LayerNorm itself.
-// count: one zeroed word per 32 rows for the whole encoder call, *sum: contributions per word so far (advanced by the launcher).
-struct RowTailReq {
-    int kind;
-    const void* gamma; const void* beta; const void* z;
-    void* out; void* out2;
-    float* mean; float* rstd;
-    float eps;
-    DropoutCfg drop;
-    uint32_t* count; uint32_t* status; uint32_t* sum;
-    int fused;
-};
 enum { GEMM_EPI_BIAS = 0, GEMM_EPI_BIAS_GELU = 1, GEMM_EPI_BIAS_DROP_RES = 2, GEMM_EPI_RES = 3, GEMM_EPI_GELU_BWD = 4 };
 int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void* resid, void* y, void* y2,
              int64_t M, int64_t N, int64_t K, const DropoutCfg& drop, hipStream_t st, int64_t ldx = 0, int64_t ldy = 0,
-             int relu = 0, ChainStep* chain = nullptr, RowTailReq* tail = nullptr);
+             int relu = 0, ChainStep* chain = nullptr);
 int gemm_dgrad(int epi, const void* dy, const void* w, const void* aux, void* dx,
-               int64_t M, int64_t N, int64_t K, hipStream_t st, int64_t lddy = 0, int act = 0, ChainStep* chain = nullptr,
-               RowTailReq* tail = nullptr);
+               int64_t M, int64_t N, int64_t K, hipStream_t st, int64_t lddy = 0, int act = 0, ChainStep* chain = nullptr);
 // up to four forward / data-gradient problems over the same rows in one launch; 1 = no grouped tile fits (nothing was launched)
 int gemm_fwd_group(int n, const void* const* x, const int64_t* ldx, const void* const* w, const void* const* bias, void* const* y,
                    const int64_t* ldy, int64_t M, const int64_t* N, int64_t K, hipStream_t st);

@@ -169,8 +169,68 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const bf16_t* __restri
     }
     const bool use_drop = drop.p > 0.f && !post_drop;
     const bool use_post = drop.p > 0.f && post_drop;
-    for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4)
-        ln_bwd_rows_batch<NC, 1>(dy, dy_extra, z, mean_in, rstd_in, gv, dz, dd, row, 0, 1, H, use_drop, use_post, drop, lane, wt);
+    for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4) {
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        const int64_t ro = (int64_t)row * H;
+        float xh[NC][4], gy[NC][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                float zv[4], dv[4];
+                unpack4(*reinterpret_cast<const u32x2*>(z + ro + ch * 4), zv);
+                unpack4(*reinterpret_cast<const u32x2*>(dy + ro + ch * 4), dv);
+                if (dy_extra != nullptr) {
+                    float ev[4];
+                    unpack4(*reinterpret_cast<const u32x2*>(dy_extra + ro + ch * 4), ev);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dv[e] += ev[e];
+                }
+                if (use_post) {
+                    float mult[4];
+                    dropout_mult4(drop, ((uint64_t)row * (uint64_t)H + (uint64_t)ch * 4) >> 2, mult);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dv[e] *= mult[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[c][e] = (zv[e] - mean) * rstd;
+                    gy[c][e] = dv[e] * gv[c][e];
+                    s1 += gy[c][e];
+                    s2 += gy[c][e] * xh[c][e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { xh[c][e] = 0.f; gy[c][e] = 0.f; }
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)H;
+        const float c2 = wave_sum(s2) / (float)H;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rstd * (gy[c][e] - c1 - xh[c][e] * c2);
+                const u32x2 packed = pack4(o);
+                out_store8c(dz + ro + ch * 4, packed, wt);
+                if (dd != nullptr) {            // dd = dropout-masked dz (a plain copy when there is no dropout)
+                    u32x2 dpk = packed;
+                    if (use_drop) {
+                        float oq[4], mult[4];
+                        unpack4(packed, oq);
+                        dropout_mult4(drop, ((uint64_t)row * (uint64_t)H + (uint64_t)ch * 4) >> 2, mult);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) oq[e] *= mult[e];
+                        dpk = pack4(oq);
+                    }
+                    out_store8c(dd + ro + ch * 4, dpk, wt);
+                }
+            }
+        }
+    }
     chain_signal(chain, blockIdx.x * 4, 4);
 }
 
