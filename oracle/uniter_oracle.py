@@ -149,19 +149,24 @@ def _head_transform(sd, prefix, x):
                       sd[prefix + '2.weight'], sd[prefix + '2.bias'])
 
 
+def mlm_head_loss(sd, cfg, h, labels, ignore_index=-100):
+    """model/layer.py:188-222 BertOnlyMLMHead (transform, decoder tied to word_embeddings, bias) + the cross entropy of
+    model/pretrain.py:129-133, un-reduced, over rows `h` [n, H]."""
+    t = 'cls.predictions.transform.'
+    act = ACT2FN[cfg.get('hidden_act', 'gelu')]                                     # model/layer.py:192-195
+    h = layer_norm(act(linear(h, sd[t + 'dense.weight'], sd[t + 'dense.bias'])),
+                   sd[t + 'LayerNorm.weight'], sd[t + 'LayerNorm.bias'])
+    scores = linear(h, sd['uniter.embeddings.word_embeddings.weight']) + sd['cls.predictions.bias']
+    return F.cross_entropy(scores, labels, ignore_index=ignore_index, reduction='none')
+
+
 def mlm_loss(sd, cfg, batch):
     """model/pretrain.py:107-127 forward_mlm + model/layer.py:188-222 (decoder tied to word_embeddings)."""
     seq = uniter_model(sd, cfg, batch['input_ids'], batch['position_ids'], batch['img_feat'], batch['img_pos_feat'],
                        batch['attn_masks'], batch['gather_index'])
     txt_part = seq[:, :batch['input_ids'].size(1), :]                              # :114 text positions only
     picked = batch['txt_labels'] != -1
-    h = txt_part[picked]
-    t = 'cls.predictions.transform.'
-    act = ACT2FN[cfg.get('hidden_act', 'gelu')]                                     # model/layer.py:192-195
-    h = layer_norm(act(linear(h, sd[t + 'dense.weight'], sd[t + 'dense.bias'])),
-                   sd[t + 'LayerNorm.weight'], sd[t + 'LayerNorm.bias'])
-    scores = linear(h, sd['uniter.embeddings.word_embeddings.weight']) + sd['cls.predictions.bias']
-    return F.cross_entropy(scores, batch['txt_labels'][picked], reduction='none'), seq
+    return mlm_head_loss(sd, cfg, txt_part[picked], batch['txt_labels'][picked]), seq
 
 
 def mrfr_loss(sd, cfg, batch):
@@ -173,17 +178,21 @@ def mrfr_loss(sd, cfg, batch):
     return F.mse_loss(pred, batch['feat_targets'].to(pred.dtype), reduction='none'), seq
 
 
+def region_classification_loss(sd, h, targets, kl=True, prefix='region_classifier.net.'):
+    """model/pretrain.py:36-47 RegionClassification over rows `h` [n, H] + the KL / hard-label cross entropy of :213-229, un-reduced."""
+    logits = linear(_head_transform(sd, prefix, h), sd[prefix + '3.weight'], sd[prefix + '3.bias'])
+    targets = targets.to(logits.dtype)
+    if kl:
+        return F.kl_div(F.log_softmax(logits, dim=-1), targets, reduction='none')
+    hard = torch.max(targets[:, 1:], dim=-1)[1] + 1
+    return F.cross_entropy(logits, hard, ignore_index=0, reduction='none')
+
+
 def mrc_loss(sd, cfg, batch, kl=True):
     """model/pretrain.py:201-229 forward_mrc + :36-47 RegionClassification."""
     seq = uniter_model(sd, cfg, batch['input_ids'], batch['position_ids'], batch['img_feat'], batch['img_pos_feat'],
                        batch['attn_masks'], batch['gather_index'], img_masks=batch['img_masks'])
-    h = _head_transform(sd, 'region_classifier.net.', seq[batch['img_mask_tgt'].bool()])
-    logits = linear(h, sd['region_classifier.net.3.weight'], sd['region_classifier.net.3.bias'])
-    targets = batch['label_targets'].to(logits.dtype)
-    if kl:
-        return F.kl_div(F.log_softmax(logits, dim=-1), targets, reduction='none'), seq
-    hard = torch.max(targets[:, 1:], dim=-1)[1] + 1
-    return F.cross_entropy(logits, hard, ignore_index=0, reduction='none'), seq
+    return region_classification_loss(sd, seq[batch['img_mask_tgt'].bool()], batch['label_targets'], kl), seq
 
 
 def itm_loss(sd, cfg, batch):
@@ -296,6 +305,14 @@ def _mha(sd, prefix, query, key, value, key_padding_mask, num_heads):
     return linear(out, sd[prefix + 'out_proj.weight'], sd[prefix + 'out_proj.bias'])
 
 
+def attention_pool(sd, x, mask, prefix='attn_pool.'):
+    """model/nlvr2.py:110-125 AttentionPool (dropout off): Linear(H,1) + ReLU scores, -1e4 at padded positions, softmax over
+    the sequence, weighted sum.  x [B, L, H], mask [B, L] (True = padded) -> [B, H]."""
+    score = torch.relu(linear(x, sd[prefix + 'fc.0.weight'], sd[prefix + 'fc.0.bias'])).squeeze(-1)
+    score = score + mask.to(x.dtype) * -1e4
+    return torch.softmax(score, dim=1).unsqueeze(1).matmul(x).squeeze(1)
+
+
 def nlvr2_paired_attn_loss(sd, cfg, batch, taps=None):
     """model/nlvr2.py:163-204 UniterForNlvr2PairedAttn.forward + :110-125 AttentionPool (dropout off).
     `taps` (a dict, tests only) receives the attention pool's inputs and outputs: 'pool_in' [left, right], 'pool_pad', 'pooled'."""
@@ -316,12 +333,7 @@ def nlvr2_paired_attn_loss(sd, cfg, batch, taps=None):
     left = fc(torch.cat([l2r, left], dim=-1)).transpose(0, 1)
     right = fc(torch.cat([r2l, right], dim=-1)).transpose(0, 1)
 
-    def pool(x, mask):
-        score = torch.relu(linear(x, sd['attn_pool.fc.0.weight'], sd['attn_pool.fc.0.bias'])).squeeze(-1)
-        score = score + mask.to(x.dtype) * -1e4
-        return torch.softmax(score, dim=1).unsqueeze(1).matmul(x).squeeze(1)
-
-    pooled = torch.cat([pool(left, lpad), pool(right, rpad)], dim=-1)
+    pooled = torch.cat([attention_pool(sd, left, lpad), attention_pool(sd, right, rpad)], dim=-1)
     if taps is not None:
         taps.update(pool_in=[left, right], pool_pad=[lpad, rpad], pooled=pooled)
     scores = linear(pooled, sd['nlvr2_output.weight'], sd['nlvr2_output.bias'])

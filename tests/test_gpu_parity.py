@@ -1074,7 +1074,7 @@ def test_packed_attention_kernel_matches_dense_masked():
 
 @pytest.mark.parametrize("L", [96, 400])
 def test_attention_pool_kernel_vs_torch_fp32(L):
-    """uniter_attn_pool_{fwd,bwd} (model/nlvr2.py:110-125) against the same formula in torch fp32 on the bf16 inputs."""
+    """uniter_attn_pool_{fwd,bwd} (model/nlvr2.py:110-125) against oracle.attention_pool in fp32 on the bf16 inputs."""
     from uniter_amd import ops
     dev = _dev()
     B, H = 6, 768
@@ -1096,8 +1096,7 @@ def test_attention_pool_kernel_vs_torch_fp32(L):
     xr = x.detach().float().requires_grad_(True)
     wr = lin.weight.detach().float().requires_grad_(True)
     br = lin.bias.detach().float().requires_grad_(True)
-    score = torch.relu(xr @ wr.t() + br).squeeze(-1) + pad.float() * -1e4
-    ref = (torch.softmax(score, dim=1).unsqueeze(1) @ xr).squeeze(1)
+    ref = O.attention_pool({'attn_pool.fc.0.weight': wr, 'attn_pool.fc.0.bias': br}, xr, pad)     # (the pool oracle.nlvr2_paired_attn_loss uses)
     (ref * w_out).sum().backward()
     torch.testing.assert_close(got[0], ref.detach().cpu(), rtol=1e-2, atol=1e-2)
     assert rel_l2(got[1], xr.grad.cpu()) <= 1e-2 and cosine(got[1], xr.grad.cpu()) >= 0.9999
@@ -1144,14 +1143,13 @@ def test_mlm_head_fused_vs_torch_fp32():
               emb, pr.bias]
     got = [loss.detach().cpu(), x.grad.float().cpu()] + [p.grad.float().cpu() for p in params]
 
-    # fp32 reference on the same (bf16-valued) parameters
+    # the oracle's head (oracle.mlm_head_loss, the function oracle.mlm_loss is built on) in fp32 on the same bf16-valued parameters
     xr = x.detach().float().requires_grad_(True)
     pf = [p.detach().float().requires_grad_(True) for p in params]
-    h = xr @ pf[0].t() + pf[1]
-    h = h * 0.5 * (1.0 + torch.erf(h / 2.0 ** 0.5))
-    h = torch.nn.functional.layer_norm(h, (H,), pf[2], pf[3], eps=1e-12)
-    logits = h @ pf[4].t() + pf[5]
-    ref = torch.nn.functional.cross_entropy(logits, labels, ignore_index=-1, reduction='none')
+    t = 'cls.predictions.transform.'
+    sd = {t + 'dense.weight': pf[0], t + 'dense.bias': pf[1], t + 'LayerNorm.weight': pf[2], t + 'LayerNorm.bias': pf[3],
+          'uniter.embeddings.word_embeddings.weight': pf[4], 'cls.predictions.bias': pf[5]}
+    ref = O.mlm_head_loss(sd, {'hidden_act': 'gelu'}, xr, labels, ignore_index=-1)
     (ref * wrow).sum().backward()
     assert float(got[0][5]) == 0.0 and float(ref.detach()[5]) == 0.0
     torch.testing.assert_close(got[0], ref.detach().cpu(), rtol=2e-2, atol=5e-2)
@@ -1195,19 +1193,21 @@ def test_region_classification_head_fused_vs_torch_fp32(kind):
     params = list(head.parameters())
     got = [loss.detach().cpu(), x.grad.float().cpu()] + [p.grad.float().cpu() for p in params]
 
+    # the oracle's head (oracle.region_classification_loss, the function oracle.mrc_loss is built on) in fp32 on the same parameters
     xr = x.detach().float().requires_grad_(True)
-    ref_head = RegionClassification(H, V).to(dev).float()
-    ref_head.load_state_dict({k: v.float() for k, v in head.state_dict().items()})
-    scores = ref_head(xr)
+    leaf = {'region_classifier.' + k: v.detach().float().requires_grad_(True) for k, v in head.named_parameters()}
     if kind == "kl":
-        ref = torch.nn.functional.kl_div(torch.log_softmax(scores, dim=-1), soft, reduction='none')
+        ref = O.region_classification_loss(leaf, xr, soft, kl=True)
         (ref * wel).sum().backward()
     else:
-        ref = torch.nn.functional.cross_entropy(scores, hard, ignore_index=0, reduction='none')
+        onehot = torch.zeros_like(soft)
+        onehot[torch.arange(n, device=dev), hard] = 1.0              # (the oracle derives the hard label from the soft one: argmax over classes 1..)
+        ref = O.region_classification_loss(leaf, xr, onehot, kl=False)
         (ref * wel[:, 0]).sum().backward()
     torch.testing.assert_close(got[0], ref.detach().cpu(), rtol=3e-2, atol=(2e-3 if kind == "kl" else 5e-2))
     assert rel_l2(got[1], xr.grad.cpu()) <= 3e-2 and cosine(got[1], xr.grad.cpu()) >= 0.999, rel_l2(got[1], xr.grad.cpu())
-    for (name, _), a, b in zip(head.named_parameters(), got[2:], [p.grad.cpu() for p in ref_head.parameters()]):
+    for (name, _), a in zip(head.named_parameters(), got[2:]):
+        b = leaf['region_classifier.' + name].grad.cpu()
         assert rel_l2(a, b) <= 4e-2 and cosine(a, b) >= 0.999, (name, rel_l2(a, b), cosine(a, b))
 
 
