@@ -119,7 +119,8 @@ class StepRunner(object):
             # layers it is 324 (1.3 rounds) and the one-rank RCCL step measures 5.49 ms against 5.26
             reducer_layers_per_bucket = int(os.environ.get("UNITER_AMD_LAYERS_PER_BUCKET", "4"))
         self.reducer = (D.GradientReducer(self.arena, self.model.uniter.encoder, layers_per_bucket=reducer_layers_per_bucket,
-                                          word_embeddings=self.model.uniter.embeddings.word_embeddings.weight)
+                                          word_embeddings=self.model.uniter.embeddings.word_embeddings.weight,
+                                          word_ids_cap=int(w['batch']) * int(w['max_txt_len']))     # (every rank's text is padded to at most this)
                         if (world > 1 or D._on()) else None)
         self.model.uniter.pack_padding = bool(pack)
         # each rank trains on its own shard (data/data.py:222): different synthetic batches per rank, resident in HBM

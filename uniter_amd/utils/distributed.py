@@ -250,8 +250,9 @@ class GradientReducer(object):
     the tokens in its batch (all-gather of ids and rows, <= B*Lt x H per rank instead of a vocab x H allreduce).
     """
 
-    def __init__(self, arena, encoder=None, layers_per_bucket=3, word_embeddings=None):
+    def __init__(self, arena, encoder=None, layers_per_bucket=3, word_embeddings=None, word_ids_cap=None):
         self.arena = arena
+        self.word_ids_cap = word_ids_cap      # most word ids (batch x padded text length) any rank hands to finish(); None: agreed per step
         self.encoder = encoder
         self.buckets = []          # (lo, hi) element ranges
         self.layer_bucket = {}
@@ -348,7 +349,17 @@ class GradientReducer(object):
         lo, hi, V, H = self.word_span
         g = self.arena.grad[lo:hi].view(V, H)
         ids = word_ids.reshape(-1).to(g.device, torch.int64)
-        n = ids.numel()
+        # ranks pad their text to their own batch's longest sentence: agree on one length (the configured cap, or the largest of
+        # this step — one scalar max-allreduce and a host read) and fill up with id 0, whose extra copies are duplicates below
+        n = self.word_ids_cap
+        if n is None:
+            nmax = torch.tensor([ids.numel()], dtype=torch.int64, device=g.device)
+            dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
+            n = int(nmax.item())
+        if ids.numel() > n:
+            raise ValueError("GradientReducer: %d word ids in this step exceed word_ids_cap=%d" % (ids.numel(), n))
+        if ids.numel() < n:
+            ids = torch.cat([ids, ids.new_zeros(n - ids.numel())])
         # first occurrence of every id in this rank's batch (the others contribute a zero row): sort, compare neighbours
         sid, order = torch.sort(ids, stable=True)
         first = torch.ones(n, dtype=torch.bool, device=g.device)
