@@ -230,7 +230,8 @@ class StepRunner(object):
                 _l.join_wgrads()                                      # the backward segment ends when every weight gradient is written
                 e2.record()
                 seg.append((e0, e1, e2))
-        # (every task but MLM reaches the word-embedding table only through the input lookup: its gradient is exchanged as rows)
+        # (every task but MLM reaches the word-embedding table only through the input lookup: its gradient is exchanged as rows;
+        #  the micro-batches of a step are the same resident batch here, so its ids are all the ids of the step)
         scale = self.reducer.finish(word_ids=None if task == 'mlm' else batch['input_ids']) if self.reducer is not None else 1.0
         clip_grad_norm_(self.optimizer, self.opts.grad_norm, grad_scale=scale)
         self.optimizer.step()

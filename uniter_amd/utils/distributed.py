@@ -422,7 +422,9 @@ class GradientReducer(object):
 
     def finish(self, word_ids=None):
         """Reduce what is left (non-encoder parameters), wait for every bucket, return the averaging factor.
-        word_ids: the step's input_ids when the word-embedding gradient is non-zero only in those rows (see the class docstring)."""
+        word_ids: EVERY input id that contributed to the gradients since they were last zeroed (under gradient accumulation: the
+        micro-batches' input_ids concatenated), when the word-embedding gradient is non-zero only in those rows (see the class
+        docstring); rows of ids that are not listed would keep this rank's local value."""
         # rows instead of the dense table from 4 ranks up (UNITER_AMD_DP_SPARSE_WORD=1 / 0 forces it): the exchange costs ~0.2 ms
         # of small kernels on the communication stream (measured on one rank) against the ~0.26 ms a 44.5 MB ring allreduce is
         # modelled to take at 8 ranks — a wash below that, and unmeasured on real links (DESIGN section 5)
