@@ -277,12 +277,12 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const AttnArgs p) {
 // pair (dS) as [query][key] panels of 64 keys in the operand tile layout; the key-tile owners then read their operands with
 // the same transposing loads that fetch Q^T and dO^T.  dK / dV see exactly the P~ / dS that dQ saw.
 //
-// Row term D[q] of the softmax backward (round 4).  dS = P (dP - D) with D = sum_k P~[q][k] dP~[q][k] = dO[q] . O[q]: the
-// prologue can only form the dot product from the STORED bf16 O, and where the softmax is nearly uniform dP - D is a small
-// difference in which the 2^-9 rounding of O shows up amplified (top layers of a 24-layer model: query / key gradients at
-// 3x the error of unfused bf16 ops).  The query-tile owner has the whole key row of its queries in registers, so it sums
-// P~ dP~ itself in fp32 while it computes dS against the approximate D0 (which keeps dP - D0 small, i.e. exactly representable
-// work for the packed bf16 it is parked in), then shifts its dS by P (D - D0) / 8 before anything consumes it.
+// Row term D[q] of the softmax backward (round 4).  dS = P (dP - D) with D = sum_k P~[q][k] dP~[q][k] (= dO[q] . O[q] in exact
+// arithmetic).  Flash-style kernels take the dot product from the STORED bf16 O; where the softmax is nearly uniform dP - D is a
+// small difference in which the 2^-9 rounding of O shows up amplified (top layers of a 24-layer model: query / key gradients at
+// 3x the error of unfused bf16 ops).  The query-tile owner has the whole key row of its queries in registers, so it keeps P and
+// dP~ of all its key tiles in fp32, sums P~ dP~ exactly as torch's softmax backward does, and forms dS once, from unrounded
+// operands, after the row sum is known — O is not read at all.
 // NKT = key tiles a query row can have (6: L <= 96, the two-unit workgroup; 8: L <= 128).
 template <int HP, int NKT>
 __global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_share_kernel(const AttnArgs p) {
@@ -314,20 +314,18 @@ __global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_share_kernel(con
     const int L = p.cu ? (p.cu[b + 1] - p.cu[b]) : Lm;         // real rows of this example
     const bf16_t* base = p.qkv + row0 * ld + h * DH;
     const bf16_t* dO = p.dctx + row0 * H + h * DH;
-    const bf16_t* O = p.ctx + row0 * H + h * DH;
     unsigned long long* stamp = ((ATTN_DBG(p) & 8) && live) ? reinterpret_cast<unsigned long long*>(p.dsum) + ((size_t)bh * 8 + (tid >> 6)) * 8 : nullptr;
     if (stamp && (tid & 63) == 0) stamp[0] = __builtin_readcyclecounter();
     attn_chain_wait<HP>(p);
     const bool wt = p.chain.signal != nullptr;
 
     if (live) {
-        // prologue: Q, K, V, dO, O, the mask and lse all leave in one burst, then go to LDS (see tile_fetch)
-        u32x4 rq[TILE_IT], rk[TILE_IT], rv[TILE_IT], rdo[TILE_IT], ro[TILE_IT];
+        // prologue: Q, K, V, dO, the mask and lse all leave in one burst, then go to LDS (see tile_fetch)
+        u32x4 rq[TILE_IT], rk[TILE_IT], rv[TILE_IT], rdo[TILE_IT];
         tile_fetch(rq, base, ld, L, Lp, tid, nthr);
         tile_fetch(rk, base + H, ld, L, Lp, tid, nthr);
         tile_fetch(rv, base + 2 * H, ld, L, Lp, tid, nthr);
         tile_fetch(rdo, dO, H, L, Lp, tid, nthr);
-        tile_fetch(ro, O, H, L, Lp, tid, nthr);
         float mbv[2], lsv[2];
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -344,23 +342,6 @@ __global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_share_kernel(con
             const int k = tid + it * nthr;
             if (k < Lp) { mb[k] = mbv[it]; lse_s[k] = lsv[it]; }
         }
-        // D[q] = sum_d dO[q][d] * O[q][d]   (rows >= L were fetched as zeros; whole waves are in or out of range)
-#pragma unroll
-        for (int it = 0; it < TILE_IT; ++it) {
-            const int idx = tid + it * nthr;
-            if (idx < Lp * 8) {
-                float a[8], o[8];
-                unpack8(rdo[it], a);
-                unpack8(ro[it], o);
-                float part = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) part += a[e] * o[e];
-                part += __shfl_xor(part, 1, WAVE);
-                part += __shfl_xor(part, 2, WAVE);
-                part += __shfl_xor(part, 4, WAVE);
-                if ((idx & 7) == 0) D_s[idx >> 3] = part;
-            }
-        }
     }
     if (stamp && (tid & 63) == 0) stamp[1] = __builtin_readcyclecounter();
     __syncthreads();
@@ -374,16 +355,17 @@ __global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_share_kernel(con
     const bool owner = live && wid < nt;
 
     // ---- query-tile owners: P~, dS (kept in registers) and dQ ----
-    u32x2 ppk[NKT], dspk[NKT], prk[NKT];   // this wave's query rows x key tile kt: lane holds keys kt*16 + 4g .. + 3 of query i
+    u32x2 ppk[NKT], dspk[NKT];             // this wave's query rows x key tile kt: lane holds keys kt*16 + 4g .. + 3 of query i
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) { ppk[kt] = u32x2{0u, 0u}; dspk[kt] = u32x2{0u, 0u}; prk[kt] = u32x2{0u, 0u}; }
+    for (int kt = 0; kt < NKT; ++kt) { ppk[kt] = u32x2{0u, 0u}; dspk[kt] = u32x2{0u, 0u}; }
     if (owner) {
         const int q = wid * 16 + i;
         const bf16x8 qf0 = at_frag(Qs, q, 0, g), qf1 = at_frag(Qs, q, 1, g);
         const bf16x8 of0 = at_frag(Os, q, 0, g), of1 = at_frag(Os, q, 1, g);
-        const float lse_q = lse_s[q], D0 = D_s[q];
+        const float lse_q = lse_s[q];
         const uint64_t drow = ((uint64_t)bh * (uint64_t)Lm + (uint64_t)q) * (uint64_t)pair_stride(Lm);
         float dacc = 0.f;                  // sum over this lane's keys of P~ dP~ (fp32, unrounded operands)
+        f32x4 pvf[NKT], dpm[NKT];          // P and the dropout-scaled dP of every key tile, until the row sum is known
 #pragma unroll
         for (int u = 0; u < NKT / 2; ++u) {
             if (u < npair) {
@@ -399,26 +381,23 @@ __global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_share_kernel(con
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag(Vs, kt * 16 + i, 1, g), of1, dp, 0, 0, 0);
                     const f32x4 mv = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
                     const uint32_t keep = (keep8 >> (4 * hf)) & 0xfu;
-                    float pd[4], pv[4], ds0[4];
+                    float pd[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float mult = drop ? (((keep >> r) & 1u) ? p.drop.scale : 0.f) : 1.f;
                         const float pr = __expf(s[r] * 0.125f + mv[r] - lse_q);
-                        pv[r] = pr;
+                        pvf[kt][r] = pr;
+                        dpm[kt][r] = dp[r] * mult;
                         pd[r] = pr * mult;
                         dacc = fmaf(pd[r], dp[r], dacc);
-                        ds0[r] = pr * (dp[r] * mult - D0) * 0.125f;
                     }
                     ppk[kt] = pack4(pd);
-                    dspk[kt] = pack4(ds0);
-                    prk[kt] = drop ? pack4(pv) : ppk[kt];
                 }
             }
         }
-        // the exact row term: the other three lane groups hold the rest of query i's keys
+        // the row term: the other three lane groups hold the rest of query i's keys
         dacc += __shfl_xor(dacc, 16, WAVE);
         dacc += __shfl_xor(dacc, 32, WAVE);
-        const float shift = (dacc - D0) * 0.125f;
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -428,11 +407,9 @@ __global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_share_kernel(con
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const int kt = 2 * u + hf;
-                    float a[4], b[4];
-                    unpack4(dspk[kt], a);
-                    unpack4(prk[kt], b);
+                    float a[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a[r] = fmaf(-shift, b[r], a[r]);
+                    for (int r = 0; r < 4; ++r) a[r] = pvf[kt][r] * (dpm[kt][r] - dacc) * 0.125f;
                     dspk[kt] = pack4(a);
                 }
                 u32x4 w;
