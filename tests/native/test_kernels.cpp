@@ -713,42 +713,6 @@ static void test_adamw() {
     UHCHK(uniter_adamw_plan_destroy(plan));
 }
 
-// --splitk T H I: the GEMMs of a layer whose output is only H wide (one tile per CU at UNITER sizes) with the contraction in one
-// launch-wide slice or as two slices combined inside the launch, every LDS-ring tile, alone
-static void bench_splitk(int64_t T, int H, int I) {
-    Timer tm;
-    HostBf X, W, Bv;
-    X.fill((size_t)T * I, 1.f); W.fill((size_t)I * H * 3, 0.05f); Bv.fill(I, 0.1f);
-    uint16_t *dX = upload(X), *dW = upload(W), *dB = upload(Bv);
-    uint16_t* dY = dalloc<uint16_t>((size_t)T * I);
-    uint16_t* dR = dalloc<uint16_t>((size_t)T * I);
-    struct Shape { const char* name; int kind; int64_t M, N, K; } shapes[] = {
-        {"ffn2 fwd  (drop+res)", 0, T, H, I}, {"out  fwd  (drop+res)", 0, T, H, H}, {"ffn1 dgrad (+res)   ", 1, T, I, H},
-        {"qkv  dgrad (+res)   ", 1, T, 3 * (int64_t)H, H}, {"out  dgrad          ", 1, T, H, H}};
-    for (auto& s : shapes) {
-        double best[3] = {1e30, 1e30, 1e30};
-        int bestc[3] = {-1, -1, -1};
-        for (int cfg = 0; cfg < kTileG8; ++cfg) {
-            const int bn = kTileBN[cfg];
-            const int64_t out_n = s.kind == 0 ? s.N : s.K;
-            if (out_n % bn != 0 || (s.kind == 1 && !(bn == 64 || bn == 128 || bn == 192))) continue;
-            printf("  %s cfg%2d %3dx%3d", s.name, cfg, kTileBM[cfg], bn);
-            for (int sp = 1; sp <= 2; ++sp) {
-                uniter_gemm_debug_force(cfg, sp);
-                double t = 1e30;
-                for (int rep = 0; rep < 2; ++rep)
-                    t = std::min(t, s.kind == 0 ? tm.run([&] { UHCHK(uniter_gemm_bias_dropout_residual_fwd(dX, dW, dB, dR, dY, s.M, s.N, s.K, 0.1f, 1, 2, 0)); })
-                                                : tm.run([&] { UHCHK(uniter_gemm_dgrad(dX, dW, dR, dY, s.M, s.N, s.K, 0)); }));
-                printf("  | %d slice%s %6.1f us", sp, sp == 1 ? " " : "s", t);
-                if (t < best[sp]) { best[sp] = t; bestc[sp] = cfg; }
-            }
-            printf("\n");
-        }
-        printf("  %s BEST one slice cfg%d %.1f us | two slices cfg%d %.1f us\n", s.name, bestc[1], best[1], bestc[2], best[2]);
-    }
-    uniter_gemm_debug_force(-1, -1);
-}
-
 // ---------------------------------------------------------------------------------------------
 // benchmark: kernels at the UNITER-base 60+36 / batch-32 shapes, and the whole 12-layer encoder
 // ---------------------------------------------------------------------------------------------
@@ -1604,12 +1568,6 @@ int main(int argc, char** argv) {
     signal(SIGSEGV, on_segv);
     bool do_bench = false, quick = false;
     for (int i = 1; i < argc; ++i) {
-        if (!strcmp(argv[i], "--splitk")) {
-            const long long T = i + 1 < argc ? atoll(argv[i + 1]) : 3072;
-            const int H = i + 2 < argc ? atoi(argv[i + 2]) : 768, I = i + 3 < argc ? atoi(argv[i + 3]) : 3072;
-            bench_splitk(T, H, I);
-            return 0;
-        }
         if (!strcmp(argv[i], "--bench")) do_bench = true;
         if (!strcmp(argv[i], "--quick")) quick = true;
         if (!strcmp(argv[i], "--enc")) {
@@ -1653,12 +1611,6 @@ int main(int argc, char** argv) {
         if (kTileBN[cfg] == 192) test_gemm(320, 384, 384, cfg, 1);
     // the eight-phase 256x256 tile: partial last row tile, odd / even K tile counts, one K tile, one and two slices (in-launch
     // combination) and four (fp32 partials + reduce kernel)
-    // two K slices combined inside the launch, forward (contraction K) and data-gradient (contraction N) layouts of every LDS-ring tile
-    for (int cfg = 0; cfg < kTileG8; ++cfg) {
-        if (quick && cfg % 7 != 3) continue;
-        test_gemm(384, 384, 1024, cfg, 2);
-        test_gemm(384, 1024, 384, cfg, 2);
-    }
     test_gemm(640, 512, 256, kTileG8, 1);
     test_gemm(640, 512, 256, kTileG8, 2);
     test_gemm(576, 256, 512, kTileG8, 2);

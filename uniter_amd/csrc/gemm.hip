@@ -288,7 +288,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
             }
         }
         if constexpr (HAS_AUX) {
-            const bf16_t* abase = (EPI == EPI_WGRAD) ? (p.accumulate && p.partial == nullptr ? p.C : nullptr) : ((p.partial == nullptr || p.pair != nullptr) ? p.aux : nullptr);
+            const bf16_t* abase = (EPI == EPI_WGRAD) ? (p.accumulate && p.partial == nullptr ? p.C : nullptr) : (p.partial == nullptr ? p.aux : nullptr);
             const int64_t ald = (EPI == EPI_WGRAD) ? p.ldc : p.ldaux;
 #pragma unroll
             for (int b = 0; b < MI; ++b)
@@ -395,60 +395,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         compute(0);
     }
 
-    // ---- two K slices combined inside the launch (forward / data-gradient layouts) -------------------------------------------------
-    // A [3072 x 768] output is 256 tiles of 96 x 96: ONE workgroup per CU, one MFMA wave per SIMD, nothing to overlap the
-    // LDS-read -> MFMA dependency of a K step with.  With the contraction cut in two the grid is 512 workgroups of half the K
-    // steps, two per CU.  The protocol is gemm8_tile's: whichever slice of a tile finishes first parks its accumulators in the
-    // tile's fp32 slab (thread-linear, write-through), the other adds them to its own (fp32 addition commutes: the result
-    // does not depend on the order of arrival) and runs the epilogue.  Counter: 0 -> 1 (first ticket) -> 2 (slab written) ->
-    // 3 (second ticket); the combiner leaves it at 0 for the next launch.  The first slice never waits, so no residency
-    // assumption is needed.
-    if constexpr (EPI != EPI_WGRAD && !TRA) {
-        if (p.pair != nullptr) {
-            constexpr int NTC = WG::NCW * 64;
-            unsigned* cnt = p.pair + (tm * tiles_n + tn);
-            float* slab = p.partial + (size_t)(tm * tiles_n + tn) * (size_t)(BM * BN);
-            unsigned* lds_flag = reinterpret_cast<unsigned*>(smem_raw);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                       // every wave is done reading the ring
-            if (t == 0) *lds_flag = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            const unsigned ticket = *lds_flag;
-            if (ticket == 0u) {                                 // first to finish: park and leave
-#pragma unroll
-                for (int a = 0; a < NI; ++a)
-#pragma unroll
-                    for (int b = 0; b < MI; ++b) {
-                        const u32x4 bits = __builtin_bit_cast(u32x4, acc[a][b]);
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"((gmem_u32x4*)(slab + ((size_t)(a * MI + b) * NTC + t) * 4)), "v"(bits) : "memory");
-                    }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (t == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
-            }
-            if (t == 0) {
-                // (bounded: a counter left dirty by an aborted launch must not hang the device)
-                for (int spin = 0; spin < (1 << 21) && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 3u; ++spin)
-                    __builtin_amdgcn_s_sleep(2);
-                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-#pragma unroll
-            for (int a = 0; a < NI; ++a) {
-                typedef __attribute__((address_space(1))) f32x4 gmem_f32x4;
-                f32x4 o[MI];
-#pragma unroll
-                for (int b = 0; b < MI; ++b)
-                    o[b] = __builtin_nontemporal_load((const gmem_f32x4*)(slab + ((size_t)(a * MI + b) * NTC + t) * 4));
-#pragma unroll
-                for (int b = 0; b < MI; ++b) acc[a][b] += o[b];
-            }
-        }
-    }
-
     // ---- epilogue ---------------------------------------------------------------------------------------------------
     // After the MFMAs a lane holds C[m][n..n+3], m = m0 + wm*WM + b*16 + i, n = n0 + wn*WN + a*16 + 4g: storing that
     // directly is 8 bytes per lane in 32-byte row pieces, and such stores are issue-bound (cycle stamps: 2.1-2.7 us of
@@ -468,7 +414,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
             }
         }
     }
-    if ((EPI == EPI_WGRAD || EPI == EPI_RES) && p.partial != nullptr && p.pair == nullptr) {   // split-K partials: already 16-byte fp32 stores
+    if ((EPI == EPI_WGRAD || EPI == EPI_RES) && p.partial != nullptr) {   // split-K partials: already 16-byte fp32 stores
 #pragma unroll
         for (int b = 0; b < MI; ++b) {
             const int m = m0 + wm * WM + b * 16 + i;
@@ -706,32 +652,6 @@ static inline void chain_bind(GemmArgs& a, int tiles_n, int splits) {
     t_chain->produced = (uint32_t)tiles_n;
 }
 
-// fp32 slabs of the in-launch two-slice combination of the LDS-ring tiles (forward / data-gradient layouts): one slab of
-// M x N floats per launch, four of them in rotation per device (launches of one stream run in order; the rotation keeps a
-// launch on another stream — there is none today — off the slab of the previous three).
-int g_splitk2 = [] { const char* e = getenv("UNITER_AMD_SPLITK2"); return e ? atoi(e) : 1; }();
-float* pair_slab(size_t floats) {
-    static std::mutex mu;
-    static float* base[16][4] = {{nullptr}};
-    static size_t cap[16][4] = {{0}};
-    static int next[16] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || floats == 0) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    const int k = next[dev];
-    next[dev] = (k + 1) & 3;
-    if (cap[dev][k] < floats) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;      // (no allocation while a graph is being recorded)
-        (void)cs;
-        if (base[dev][k] != nullptr) { (void)hipDeviceSynchronize(); (void)hipFree(base[dev][k]); base[dev][k] = nullptr; cap[dev][k] = 0; }
-        float* q = nullptr;
-        if (hipMalloc(&q, floats * sizeof(float)) != hipSuccess) return nullptr;
-        base[dev][k] = q;
-        cap[dev][k] = floats;
-    }
-    return base[dev][k];
-}
-
 template <bool TRA, bool TRB, int EPI>
 int launch_g8(const GemmArgs& a_in, int splits, hipStream_t st) {
     GemmArgs a = a_in;
@@ -815,17 +735,6 @@ int launch_cfg(const GemmArgs& a_in, int splits, hipStream_t st) {
         UH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, TRA, TRB, EPI, NSTAGE, WS>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
-    }
-    if constexpr (EPI != EPI_WGRAD && !TRA) {
-        if (splits == 2) {                                  // two K slices combined inside the launch (gemm_tile)
-            a.k_per_split = ((a.K / 2 + 63) / 64) * 64;
-            a.pair = g8_pair_counters(tiles_m * tiles_n);
-            a.partial = pair_slab((size_t)tiles_m * tiles_n * (size_t)(BM * BN));
-            if (a.pair == nullptr || a.partial == nullptr || a.k_per_split >= a.K) { uh_set_error("gemm: no workspace for the in-launch K-slice combination"); return -1; }
-        } else if (splits != 1) {
-            uh_set_error("gemm: forward / data-gradient launches take one or two K slices");
-            return -1;
-        }
     }
     dim3 grid(tiles_m * tiles_n, splits, 1);
     chain_bind(a, tiles_n, splits);
@@ -1049,13 +958,11 @@ bool cfg_legal(int kind, int cfg, int64_t M, int64_t N, int64_t K, int splits) {
     const int64_t contraction = kind == 0 ? K : (kind == 1 ? N : M);
     const int64_t out_m = kind == 2 ? N : M, out_n = kind == 0 ? N : K;
     if (t.ws >= 3) {                                        // the deep-pipelined tiles: 256 x 256 (3) and 192 x 192 (4)
-        if (kind != 2 && splits != 1) return false;
         if (out_n % t.bn != 0 || contraction % 64 != 0 || contraction < (int64_t)64 * splits) return false;
         return kind != 2 || out_m % t.bm == 0;
     }
     const bool p2m = t.bm == 64 || t.bm == 128, p2n = t.bn == 64 || t.bn == 128 || t.bn == 192;
     if (t.ws && contraction % (64 * (int64_t)splits) != 0) return false;
-    if (kind != 2 && splits != 1 && (splits != 2 || contraction % 128 != 0 || contraction < 1024)) return false;   // in-launch pair of K slices
     if (kind == 0) return N % t.bn == 0;
     if (kind == 1) return p2n && K % t.bn == 0;
     return p2m && p2n && N % t.bm == 0 && K % t.bn == 0;
@@ -1164,15 +1071,12 @@ int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void
     a.relu = relu;
     a.drop = drop;
     int cfg = pick_cfg((int)M, (int)N, false, false, K % 64 == 0);
-    int sp = 1;
     Tuned tn;
-    if (g_force_cfg < 0 && tuned_lookup(0, M, N, K, &tn)) { cfg = tn.cfg; sp = tn.splits; }
-    if (g_force_cfg >= 0 && g_force_splits > 0) sp = g_force_splits;
-    if (sp != 1 && (!g_splitk2 || chain != nullptr || ldy != N || !cfg_legal(0, cfg, M, N, K, sp))) sp = 1;
+    if (g_force_cfg < 0 && tuned_lookup(0, M, N, K, &tn)) cfg = tn.cfg;
     switch (epi) {
-        case EPI_BIAS: return launch_gemm<false, false, EPI_BIAS>(a, cfg, sp, st);
-        case EPI_BIAS_GELU: return launch_gemm<false, false, EPI_BIAS_GELU>(a, cfg, sp, st);
-        case EPI_BIAS_DROP_RES: return launch_gemm<false, false, EPI_BIAS_DROP_RES>(a, cfg, sp, st);
+        case EPI_BIAS: return launch_gemm<false, false, EPI_BIAS>(a, cfg, 1, st);
+        case EPI_BIAS_GELU: return launch_gemm<false, false, EPI_BIAS_GELU>(a, cfg, 1, st);
+        case EPI_BIAS_DROP_RES: return launch_gemm<false, false, EPI_BIAS_DROP_RES>(a, cfg, 1, st);
         default: uh_set_error("gemm_fwd: bad epilogue"); return -1;
     }
 }
@@ -1199,13 +1103,10 @@ int gemm_dgrad(int epi, const void* dy, const void* w, const void* aux, void* dx
     a.accumulate = 0;
     a.drop = make_dropout(0.f, 0, 0);
     int cfg = pick_cfg((int)M, (int)K, false, true, N % 64 == 0);
-    int sp = 1;
     Tuned tn;
-    if (g_force_cfg < 0 && tuned_lookup(1, M, N, K, &tn)) { cfg = tn.cfg; sp = tn.splits; }
-    if (g_force_cfg >= 0 && g_force_splits > 0) sp = g_force_splits;
-    if (sp != 1 && (!g_splitk2 || chain != nullptr || !cfg_legal(1, cfg, M, N, K, sp))) sp = 1;
-    if (epi == EPI_RES) return launch_gemm<false, true, EPI_RES>(a, cfg, sp, st);
-    if (epi == EPI_GELU_BWD) return launch_gemm<false, true, EPI_GELU_BWD>(a, cfg, sp, st);
+    if (g_force_cfg < 0 && tuned_lookup(1, M, N, K, &tn)) cfg = tn.cfg;
+    if (epi == EPI_RES) return launch_gemm<false, true, EPI_RES>(a, cfg, 1, st);
+    if (epi == EPI_GELU_BWD) return launch_gemm<false, true, EPI_GELU_BWD>(a, cfg, 1, st);
     uh_set_error("gemm_dgrad: bad epilogue");
     return -1;
 }
@@ -1837,7 +1738,7 @@ int gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, hipStream_t st) {
     std::vector<std::pair<float, Tuned>> ranked;
     const DropoutCfg nodrop = make_dropout(0.f, 0, 0);
     for (int cfg = 0; cfg < kNumTiles && rc == 0; ++cfg) {
-        for (int sp = 1; sp <= (kind == 2 ? 4 : (g_splitk2 ? 2 : 1)) && rc == 0; sp *= 2) {
+        for (int sp = 1; sp <= (kind == 2 ? 4 : 1) && rc == 0; sp *= 2) {
             if (!cfg_legal(kind, cfg, M, N, K, sp)) continue;
             g_force_cfg = cfg;
             g_force_splits = sp;
@@ -1898,7 +1799,7 @@ int gemm_set_tuned(int kind, int64_t M, int64_t N, int64_t K, int cfg, int split
         return 0;
     }
     if (kind < 0 || kind > 2 || cfg < 0 || cfg >= kNumTiles) { uh_set_error("gemm_set_tuned: bad kind / tile index"); return -1; }
-    if (splits < 1 || splits > 4 || (kind != 2 && splits > 2)) { uh_set_error("gemm_set_tuned: bad split count (<= 4 for wgrad, <= 2 for the other layouts)"); return -1; }
+    if (splits < 1 || splits > 4 || (kind != 2 && splits != 1)) { uh_set_error("gemm_set_tuned: bad split count (split-K is a wgrad option, <= 4)"); return -1; }
     // same legality rules as the autotune sweep
     if (!cfg_legal(kind, cfg, M, N, K, splits)) {
         uh_set_error("gemm_set_tuned: tile %d (%dx%d) is not legal for kind %d M=%lld N=%lld K=%lld", cfg, kTiles[cfg].bm, kTiles[cfg].bn, kind, (long long)M, (long long)N, (long long)K);
