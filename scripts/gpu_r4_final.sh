@@ -30,15 +30,13 @@ timeout 600 $T > "$OUT/native_harness.log" 2>&1; echo "harness rc=$?"; grep -c "
 timeout 300 $T --enc > "$OUT/native_encoder.log" 2>&1; grep -E "ENCODER|overlapped|in-order" "$OUT/native_encoder.log"
 timeout 300 $T --enc large > "$OUT/native_encoder_large96.log" 2>&1; grep "ENCODER" "$OUT/native_encoder_large96.log" | tail -1
 timeout 300 $T --enc large178 > "$OUT/native_encoder_large178.log" 2>&1; grep "ENCODER" "$OUT/native_encoder_large178.log" | tail -1
-timeout 120 aux_bin/anyorder_probe 100 6 > "$OUT/anyorder_probe.log" 2>&1; echo "probe rc=$?"
 {
   echo "# python bench.py --no-cpu-baseline --no-kernel-timing --steps 30 --warmup 5 ; UNITER_DIST_FORCE=1 = one-rank RCCL group (reducer, collectives, joins) on the one GPU of the box"
   timeout 300 python bench.py --no-cpu-baseline --no-kernel-timing --steps 30 --warmup 5 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('no process group:', d['ms_per_step'], 'ms/step', d['value'], 'ex/s')"
-  for lpb in 4 6 12; do
+  for lpb in 4 6; do
     UNITER_DIST_FORCE=1 UNITER_BENCH_LAYERS_PER_BUCKET=$lpb timeout 300 python bench.py --no-cpu-baseline --no-kernel-timing --steps 30 --warmup 5 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('one-rank RCCL group, ONE backward call + bucket flags, $lpb layers per bucket:', d['ms_per_step'], 'ms/step', d['value'], 'ex/s')"
   done
   UNITER_DIST_FORCE=1 UNITER_AMD_DP_SINGLE_LAUNCH=0 UNITER_BENCH_LAYERS_PER_BUCKET=4 timeout 300 python bench.py --no-cpu-baseline --no-kernel-timing --steps 30 --warmup 5 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('one-rank RCCL group, one backward call PER BUCKET (round 3), 4 layers per bucket:', d['ms_per_step'], 'ms/step', d['value'], 'ex/s')"
-  UNITER_DIST_FORCE=1 UNITER_AMD_DP_SPARSE_WORD=1 UNITER_BENCH_LAYERS_PER_BUCKET=4 timeout 300 python bench.py --no-cpu-baseline --no-kernel-timing --steps 30 --warmup 5 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('one-rank RCCL group, bucket flags, word-embedding gradient as rows (forced):', d['ms_per_step'], 'ms/step', d['value'], 'ex/s')"
   timeout 300 python bench.py --no-cpu-baseline --no-kernel-timing --steps 30 --warmup 5 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('no process group (again):', d['ms_per_step'], 'ms/step', d['value'], 'ex/s')"
 } > "$OUT/dp_one_rank_rccl.txt" 2>&1
 cat "$OUT/dp_one_rank_rccl.txt"
