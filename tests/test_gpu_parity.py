@@ -417,6 +417,30 @@ def test_deferred_parameter_gradients_match_per_layer_launches(full_model, monke
         g_join = grads()
     finally:
         enc.grad_ready_hook = old_hook
+    # data-parallel form of the launch: tiles walked bucket by bucket (4 layers each), a flag per bucket — same gradients (the plain
+    # walk runs its few leftover tiles as two K slices, i.e. adds their fp32 partial sums in another order), flags raised
+    import ctypes
+    from uniter_amd.utils import distributed as D
+    lib = _lib.load()
+    seen = []
+
+    def on_layer(layer):                                           # (runs on autograd's thread, whose launch this is)
+        if layer != 0:
+            return
+        nb = ctypes.c_int32(0)
+        lib.uniter_encoder_grad_bucket_count(ctypes.byref(nb))
+        seen.append(nb.value)
+        for k in range(nb.value):                                  # the stream waits for every bucket's flag: must not hang
+            lib.uniter_encoder_bucket_wait(ctypes.c_int32(k), ctypes.c_void_p(_lib.stream_ptr()))
+    try:
+        enc.grad_ready_hook = D._LayerHook(on_layer, set(), joins_side_stream=False, defer_wgrad_join=True, grad_buckets=lambda: 4)
+        g_bucket = grads()
+        assert seen == [3], seen
+    finally:
+        enc.grad_ready_hook = old_hook
+    for n in g_def:
+        r = rel_l2(g_bucket[n], g_def[n])
+        assert r < (1e-3 if n.endswith('weight') and 'LayerNorm' not in n else 4e-3), ("bucketed", n, r)
     monkeypatch.setattr(ops, "_WGRAD_STAGE", False)
     g_layer = grads()
     assert set(g_def) == set(g_layer) == set(g_join)
