@@ -430,12 +430,31 @@ def test_deferred_parameter_gradients_match_per_layer_launches(full_model, monke
         nb = ctypes.c_int32(0)
         lib.uniter_encoder_grad_bucket_count(ctypes.byref(nb))
         seen.append(nb.value)
-        for k in range(nb.value):                                  # the stream waits for every bucket's flag: must not hang
-            lib.uniter_encoder_bucket_wait(ctypes.c_int32(k), ctypes.c_void_p(_lib.stream_ptr()))
+        sp = ctypes.c_void_p()
+        lib.uniter_encoder_side_stream(ctypes.byref(sp))
+        done = torch.cuda.Event(enable_timing=True)
+        done.record(torch.cuda.ExternalStream(sp.value))           # the end of the deferred launch (it is already enqueued there)
+        raised.append(done)
+        with torch.cuda.stream(watch):                             # a stream of its own waits for every bucket's flag in turn
+            for k in range(nb.value):
+                lib.uniter_encoder_bucket_wait(ctypes.c_int32(k), ctypes.c_void_p(watch.cuda_stream))
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(watch)
+                raised.append(ev)
+    watch, raised = torch.cuda.Stream(), []
+    with torch.cuda.stream(watch):                                 # (a stream's hardware queue is set up at its first submission: not inside the measurement)
+        torch.zeros(8, device=_dev()).add_(1)
+    torch.cuda.synchronize()
     try:
         enc.grad_ready_hook = D._LayerHook(on_layer, set(), joins_side_stream=False, defer_wgrad_join=True, grad_buckets=lambda: 4)
         g_bucket = grads()
         assert seen == [3], seen
+        # the buckets complete IN ORDER, a good part of the launch apart (a bucket's LayerNorm strips run ahead of its tiles; left to
+        # the end of the launch they would hold every bucket but the first until then) — what lets an allreduce start early
+        done, flags = raised[0], raised[1:]
+        before_end = [flags[k].elapsed_time(done) * 1e3 for k in range(3)]
+        print("bucket flags of the deferred launch raised %.0f / %.0f / %.0f us before its end" % tuple(before_end))
+        assert before_end[0] > before_end[1] + 40.0 and before_end[1] > before_end[2] + 40.0, before_end
     finally:
         enc.grad_ready_hook = old_hook
     for n in g_def:

@@ -1489,11 +1489,18 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
         bk.slot_start[0] = 0;
         for (int k = 0; k < bk.nb; ++k) bk.slot_start[k + 1] = bk.slot_start[k] + (bk.tile_start[k + 1] - bk.tile_start[k] + 7) / 8;
         per_bucketed = bk.slot_start[bk.nb];
+        for (int k = 0; k <= bk.nb; ++k) bk.strip_start[k] = -1;
+        int prev_ln = 0;
         for (int j = 0; j < n_ln; ++j) {
             const int k = buckets->ln_bucket[j];
-            if (k < 0 || k >= bk.nb) { uh_set_error("gemm_wgrad_multi: LayerNorm job bucket out of range"); return -1; }
+            if (k < prev_ln || k >= bk.nb) { uh_set_error("gemm_wgrad_multi: LayerNorm job buckets must be non-decreasing and < nb"); return -1; }
+            prev_ln = k;
+            if (bk.strip_start[k] < 0) bk.strip_start[k] = j * ln_strips_per_job;
             bk.total[k] += (unsigned)ln_strips_per_job;
         }
+        bk.strip_start[bk.nb] = n_ln * ln_strips_per_job;
+        for (int k = bk.nb - 1; k >= 0; --k)
+            if (bk.strip_start[k] < 0) bk.strip_start[k] = bk.strip_start[k + 1];     // a bucket without LayerNorm jobs
         for (int k = 0; k < bk.nb; ++k) {
             if (bk.total[k] == 0) { uh_set_error("gemm_wgrad_multi: empty bucket %d", k); return -1; }
             bk.flag[k] = buckets->flag[k];
@@ -1582,7 +1589,13 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
         attr_done = true;
     }
     LaunchTimer lt(TIME_GEMM_WGRAD_GROUP, M, welems, n, st);
-    hipLaunchKernelGGL(gemm8_multi_kernel, dim3(gemm_blocks + strips + n_ln * ln_strips_per_job), dim3(G8_THREADS), G8_LDS_BYTES, st,
+    int grid_blocks = gemm_blocks + strips + n_ln * ln_strips_per_job;
+    if (buckets != nullptr) {                               // (the kernel's bucketed block order: padded strips, then tiles, per bucket)
+        grid_blocks = 0;
+        for (int k = 0; k < bk.nb; ++k)
+            grid_blocks += ((bk.strip_start[k + 1] - bk.strip_start[k] + 7) & ~7) + 8 * (bk.slot_start[k + 1] - bk.slot_start[k]);
+    }
+    hipLaunchKernelGGL(gemm8_multi_kernel, dim3(grid_blocks), dim3(G8_THREADS), G8_LDS_BYTES, st,
                        (const GemmArgs*)T.dev, (const int*)((const char*)T.dev + meta_off), n, per, full, gemm_blocks,
                        (const G8LnJob*)((const char*)T.dev + ln_off), ln_strips_per_job, strips, tail_pairs, tail_slabs, stamp_dev,
                        lead_strips, bk, lead_tiles, lead_strips2);

@@ -960,6 +960,7 @@ struct G8Buckets {
     int tile_start[G8_MAX_BUCKETS + 1];      // first tile (linear order) of every bucket
     int slot_start[G8_MAX_BUCKETS + 1];      // first slot of every bucket inside an XCD's walk (cumulative per-XCD shares)
     unsigned total[G8_MAX_BUCKETS];          // work items (tiles + LayerNorm strips) of every bucket
+    int strip_start[G8_MAX_BUCKETS + 1];     // first LayerNorm strip (job order) of every bucket: a bucket's strips run AHEAD of its tiles
     unsigned* count;                         // [nb] arrivals, left at zero by the last arrival
     unsigned* flag[G8_MAX_BUCKETS];          // signal memory, one word per bucket
     unsigned epoch;                          // value written to a completed bucket's flag
@@ -1000,7 +1001,26 @@ __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_multi_kernel(const GemmAr
     // when the small kernels of the caller's stream (the embedding backward runs beside this launch) get to run at all: nothing
     // can share a CU with a tile, and a kernel launched beside this one waits for the next turnover.
     int b = (int)blockIdx.x;
-    {
+    if (bk.nb > 0) {
+        // Bucketed launch: hardware order = for every bucket its LayerNorm strips (padded to a multiple of 8 blocks, so that a
+        // tile keeps the XCD its index implies), then its tiles — a bucket's flag can only rise when ALL its items are done, and
+        // strips left to the end of the launch (the plain order below) would hold every bucket but the first until then.  The
+        // strips ahead of a bucket's tiles also stagger the CUs, as the leading strips of the plain order do.
+        int base = 0, mapped = -1;
+        for (int k = 0; k < bk.nb && mapped < 0; ++k) {
+            const int sk = bk.strip_start[k + 1] - bk.strip_start[k], skp = (sk + 7) & ~7;
+            const int tk = 8 * (bk.slot_start[k + 1] - bk.slot_start[k]);
+            if (b < base + skp) {
+                if (b - base >= sk) return;                  // padding block
+                mapped = gemm_blocks + bias_strips + bk.strip_start[k] + (b - base);
+            } else if (b < base + skp + tk) {
+                mapped = 8 * bk.slot_start[k] + (b - base - skp);
+            }
+            base += skp + tk;
+        }
+        if (mapped < 0) return;
+        b = mapped;
+    } else {
         const int work = gemm_blocks + bias_strips;          // tiles (+ bias strips) in the logical order; LayerNorm strips follow
         const int s12 = lead_strips + lead_strips2;
         if (b < lead_tiles) { /* a leading tile: already at its index */ }
