@@ -88,3 +88,52 @@ def flatten(batch, prefix=''):
         else:
             flat[prefix + k] = np.asarray(v)
     return flat
+
+
+# ---- a small retrieval corpus behind duck-typed databases (both the reference's and this package's dataset methods only call
+#      txt_db[id], txt_db.combine_inputs, img_db[name] and img_db.name2nbb) -------------------------------------------------------
+class FakeTxtDb(object):
+    cls_, sep = CLS_ID, SEP_ID
+
+    def __init__(self, examples):
+        self.examples = examples
+
+    def __getitem__(self, id_):
+        return {k: (list(v) if isinstance(v, list) else v) for k, v in self.examples[id_].items()}
+
+    def combine_inputs(self, *inputs):
+        ids = [self.cls_]
+        for part in inputs:
+            ids.extend(list(part) + [self.sep])
+        return torch.tensor(ids)
+
+
+class FakeImgDb(object):
+    def __init__(self, names, seed):
+        r = np.random.RandomState(seed)
+        self.name2nbb = {n: int(r.randint(2, 9)) for n in names}
+        self.feats = {n: (torch.from_numpy(r.randn(self.name2nbb[n], IMG_DIM).astype(np.float32)), _boxes(r, self.name2nbb[n])) for n in names}
+
+    def __getitem__(self, name):
+        return self.feats[name]
+
+
+def retrieval_corpus(seed, n_img=7, n_txt=15):
+    r = np.random.RandomState(500 + seed)
+    names = ['im%02d' % k for k in range(n_img)]
+    examples, txt2img, img2txts = {}, {}, {}
+    for k in range(n_txt):
+        img = names[k % n_img] if k < n_img else names[int(r.randint(0, n_img))]
+        tid = 't%02d' % k
+        examples[tid] = {'input_ids': [int(t) for t in r.randint(VOCAB_RANGE[0], 2000, size=int(r.randint(1, 9)))], 'img_fname': img}
+        txt2img[tid] = img
+        img2txts.setdefault(img, []).append(tid)
+    return FakeTxtDb(examples), FakeImgDb(names, 900 + seed), list(examples.keys()), txt2img, img2txts
+
+
+def bare(cls, **attrs):
+    """An instance of a dataset class without its constructor (which opens databases), with the attributes its methods read."""
+    obj = object.__new__(cls)
+    for k, v in attrs.items():
+        setattr(obj, k, v)
+    return obj

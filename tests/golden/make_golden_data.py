@@ -88,6 +88,29 @@ def main(out_path):
             batch = collates[task](dc.example_tuples(task, seed))
             for key, arr in dc.flatten(batch).items():
                 g['collate/%s/%d/%s' % (task, seed, key)] = arr
+    # retrieval datasets over the duck-typed corpus of data_cases.retrieval_corpus
+    from collections import defaultdict
+    itm = ref['itm']
+    for seed in range(2):
+        txt_db, img_db, ids, txt2img, img2txts = dc.retrieval_corpus(seed)
+        val = dc.bare(itm.ItmValDataset, txt_db=txt_db, img_db=img_db, ids=ids, txt2img=txt2img, img2txts=img2txts,
+                      all_img_ids=list(img2txts.keys()), bs=4)
+        for i in (0, 5, len(ids) - 1):
+            for key, arr in dc.flatten(itm.itm_val_collate([val[i]])).items():
+                g['itm_val/%d/%d/%s' % (seed, i, key)] = arr
+        ev = dc.bare(itm.ItmEvalDataset, txt_db=txt_db, img_db=img_db, ids=ids, txt2img=txt2img, img2txts=img2txts, bs=3,
+                     all_img_ids=sorted(list(img2txts.keys()), key=lambda n: img_db.name2nbb[n]))
+        for m, mb in enumerate(itm.itm_eval_collate([ev[2]])):
+            for key, arr in dc.flatten(mb).items():
+                g['itm_eval/%d/%d/%s' % (seed, m, key)] = arr
+        i2t = defaultdict(list)
+        for t, im in txt2img.items():
+            i2t[im].append(t)
+        rk = dc.bare(itm.ItmRankDataset, txt_db=txt_db, img_db=img_db, ids=ids, txt2img=txt2img, img2txts=i2t,
+                     img_name_list=list(i2t.keys()), neg_sample_size=2)
+        random.seed(40 + seed)
+        for key, arr in dc.flatten(itm.itm_rank_collate([rk[i] for i in (0, 4, 9)])).items():
+            g['itm_rank/%d/%s' % (seed, key)] = arr
     np.savez_compressed(out_path, **g)
     print("wrote %s: %d arrays" % (out_path, len(g)))
 

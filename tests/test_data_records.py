@@ -81,6 +81,39 @@ def test_batch_builders_bit_exact_vs_reference(gold, task):
             assert np.array_equal(got, ref), (task, seed, key)
 
 
+def test_retrieval_datasets_bit_exact_vs_reference(gold):
+    """ItmValDataset / ItmEvalDataset / ItmRankDataset (+ their collates) over the duck-typed corpus the golden generator gave the
+    reference's classes: the same batches, the same negatives draw for draw."""
+    from uniter_amd.data import ItmEvalDataset, ItmRankDataset, ItmValDataset, itm_eval_collate, itm_rank_collate, itm_val_collate
+
+    def same(prefix, batch):
+        flat = dc.flatten(batch)
+        want = {k[len(prefix):]: gold[k] for k in gold.files if k.startswith(prefix)}
+        assert sorted(flat) == sorted(want), (prefix, sorted(set(flat) ^ set(want)))
+        for key, ref in want.items():
+            assert flat[key].dtype == ref.dtype and np.array_equal(flat[key], ref), (prefix, key)
+    for seed in range(2):
+        txt_db, img_db, ids, txt2img, img2txts = dc.retrieval_corpus(seed)
+        val = dc.bare(ItmValDataset, txt_db=txt_db, img_db=img_db, ids=ids, txt2img=txt2img, img2txts=img2txts,
+                      all_img_ids=list(img2txts.keys()), bs=4)
+        for i in (0, 5, len(ids) - 1):
+            same('itm_val/%d/%d/' % (seed, i), itm_val_collate([val[i]]))
+        ev = dc.bare(ItmEvalDataset, txt_db=txt_db, img_db=img_db, ids=ids, txt2img=txt2img, img2txts=img2txts, bs=3,
+                     all_img_ids=sorted(list(img2txts.keys()), key=lambda n: img_db.name2nbb[n]))
+        mbs = itm_eval_collate([ev[2]])
+        assert len(mbs) == 3
+        for m, mb in enumerate(mbs):
+            same('itm_eval/%d/%d/' % (seed, m), mb)
+        i2t = {}
+        for t, im in txt2img.items():
+            i2t.setdefault(im, []).append(t)
+        rk = dc.bare(ItmRankDataset, txt_db=txt_db, img_db=img_db, ids=ids, txt2img=txt2img, img2txts=i2t, img_name_list=list(i2t.keys()),
+                     neg_sample_size=2, rng=random.Random(40 + seed))
+        same('itm_rank/%d/' % seed, itm_rank_collate([rk[i] for i in (0, 4, 9)]))
+    with pytest.raises(AssertionError):
+        itm_val_collate([1, 2])
+
+
 def test_golden_recipe_regenerates_data_fixture(tmp_path):
     if not os.path.isdir('/root/reference/data'):
         pytest.skip("the reference checkout is not on this machine")
@@ -259,6 +292,11 @@ def _build_db(root, compress, n_img=9, n_txt=23, with_pack=False, precomputed_nb
     writer.close()
     json.dump(id2len, open(os.path.join(txt_dir, 'id2len.json'), 'w'))
     json.dump(txt2img, open(os.path.join(txt_dir, 'txt2img.json'), 'w'))
+    if not two_images:
+        img2txts = {}
+        for tid, fname in txt2img.items():
+            img2txts.setdefault(fname, []).append(tid)
+        json.dump(img2txts, open(os.path.join(txt_dir, 'img2txts.json'), 'w'))
     json.dump({'CLS': 1, 'SEP': 2, 'MASK': 3, 'v_range': [10, 96]}, open(os.path.join(txt_dir, 'meta.json'), 'w'))
     return txt_dir, img_dir, images, name2nbb, examples
 
@@ -377,6 +415,17 @@ def test_datasets_and_loaders_over_a_database(tmp_path):
     assert b['targets'].shape == (4, 13) and b['targets'].sum(1).tolist() == [1.0] * 4
     ev = vqa_eval_collate([VqaEvalDataset(13, txt_db, img_db)[i] for i in range(3)])
     assert ev['qids'] == ['q0', 'q1', 'q2'] and ev['targets'].shape == (3, 13)
+    # retrieval evaluation through the real constructors: one text against its image + the next three, then against all images
+    from uniter_amd.data import ItmEvalDataset, ItmValDataset, VeDataset, itm_val_collate, ve_collate
+    val = ItmValDataset(txt_db, img_db, mini_batch_size=4)
+    vb = itm_val_collate([val[5]])
+    assert vb['input_ids'].shape[0] == 4 and torch.equal(vb['input_ids'][0], vb['input_ids'][3]) and not hasattr(val, 'lens')
+    assert int(vb['attn_masks'][0].sum()) == vb['input_ids'].size(1) + name2nbb[examples['q5']['img_fname']]
+    mbs = ItmEvalDataset(txt_db, img_db, mini_batch_size=4)[5]
+    assert [m['img_feat'].size(0) for m in mbs] == [4, 4, 1]
+    counts = [int(m['attn_masks'][r].sum()) - m['input_ids'].size(1) for m in mbs for r in range(m['attn_masks'].size(0))]
+    assert counts == sorted(counts) and sorted(counts) == sorted(name2nbb.values())       # all images, by box count
+    assert VeDataset.__mro__[1] is VqaDataset and ve_collate is vqa_collate
     both = ConcatDatasetWithLens([vqa, vqa])
     assert len(both) == 46 and both.lens == vqa.lens * 2 and both.__len__() == 46
 

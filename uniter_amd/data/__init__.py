@@ -10,6 +10,8 @@ from .data import (TxtTokLmdb, TxtLmdb, DetectFeatLmdb, ImageLmdbGroup, ConcatDa
 from .store import FeaturePack, LmdbStore, PackStore, PackWriter, convert_store, open_store  # noqa: F401
 from .tasks import (MlmDataset, mlm_collate, MrfrDataset, MrcDataset, mrfr_collate, mrc_collate,  # noqa: F401
                     TokenBucketSamplerForItm, ItmDataset, itm_collate, itm_ot_collate,
+                    ItmRankDataset, ItmValDataset, ItmEvalDataset, itm_rank_collate, itm_val_collate, itm_eval_collate,
+                    VeDataset, VeEvalDataset, ve_collate, ve_eval_collate,
                     Nlvr2PairedDataset, Nlvr2PairedEvalDataset, Nlvr2TripletDataset, Nlvr2TripletEvalDataset,
                     nlvr2_paired_collate, nlvr2_paired_eval_collate, nlvr2_triplet_collate, nlvr2_triplet_eval_collate,
                     VqaDataset, VqaEvalDataset, vqa_collate, vqa_eval_collate, joint_batch, random_word)

@@ -276,6 +276,114 @@ def itm_ot_collate(inputs):
     return batch
 
 
+# ---- image-text retrieval: ranking batches for training, one text against many images for evaluation (data/itm.py:185-468) ----
+def _text_image_rows(dataset, pairs):
+    """[(text id, image name), ...] -> [(input_ids, img_feat, img_pos_feat, attn_masks), ...]"""
+    rows = []
+    for txt_id, img in pairs:
+        input_ids = dataset.txt_db.combine_inputs(dataset.txt_db[txt_id]['input_ids'])
+        img_feat, img_pos_feat, num_bb = dataset._get_img_feat(img)
+        rows.append((input_ids, img_feat, img_pos_feat, torch.ones(len(input_ids) + num_bb, dtype=torch.long)))
+    return rows
+
+
+class ItmRankDataset(DetectFeatTxtTokDataset):
+    """Example i -> 1 + 2 * neg_sample_size rows: the aligned pair first, then the text with `neg_sample_size` other images, then
+    `neg_sample_size` other texts with the image (the margin ranking loss reads the rows in that order)."""
+
+    def __init__(self, txt_db, img_db, neg_sample_size=1, rng=_random):
+        assert neg_sample_size > 0, "ItmRankDataset need at least 1 negative sample"
+        super().__init__(txt_db, img_db)
+        self.rng = rng
+        txt2img = self.txt_db.txt2img
+        self.txt2img = {id_: txt2img[id_] for id_ in self.ids}
+        self.img2txts = {}                                             # images of THIS rank's texts
+        for id_, img in self.txt2img.items():
+            self.img2txts.setdefault(img, []).append(id_)
+        self.img_name_list = list(self.img2txts.keys())
+        self.neg_sample_size = neg_sample_size
+
+    def __getitem__(self, i):
+        txt_id = self.ids[i]
+        img = self.txt2img[txt_id]
+        other_imgs = sample_negative(self.img_name_list, [img], self.neg_sample_size, self.rng)
+        other_txts = sample_negative(self.ids, self.img2txts[img], self.neg_sample_size, self.rng)
+        rows = _text_image_rows(self, [(txt_id, img)] + [(txt_id, o) for o in other_imgs] + [(o, img) for o in other_txts])
+        assert len(rows) == 1 + 2 * self.neg_sample_size
+        return rows
+
+
+def itm_rank_collate(inputs):
+    sample_size = len(inputs[0])
+    assert all(len(rows) == sample_size for rows in inputs)
+    input_ids, img_feats, img_pos_feats, attn_masks = _columns([row for rows in inputs for row in rows])
+    batch, _, _ = joint_batch(input_ids, img_feats, img_pos_feats, attn_masks)
+    batch['sample_size'] = sample_size
+    return batch
+
+
+class ItmValDataset(DetectFeatTxtTokDataset):
+    """Retrieval validation: text i against its own image (row 0) and the `mini_batch_size - 1` images that follow it in the
+    image list (wrapping around) — one ready-made batch per example (the loader's batch size is 1)."""
+
+    def __init__(self, db_dir, img_dir, mini_batch_size=400):
+        super().__init__(db_dir, img_dir)
+        del self.lens
+        self.txt2img = self.txt_db.txt2img
+        self.img2txts = self.txt_db.img2txts
+        self.all_img_ids = list(self.img2txts.keys())
+        assert len(self.img2txts) >= mini_batch_size > 0
+        self.bs = mini_batch_size
+
+    def _get_batch_ids(self, i):
+        img = self.txt2img[self.ids[i]]
+        at = self.all_img_ids.index(img)
+        ring = self.all_img_ids[at + 1:] + self.all_img_ids[:at]     # every other image, starting behind the true one
+        others = ring[:self.bs - 1]
+        assert len(others) == self.bs - 1, "Did not sample enough neg samples"
+        return img, others
+
+    def __getitem__(self, i):
+        img, others = self._get_batch_ids(i)
+        return self.get_batch(i, [img] + others)
+
+    def get_batch(self, i, img_ids):
+        """The same text in every row, one image per row: input_ids [n, tl] (position_ids [1, tl]) + padded regions."""
+        example = DetectFeatTxtTokDataset.__getitem__(self, i)
+        ids = self.txt_db.combine_inputs(example['input_ids'])
+        n, tl = len(img_ids), int(ids.size(0))
+        feats, boxes, num_bbs = _columns([self._get_img_feat(img) for img in img_ids])
+        nbb = torch.as_tensor(num_bbs, dtype=torch.long).unsqueeze(1)
+        width = tl + max(num_bbs)
+        attn_masks = (torch.arange(width, dtype=torch.long).unsqueeze(0) < tl + nbb).long()
+        return {'input_ids': ids.unsqueeze(0).expand(n, -1).clone(),
+                'position_ids': torch.arange(0, tl, dtype=torch.long).unsqueeze(0),
+                'img_feat': pad_tensors(list(feats), list(num_bbs)),
+                'img_pos_feat': pad_tensors(list(boxes), list(num_bbs)),
+                'attn_masks': attn_masks,
+                'gather_index': get_gather_index([tl] * n, list(num_bbs), n, tl, width)}
+
+
+def itm_val_collate(inputs):
+    assert len(inputs) == 1, "input batch size > 1"
+    return inputs[0]
+
+
+class ItmEvalDataset(ItmValDataset):
+    """Full retrieval evaluation: text i against ALL images, as a list of mini-batches over the image list sorted by box count
+    (so that a mini-batch pads little)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.all_img_ids = sorted(list(self.all_img_ids), key=lambda img: self.img_db.name2nbb[img])
+
+    def __getitem__(self, i):
+        return [self.get_batch(i, self.all_img_ids[st:st + self.bs]) for st in range(0, len(self.all_img_ids), self.bs)]
+
+
+itm_eval_collate = itm_val_collate
+
+
 # ---- NLVR2 (data/nlvr2.py) ----------------------------------------------------------------------------------------------------------------
 class _Nlvr2Base(DetectFeatTxtTokDataset):
     _txt_copies = 1
@@ -416,3 +524,18 @@ def vqa_eval_collate(inputs):
     batch['targets'] = None if targets[0] is None else torch.stack(targets, dim=0)
     batch['qids'] = qids
     return batch
+
+
+# ---- visual entailment (data/ve.py): the VQA pipeline with three answers ------------------------------------------------------------
+class VeDataset(VqaDataset):
+    def __init__(self, *args, **kwargs):
+        super().__init__(3, *args, **kwargs)
+
+
+class VeEvalDataset(VqaEvalDataset):
+    def __init__(self, *args, **kwargs):
+        super().__init__(3, *args, **kwargs)
+
+
+ve_collate = vqa_collate
+ve_eval_collate = vqa_eval_collate
