@@ -71,6 +71,8 @@ class DetectFeatLmdb(object):
             self.name2nbb = self._compute_nbb()
 
     def _record(self, file_name, fields=None):
+        if self.env is None:
+            raise KeyError("%s is not in the feature pack of %s and there is no record database beside it" % (file_name, self.img_dir))
         blob = self.env.get(file_name)
         if blob is None:
             raise KeyError(file_name)
