@@ -312,13 +312,15 @@ class GradientReducer(object):
         self._tokens = {}               # single-launch mode: bucket -> (flag address, value) noted by the backward hook
         self._pending = []
         self._early_done = False
+        self._chain_done = None         # single-launch mode: event on the compute stream at the end of the encoder's backward chain
         if _on() and self.arena.grad.is_cuda and self._stream is None:
             self._stream = torch.cuda.Stream()
 
-    def _reduce_range(self, lo, hi, token=None):
+    def _reduce_range(self, lo, hi, token=None, after=None):
         """Sum-allreduce of arena.grad[lo:hi] on the communication stream.  token = (flag address, value) of a gradient bucket
-        of the single deferred launch: the collective goes behind a wait for that flag; else behind the current stream (and,
-        for encoder ranges of the per-bucket path, the library's weight-gradient stream)."""
+        of the single deferred launch: the collective goes behind a wait for that flag; else behind `after` (an event recorded
+        earlier on the compute stream) or, without one, behind the compute stream as it stands now (and, for encoder ranges of the
+        per-bucket path, the library's weight-gradient stream)."""
         if not _on() or hi <= lo:
             return
         g = self.arena.grad[lo:hi]
@@ -330,8 +332,10 @@ class GradientReducer(object):
                                                    ctypes.c_uint32(token[1]))
                 self.last_flag_waits += 1
             else:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
+                ev = after
+                if ev is None:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())
                 self._stream.wait_event(ev)
                 if not self.single_launch:
                     # the weight gradients of the bucket come from the library's side stream, which the current stream has not
@@ -405,6 +409,12 @@ class GradientReducer(object):
             # when the deferred launch already owns every CU and do not run until it ends (rocprofv3 trace).
             from .. import _lib
             lib = _lib.load()
+            if self._chain_done is None:
+                # the compute stream as it stands right after the encoder's backward call: the heads' gradients (final before that
+                # call) may be reduced from here on, and the communication stream must not be held back by what the compute stream
+                # does later (the embedding backward runs beside the deferred launch whose buckets it waits for)
+                self._chain_done = torch.cuda.Event()
+                self._chain_done.record(torch.cuda.current_stream())
             n = ctypes.c_int32(0)
             lib.uniter_encoder_grad_bucket_count(ctypes.byref(n))
             if b < n.value:
@@ -437,7 +447,7 @@ class GradientReducer(object):
             else:
                 if not self._early_done:
                     for lo, hi in self.rest_early:
-                        self._reduce_range(lo, hi)
+                        self._reduce_range(lo, hi, after=self._chain_done if self.single_launch else None)
                 if self.single_launch and self._tokens:
                     # the buckets the backward hook noted, in the order the deferred launch completes them
                     if any(t is None for t in self._tokens.values()):
