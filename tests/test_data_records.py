@@ -341,6 +341,14 @@ def test_image_database_record_path_and_decode_free_path_agree(tmp_path, compres
             assert np.array_equal(bb.numpy(), arrays['norm_bb'][:nbb].astype(np.float32))
             dump = db.get_dump(fname)
             assert dump['soft_labels'].dtype == np.float32 and dump['soft_labels'].shape == (nbb, 11)
+    # keep_half: the stored fp16 features as they are (the GPU casts to bf16 from either form with the same result), boxes in fp32
+    os.rename(os.path.join(img_dir, 'moved'), os.path.join(img_dir, packed.db_name + '.pack'))
+    half = DetectFeatLmdb(img_dir, 0.2, 10, 4, 36, compress, keep_half=True)
+    for fname in list(images)[:3]:
+        f16, b32 = half[fname]
+        f32, _ = records[fname]
+        assert f16.dtype == torch.float16 and b32.dtype == torch.float32 and torch.equal(f16.float(), f32)
+        assert torch.equal(f16.to(torch.bfloat16), f32.to(torch.bfloat16))
     # box counts computed from the stored confidences when they are not precomputed ('all' database)
     _, img_dir2, _, name2nbb2, _ = _build_db(str(tmp_path / 'b'), compress, precomputed_nbb=False)
     assert DetectFeatLmdb(img_dir2, 0.2, 10, 4, 36, compress).name2nbb == name2nbb2

@@ -6,8 +6,9 @@ from ..utils.synthetic import get_gather_index  # noqa: F401  (data/data.py:271-
 
 def pad_tensors(tensors, lens=None, pad=0):
     """List of B tensors [T_i, D] -> one [B, max T, D] tensor, rows beyond T_i filled with `pad` (data/data.py:250-263)."""
-    if lens is None:
-        lens = [int(t.size(0)) for t in tensors]
+    sizes = [int(t.size(0)) for t in tensors]
+    if lens is None or list(lens) == sizes:                      # the usual case: one C++ loop instead of a Python loop of row copies
+        return torch.nn.utils.rnn.pad_sequence(list(tensors), batch_first=True, padding_value=pad)
     out = tensors[0].new_full((len(tensors), max(lens), tensors[0].size(-1)), pad)
     for row, (t, n) in enumerate(zip(tensors, lens)):
         out[row, :n] = t[:n]

@@ -46,8 +46,12 @@ class DetectFeatLmdb(object):
     per-image box counts (nbb_th...json) are not precomputed: 'all' / 'all_compressed' and the counts are computed from the
     stored confidences on opening (the reference reads self.conf_th there without ever setting it; here it is set)."""
 
-    def __init__(self, img_dir, conf_th=0.2, max_bb=100, min_bb=10, num_bb=36, compress=True):
+    def __init__(self, img_dir, conf_th=0.2, max_bb=100, min_bb=10, num_bb=36, compress=True, keep_half=False):
         self.img_dir = img_dir
+        # keep_half: hand out the stored fp16 region features as fp16 tensors (the reference converts to fp32 per image).  The batch then
+        # travels to the GPU at half the bytes and PrefetchLoader(float_dtype=bf16) casts it there — fp16 -> bf16 rounds exactly as
+        # fp16 -> fp32 -> bf16 does, so the model sees the same inputs
+        self.keep_half = keep_half
         self.conf_th, self.max_bb, self.min_bb, self.num_bb = conf_th, max_bb, min_bb, num_bb
         if conf_th == -1:
             db_name = 'feat_numbb%d' % num_bb
@@ -102,7 +106,9 @@ class DetectFeatLmdb(object):
         else:
             rec = self._record(file_name, ['features', 'norm_bb'])
             feat, bb = rec['features'][:nbb, :], rec['norm_bb'][:nbb, :]
-        return (torch.from_numpy(np.array(feat, dtype=np.float32)), torch.from_numpy(np.array(bb, dtype=np.float32)))
+        dtype = np.float16 if (self.keep_half and np.asarray(feat).dtype == np.float16) else np.float32
+        # (the boxes stay fp32: the area w*h appended to them is then computed exactly as the reference computes it)
+        return (torch.from_numpy(np.array(feat, dtype=dtype)), torch.from_numpy(np.array(bb, dtype=np.float32)))
 
     def close(self):
         if self.env is not None:
@@ -189,7 +195,10 @@ def get_ids_and_lens(db):
 
 def box_features(bb):
     """[x1, y1, x2, y2, w, h] -> the 7-d position feature with the area w*h appended (data/data.py:245)."""
-    return torch.cat([bb, bb[:, 4:5] * bb[:, 5:]], dim=-1)
+    out = bb.new_empty(bb.size(0), 7)
+    out[:, :6] = bb
+    torch.mul(bb[:, 4], bb[:, 5], out=out[:, 6])
+    return out
 
 
 class DetectFeatTxtTokDataset(Dataset):
@@ -233,11 +242,12 @@ class ImageLmdbGroup(object):
     """Opens image databases on demand with one set of box-count parameters.  data/data.py:299-312 (which re-opens a path on
     every lookup because it never stores the handle; here it is cached)."""
 
-    def __init__(self, conf_th, max_bb, min_bb, num_bb, compress):
+    def __init__(self, conf_th, max_bb, min_bb, num_bb, compress, keep_half=False):
         self.path2imgdb = {}
         self.conf_th, self.max_bb, self.min_bb, self.num_bb, self.compress = conf_th, max_bb, min_bb, num_bb, compress
+        self.keep_half = keep_half
 
     def __getitem__(self, path):
         if path not in self.path2imgdb:
-            self.path2imgdb[path] = DetectFeatLmdb(path, self.conf_th, self.max_bb, self.min_bb, self.num_bb, self.compress)
+            self.path2imgdb[path] = DetectFeatLmdb(path, self.conf_th, self.max_bb, self.min_bb, self.num_bb, self.compress, self.keep_half)
         return self.path2imgdb[path]

@@ -20,12 +20,8 @@ from .sampler import TokenBucketSampler
 # ---- shared batch pieces ---------------------------------------------------------------------------------------------------
 def _pad_1d(seqs, value, dtype=None):
     """List of 1-D tensors -> [n, max len] filled with `value` (torch.nn.utils.rnn.pad_sequence(batch_first=True))."""
-    n = len(seqs)
-    longest = max(int(s.size(0)) for s in seqs)
-    out = torch.full((n, longest), value, dtype=dtype if dtype is not None else seqs[0].dtype)
-    for row, s in enumerate(seqs):
-        out[row, :s.size(0)] = s
-    return out
+    out = torch.nn.utils.rnn.pad_sequence(list(seqs), batch_first=True, padding_value=value)
+    return out if dtype is None or out.dtype == dtype else out.to(dtype)
 
 
 def joint_batch(input_ids, img_feats, img_pos_feats, attn_masks):
