@@ -111,6 +111,18 @@ def main(out_path):
         random.seed(40 + seed)
         for key, arr in dc.flatten(itm.itm_rank_collate([rk[i] for i in (0, 4, 9)])).items():
             g['itm_rank/%d/%s' % (seed, key)] = arr
+        # hard-negative ranking batches (the image-side class passes the LAST text's length as the region offset of the gather
+        # index, data/itm.py:360 — recorded as the reference computes it; the test knows)
+        hn_t = dc.bare(itm.ItmRankDatasetHardNegFromText, txt_db=txt_db, img_db=img_db, ids=ids, txt2img=txt2img, img2txts=img2txts,
+                       img_name_list=list(img2txts.keys()), neg_sample_size=3)
+        hn_i = dc.bare(itm.ItmRankDatasetHardNegFromImage, txt_db=txt_db, img_db=img_db, ids=ids, txt2img=txt2img, img2txts=img2txts,
+                       txt_name_list=list(txt2img.keys()), neg_sample_size=3)
+        random.seed(70 + seed)
+        for i in (1, 6, 11):
+            for key, arr in dc.flatten(itm.itm_rank_hn_collate([hn_t[i]])).items():
+                g['itm_hn_text/%d/%d/%s' % (seed, i, key)] = arr
+            for key, arr in dc.flatten(itm.itm_rank_hn_collate([hn_i[i]])).items():
+                g['itm_hn_image/%d/%d/%s' % (seed, i, key)] = arr
     np.savez_compressed(out_path, **g)
     print("wrote %s: %d arrays" % (out_path, len(g)))
 

@@ -110,6 +110,32 @@ def test_retrieval_datasets_bit_exact_vs_reference(gold):
         rk = dc.bare(ItmRankDataset, txt_db=txt_db, img_db=img_db, ids=ids, txt2img=txt2img, img2txts=i2t, img_name_list=list(i2t.keys()),
                      neg_sample_size=2, rng=random.Random(40 + seed))
         same('itm_rank/%d/' % seed, itm_rank_collate([rk[i] for i in (0, 4, 9)]))
+        from uniter_amd.data import ItmRankDatasetHardNegFromImage, ItmRankDatasetHardNegFromText, get_gather_index, itm_rank_hn_collate
+        rng = random.Random(70 + seed)
+        hn_t = dc.bare(ItmRankDatasetHardNegFromText, txt_db=txt_db, img_db=img_db, ids=ids, txt2img=txt2img, img2txts=img2txts,
+                       img_name_list=list(img2txts.keys()), neg_sample_size=3, rng=rng)
+        hn_i = dc.bare(ItmRankDatasetHardNegFromImage, txt_db=txt_db, img_db=img_db, ids=ids, txt2img=txt2img, img2txts=img2txts,
+                       txt_name_list=list(txt2img.keys()), neg_sample_size=3, rng=rng)
+        for i in (1, 6, 11):
+            same('itm_hn_text/%d/%d/' % (seed, i), itm_rank_hn_collate([hn_t[i]]))
+            got = itm_rank_hn_collate([hn_i[i]])
+            # one deliberate difference: the reference offsets the region block of the gather index by the LAST text's length
+            # (a loop variable left over, data/itm.py:360) instead of the padded text width the index is defined against
+            ref_gi = gold['itm_hn_image/%d/%d/gather_index' % (seed, i)]
+            lens = (got['input_ids'] != 0).sum(1).tolist()
+            nbb = int(got['img_feat'].size(1))
+            if lens[-1] == max(lens):
+                assert np.array_equal(got['gather_index'].numpy(), ref_gi)
+            else:
+                assert np.array_equal(get_gather_index(lens, [nbb] * 4, 4, lens[-1], ref_gi.shape[1]).numpy(), ref_gi)      # what the reference did
+                assert np.array_equal(got['gather_index'].numpy(), get_gather_index(lens, [nbb] * 4, 4, max(lens), ref_gi.shape[1]).numpy())
+            got.pop('gather_index')
+            prefix = 'itm_hn_image/%d/%d/' % (seed, i)
+            flat = dc.flatten(got)
+            want = {k[len(prefix):]: gold[k] for k in gold.files if k.startswith(prefix) and 'gather_index' not in k}
+            assert sorted(flat) == sorted(want)
+            for key, ref in want.items():
+                assert flat[key].dtype == ref.dtype and np.array_equal(flat[key], ref), (prefix, key)
     with pytest.raises(AssertionError):
         itm_val_collate([1, 2])
 

@@ -11,6 +11,7 @@ from .store import FeaturePack, LmdbStore, PackStore, PackWriter, convert_store,
 from .tasks import (MlmDataset, mlm_collate, MrfrDataset, MrcDataset, mrfr_collate, mrc_collate,  # noqa: F401
                     TokenBucketSamplerForItm, ItmDataset, itm_collate, itm_ot_collate,
                     ItmRankDataset, ItmValDataset, ItmEvalDataset, itm_rank_collate, itm_val_collate, itm_eval_collate,
+                    ItmRankDatasetHardNegFromText, ItmRankDatasetHardNegFromImage, itm_rank_hn_collate,
                     VeDataset, VeEvalDataset, ve_collate, ve_eval_collate,
                     Nlvr2PairedDataset, Nlvr2PairedEvalDataset, Nlvr2TripletDataset, Nlvr2TripletEvalDataset,
                     nlvr2_paired_collate, nlvr2_paired_eval_collate, nlvr2_triplet_collate, nlvr2_triplet_eval_collate,

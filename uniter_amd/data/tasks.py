@@ -318,6 +318,74 @@ def itm_rank_collate(inputs):
     return batch
 
 
+class _HardNegBase(DetectFeatTxtTokDataset):
+    def __init__(self, txt_db, img_db, neg_sample_size=1, rng=_random):
+        assert neg_sample_size > 0, "need at least 1 negative sample"
+        super().__init__(txt_db, img_db)
+        self.rng = rng
+        txt2img = self.txt_db.txt2img
+        self.txt2img = {id_: txt2img[id_] for id_ in self.ids}
+        self.img2txts = self.txt_db.img2txts
+        self.neg_sample_size = neg_sample_size
+
+
+class ItmRankDatasetHardNegFromText(_HardNegBase):
+    """One text against its image (row 0) and `neg_sample_size` other images: a ready-made batch with ONE text row
+    (input_ids [1, tl]) that the model broadcasts over the image rows (hard negatives are mined over such batches)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.img_name_list = list(self.img2txts.keys())
+
+    def __getitem__(self, i):
+        txt_id = self.ids[i]
+        img = self.txt2img[txt_id]
+        ids = self.txt_db.combine_inputs(self.txt_db[txt_id]['input_ids'])
+        imgs = [img] + sample_negative(self.img_name_list, [img], self.neg_sample_size, self.rng)
+        feats, boxes, num_bbs = _columns([self._get_img_feat(name) for name in imgs])
+        n, tl = len(imgs), int(ids.size(0))
+        width = tl + max(num_bbs)
+        nbb = torch.as_tensor(num_bbs, dtype=torch.long).unsqueeze(1)
+        return {'input_ids': ids.unsqueeze(0),
+                'position_ids': torch.arange(0, tl, dtype=torch.long).unsqueeze(0),
+                'img_feat': pad_tensors(list(feats), list(num_bbs)),
+                'img_pos_feat': pad_tensors(list(boxes), list(num_bbs)),
+                'attn_masks': (torch.arange(width, dtype=torch.long).unsqueeze(0) < tl + nbb).long(),
+                'gather_index': get_gather_index([tl] * n, list(num_bbs), n, tl, width)}
+
+
+class ItmRankDatasetHardNegFromImage(_HardNegBase):
+    """One image (ONE image row) against its text (row 0) and `neg_sample_size` other texts."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.txt_name_list = list(self.txt2img.keys())
+
+    def __getitem__(self, i):
+        txt_id = self.ids[i]
+        img = self.txt2img[txt_id]
+        img_feat, img_pos_feat, nbb = self._get_img_feat(img)
+        txts = [txt_id] + sample_negative(self.txt_name_list, self.img2txts[img], self.neg_sample_size, self.rng)
+        rows = [self.txt_db.combine_inputs(self.txt_db[t]['input_ids']) for t in txts]
+        txt_lens = [int(r.size(0)) for r in rows]
+        input_ids = _pad_1d(rows, 0)
+        width = max(txt_lens) + nbb
+        tl = torch.as_tensor(txt_lens, dtype=torch.long).unsqueeze(1)
+        # (the reference passes the LAST text's length as the gather offset of the region block — data/itm.py:360; the padded
+        #  width is what the offset means, and both agree whenever the last text is the longest; the padded width is used here)
+        return {'input_ids': input_ids,
+                'position_ids': torch.arange(0, input_ids.size(1), dtype=torch.long).unsqueeze(0),
+                'img_feat': img_feat.unsqueeze(0),
+                'img_pos_feat': img_pos_feat.unsqueeze(0),
+                'attn_masks': (torch.arange(width, dtype=torch.long).unsqueeze(0) < tl + nbb).long(),
+                'gather_index': get_gather_index(txt_lens, [nbb] * len(txts), len(txts), int(input_ids.size(1)), width)}
+
+
+def itm_rank_hn_collate(inputs):
+    assert len(inputs) == 1
+    return inputs[0]
+
+
 class ItmValDataset(DetectFeatTxtTokDataset):
     """Retrieval validation: text i against its own image (row 0) and the `mini_batch_size - 1` images that follow it in the
     image list (wrapping around) — one ready-made batch per example (the loader's batch size is 1)."""
