@@ -1,7 +1,7 @@
 // l2_carry_probe.cpp — does an XCD's L2 keep what a kernel wrote for the NEXT kernel on the same stream?
 // (a row-block -> XCD affinity across the kernel chain only pays if it does.)
 // Kernel W: workgroup b (256 of them; hardware block b runs on XCD b % 8) writes slice b (64 KiB) with the default store policy
-// or write-through.  Kernel R: workgroup b reads slice (b + shift) % 256 and stamps the wall clock around the read.
+// , write-through (sc1) or non-temporal.  Kernel R: workgroup b reads slice (b + shift) % 256 and stamps the wall clock around the read.
 // shift 0: the reader sits where the writer sat; shift 8: another CU of the same XCD; shift 1: the neighbouring XCD.
 // build: hipcc --offload-arch=gfx950 -O3 -o aux_bin/l2_carry_probe tests/native/l2_carry_probe.cpp
 #include <hip/hip_runtime.h>
@@ -19,6 +19,7 @@ __global__ __launch_bounds__(THREADS) void writer(char* buf, unsigned tag) {
     for (int i = threadIdx.x * 16; i < SLICE; i += THREADS * 16) {
         u32x4 v = {tag, (unsigned)i, blockIdx.x, 1u};
         if (POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"((gmem_u32x4*)(s + i)), "v"(v) : "memory");
+        else if (POLICY == 2) __builtin_nontemporal_store(v, (gmem_u32x4*)(s + i));
         else *(u32x4*)(s + i) = v;
     }
 }
@@ -48,13 +49,14 @@ int main() {
     CHK(hipMemset(bad, 0, 4));
     std::vector<unsigned long long> h(WGS);
     unsigned tag = 100;
-    for (int policy = 0; policy < 2; ++policy)
-        for (int shift : {0, 8, 1, 4, 0, 8, 1}) {
+    for (int policy = 0; policy < 3; ++policy)
+        for (int shift : {0, 8, 1, 0, 8, 1}) {
             double sum = 0; std::vector<double> med;
             for (int rep = 0; rep < 20; ++rep) {
                 ++tag;
                 if (policy == 0) hipLaunchKernelGGL(writer<0>, dim3(WGS), dim3(THREADS), 0, 0, buf, tag);
-                else hipLaunchKernelGGL(writer<1>, dim3(WGS), dim3(THREADS), 0, 0, buf, tag);
+                else if (policy == 1) hipLaunchKernelGGL(writer<1>, dim3(WGS), dim3(THREADS), 0, 0, buf, tag);
+                else hipLaunchKernelGGL(writer<2>, dim3(WGS), dim3(THREADS), 0, 0, buf, tag);
                 hipLaunchKernelGGL(reader, dim3(WGS), dim3(THREADS), 0, 0, (const char*)buf, shift, tag, st, bad);
                 CHK(hipDeviceSynchronize());
                 CHK(hipMemcpy(h.data(), st, WGS * 8, hipMemcpyDeviceToHost));
@@ -63,7 +65,7 @@ int main() {
             }
             std::sort(med.begin(), med.end());
             (void)sum;
-            printf("writer stores %-13s reader shift %d (%s): median time of a workgroup's 64 KiB read %.2f us\n", policy ? "write-through" : "default", shift,
+            printf("writer stores %-13s reader shift %d (%s): median time of a workgroup's 64 KiB read %.2f us\n", policy == 0 ? "default" : (policy == 1 ? "write-through" : "non-temporal"), shift,
                    shift == 0 ? "same CU slot" : (shift % 8 == 0 ? "same XCD" : "other XCD"), med[med.size() / 2]);
         }
     unsigned hb = 0; CHK(hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost));
