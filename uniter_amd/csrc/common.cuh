@@ -159,6 +159,22 @@ __device__ __forceinline__ void chain_signal(const ChainLink& c, const int row0,
     if ((int)threadIdx.x < nu) __hip_atomic_fetch_add(c.signal + u0 + (int)threadIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// bijective XCD-aware block remap (cdna_hip_programming.md T1): consecutive hardware block ids go to
+// different XCDs; give each XCD a contiguous range of logical tiles so neighbours share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + loc;
+}
+// XCD affinity of a kernel chain (UNITER_AMD_XCD_AFFINITY=1; bit 0 of ChainLink.pad): every kernel of
+// the encoder gives XCD x the x-th contiguous eighth of its rows (attention units of an example, LayerNorm rows, GEMM row
+// blocks through the 8-row XCD grid of tile_of_block), so that what a kernel reads from its predecessor's output was written
+// on its own XCD and is still in that L2 (tests/native/l2_carry_probe.cpp: 0.68 us against 2.3 us per 64 KiB).
+__device__ __forceinline__ int affine_block(const ChainLink& c) {
+    return (c.pad & 1u) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+}
+
 // output stores of a kernel that may run inside a chain: write-through when it signals, the kernel's usual policy otherwise
 __device__ __forceinline__ void out_store16c(void* p, const u32x4 v, const bool wt) {
     if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"((gmem_u32x4*)p), "v"(v) : "memory");

@@ -663,6 +663,7 @@ int launch_g8(const GemmArgs& a_in, int splits, hipStream_t st) {
     if (EPI == EPI_WGRAD && a.C2 != nullptr) { uh_set_error("gemm: the eight-phase tile does not produce the bias gradient"); return -1; }
     const int tiles_m = (a.M + 255) / 256, tiles_n = a.N / 256;
     a.xr = pick_xr(tiles_m, tiles_n, 256, 256);
+    if (!TRA && uh::xcd_affinity() && tiles_m % 8 == 0) a.xr = 8;
     a.pair = nullptr;
     if (EPI == EPI_WGRAD && splits == 2 && a.partial != nullptr) {
         a.pair = g8_pair_counters(tiles_m * tiles_n);
@@ -699,6 +700,7 @@ int launch_g6(const GemmArgs& a_in, int splits, hipStream_t st) {
     if (EPI == EPI_WGRAD && a.C2 != nullptr) { uh_set_error("gemm: the three-phase tile does not produce the bias gradient"); return -1; }
     const int tiles_m = (a.M + 191) / 192, tiles_n = a.N / 192;
     a.xr = pick_xr(tiles_m, tiles_n, 192, 192);
+    if (!TRA && uh::xcd_affinity() && tiles_m % 8 == 0) a.xr = 8;
     a.pair = nullptr;
     static bool attr_done = false;
     if (!attr_done) {
@@ -726,6 +728,7 @@ int launch_cfg(const GemmArgs& a_in, int splits, hipStream_t st) {
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
     a.xr = pick_xr(tiles_m, tiles_n, BM, BN);
+    if (!TRA && uh::xcd_affinity() && tiles_m % 8 == 0) a.xr = 8;      // whole row blocks per XCD (common.cuh: affine_block)
 #ifdef UNITER_GEMM_PROBE
     a.probe = g_probe;
 #endif

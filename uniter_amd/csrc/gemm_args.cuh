@@ -36,15 +36,6 @@ struct GemmArgs {
     ChainLink chain;      // overlapped kernel chain (common.cuh): wait for the M-side rows' producer, signal the output rows
 };
 
-// bijective XCD-aware block remap (cdna_hip_programming.md T1): consecutive hardware block ids go to
-// different XCDs; give each XCD a contiguous range of logical tiles so neighbours share an L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-    const int q = nblk >> 3, r = nblk & 7;
-    const int xcd = bid & 7, loc = bid >> 3;
-    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + loc;
-}
-
 // blockIdx -> (tile row, tile column) for a tiles_m x tiles_n grid: the caller's choice (xr < 0), 2-D XCD blocking
 // (xr > 0: hardware block b runs on XCD b % 8; XCD (xi, xj) of an xr x xc grid owns a (tiles_m/xr) x (tiles_n/xc)
 // sub-block of tiles, so its private L2 holds only that sub-block's operand rows) or contiguous 1-D ranges per XCD.

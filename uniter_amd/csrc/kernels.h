@@ -5,6 +5,7 @@
 #include <hip/hip_ext.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "common.cuh"
 
 struct DropoutCfg;
@@ -27,6 +28,12 @@ template <typename K, typename... Args>
 inline void chain_launch(const ChainStep* cs, K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
     if (cs != nullptr && cs->anyorder) hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, nullptr, nullptr, hipExtAnyOrderLaunch, args...);
     else hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+}
+
+// UNITER_AMD_XCD_AFFINITY=1 (experiment, default off): one row-block -> XCD map for all kernels of the encoder chain (common.cuh: affine_block)
+inline bool xcd_affinity() {
+    static const bool on = [] { const char* e = getenv("UNITER_AMD_XCD_AFFINITY"); return e != nullptr && atoi(e) != 0; }();
+    return on;
 }
 
 // ---- capi.hip: optional per-launch timing (uniter_hip_timing_begin / _end) ----

@@ -19,10 +19,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      int rows, int H, float eps, const DropoutCfg drop, const ChainLink chain) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int row = blockIdx.x * ROWS_PER_BLOCK + wid;
-    chain_wait(chain, blockIdx.x * ROWS_PER_BLOCK, ROWS_PER_BLOCK);      // overlapped chain (common.cuh): z rows of this block
+    const int blk = affine_block(chain);
+    const int row = blk * ROWS_PER_BLOCK + wid;
+    chain_wait(chain, blk * ROWS_PER_BLOCK, ROWS_PER_BLOCK);      // overlapped chain (common.cuh): z rows of this block
     if (row < rows) ln_fwd_row<NC, false>(z, gamma, beta, y, mean_out, rstd_out, row, H, eps, drop, lane, chain.signal != nullptr);
-    chain_signal(chain, blockIdx.x * ROWS_PER_BLOCK, ROWS_PER_BLOCK);
+    chain_signal(chain, blk * ROWS_PER_BLOCK, ROWS_PER_BLOCK);
 }
 
 // Backward.  partial layout: [gridDim.x][3][H] fp32 = per-block column sums of (dgamma, dbeta, dbias).
@@ -158,7 +159,8 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const bf16_t* __restri
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int nch = H >> 2;
     // overlapped chain (common.cuh): such launches cover all rows in one pass of the grid, so a block owns rows 4b .. 4b+3
-    chain_wait(chain, blockIdx.x * 4, 4);
+    const int blk = affine_block(chain);
+    chain_wait(chain, blk * 4, 4);
     const bool wt = chain.signal != nullptr;
     float gv[NC][4];
 #pragma unroll
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const bf16_t* __restri
     }
     const bool use_drop = drop.p > 0.f && !post_drop;
     const bool use_post = drop.p > 0.f && post_drop;
-    for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4) {
+    for (int row = blk * 4 + wid; row < rows; row += gridDim.x * 4) {
         const float mean = mean_in[row], rstd = rstd_in[row];
         const int64_t ro = (int64_t)row * H;
         float xh[NC][4], gy[NC][4];
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const bf16_t* __restri
             }
         }
     }
-    chain_signal(chain, blockIdx.x * 4, 4);
+    chain_signal(chain, blk * 4, 4);
 }
 
 // Column part: per-block partial sums over rows of (dy*xhat, dy, d) with d = `dsrc` (the bf16 dd / dz the row kernel
@@ -411,6 +413,7 @@ int layernorm_fwd(const void* z, const void* gamma, const void* beta, void* y, f
         if (rows % 32 == 0) { link = chain->link; chain->produced = 32 / ROWS_PER_BLOCK; }
         else { chain->anyorder = 0; chain->produced = 0; }
     }
+    if (link.signal == nullptr && link.wait == nullptr && uh::xcd_affinity()) link.pad = 1;
 #define LN_FWD(NCV)                                                                                         \
     chain_launch(chain, ln_fwd_kernel<NCV>, grid, block, 0, st, (const bf16_t*)z, (const bf16_t*)gamma,     \
                  (const bf16_t*)beta, (bf16_t*)y, mean, rstd, (int)rows, (int)H, eps, drop, link)
@@ -453,6 +456,7 @@ int layernorm_bwd_rows(const void* dy, const void* dy_extra, const void* z, cons
         else { chain->anyorder = 0; chain->produced = 0; }
     }
     if (link.signal == nullptr && link.wait == nullptr && nb > 4096) nb = 4096;
+    if (link.signal == nullptr && link.wait == nullptr && uh::xcd_affinity() && nb * 4 == rows) link.pad = 1;   // (one pass of the grid: XCD-contiguous rows)
 #define LN_ROWS(NCV)                                                                                                   \
     chain_launch(chain, ln_bwd_rows_kernel<NCV>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)dy,             \
                  (const bf16_t*)dy_extra, (const bf16_t*)z, mean, rstd, (const bf16_t*)gamma, (bf16_t*)dz,             \
