@@ -371,6 +371,9 @@ def main():
                     help="NOT the headline config: ragged synthetic batch (10-60 text tokens, 10-36 regions per sequence) "
                          "to measure padding-free execution (SURVEY.md section 8 f-3)")
     ap.add_argument("--pack", action="store_true", help="run the encoder on real tokens only (UniterModel.pack_padding)")
+    ap.add_argument("--merge-accum", action="store_true",
+                    help="c3 / c4 / c5: run the micro-batches of an optimizer step as ONE batch (uniter_amd/data/merge.py: same "
+                         "examples, loss and gradients as the accumulation loop); the line says so in config.micro_batches_merged")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--parity-file", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -398,7 +401,7 @@ def main():
     lpb = int(os.environ["UNITER_BENCH_LAYERS_PER_BUCKET"]) if "UNITER_BENCH_LAYERS_PER_BUCKET" in os.environ else None
     overlap = bool(args.overlap and not args.graph)
     runner = StepRunner(args.config, device, rank=rank, world=world, seed=77, ragged=args.ragged, pack=args.pack,
-                        overlap=overlap, cfg_path=cfg_path, reducer_layers_per_bucket=lpb)
+                        overlap=overlap, cfg_path=cfg_path, reducer_layers_per_bucket=lpb, merge_accum=args.merge_accum)
     first_batch = next(iter(runner.batches.values()))
     real_tokens = int(first_batch['attn_masks'].sum().item())
 
@@ -517,9 +520,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.config, w['desc']),
                        "global_batch": B * world, "micro_batch": w['batch'], "grad_accumulation": w['accum'], "seq_len": L,
+                       "micro_batches_merged": bool(runner.merge_accum),
                        "parallelism": "dp%d" % world, "launch": mode, "optimizer_overlap": overlap,
                        "ragged": bool(args.ragged), "pack_padding": bool(args.pack),
-                       "real_token_fraction": round(real_tokens / float(w['batch'] * first_batch['attn_masks'].size(1)), 3),
+                       "real_token_fraction": round(real_tokens / float(first_batch['attn_masks'].numel()), 3),
                        "examples": "encoder sequences per optimizer step" + (" (32/GPU = 16 NLVR2 pairs)" if args.config == 'c2' else ""),
                        "task_draws": runner.task_counts},
             "final_loss": round(final_loss, 4),

@@ -52,3 +52,56 @@ def test_xcd_affinity_leaves_the_step_bit_identical(tmp_path, workload):
     assert ok, ("XCD affinity changed the result", diff)
     print("xcd affinity, %s: %d parameters identical after 2 steps" % (workload, base["n_params"]))
 
+
+
+@pytest.mark.parametrize("workload", ["c3", "c4"])
+def test_merged_micro_batches_give_the_accumulation_loops_gradients(workload):
+    """StepRunner(merge_accum=True) (uniter_amd/data/merge.py; bench.py --merge-accum): the micro-batches of an optimizer step as
+    ONE batch.  Dropout off, every task of the workload's mix: the loss and the gradient of every parameter against the
+    accumulation loop on the same weights.  Not bit-identical — the loop rounds the summed gradient to bf16 once per micro-step,
+    the merged launch once; weight-gradient contractions run over twice / four times the tokens — so the bound is the one the
+    parity tests use between two bf16 evaluations of the same function (relative L2 <= 2e-2 per tensor, cosine >= 0.999).
+    The CPU half (exact equality of the merged batch with the collate's, fp32 equality of the loss and gradients through the
+    oracle) is tests/test_merge_accumulation.py."""
+    import torch
+    from uniter_amd import _lib
+    from uniter_amd.train import StepRunner
+    from uniter_amd.utils.misc import set_dropout
+    dev = torch.device("cuda", 0)
+    out = {}
+    for merged in (False, True):
+        r = StepRunner(workload, dev, seed=77, merge_accum=merged)
+        assert r.merge_accum == merged
+        set_dropout(r.model, 0.0)
+        res = {}
+        for task, batch in r.batches.items():
+            for p in r.model.parameters():
+                p.grad = None
+            total = 0.0
+            for _ in range(1 if merged else r.w['accum']):
+                loss = r._loss(task, batch)
+                loss.backward()
+                total += float(loss.detach())
+            _lib.join_wgrads()
+            torch.cuda.synchronize()
+            res[task] = (total, {n: p.grad.detach().float().clone() for n, p in r.model.named_parameters() if p.grad is not None})
+        out[merged] = res
+        del r
+        torch.cuda.empty_cache()
+    for task in out[False]:
+        l0, g0 = out[False][task]
+        l1, g1 = out[True][task]
+        assert abs(l1 - l0) <= 5e-3 * max(1.0, abs(l0)), (task, l0, l1)
+        assert sorted(g0) == sorted(g1), task
+        worst = (0.0, None)
+        for n in g0:
+            a, b = g1[n].double().flatten(), g0[n].double().flatten()
+            if float(b.norm()) == 0.0:
+                assert float(a.abs().max()) < 1e-6, (task, n)
+                continue
+            rel = float((a - b).norm() / b.norm())
+            cos = float((a * b).sum() / (a.norm() * b.norm()))
+            worst = max(worst, (rel, n))
+            assert rel <= 2e-2 and cos >= 0.999, (task, n, rel, cos)
+        print("merged vs accumulated, %s / %s: loss %.5f vs %.5f, %d gradients, worst rel-L2 %.2e (%s)"
+              % (workload, task, l1, l0, len(g0), worst[0], worst[1]))

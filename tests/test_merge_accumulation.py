@@ -1,0 +1,208 @@
+"""Gradient accumulation as one large batch (uniter_amd/data/merge.py; reference loop pretrain.py:264-312, train_vqa.py:183-206,
+collates data/{mlm,mrm,itm,vqa,nlvr2}.py).  CPU only:
+
+  (1) merge_batches(collate(A), collate(B), ...) == collate(A + B + ...), key for key and bit for bit, for every task's batch
+      builder, with micro-batches of different padded widths;
+  (2) accumulated_loss / accumulated_itm_ot_loss of the merged batch's un-reduced loss == the sum of the reference's per-micro-
+      batch reductions, values and all parameter gradients, computed with the oracle (which tests/golden pins to the reference).
+"""
+import random
+
+import pytest
+import torch
+
+from oracle import uniter_oracle as O
+from tests.common import IMG_DIM, LABEL_DIM, N_ANS
+from uniter_amd.data import tasks as T
+from uniter_amd.data.merge import accumulated_itm_ot_loss, accumulated_loss, merge_batches
+
+VOCAB = 96
+
+
+def _example(rng, gen, max_tl, max_nbb):
+    tl, nbb = rng.randint(3, max_tl), rng.randint(2, max_nbb)
+    ids = torch.tensor([rng.randint(5, VOCAB - 1) for _ in range(tl)], dtype=torch.long)
+    feat = torch.randn(nbb, IMG_DIM, generator=gen).abs()
+    xy = torch.rand(nbb, 2, generator=gen) * 0.6
+    wh = torch.rand(nbb, 2, generator=gen) * 0.35 + 0.05
+    pos = torch.cat([xy, xy + wh, wh, wh[:, :1] * wh[:, 1:]], dim=-1)
+    return ids, feat, pos, torch.ones(tl + nbb, dtype=torch.long)
+
+
+def _task_example(task, rng, gen, max_tl, max_nbb):
+    ids, feat, pos, mask = _example(rng, gen, max_tl, max_nbb)
+    tl, nbb = ids.numel(), feat.size(0)
+    if task == 'mlm':
+        labels = torch.full((tl,), -1, dtype=torch.long)
+        k = rng.randrange(tl)
+        labels[k] = ids[k]
+        if rng.random() < 0.5:
+            k2 = rng.randrange(tl)
+            labels[k2] = ids[k2]
+        return ids, feat, pos, mask, labels
+    if task in ('mrfr', 'mrc'):
+        img_mask = T._get_img_mask(0.3, nbb, rng)
+        tgt = T._get_img_tgt_mask(img_mask, tl)
+        if task == 'mrfr':
+            return ids, feat, pos, mask, img_mask, tgt
+        soft = torch.softmax(torch.randn(nbb, LABEL_DIM, generator=gen), dim=-1)
+        return ids, feat, pos, soft, mask, img_mask, tgt
+    if task in ('itm', 'itm_ot'):
+        return ids, feat, pos, mask, torch.full((1,), rng.randint(0, 1), dtype=torch.long)
+    if task == 'vqa':
+        tgt = torch.zeros(N_ANS)
+        tgt[rng.randrange(N_ANS)] = rng.choice([0.3, 0.6, 0.9, 1.0])
+        return ids, feat, pos, mask, tgt
+    if task == 'nlvr2':
+        rows = []
+        for k in range(2):
+            _, f2, p2, _ = _example(rng, gen, max_tl, max_nbb)
+            rows.append((ids, f2, p2, torch.ones(tl + f2.size(0), dtype=torch.long), torch.full((f2.size(0),), k + 1, dtype=torch.long)))
+        return tuple(rows), rng.randint(0, 1)
+    raise ValueError(task)
+
+
+COLLATE = {'mlm': T.mlm_collate, 'mrfr': T.mrfr_collate, 'mrc': T.mrc_collate, 'itm': T.itm_collate, 'itm_ot': T.itm_ot_collate,
+           'vqa': T.vqa_collate, 'nlvr2': T.nlvr2_paired_collate}
+
+
+def _micro_batches(task, seed, sizes=(3, 4, 2), widths=((9, 6), (14, 9), (6, 11))):
+    """Example lists of micro-batches whose padded text / region widths differ (the merged batch must re-pad and re-index)."""
+    rng, gen = random.Random(seed), torch.Generator().manual_seed(seed)
+    return [[_task_example(task, rng, gen, tl, nbb) for _ in range(n)] for n, (tl, nbb) in zip(sizes, widths)]
+
+
+def _assert_same(a, b, path=''):
+    assert type(a) is type(b) or (a is None) == (b is None), (path, type(a), type(b))
+    if isinstance(a, dict):
+        assert sorted(a) == sorted(b), (path, sorted(a), sorted(b))
+        for k in a:
+            _assert_same(a[k], b[k], path + '/' + str(k))
+    elif isinstance(a, torch.Tensor):
+        assert a.dtype == b.dtype and a.shape == b.shape, (path, a.dtype, b.dtype, a.shape, b.shape)
+        assert torch.equal(a, b), path
+    else:
+        assert a == b, (path, a, b)
+
+
+@pytest.mark.parametrize("task", sorted(COLLATE))
+def test_merged_micro_batches_equal_one_collate_of_all_examples(task):
+    micro = _micro_batches(task, seed=11)
+    merged = merge_batches([COLLATE[task](m) for m in micro])
+    whole = COLLATE[task]([e for m in micro for e in m])
+    info = merged.pop('micro')
+    _assert_same(merged, whole)
+    pairs = 2 if task == 'nlvr2' else 1
+    assert info['rows'] == [pairs * len(m) for m in micro]
+    if task == 'mlm':
+        assert info['loss_rows'] == [sum(int((e[4] != -1).sum()) for e in m) for m in micro]
+    elif task in ('mrfr', 'mrc'):
+        assert info['loss_rows'] == [sum(int(e[-2].sum()) for e in m) for m in micro]
+    else:
+        assert info['loss_rows'] == [len(m) for m in micro]
+
+
+def test_merge_rejects_mixed_tasks_and_single_modality():
+    a = T.mlm_collate(_micro_batches('mlm', 1)[0])
+    b = T.itm_collate(_micro_batches('itm', 1)[0])
+    with pytest.raises(ValueError):
+        merge_batches([a, b])
+    c = dict(a, img_feat=None)
+    with pytest.raises(ValueError):
+        merge_batches([c, c])
+    with pytest.raises(ValueError):
+        merge_batches([])
+
+
+def test_merge_of_one_batch_is_that_batch():
+    a = T.itm_ot_collate(_micro_batches('itm_ot', 5)[1])
+    m = merge_batches([a])
+    m.pop('micro')
+    _assert_same(m, a)
+
+
+# ---- (2) the accumulated loss and its gradients against the oracle -----------------------------------------------------------------
+def _leafs(sd):
+    out = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    if 'uniter.embeddings.word_embeddings.weight' in out:
+        out['cls.predictions.decoder.weight'] = out['uniter.embeddings.word_embeddings.weight']
+    return out
+
+
+def _loop_loss(task, sd, cfg, b):
+    """The scalar one micro-step of the reference's loop back-propagates."""
+    if task == 'mlm':
+        return O.mlm_loss(sd, cfg, b)[0].mean()                              # pretrain.py:295
+    if task == 'mrfr':
+        return O.mrfr_loss(sd, cfg, b)[0].mean()
+    if task == 'mrc':
+        return O.mrc_loss(sd, cfg, b, kl=True)[0].mean()
+    if task == 'itm':
+        return O.itm_loss(sd, cfg, b)[0].mean()
+    if task == 'itm_ot':
+        return O.itm_ot_loss(sd, cfg, b, ot_lambda=0.1)[0]                   # pretrain.py:270-290
+    if task == 'vqa':
+        loss = O.vqa_loss(sd, cfg, b)[0]
+        return loss.mean() * loss.size(1)                                    # train_vqa.py:188
+    if task == 'nlvr2':
+        return O.nlvr2_paired_attn_loss(sd, cfg, b)[0].mean()
+    raise ValueError(task)
+
+
+def _merged_loss(task, sd, cfg, b):
+    micro = b['micro']
+    if task == 'mlm':
+        return accumulated_loss(O.mlm_loss(sd, cfg, b)[0], micro)
+    if task == 'mrfr':
+        return accumulated_loss(O.mrfr_loss(sd, cfg, b)[0], micro)
+    if task == 'mrc':
+        return accumulated_loss(O.mrc_loss(sd, cfg, b, kl=True)[0], micro)
+    if task == 'itm':
+        return accumulated_loss(O.itm_loss(sd, cfg, b)[0], micro)
+    if task == 'itm_ot':
+        _, itm, dist, _ = O.itm_ot_loss(sd, cfg, b, ot_lambda=0.1)
+        t = b['targets']
+        return accumulated_itm_ot_loss(itm, (dist[t == 1], dist[t == 0]), t, micro, 0.1)
+    if task == 'vqa':
+        loss = O.vqa_loss(sd, cfg, b)[0]
+        return accumulated_loss(loss, micro, scale=loss.size(1))
+    if task == 'nlvr2':
+        return accumulated_loss(O.nlvr2_paired_attn_loss(sd, cfg, b)[0], micro)
+    raise ValueError(task)
+
+
+def _bool_pads(b):
+    """The oracle's OT restatement takes bool pads (the reference's uint8 masks do not run on torch 2.10)."""
+    if b.get('ot_inputs'):
+        o = b['ot_inputs']
+        b['ot_inputs'] = dict(o, txt_pad=o['txt_pad'].bool(), img_pad=o['img_pad'].bool())
+    return b
+
+
+@pytest.mark.parametrize("task", ['mlm', 'mrfr', 'mrc', 'itm', 'itm_ot', 'vqa', 'nlvr2'])
+def test_accumulated_loss_of_the_merged_batch_equals_the_accumulation_loop(golden, task):
+    w = golden.weights('pre')
+    if task == 'vqa':
+        w.update(golden.weights('vqa'))
+    if task == 'nlvr2':
+        w.update(golden.weights('nlvr2'))
+    micro = [_bool_pads(COLLATE[task](m)) for m in _micro_batches(task, seed=23, widths=((9, 6), (14, 9), (6, 11)))]
+    # the accumulation loop: one backward per micro-batch, gradients add up (pretrain.py:296-303)
+    sd = _leafs(w)
+    total = 0.0
+    for b in micro:
+        loss = _loop_loss(task, sd, golden.cfg, b)
+        loss.backward()
+        total += float(loss.detach())
+    loop_grads = {k: v.grad.clone() for k, v in sd.items() if v.grad is not None}
+    # one forward / backward over the merged batch
+    sd2 = _leafs(w)
+    merged = _bool_pads(merge_batches(micro))
+    loss = _merged_loss(task, sd2, golden.cfg, merged)
+    loss.backward()
+    assert abs(float(loss) - total) <= 1e-5 * max(1.0, abs(total)), (float(loss), total)
+    assert len(loop_grads) > 20
+    for k, g in loop_grads.items():
+        g2 = sd2[k].grad
+        assert g2 is not None, k
+        torch.testing.assert_close(g2, g, rtol=2e-4, atol=2e-6, msg=lambda m: "%s: %s" % (k, m))

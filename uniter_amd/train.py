@@ -93,7 +93,7 @@ class StepRunner(object):
     """Model + optimizer + resident synthetic batches of one workload; `train_step()` runs one optimizer step."""
 
     def __init__(self, name, device, rank=0, world=1, seed=77, ragged=False, pack=False, overlap=False, cfg_path=None,
-                 reducer_layers_per_bucket=None):
+                 reducer_layers_per_bucket=None, merge_accum=False):
         from .optim import build_optimizer, build_vqa_optimizer, overlap_boundaries
         from .utils import distributed as D
         from .utils.arena import flatten_model
@@ -103,6 +103,9 @@ class StepRunner(object):
             raise ValueError("unknown workload %r (have %s)" % (name, sorted(WORKLOADS)))
         w = dict(WORKLOADS[name])
         self.name, self.w, self.opts = name, w, _Opts(w)
+        # merge_accum: the `accum` micro-batches of an optimizer step run as ONE batch of accum x batch sequences (data/merge.py:
+        # same examples, same loss, same gradients as the accumulation loop; GEMMs accum times as tall).  Default off.
+        self.merge_accum = bool(merge_accum) and int(w['accum']) > 1
         self.device, self.rank, self.world = device, rank, world
         self.model = build_model(w['model'], w['cfg'], device, seed, cfg_path or "/tmp/uniter_cfg_%s_%d.json" % (name, rank))
         set_dropout(self.model, w['dropout'])
@@ -120,7 +123,7 @@ class StepRunner(object):
             reducer_layers_per_bucket = int(os.environ.get("UNITER_AMD_LAYERS_PER_BUCKET", "4"))
         self.reducer = (D.GradientReducer(self.arena, self.model.uniter.encoder, layers_per_bucket=reducer_layers_per_bucket,
                                           word_embeddings=self.model.uniter.embeddings.word_embeddings.weight,
-                                          word_ids_cap=int(w['batch']) * int(w['max_txt_len']))     # (every rank's text is padded to at most this)
+                                          word_ids_cap=int(w['batch']) * int(w['max_txt_len']) * (int(w['accum']) if self.merge_accum else 1))     # (every rank's text is padded to at most this)
                         if (world > 1 or D._on()) else None)
         self.model.uniter.pack_padding = bool(pack)
         # each rank trains on its own shard (data/data.py:222): different synthetic batches per rank, resident in HBM
@@ -134,6 +137,9 @@ class StepRunner(object):
             b['img_pos_feat'] = b['img_pos_feat'].to(torch.bfloat16)
             if 'feat_targets' in b:
                 b['feat_targets'] = b['feat_targets'].to(torch.bfloat16)
+            if self.merge_accum:
+                from .data.merge import merge_batches
+                b = merge_batches([b] * int(w['accum']))              # (the micro-batches of a step are the same resident batch here)
             self.batches[t] = b
         if self.reducer is None:
             # single process: the backward call returns without joining the weight-gradient stream; clip_grad_norm_ / step join
@@ -174,21 +180,29 @@ class StepRunner(object):
 
     def _loss(self, task, batch):
         kind = self.w['model']
+        micro = batch.get('micro') if self.merge_accum else None      # merged micro-batches: per-micro-batch reductions, summed
+        if micro is not None:
+            from .data.merge import accumulated_itm_ot_loss, accumulated_loss
         if kind == 'nlvr2':
-            return self.model(batch, compute_loss=True).mean()
+            loss = self.model(batch, compute_loss=True)
+            return loss.mean() if micro is None else accumulated_loss(loss, micro)
         if kind == 'vqa':
             loss = self.model(batch, compute_loss=True)
+            if micro is not None:
+                return accumulated_loss(loss, micro, scale=batch['targets'].size(1))
             return loss.mean() * batch['targets'].size(1)             # train_vqa.py:188
         loss = self.model(batch, task=task, compute_loss=True)
         if task.startswith('itm'):                                    # pretrain.py:270-290
             itm_loss, ot_loss = loss
+            if micro is not None:
+                return accumulated_itm_ot_loss(itm_loss, ot_loss, batch['targets'], micro, self.w['itm_ot_lambda'])
             itm_loss = itm_loss.mean()
             if ot_loss is not None:
                 ot_pos, ot_neg = ot_loss
                 ot = (ot_pos.sum() - ot_neg.sum()) / (ot_pos.size(0) + ot_neg.size(0))
                 return itm_loss + self.w['itm_ot_lambda'] * ot
             return itm_loss
-        return loss.mean()
+        return loss.mean() if micro is None else accumulated_loss(loss, micro)
 
     def warm_up_tasks(self):
         """One untimed optimizer step per task of the mix, so that one-off work (tile selection for a task's head shapes,
@@ -210,7 +224,7 @@ class StepRunner(object):
             task = self._forced_task
         self.task_counts[task] += 1
         batch = self.batches[task]
-        accum = self.w['accum']
+        accum = 1 if self.merge_accum else self.w['accum']          # merged: one forward / backward over all micro-batches
         self._schedule_lr()
         loss = None
         seg = getattr(self, 'segment_events', None)                   # bench.py: GPU time of the forward / backward segments
