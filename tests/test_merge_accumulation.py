@@ -206,3 +206,26 @@ def test_accumulated_loss_of_the_merged_batch_equals_the_accumulation_loop(golde
         g2 = sd2[k].grad
         assert g2 is not None, k
         torch.testing.assert_close(g2, g, rtol=2e-4, atol=2e-6, msg=lambda m: "%s: %s" % (k, m))
+
+
+def test_meta_loader_hands_out_one_merged_batch_per_optimizer_step():
+    """MetaLoader(merge_micro_batches=True): the accumulation group of a step (one task, data/loader.py:42-47) arrives as one
+    batch equal to the collate of the group's examples; PrefetchLoader (pass-through on the CPU) keeps `micro` and adds seq_lens."""
+    from uniter_amd.data import MetaLoader, PrefetchLoader
+    groups = {t: _micro_batches(t, seed=31 + i, sizes=(2, 3, 2, 4), widths=((7, 5), (12, 8), (9, 9), (5, 4)))
+              for i, t in enumerate(('mlm', 'itm_ot'))}
+    loaders = {t: [COLLATE[t](m) for m in g] for t, g in groups.items()}
+    meta = MetaLoader({t: (l, 1) for t, l in loaders.items()}, accum_steps=2, rng=random.Random(3), merge_micro_batches=True)
+    seen = {t: 0 for t in loaders}
+    it = iter(PrefetchLoader(meta))
+    for _ in range(6):
+        task, batch = next(it)
+        k = seen[task] % 2                                     # every task's loader holds two accumulation groups and restarts
+        seen[task] += 1
+        whole = COLLATE[task]([e for m in groups[task][2 * k:2 * k + 2] for e in m])
+        info = batch.pop('micro')
+        lens = batch.pop('seq_lens')
+        assert lens == [int(v) for v in whole['attn_masks'].sum(1)]
+        _assert_same(batch, whole)
+        assert info['rows'] == [len(m) for m in groups[task][2 * k:2 * k + 2]]
+    assert all(v > 0 for v in seen.values())

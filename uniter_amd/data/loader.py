@@ -118,9 +118,13 @@ class PrefetchLoader(object):
 class MetaLoader(object):
     """Infinite iterator over (task name, batch): `loaders` maps a task name to a loader or a (loader, ratio) pair; a task
     is drawn (proportionally to its ratio) once per `accum_steps` batches, so that all micro-batches of one optimiser step
-    come from one task; exhausted loaders restart (data/loader.py:17-56)."""
+    come from one task; exhausted loaders restart (data/loader.py:17-56).
 
-    def __init__(self, loaders, accum_steps=1, distributed=False, rng=None):
+    merge_micro_batches=True hands out ONE batch per optimiser step instead: the step's `accum_steps` batches concatenated by
+    data/merge.py (`batch['micro']` carries what `accumulated_loss` needs to reproduce the loop's per-micro-batch means); the
+    training loop then runs with an accumulation count of 1.  Done on the host, before PrefetchLoader's copy."""
+
+    def __init__(self, loaders, accum_steps=1, distributed=False, rng=None, merge_micro_batches=False):
         if not isinstance(loaders, dict) or not loaders:
             raise ValueError("loaders must be a non-empty dict")
         self.name2loader, self.name2iter, self.sampling_pools = {}, {}, []
@@ -133,6 +137,7 @@ class MetaLoader(object):
         self.distributed = distributed
         self.step = 0
         self._rng = rng if rng is not None else random
+        self.merge_micro_batches = bool(merge_micro_batches) and int(accum_steps) > 1
 
     def _agree(self, task):
         if not (self.distributed and torch.distributed.is_available() and torch.distributed.is_initialized()
@@ -143,6 +148,18 @@ class MetaLoader(object):
         return box[0]
 
     def __iter__(self):
+        if not self.merge_micro_batches:
+            yield from self._micro_batches()
+            return
+        from .merge import merge_batches
+        group = []
+        for task, batch in self._micro_batches():
+            group.append(batch)
+            if len(group) == self.accum_steps:
+                yield task, merge_batches(group)
+                group = []
+
+    def _micro_batches(self):
         task = self.sampling_pools[0]
         while True:
             if self.step % self.accum_steps == 0:
