@@ -23,7 +23,7 @@ def _digests(tmp_path, workload, steps, **switches):
     # one tile table for all runs of a comparison: the first run saves what it used (factory table or a fresh sweep), the
     # later ones load it — a switch must not be able to hide behind a different tile choice
     env = dict(os.environ, UNITER_AMD_TUNE_CACHE=str(tmp_path / ("tiles_%s.json" % workload)), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("UNITER_AMD_XCD_AFFINITY",):
+    for k in ("UNITER_AMD_XCD_AFFINITY", "UNITER_AMD_ADAMW_NT"):
         env.pop(k, None)
     env.update({k: str(v) for k, v in switches.items()})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "step_digest_script.py"), workload, str(steps)],
@@ -52,6 +52,15 @@ def test_xcd_affinity_leaves_the_step_bit_identical(tmp_path, workload):
     assert ok, ("XCD affinity changed the result", diff)
     print("xcd affinity, %s: %d parameters identical after 2 steps" % (workload, base["n_params"]))
 
+
+
+def test_non_temporal_adamw_streams_leave_the_step_bit_identical(tmp_path):
+    """UNITER_AMD_ADAMW_NT=1 (csrc/adamw.hip: adamw_kernel<true>): the fp32 master / moment streams of the update and the
+    gradient read carry the non-temporal hint.  A cache policy: three optimizer steps must end on the same parameters."""
+    base = _digests(tmp_path, "c2", 3)
+    nt = _digests(tmp_path, "c2", 3, UNITER_AMD_ADAMW_NT=1)
+    ok, diff = _same(base, nt)
+    assert ok, ("non-temporal AdamW streams changed the result", diff)
 
 
 @pytest.mark.parametrize("workload", ["c3", "c4"])

@@ -54,6 +54,25 @@ struct Plan {
 
 // `zero_grads`: the gradient element is overwritten with zero once it has been read — optimizer.zero_grad() folded into
 // the update (same bytes written as the separate memset, one pass and one launch fewer).
+// NT = the update's streams (every byte is touched exactly once) are loaded and stored with the non-temporal hint, so that they
+// do not displace what the next forward pass wants to find in the L2s / the Infinity Cache (UNITER_AMD_ADAMW_NT=1; experiment,
+// default off).  Same arithmetic either way.
+// (the table hands the kernel generic pointers; named as global at the access they become global_load / global_store
+//  instead of flat instructions, like every other kernel of the library — common.cuh: ldg16)
+template <bool NT, typename V>
+__device__ __forceinline__ V adam_ld(const V* p) {
+    typedef __attribute__((address_space(1))) V GV;
+    if constexpr (NT) return __builtin_nontemporal_load((const GV*)p);
+    else return *(const GV*)p;
+}
+template <bool NT, typename V>
+__device__ __forceinline__ void adam_st(V* p, const V v) {
+    typedef __attribute__((address_space(1))) V GV;
+    if constexpr (NT) __builtin_nontemporal_store(v, (GV*)p);
+    else *(GV*)p = v;
+}
+
+template <bool NT>
 __global__ __launch_bounds__(256) void adamw_kernel(const DevTensor* __restrict__ tensors,
                                                     const ChunkRef* __restrict__ chunks, int64_t chunk_begin, int64_t n_chunks,
                                                     const HyperTable hyp, const GroupHyper* __restrict__ hyp_dev,
@@ -73,11 +92,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(const DevTensor* __restrict_
             const bool vec = (n == 4);
             float* pm = t.is_bf16 ? t.master : (float*)t.param;
             if (vec) {
-                if (t.is_bf16) unpack4(*reinterpret_cast<const u32x2*>((const bf16_t*)t.grad + idx), g);
-                else { const f32x4 q = *reinterpret_cast<const f32x4*>((const float*)t.grad + idx); g[0] = q[0]; g[1] = q[1]; g[2] = q[2]; g[3] = q[3]; }
-                const f32x4 pq = *reinterpret_cast<const f32x4*>(pm + idx);
-                const f32x4 mq = *reinterpret_cast<const f32x4*>(t.m + idx);
-                const f32x4 vq = *reinterpret_cast<const f32x4*>(t.v + idx);
+                if (t.is_bf16) unpack4(adam_ld<NT>(reinterpret_cast<const u32x2*>((const bf16_t*)t.grad + idx)), g);
+                else { const f32x4 q = adam_ld<NT>(reinterpret_cast<const f32x4*>((const float*)t.grad + idx)); g[0] = q[0]; g[1] = q[1]; g[2] = q[2]; g[3] = q[3]; }
+                const f32x4 pq = adam_ld<NT>(reinterpret_cast<const f32x4*>(pm + idx));
+                const f32x4 mq = adam_ld<NT>(reinterpret_cast<const f32x4*>(t.m + idx));
+                const f32x4 vq = adam_ld<NT>(reinterpret_cast<const f32x4*>(t.v + idx));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { p[e] = pq[e]; m[e] = mq[e]; v[e] = vq[e]; }
             } else {
@@ -99,13 +118,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(const DevTensor* __restrict_
                 if (h.wd > 0.f) p[e] = p[e] - h.lr * h.wd * p[e];
             }
             if (vec) {
-                *reinterpret_cast<f32x4*>(pm + idx) = f32x4{p[0], p[1], p[2], p[3]};
-                *reinterpret_cast<f32x4*>(t.m + idx) = f32x4{m[0], m[1], m[2], m[3]};
-                *reinterpret_cast<f32x4*>(t.v + idx) = f32x4{v[0], v[1], v[2], v[3]};
-                if (t.is_bf16) *reinterpret_cast<u32x2*>((bf16_t*)t.param + idx) = pack4(p);
+                adam_st<NT>(reinterpret_cast<f32x4*>(pm + idx), f32x4{p[0], p[1], p[2], p[3]});
+                adam_st<NT>(reinterpret_cast<f32x4*>(t.m + idx), f32x4{m[0], m[1], m[2], m[3]});
+                adam_st<NT>(reinterpret_cast<f32x4*>(t.v + idx), f32x4{v[0], v[1], v[2], v[3]});
+                // (the bf16 weights are what the next forward pass reads, the zeroed gradients what the next backward pass
+                //  accumulates into: both keep the default policy)
+                if (t.is_bf16) adam_st<false>(reinterpret_cast<u32x2*>((bf16_t*)t.param + idx), pack4(p));
                 if (zero_grads) {
-                    if (t.is_bf16) *reinterpret_cast<u32x2*>((bf16_t*)t.grad + idx) = u32x2{0u, 0u};
-                    else *reinterpret_cast<f32x4*>((float*)t.grad + idx) = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (t.is_bf16) adam_st<false>(reinterpret_cast<u32x2*>((bf16_t*)t.grad + idx), u32x2{0u, 0u});
+                    else adam_st<false>(reinterpret_cast<f32x4*>((float*)t.grad + idx), f32x4{0.f, 0.f, 0.f, 0.f});
                 }
             } else {
                 for (int e = 0; e < n; ++e) {
@@ -301,6 +322,20 @@ static int fill_hyper(const UniterAdamGroup* groups, int32_t n_groups, HyperTabl
 static int adamw_step_impl(void* plan, const UniterAdamGroup* groups, int32_t n_groups, const float* clip_coef, int zero_grads,
                            void* stream);
 
+static bool adamw_nt() {
+    static const bool on = [] { const char* e = getenv("UNITER_AMD_ADAMW_NT"); return e != nullptr && atoi(e) != 0; }();
+    return on;
+}
+static void adamw_launch(int64_t blocks, hipStream_t st, const DevTensor* tensors, const ChunkRef* chunks, int64_t begin, int64_t end,
+                         const HyperTable& ht, const GroupHyper* dev_hyper, const float* clip_coef, int zero_grads) {
+    if (adamw_nt())
+        hipLaunchKernelGGL(adamw_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, tensors, chunks, begin, end, ht, dev_hyper,
+                           clip_coef, zero_grads);
+    else
+        hipLaunchKernelGGL(adamw_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, tensors, chunks, begin, end, ht, dev_hyper,
+                           clip_coef, zero_grads);
+}
+
 int uniter_adamw_step(void* plan, const UniterAdamGroup* groups, int32_t n_groups,
                       const float* clip_coef, void* stream) {
     return adamw_step_impl(plan, groups, n_groups, clip_coef, 0, stream);
@@ -321,9 +356,8 @@ static int adamw_step_impl(void* plan, const UniterAdamGroup* groups, int32_t n_
     // enough blocks to fill the chip several times over; chunks are grid-strided
     int64_t blocks = p->n_chunks < 8192 ? p->n_chunks : 8192;
     uh::LaunchTimer lt(uh::TIME_ADAMW, p->n_chunks, 0, 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const DevTensor*)p->d_tensors, (const ChunkRef*)p->d_chunks, (int64_t)0, p->n_chunks, ht, (const GroupHyper*)nullptr,
-                       clip_coef, zero_grads);
+    adamw_launch(blocks, (hipStream_t)stream, (const DevTensor*)p->d_tensors, (const ChunkRef*)p->d_chunks, (int64_t)0, p->n_chunks, ht,
+                 (const GroupHyper*)nullptr, clip_coef, zero_grads);
     UH_LAUNCH_CHECK();
     return 0;
 }
@@ -335,9 +369,8 @@ int uniter_adamw_step_dev(void* plan, const float* dev_hyper, int32_t n_groups, 
     HyperTable ht{};
     int64_t blocks = p->n_chunks < 8192 ? p->n_chunks : 8192;
     uh::LaunchTimer lt(uh::TIME_ADAMW, p->n_chunks, 0, 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const DevTensor*)p->d_tensors, (const ChunkRef*)p->d_chunks, (int64_t)0, p->n_chunks, ht,
-                       (const GroupHyper*)dev_hyper, clip_coef, 0);
+    adamw_launch(blocks, (hipStream_t)stream, (const DevTensor*)p->d_tensors, (const ChunkRef*)p->d_chunks, (int64_t)0, p->n_chunks, ht,
+                 (const GroupHyper*)dev_hyper, clip_coef, 0);
     UH_LAUNCH_CHECK();
     return 0;
 }
@@ -427,8 +460,8 @@ int uniter_adamw_step_async(void* plan, const UniterAdamGroup* groups, int32_t n
         if (throttle > 0 && sgm >= full_segs && blocks > throttle) blocks = throttle;
         {
             uh::LaunchTimer lt(uh::TIME_ADAMW, n, 0, 0, side);
-            hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, side, (const DevTensor*)p->d_tensors,
-                               (const ChunkRef*)p->d_chunks, begin, end, ht, (const GroupHyper*)nullptr, clip_coef, (int)zero_grads);
+            adamw_launch(blocks, side, (const DevTensor*)p->d_tensors, (const ChunkRef*)p->d_chunks, begin, end, ht,
+                         (const GroupHyper*)nullptr, clip_coef, (int)zero_grads);
             UH_LAUNCH_CHECK();
         }
         hipEvent_t ev = g_pt.pool[g_pt.pending.size()];
