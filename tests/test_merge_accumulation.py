@@ -229,3 +229,44 @@ def test_meta_loader_hands_out_one_merged_batch_per_optimizer_step():
         _assert_same(batch, whole)
         assert info['rows'] == [len(m) for m in groups[task][2 * k:2 * k + 2]]
     assert all(v > 0 for v in seen.values())
+
+
+@pytest.mark.parametrize("kind,task", [('nlvr2', 'nlvr2'), ('vqa', 'vqa'), ('pretrain', 'mlm'), ('pretrain', 'itm')])
+def test_step_runner_loss_reduction_merged_equals_loop(kind, task):
+    """uniter_amd.train.StepRunner._loss (the scalar the bench's step back-propagates) with and without merged micro-batches, on a
+    stand-in model that returns fixed un-reduced losses: the merged scalar is the sum of the loop's per-micro-batch scalars."""
+    from uniter_amd.train import StepRunner
+    gen = torch.Generator().manual_seed(5)
+    rows = [3, 5, 2]                                            # loss rows of three micro-batches
+    cols = 13 if kind == 'vqa' else None
+    parts = [torch.rand((n, cols) if cols else (n,), generator=gen) for n in rows]
+    targets = [torch.randint(0, 2, (n,), generator=gen) for n in rows]
+    ot = [torch.rand(n, generator=gen) for n in rows]
+
+    class _Model(object):
+        def __call__(self, batch, task=None, compute_loss=True):
+            i = batch['which']
+            loss = torch.cat(parts) if i is None else parts[i]
+            if task == 'itm':
+                t = torch.cat(targets) if i is None else targets[i]
+                d = torch.cat(ot) if i is None else ot[i]
+                return loss, (d[t == 1], d[t == 0])
+            return loss
+
+    def runner(merged):
+        r = StepRunner.__new__(StepRunner)
+        r.w = {'model': kind, 'itm_ot_lambda': 0.1}
+        r.model = _Model()
+        r.merge_accum = merged
+        return r
+
+    def batch(i):
+        t = torch.cat(targets) if i is None else targets[i]
+        b = {'which': i, 'targets': torch.zeros(t.numel(), cols) if cols else t}
+        if i is None:
+            b['micro'] = {'rows': rows, 'loss_rows': rows}
+        return b
+
+    loop = sum(float(runner(False)._loss(task, batch(i))) for i in range(3))
+    merged = float(runner(True)._loss(task, batch(None)))
+    assert abs(loop - merged) <= 1e-6 * max(1.0, abs(loop)), (loop, merged)
