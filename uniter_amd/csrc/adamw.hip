@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void gradsq_kernel(const DevTensor* __restrict
             for (int it = 0; it < CHUNK / (256 * 4); ++it) {
                 const int64_t idx = base + ((int64_t)it * 256 + threadIdx.x) * 4;
                 raw[it] = u32x2{0u, 0u};
-                if (idx + 4 <= t.numel) raw[it] = *reinterpret_cast<const u32x2*>((const bf16_t*)t.grad + idx);
+                if (idx + 4 <= t.numel) raw[it] = adam_ld<false>(reinterpret_cast<const u32x2*>((const bf16_t*)t.grad + idx));
             }
 #pragma unroll
             for (int it = 0; it < CHUNK / (256 * 4); ++it) {
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void gradsq_kernel(const DevTensor* __restrict
                 if (idx >= t.numel) break;
                 const int n = (t.numel - idx >= 4) ? 4 : (int)(t.numel - idx);
                 if (n == 4) {
-                    const f32x4 q = *reinterpret_cast<const f32x4*>((const float*)t.grad + idx);
+                    const f32x4 q = adam_ld<false>(reinterpret_cast<const f32x4*>((const float*)t.grad + idx));
                     acc += (q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]);
                 } else {
                     for (int e = 0; e < n; ++e) { const float ge = ((const float*)t.grad)[idx + e]; acc += ge * ge; }
