@@ -534,3 +534,56 @@ def test_database_to_gpu_step_equals_direct_batches(tmp_path):
             assert a.shape == (len(idx),) and torch.equal(a, b) and torch.isfinite(a).all()
             n += len(idx)
     assert n == 37
+
+
+def test_token_bucket_batches_merge_into_one_batch_per_optimizer_step(tmp_path):
+    """Database -> MlmDataset / ItmDataset -> TokenBucketSampler -> DataLoader -> MetaLoader(accum_steps=2, merge_micro_batches=True):
+    every batch the loop receives equals the collate of the examples of its two token-bucket micro-batches (whose padded widths
+    differ), and `micro` carries the per-micro-batch row counts the loss reduction needs (uniter_amd/data/merge.py)."""
+    from uniter_amd.data import MetaLoader
+    txt_dir, img_dir, _, _, _ = _build_db(str(tmp_path / 'merge'), False)
+    txt_db = TxtTokLmdb(txt_dir, max_txt_len=-1)
+    img_db = ImageLmdbGroup(0.2, 10, 4, 36, False)[img_dir]
+
+    class _Fixed(MlmDataset):                      # deterministic masking, so the same example can be drawn twice
+        def create_mlm_io(self, input_ids):
+            ids = torch.tensor([self.txt_db.cls_] + list(input_ids) + [self.txt_db.sep])
+            labels = torch.full_like(ids, -1)
+            labels[1] = ids[1]
+            ids = ids.clone()
+            ids[1] = self.txt_db.mask
+            return ids, labels
+    mlm = _Fixed(txt_db, img_db)
+    itm = ItmDataset(txt_db, img_db, neg_sample_p=0.5, rng=random.Random(2), np_rng=np.random.RandomState(4))
+
+    def loader(ds, collate, seed):
+        sampler = TokenBucketSampler(ds.lens, bucket_size=8, batch_size=96, size_multiple=2, rng=random.Random(seed))
+        batches = [b for b in sampler]                                     # (the sampler refuses len(), as upstream)
+        return torch.utils.data.DataLoader(ds, batch_sampler=batches, collate_fn=collate, num_workers=0), batches
+    l_mlm, b_mlm = loader(mlm, mlm_collate, 1)
+    l_itm, b_itm = loader(itm, itm_ot_collate, 2)
+    assert len(b_mlm) >= 4 and len({len(b) for b in b_mlm}) > 1               # ragged micro-batches
+    meta = MetaLoader({'mlm': (l_mlm, 1), 'itm': (l_itm, 1)}, accum_steps=2, rng=random.Random(9), merge_micro_batches=True)
+    cursor = {'mlm': 0, 'itm': 0}
+    plan = {'mlm': (mlm, mlm_collate, b_mlm), 'itm': (itm, itm_ot_collate, b_itm)}
+    it = iter(meta)
+    widths = set()
+    for _ in range(5):
+        task, batch = next(it)
+        ds, collate, batches = plan[task]
+        k = cursor[task]
+        if k + 2 > len(batches):                                               # (an exhausted loader restarts: data/loader.py:50-54)
+            break
+        cursor[task] = k + 2
+        group = batches[k] + batches[k + 1]
+        whole = collate([ds[i] for i in group])
+        info = batch.pop('micro')
+        assert info['rows'] == [len(batches[k]), len(batches[k + 1])]
+        assert sorted(batch) == sorted(whole)
+        for key, v in whole.items():
+            if isinstance(v, dict):
+                assert all(torch.equal(v[q], batch[key][q]) if isinstance(v[q], torch.Tensor) else v[q] == batch[key][q] for q in v), key
+            else:
+                assert torch.equal(v, batch[key]), (task, key)
+        widths.add((collate([ds[i] for i in batches[k]])['input_ids'].size(1), collate([ds[i] for i in batches[k + 1]])['input_ids'].size(1)))
+    assert any(a != b for a, b in widths)                                      # at least one step merged micro-batches of different text widths
