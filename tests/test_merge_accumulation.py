@@ -270,3 +270,19 @@ def test_step_runner_loss_reduction_merged_equals_loop(kind, task):
     loop = sum(float(runner(False)._loss(task, batch(i))) for i in range(3))
     merged = float(runner(True)._loss(task, batch(None)))
     assert abs(loop - merged) <= 1e-6 * max(1.0, abs(loop)), (loop, merged)
+
+
+def test_padding_overhead_of_merged_token_bucket_batches():
+    """Merging micro-batches of different widths pads the narrow one to the wide one: `padding_overhead` makes the cost of dense
+    execution visible (the packed path computes real tokens only)."""
+    from uniter_amd.data.merge import padding_overhead
+    rng, gen = random.Random(1), torch.Generator().manual_seed(1)
+    narrow = [_task_example('itm', rng, gen, 4, 3) for _ in range(8)]
+    wide = [_task_example('itm', rng, gen, 30, 20) for _ in range(2)]
+    a, b = T.itm_collate(narrow), T.itm_collate(wide)
+    m = merge_batches([a, b])
+    real = int(a['attn_masks'].sum() + b['attn_masks'].sum())
+    assert abs(padding_overhead(m) - m['attn_masks'].numel() / real) < 1e-9
+    dense_separately = (a['attn_masks'].numel() + b['attn_masks'].numel()) / real
+    assert padding_overhead(m) > 1.5 * dense_separately
+    assert padding_overhead(merge_batches([a, a])) == padding_overhead(a)

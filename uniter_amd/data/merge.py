@@ -11,6 +11,11 @@ four times as tall — the shape this chip is efficient at (DESIGN.md section 11
   accumulated_loss(loss, ...)    the un-reduced loss of the merged batch -> sum over micro-batches of the reference's per-micro-
                                  batch reduction, i.e. exactly the scalar whose gradient the accumulation loop produces
 
+Token-bucket micro-batches (data/sampler.py:31-57) of one step can have very different padded widths — 64 sequences of 40
+tokens and 16 of 160 merge into 80 rows padded to 160, 2.5x the tokens of the two batches run separately.  With real (ragged)
+data the merged batch therefore belongs on the padding-free path (`UniterModel.pack_padding`), which
+computes real tokens only; `padding_overhead(batch)` reports what dense execution of a merged batch would waste.
+
 `tests/test_merge_accumulation.py` checks the first against the collate functions of `uniter_amd.data.tasks` (bit-exact) and
 the second against the oracle's accumulated gradients.
 """
@@ -103,6 +108,14 @@ def merge_batches(batches):
     rows = [int(b['input_ids'].size(0)) for b in batches]
     out['micro'] = {'rows': rows, 'loss_rows': [_loss_rows(b) for b in batches]}
     return out
+
+
+def padding_overhead(batch):
+    """Tokens a dense forward pass computes for `batch` divided by its real tokens (1.0 = no padding).  For a merged batch compare
+    with the micro-batches' own figures: merging batches of different widths raises it, the packed path is unaffected."""
+    masks = batch['attn_masks']
+    real = int(masks.ne(0).sum().item())
+    return float(masks.numel()) / float(max(real, 1))
 
 
 def _loss_rows(b):
