@@ -19,9 +19,10 @@ fi
 if [[ $PART == *b* ]]; then
   {
     for rep in 1 2; do
-      timeout 300 python bench.py --no-cpu-baseline --steps 40 --warmup 8 2>/dev/null | line "c2 default maps (run $rep)"
-      UNITER_AMD_XCD_AFFINITY=1 timeout 300 python bench.py --no-cpu-baseline --steps 40 --warmup 8 2>/dev/null | line "c2 UNITER_AMD_XCD_AFFINITY=1 (run $rep)"
+      timeout 300 python bench.py --no-cpu-baseline --steps 40 --warmup 8 2>/dev/null | tee "$OUT/c2_default_$rep.json" | line "c2 default maps (run $rep)"
+      UNITER_AMD_XCD_AFFINITY=1 timeout 300 python bench.py --no-cpu-baseline --steps 40 --warmup 8 2>/dev/null | tee "$OUT/c2_affinity_$rep.json" | line "c2 UNITER_AMD_XCD_AFFINITY=1 (run $rep)"
     done
+    echo "--- per-kernel, default (A) vs affinity (B), second pair"; python scripts/compare_bench.py "$OUT/c2_default_2.json" "$OUT/c2_affinity_2.json" | head -30
     timeout 200 python scripts/time_adamw.py 2>/dev/null | tail -1 | sed 's/^/default policy: /'
     UNITER_AMD_ADAMW_NT=1 timeout 200 python scripts/time_adamw.py 2>/dev/null | tail -1 | sed 's/^/UNITER_AMD_ADAMW_NT=1: /'
     UNITER_AMD_ADAMW_NT=1 timeout 300 python bench.py --no-cpu-baseline --steps 40 --warmup 8 2>/dev/null | line "c2 UNITER_AMD_ADAMW_NT=1"
