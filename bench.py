@@ -128,6 +128,33 @@ def pmc_traffic(kind_id, shape):
             "kernel": e["kernel"], "grid": e["grid"], "source": os.path.basename(files[-1])}
 
 
+def pmc_step_traffic():
+    """Fabric-side bytes per optimizer step of every kernel of the forward + backward segments (everything but the optimizer's
+    kernels), summed from the committed PMC passes (profiles/*_pmc_traffic.json: `by_kernel` rows, bytes per step).  None if
+    the newest file has no such table."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        doc = json.load(open(files[-1]))
+    except (OSError, ValueError):
+        return None
+    rows = doc.get("by_kernel")
+    if not rows:
+        return None
+    tot = 0.0
+    opt = 0.0
+    for r in rows:
+        b = float(r.get("hbm_bytes_per_step", 0.0))
+        if "adamw" in r.get("kernel", "") or "gradsq" in r.get("kernel", ""):
+            opt += b
+        else:
+            tot += b
+    return {"fwd_bwd_bytes_per_step": int(tot), "optimizer_bytes_per_step": int(opt), "source": os.path.basename(files[-1]),
+            "note": "FETCH_SIZE (x2: the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE per kernel family, separate --pmc passes"}
+
+
 def usable_cores():
     """Host cores this process may actually use: affinity mask and cgroup CPU quota, not the raw host count."""
     try:
@@ -357,6 +384,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--windows", type=int, default=3,
+                    help="timed windows of --steps optimizer steps each; the line reports the median window (min / max beside it)")
     ap.add_argument("--config", default="c2", choices=sorted(WORKLOADS),
                     help="c2 = the headline workload (BASELINE.json metric); c3 / c4 / c5 = the other north-star "
                          "configurations as one GPU's share of the job (uniter_amd/train.py)")
@@ -441,20 +470,28 @@ def main():
         runner.warm_up_tasks()                # every task of the mix once, untimed (on top of the W warm-up steps)
     for _ in range(args.warmup):
         train_step()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = train_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # The timed region: `--windows` windows (default 3) of EXACTLY `--steps` optimizer steps each, every window bracketed by a
+    # barrier + torch.cuda.synchronize() on both sides, its time the MAX over ranks.  `value` / `ms_per_step` are those of the
+    # MEDIAN window (min and max beside them): one 90 ms window on boxes that differ by several per cent cannot resolve a
+    # round-over-round change of 1-2 %.
+    window_s = []
+    for _ in range(max(1, args.windows)):
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = train_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t.item())
+        window_s.append(el)
+    elapsed = sorted(window_s)[len(window_s) // 2]
     final_loss = float(loss.item())
     assert final_loss == final_loss, "loss is NaN"
 
@@ -476,39 +513,46 @@ def main():
         value = B * world * args.steps / elapsed
         flop_step = runner.flop_per_step()
         step_tf = flop_step / (ms * 1e-3) * 1e-12
-        roofline = None
+        # roofline: the north star states its target on the ENCODER's forward + backward (>= 40 % of the dense bf16 MFMA peak), so
+        # that is what `achieved` / `frac` are: algorithmic encoder FLOP per step (n_layers x (24 T H^2 +
+        # 4 T L H), x3 for fwd + bwd) over the GPU time of model(batch) + loss.backward(), measured in this run with HIP events on
+        # the compute stream.  The launch with the most MFMA time per step keeps its own figure under `dominant_kernel`.
+        roofline = {"bound": "mfma", "kernel": "encoder forward + backward (all kernels of model(batch) and loss.backward(); embeddings and task head included in the time, excluded from the FLOP)",
+                    "achieved": round(step_tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(step_tf / MFMA_PEAK_TFLOPS, 4),
+                    "traffic": None, "subject": "whole step (no segment events in this mode)",
+                    "step": {"algorithmic_tflop_per_step": round(flop_step * 1e-12, 4), "achieved": round(step_tf, 1),
+                             "frac": round(step_tf / MFMA_PEAK_TFLOPS, 4),
+                             "note": "encoder fwd+bwd algorithmic FLOP (heads, embeddings, optimizer excluded) / whole step time (median window)"}}
+        if segments is not None:
+            fwd_ms, bwd_ms = segments
+            fb_tf = flop_step / ((fwd_ms + bwd_ms) * 1e-3) * 1e-12
+            roofline.update({"achieved": round(fb_tf, 1), "frac": round(fb_tf / MFMA_PEAK_TFLOPS, 4), "subject": "encoder_fwd_bwd"})
+            roofline["encoder_fwd_bwd"] = {"fwd_ms": round(fwd_ms, 3), "bwd_ms": round(bwd_ms, 3), "achieved": round(fb_tf, 1),
+                                           "frac": round(fb_tf / MFMA_PEAK_TFLOPS, 4), "unit": "TFLOP/s",
+                                           "measured": "HIP events on the compute stream around model(batch) and loss.backward() "
+                                                       "over extra optimizer steps after the timed region (per optimizer step)"}
         if kernels is not None:
             mfma = [k for k in kernels if k["tflops"] is not None]
             dom = max(mfma, key=lambda k: k["us_per_step"])
             M, N, K = dom["shape"]
             traffic = pmc_traffic(dom["kind_id"], dom["shape"])
             label = "%s M%d N%d K%d" % (dom["kernel"], M, N, K)
-            note = ("in the backward pass this kernel shares the GPU with the wgrad side stream, so the in-situ duration is "
-                    "longer than the kernel alone (DESIGN.md section 5)")
+            note = "in situ (the kernel's own stream)"
             if dom["kind_id"] == 13 and K > 4:
                 # the deferred launch: every weight / bias / LayerNorm parameter gradient of one backward call (K problems
-                # = 4 per layer) over M tokens, N = weight elements of all its problems (DESIGN.md section 9.5)
+                # = 4 per layer) over M tokens, N = weight elements of all its problems (DESIGN.md section 4)
                 label = "deferred weight gradients of %d layers in one launch (gemm8_multi_kernel): %d tokens x %d weight elements" % (K // 4, M, N)
                 note = ("the launch runs on the library's weight-gradient stream after the backward chain of the call; the "
-                        "embedding backward of the main stream overlaps its tail (DESIGN.md section 9.5)")
-            roofline = {"bound": "mfma", "kernel": label, "achieved": dom["tflops"],
-                        "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4),
-                        "traffic": None if traffic is None else traffic["hbm_bytes"],
-                        "traffic_detail": traffic,
-                        "avg_launch_us": dom["us"], "launches_per_step": dom["launches_per_step"],
-                        "measured": "HIP events around every launch on its own stream during %d extra optimizer steps; %s" % (tsteps, note),
-                        "step": {"algorithmic_tflop_per_step": round(flop_step * 1e-12, 4), "achieved": round(step_tf, 1),
-                                 "frac": round(step_tf / MFMA_PEAK_TFLOPS, 4),
-                                 "note": "encoder fwd+bwd algorithmic FLOP (heads, embeddings, optimizer excluded) / whole step time"}}
-            if segments is not None:
-                fwd_ms, bwd_ms = segments
-                fb_tf = flop_step / ((fwd_ms + bwd_ms) * 1e-3) * 1e-12
-                # the north star states its 40 % target on forward + backward: the same FLOP over the GPU time of those two
-                # segments only (they still contain the embeddings and the task head, so this is a lower bound for the encoder)
-                roofline["encoder_fwd_bwd"] = {"fwd_ms": round(fwd_ms, 3), "bwd_ms": round(bwd_ms, 3), "achieved": round(fb_tf, 1),
-                                               "frac": round(fb_tf / MFMA_PEAK_TFLOPS, 4), "unit": "TFLOP/s",
-                                               "measured": "HIP events on the compute stream around model(batch) and loss.backward() "
-                                                           "over extra optimizer steps after the timed region (per optimizer step)"}
+                        "embedding backward of the main stream overlaps its tail")
+            roofline["dominant_kernel"] = {"kernel": label, "achieved": dom["tflops"], "unit": "TFLOP/s",
+                                           "frac": round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4),
+                                           "avg_launch_us": dom["us"], "launches_per_step": dom["launches_per_step"],
+                                           "traffic": None if traffic is None else traffic["hbm_bytes"], "traffic_detail": traffic,
+                                           "measured": "HIP events around every launch on its own stream during %d extra optimizer steps; %s" % (tsteps, note)}
+            step_traffic = pmc_step_traffic()
+            if step_traffic is not None:
+                roofline["traffic"] = step_traffic["fwd_bwd_bytes_per_step"]
+                roofline["traffic_detail"] = step_traffic
         metric = "train examples/sec UNITER-base seq=60txt+36img bs32/GPU"
         if args.config != 'c2':
             metric = "train examples/sec (%s: %s seq=%dtxt+%dimg bs%dx%d/GPU)" % (
@@ -530,8 +574,12 @@ def main():
             "roofline": roofline,
             # `roofline.achieved` / `avg_launch_us` are measured in THIS run (HIP events); `roofline.traffic` is not: it is the
             # per-launch PMC figure of the committed rocprofv3 passes (profiles/*_pmc_traffic.json, separate --pmc runs)
-            "traffic_source": None if roofline is None or roofline.get("traffic") is None else
+            "traffic_source": None if roofline.get("traffic") is None else
                               "committed (%s; not measured in this run)" % roofline["traffic_detail"].get("source", "profiles/*_pmc_traffic.json"),
+            "timed_windows": {"n": len(window_s), "steps_each": args.steps, "reported": "median",
+                              "ms_per_step": [round(x / args.steps * 1e3, 3) for x in window_s],
+                              "ms_per_step_min": round(min(window_s) / args.steps * 1e3, 3),
+                              "ms_per_step_max": round(max(window_s) / args.steps * 1e3, 3)},
         }
         if kernels is not None:
             result["kernels"] = kernels

@@ -258,7 +258,20 @@ def pmc_traffic(fetch_csv, write_csv, dst):
                 by_shape["13:%d:%d:%d" % (g3[0]["M"], layers * (H * I + I * H + H * H + 3 * H * H), 4 * layers)] = {
                     "kernel": short(name), "grid": grid, "dispatches": len(fv), "shares_template_with": 0,
                     "hbm_read_bytes": round(rd), "hbm_write_bytes": round(wr), "hbm_bytes": round(rd + wr)}
-    json.dump({"by_shape": by_shape, "per_kernel": per,
+    # every kernel family of the step (not only the GEMMs): bytes per optimizer step = sum over the family's dispatches / steps,
+    # steps = number of AdamW launches of the pass (bench.py's roofline.traffic sums the non-optimizer rows)
+    n_steps = max([len(v) for (name, _), v in fetch.items() if "adamw_kernel" in name] or [1])
+    fam = collections.defaultdict(lambda: [0.0, 0.0, 0])
+    for (name, grid), fv in fetch.items():
+        a = fam[family(name)]
+        a[0] += 2.0 * sum(fv) * 1024.0
+        a[2] += len(fv)
+    for (name, grid), wv in write.items():
+        fam[family(name)][1] += sum(wv) * 1024.0
+    by_kernel = [{"kernel": k, "launches_per_step": round(v[2] / n_steps, 2), "hbm_read_bytes_per_step": round(v[0] / n_steps),
+                  "hbm_write_bytes_per_step": round(v[1] / n_steps), "hbm_bytes_per_step": round((v[0] + v[1]) / n_steps)}
+                 for k, v in sorted(fam.items(), key=lambda kv: -(kv[1][0] + kv[1][1]))]
+    json.dump({"by_shape": by_shape, "per_kernel": per, "by_kernel": by_kernel, "steps_in_pass": n_steps,
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over "
                          "`python bench.py --steps 3 --warmup 2` with pinned tile choices",
                "correction": "KiB -> bytes; FETCH_SIZE doubled on gfx950 (128-B requests of wide coalesced reads are tallied "

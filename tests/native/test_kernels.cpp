@@ -1497,6 +1497,48 @@ static int run_g8(int argc, char** argv, int at) {
     return g_fail;
 }
 
+
+// --roofs [iters] [M] : the eight GEMMs of a UNITER-base layer's forward / data-gradient chain, each alone on hot operands with the
+// tile the shipped table picks (or UNITER_ROOFS_CFG=<tile> for all of them), `iters` launches each.  Prints one TIME line per
+// shape; meant to run under `rocprofv3 --pmc ... --kernel-trace` (scripts/gpu_r5_roofs.sh), where the dispatches of the CSV
+// appear in this order, 3 warm-up + iters per shape.
+static int run_roofs(int argc, char** argv, int at) {
+    const int iters = at < argc ? atoi(argv[at]) : 10;
+    const int64_t M = at + 1 < argc ? atoll(argv[at + 1]) : 3072;
+    const int64_t H = 768, I = 3072;
+    load_tuned_json(getenv("UNITER_TUNED_JSON") ? getenv("UNITER_TUNED_JSON") : "uniter_amd/tuned/gfx950.json");
+    const char* fc = getenv("UNITER_ROOFS_CFG");
+    uniter_gemm_debug_force(fc ? atoi(fc) : -1, fc ? 1 : -1);
+    HostBf A, W, Bv;
+    A.fill((size_t)M * I, 1.f); W.fill((size_t)I * I, 0.05f); Bv.fill((size_t)I, 0.1f);
+    uint16_t *dA = upload(A), *dW = upload(W), *dB = upload(Bv), *dR = upload(A);
+    uint16_t *dO = dalloc<uint16_t>((size_t)M * I), *dO2 = dalloc<uint16_t>((size_t)M * I);
+    struct Shape { const char* name; int kind; int64_t N, K; } shapes[] = {
+        {"qkv_fwd", 0, 3 * H, H}, {"out_fwd", 1, H, H}, {"ffn1_fwd_gelu", 2, I, H}, {"ffn2_fwd", 1, H, I},
+        {"ffn2_dgrad_gelu", 3, H, I}, {"ffn1_dgrad", 4, I, H}, {"out_dgrad", 5, H, H}, {"qkv_dgrad", 4, 3 * H, H}};
+    Timer tm;
+    for (const Shape& s : shapes) {
+        const int64_t N = s.N, K = s.K;
+        auto fn = [&] {
+            switch (s.kind) {
+                case 0: UHCHK(uniter_gemm_bias_fwd(dA, dW, dB, dO, M, N, K, 0)); break;
+                case 1: UHCHK(uniter_gemm_bias_dropout_residual_fwd(dA, dW, dB, dR, dO, M, N, K, 0.1f, 1234u, 0u, 0)); break;
+                case 2: UHCHK(uniter_gemm_bias_gelu_fwd(dA, dW, dB, dO, dO2, M, N, K, 0)); break;
+                case 3: UHCHK(uniter_gemm_dgrad_gelu(dA, dW, dR, dO, M, N, K, 0)); break;
+                case 4: UHCHK(uniter_gemm_dgrad(dA, dW, dR, dO, M, N, K, 0)); break;
+                default: UHCHK(uniter_gemm_dgrad(dA, dW, nullptr, dO, M, N, K, 0)); break;
+            }
+        };
+        const double us = tm.run(fn, 3, iters);
+        int32_t ch[2] = {-1, -1};
+        uniter_gemm_tuned_choice(s.kind == 0 || s.kind == 1 || s.kind == 2 ? 0 : 1, M, N, K, ch);
+        printf("  ROOF %-16s M%lld N%lld K%lld tile %d : %7.2f us  %7.1f TF\n", s.name, (long long)M, (long long)N, (long long)K, fc ? atoi(fc) : ch[0], us,
+               2.0 * M * N * K / us * 1e-6);
+    }
+    uniter_gemm_debug_force(-1, -1);
+    return 0;
+}
+
 static void on_segv(int) {                 // where did it die: raw return addresses + symbols to stderr
     void* bt[48];
     const int n = backtrace(bt, 48);
@@ -1593,6 +1635,11 @@ int main(int argc, char** argv) {
             int32_t inf[4];
             UHCHK(uniter_hip_device_info(inf));
             return run_attn(argc, argv, i + 1);
+        }
+        if (!strcmp(argv[i], "--roofs")) {
+            int32_t inf[4];
+            UHCHK(uniter_hip_device_info(inf));
+            return run_roofs(argc, argv, i + 1);
         }
         if (!strcmp(argv[i], "--one")) {
             int32_t inf[4];

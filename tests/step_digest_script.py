@@ -17,7 +17,7 @@ import torch  # noqa: E402
 
 
 def _digest(t):
-    return hashlib.sha256(t.detach().contiguous().cpu().view(torch.uint8).numpy().tobytes()).hexdigest()[:16]
+    return hashlib.sha256(t.detach().contiguous().cpu().reshape(-1).view(torch.uint8).numpy().tobytes()).hexdigest()[:16]
 
 
 def main():

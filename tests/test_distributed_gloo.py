@@ -148,8 +148,7 @@ def _case_sparse_word_rows(rank, world, D):
                 model.uniter.encoder.grad_ready_hook(l)
             if sparse and big_vocab:
                 os.environ["UNITER_AMD_DP_WORD_COMPACT"] = "1"
-            if world < 4:
-                os.environ["UNITER_AMD_DP_SPARSE_WORD"] = "1"     # (two ranks: below the automatic threshold; from four ranks it is the default)
+            os.environ["UNITER_AMD_DP_SPARSE_WORD"] = "1"         # the row exchange is opt-in at every world size
             scale = reducer.finish(word_ids=ids if sparse else None)
             os.environ.pop("UNITER_AMD_DP_WORD_COMPACT", None)
             os.environ.pop("UNITER_AMD_DP_SPARSE_WORD", None)

@@ -239,3 +239,25 @@ def test_pack_indices_layout():
     assert total == 5 and extra == [16, 16, 16, 11] and int(cu[-1]) == 64
     with pytest.raises(ValueError):
         pack_indices([9], max_len=8)
+
+
+def test_noop_and_parse_with_config(tmp_path):
+    """utils/misc.py:17-36 of the reference: rank > 0 stand-ins, and --config JSON below the command line in precedence."""
+    import argparse
+    import json
+    from uniter_amd.utils.misc import NoOp, parse_with_config
+    n = NoOp()
+    assert n.update(3) is None and n.add_scalar("x", 1.0, step=2) is None and n.close() is None
+    cfg = tmp_path / "c.json"
+    cfg.write_text(json.dumps({"learning_rate": 5e-5, "train_batch_size": 4096, "extra_key": [1, 2]}))
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config")
+    ap.add_argument("--learning_rate", type=float, default=3e-5)
+    ap.add_argument("--train_batch_size", type=int, default=1024)
+    a = parse_with_config(ap, ["--config", str(cfg), "--learning_rate=1e-4"])
+    assert a.learning_rate == 1e-4                    # spelled on the command line: wins over the file
+    assert a.train_batch_size == 4096                 # only in the file (the parser's default loses)
+    assert a.extra_key == [1, 2]                      # keys the parser does not know are attached too
+    assert not hasattr(a, "config")
+    b = parse_with_config(ap, ["--train_batch_size", "8"])
+    assert b.train_batch_size == 8 and b.learning_rate == 3e-5 and not hasattr(b, "config")

@@ -134,6 +134,11 @@ struct G8Epi {
     // Output stores are write-through (sc1), not the `nt` of the smaller tiles: a lane row of these tiles writes 32- and
     // 64-byte pieces of a 128-byte line that a neighbouring wave completes, and `nt` partial lines measured 1.8x slower on
     // the two-output GELU epilogue (49.6 -> 27.3 us for 3072 x 3072 x 768; default-policy stores 29.6 us).
+    // INVARIANT (the bucketed deferred launch depends on it, g8_bucket_arrive below): EVERY output store of a tile epilogue is
+    // write-through (sc1).  A bucket's flag is raised for another stream (the RCCL stream's hipStreamWaitValue32) after a
+    // RELAXED agent-scope count of work items whose stores were only drained with s_waitcnt vmcnt(0); that publishes sc1
+    // stores and nothing else.  An epilogue that adds a plain (write-back) store must pass plain_stores = true for its work
+    // item, which makes the arrival a RELEASE (one buffer_wbl2 of this XCD's L2).
     template <int W>
     __device__ __forceinline__ static void store(bf16_t* dst, const float (&x)[W]) {
         if constexpr (W == 8) {

@@ -253,6 +253,11 @@ def decode_img_record(blob, compress=True, fields=None):
         rec = unpackb(blob)
         return rec if fields is None else {k: rec[k] for k in fields}
     with io.BytesIO(bytes(blob)) as reader:
-        archive = np.load(reader, allow_pickle=True)
+        # feature records are plain numeric arrays (features, norm_bb, conf, soft_labels): no pickle, so that a crafted feature
+        # database cannot execute code in the loader workers (the reference's allow_pickle=True is not needed for its own files)
+        archive = np.load(reader, allow_pickle=False)
         names = archive.files if fields is None else fields
-        return {k: archive[k] for k in names}
+        try:
+            return {k: archive[k] for k in names}
+        except ValueError as e:
+            raise ValueError("decode_img_record: the record holds an object array (pickled data), which this loader refuses: %s" % e)

@@ -97,11 +97,19 @@ class PackStore(object):
         return len(self._records)
 
     def close(self):
+        # slices handed out by get() may still be alive: memoryview.release() / mmap.close() then raise BufferError.  Drop our
+        # references in that case (the mapping is unmapped when the last slice dies) instead of leaving the object half closed.
         if self._view is not None:
-            self._view.release()
+            try:
+                self._view.release()
+            except BufferError:
+                pass
             self._view = None
         if self._map is not None:
-            self._map.close()
+            try:
+                self._map.close()
+            except BufferError:
+                pass
             self._map = None
         if self._file is not None:
             self._file.close()

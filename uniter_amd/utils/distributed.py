@@ -245,8 +245,8 @@ class GradientReducer(object):
     whose shorter launches filled the chip less well (+12 % per step before a byte crossed xGMI).  UNITER_AMD_DP_SINGLE_LAUNCH=0
     keeps the per-bucket calls.
 
-    finish(word_ids=...) exchanges the word-embedding gradient as touched rows when the step's loss reaches that table only
-    through the input lookup (every task but MLM, whose tied decoder makes the gradient dense): each rank contributes the rows of
+    finish(word_ids=...) with UNITER_AMD_DP_SPARSE_WORD=1 (opt-in) exchanges the word-embedding gradient as touched rows when the
+    step's loss reaches that table only through the input lookup (every task but MLM, whose tied decoder makes the gradient dense): each rank contributes the rows of
     the tokens in its batch (all-gather of ids and rows, <= B*Lt x H per rank instead of a vocab x H allreduce).
     """
 
@@ -355,13 +355,15 @@ class GradientReducer(object):
         ids = word_ids.reshape(-1).to(g.device, torch.int64)
         # ranks pad their text to their own batch's longest sentence: agree on one length (the configured cap, or the largest of
         # this step — one scalar max-allreduce and a host read) and fill up with id 0, whose extra copies are duplicates below
-        n = self.word_ids_cap
-        if n is None:
-            nmax = torch.tensor([ids.numel()], dtype=torch.int64, device=g.device)
-            dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
-            n = int(nmax.item())
-        if ids.numel() > n:
-            raise ValueError("GradientReducer: %d word ids in this step exceed word_ids_cap=%d" % (ids.numel(), n))
+        # The count is validated COLLECTIVELY: every rank learns the largest count of the step before any rank can raise, so an
+        # overflow of word_ids_cap is an error on all ranks at the same point instead of one rank raising while the others sit
+        # in all_gather.
+        nmax = torch.tensor([ids.numel()], dtype=torch.int64, device=g.device)
+        dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
+        nmax = int(nmax.item())
+        n = self.word_ids_cap if self.word_ids_cap is not None else nmax
+        if nmax > n:
+            raise ValueError("GradientReducer: %d word ids on some rank in this step exceed word_ids_cap=%d" % (nmax, n))
         if ids.numel() < n:
             ids = torch.cat([ids, ids.new_zeros(n - ids.numel())])
         # first occurrence of every id in this rank's batch (the others contribute a zero row): sort, compare neighbours
@@ -435,12 +437,12 @@ class GradientReducer(object):
         word_ids: EVERY input id that contributed to the gradients since they were last zeroed (under gradient accumulation: the
         micro-batches' input_ids concatenated), when the word-embedding gradient is non-zero only in those rows (see the class
         docstring); rows of ids that are not listed would keep this rank's local value."""
-        # rows instead of the dense table from 4 ranks up (UNITER_AMD_DP_SPARSE_WORD=1 / 0 forces it): the exchange costs ~0.2 ms
-        # of small kernels on the communication stream (measured on one rank) against the ~0.26 ms a 44.5 MB ring allreduce is
-        # modelled to take at 8 ranks — a wash below that, and unmeasured on real links (DESIGN section 5)
-        want = os.environ.get("UNITER_AMD_DP_SPARSE_WORD")
+        # rows instead of the dense table: OPT-IN (UNITER_AMD_DP_SPARSE_WORD=1).  The exchange costs ~0.2 ms of small kernels on
+        # the communication stream (measured on one rank) against the ~0.26 ms a 44.5 MB ring allreduce is modelled to take at
+        # 8 ranks, and it is only correct when `word_ids` lists EVERY id that contributed since zero_grad (rows of omitted ids
+        # would silently keep the rank-local value): unmeasured on real links, so the dense allreduce stays the default
         sparse = self._armed and _on() and word_ids is not None and self.word_span is not None \
-            and (want == "1" or (want is None and size() >= 4))
+            and os.environ.get("UNITER_AMD_DP_SPARSE_WORD") == "1"
         if self._armed:
             if self.encoder is None:
                 self._reduce_range(0, self.arena.numel)
