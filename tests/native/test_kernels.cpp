@@ -260,15 +260,17 @@ static const int kTileBM[] = {128, 128, 64, 64, 96, 192, 192, 128, 96, 128, 96, 
                               96, 128, 192, 128,
                               128, 128, 192, 96, 192, 128, 192, 128, 64, 192,
                               96, 96, 128, 128,
-                              256, 192};
+                              256, 192,
+                              96, 192, 192, 192, 128, 192, 128};
 static const int kTileBN[] = {128, 64, 128, 64, 192, 96, 128, 192, 128, 96, 96, 64, 64, 64, 128, 64, 96, 64, 128, 96,
                               128, 192, 96, 64, 128, 96, 64, 128, 96, 64,
                               64, 128, 96, 128, 64, 64, 64, 128, 96, 64,
                               128, 96, 64, 128,
                               128, 128, 192, 192, 96, 192, 128, 64, 128, 64,
                               128, 128, 96, 96,
-                              256, 192};
-static const int kNumTiles = 60;     // 13..19 are 3-stage rings, 20..29 wave-specialised (4 compute + 4 loader waves), 58 the eight-phase 256x256 tile
+                              256, 192,
+                              192, 96, 192, 192, 192, 128, 128};
+static const int kNumTiles = 67;     // 13..19 are 3-stage rings, 20..29 wave-specialised (4 compute + 4 loader waves), 58 the eight-phase 256x256 tile
 static const int kTileG8 = 58, kTileG6 = 59;   // the deep-pipelined 256x256 / 192x192 tiles
 
 static void test_gemm(int M, int N, int K, int cfg, int splits) {
@@ -1539,6 +1541,51 @@ static int run_roofs(int argc, char** argv, int at) {
     return 0;
 }
 
+// --sweep [iters] : every tile of the table on each of the eight chain shapes (alone, hot operands), one line per (shape, tile);
+// the best tile per shape at the end.  In-process (one allocation, no per-tile process start): ~10 s for all 67 tiles.
+static int run_sweep(int argc, char** argv, int at) {
+    const int iters = at < argc ? atoi(argv[at]) : 10;
+    const int64_t M = 3072, H = 768, I = 3072;
+    HostBf A, W, Bv;
+    A.fill((size_t)M * I, 1.f); W.fill((size_t)I * I, 0.05f); Bv.fill((size_t)I, 0.1f);
+    uint16_t *dA = upload(A), *dW = upload(W), *dB = upload(Bv), *dR = upload(A);
+    uint16_t *dO = dalloc<uint16_t>((size_t)M * I), *dO2 = dalloc<uint16_t>((size_t)M * I);
+    struct Shape { const char* name; int kind; int64_t N, K; } shapes[] = {
+        {"qkv_fwd", 0, 3 * H, H}, {"out_fwd", 1, H, H}, {"ffn1_fwd_gelu", 2, I, H}, {"ffn2_fwd", 1, H, I},
+        {"ffn2_dgrad_gelu", 3, H, I}, {"ffn1_dgrad", 4, I, H}, {"out_dgrad", 5, H, H}, {"qkv_dgrad", 4, 3 * H, H}};
+    Timer tm;
+    for (const Shape& s : shapes) {
+        const int64_t N = s.N, K = s.K;
+        const bool dgrad = s.kind >= 3;
+        const int64_t out_cols = dgrad ? K : N;             // width of the output (tile columns)
+        auto fn = [&]() -> int {
+            switch (s.kind) {
+                case 0: return uniter_gemm_bias_fwd(dA, dW, dB, dO, M, N, K, 0);
+                case 1: return uniter_gemm_bias_dropout_residual_fwd(dA, dW, dB, dR, dO, M, N, K, 0.1f, 1234u, 0u, 0);
+                case 2: return uniter_gemm_bias_gelu_fwd(dA, dW, dB, dO, dO2, M, N, K, 0);
+                case 3: return uniter_gemm_dgrad_gelu(dA, dW, dR, dO, M, N, K, 0);
+                case 4: return uniter_gemm_dgrad(dA, dW, dR, dO, M, N, K, 0);
+                default: return uniter_gemm_dgrad(dA, dW, nullptr, dO, M, N, K, 0);
+            }
+        };
+        double best = 1e30; int best_cfg = -1;
+        for (int cfg = 0; cfg < kNumTiles; ++cfg) {
+            const int bn = kTileBN[cfg];
+            if (out_cols % bn != 0) continue;
+            if (dgrad && !(bn == 64 || bn == 128 || bn == 192 || cfg == kTileG8 || cfg == kTileG6)) continue;   // K-strided N-side operand
+            uniter_gemm_debug_force(cfg, 1);
+            if (fn() != 0) { HIPCHK(hipDeviceSynchronize()); continue; }
+            HIPCHK(hipDeviceSynchronize());
+            const double us = tm.run([&] { UHCHK(fn()); }, 2, iters);
+            printf("  SWEEP %-16s tile %2d %3dx%3d : %7.2f us\n", s.name, cfg, kTileBM[cfg], bn, us);
+            if (us < best) { best = us; best_cfg = cfg; }
+        }
+        printf("  BEST  %-16s tile %2d %3dx%3d : %7.2f us  %7.1f TF\n", s.name, best_cfg, kTileBM[best_cfg], kTileBN[best_cfg], best, 2.0 * M * N * K / best * 1e-6);
+    }
+    uniter_gemm_debug_force(-1, -1);
+    return 0;
+}
+
 static void on_segv(int) {                 // where did it die: raw return addresses + symbols to stderr
     void* bt[48];
     const int n = backtrace(bt, 48);
@@ -1635,6 +1682,11 @@ int main(int argc, char** argv) {
             int32_t inf[4];
             UHCHK(uniter_hip_device_info(inf));
             return run_attn(argc, argv, i + 1);
+        }
+        if (!strcmp(argv[i], "--sweep")) {
+            int32_t inf[4];
+            UHCHK(uniter_hip_device_info(inf));
+            return run_sweep(argc, argv, i + 1);
         }
         if (!strcmp(argv[i], "--roofs")) {
             int32_t inf[4];

@@ -23,7 +23,7 @@ def _digests(tmp_path, workload, steps, **switches):
     # one tile table for all runs of a comparison: the first run saves what it used (factory table or a fresh sweep), the
     # later ones load it — a switch must not be able to hide behind a different tile choice
     env = dict(os.environ, UNITER_AMD_TUNE_CACHE=str(tmp_path / ("tiles_%s.json" % workload)), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("UNITER_AMD_XCD_AFFINITY", "UNITER_AMD_ADAMW_NT"):
+    for k in ("UNITER_AMD_ADAMW_NT",):
         env.pop(k, None)
     env.update({k: str(v) for k, v in switches.items()})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "step_digest_script.py"), workload, str(steps)],
@@ -36,23 +36,6 @@ def _digests(tmp_path, workload, steps, **switches):
 def _same(a, b):
     diff = [n for n in a["per_param"] if a["per_param"][n] != b["per_param"][n]]
     return a["losses"] == b["losses"] and not diff, diff[:8]
-
-
-@pytest.mark.parametrize("workload", ["c2", "c3"])
-def test_xcd_affinity_leaves_the_step_bit_identical(tmp_path, workload):
-    """UNITER_AMD_XCD_AFFINITY=1 (csrc/common.cuh: affine_block): GEMM tiles on an 8-row XCD grid,
-    attention units and LayerNorm rows in XCD-contiguous order.  Index permutations only: two optimizer steps with dropout on
-    must produce the same losses and parameters, bit for bit, as the default maps (and the default must repeat itself)."""
-    base = _digests(tmp_path, workload, 2)
-    if os.environ.get("UNITER_EXPERIMENTS_QUICK") != "1":
-        again = _digests(tmp_path, workload, 2)
-        ok, diff = _same(base, again)
-        assert ok, ("the default step does not repeat itself", diff)
-    aff = _digests(tmp_path, workload, 2, UNITER_AMD_XCD_AFFINITY=1)
-    ok, diff = _same(base, aff)
-    assert ok, ("XCD affinity changed the result", diff)
-    print("xcd affinity, %s: %d parameters identical after 2 steps" % (workload, base["n_params"]))
-
 
 
 def test_non_temporal_adamw_streams_leave_the_step_bit_identical(tmp_path):

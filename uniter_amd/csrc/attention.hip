@@ -35,7 +35,7 @@ template <int MAXKT, int MAXT = 512>
 __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     attn_chain_wait<1>(p);
-    attn_fwd_unit<MAXKT, false>(p, affine_block(p.chain), smem_raw);
+    attn_fwd_unit<MAXKT, false>(p, (int)blockIdx.x, smem_raw);
     attn_chain_signal<1>(p);
 }
 
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const AttnArgs p) {
     uint8_t* keep_s = reinterpret_cast<uint8_t*>(D_s + Lp);     // dropout keep nibbles [q][Lp/4], written by sweep 1
     const int kstride = Lp >> 2;
 
-    const int bh_raw = affine_block(p.chain) * HP + slot;
+    const int bh_raw = (int)blockIdx.x * HP + slot;
     const bool live = bh_raw < p.B * p.heads;                   // (an odd unit count leaves the last workgroup's second team idle)
     const int bh = live ? bh_raw : 0;
     const int b = bh / p.heads, h = bh % p.heads;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_share_kernel(con
     float* lse_s = mb + Lp;
     float* D_s = lse_s + Lp;
 
-    const int bh_raw = affine_block(p.chain) * HP + slot;
+    const int bh_raw = (int)blockIdx.x * HP + slot;
     const bool live = bh_raw < p.B * p.heads;                   // (an odd unit count leaves the last workgroup's second team idle)
     const int bh = live ? bh_raw : 0;
     const int b = bh / p.heads, h = bh % p.heads;
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnArgs p) {
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* Vs = Ks + Lp * 64;
     float* mb = reinterpret_cast<float*>(Vs + Lp * 64);
-    const int bh = affine_block(p.chain);
+    const int bh = (int)blockIdx.x;
     const int b = bh / p.heads, h = bh % p.heads;
     const int H = p.heads * DH;
     const int64_t ld = 3 * (int64_t)H;
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const AttnArgs p) {
     bf16_t* Os = Qs + Lp * 64;            // dO
     float* lse_s = reinterpret_cast<float*>(Os + Lp * 64);
     float* D_s = lse_s + Lp;
-    const int bh = affine_block(p.chain);
+    const int bh = (int)blockIdx.x;
     const int b = bh / p.heads, h = bh % p.heads;
     const int H = p.heads * DH;
     const int64_t ld = 3 * (int64_t)H;
@@ -758,7 +758,6 @@ bool attention_chainable(int64_t L, const int32_t* cu) { return cu == nullptr &&
 // binds a chain step to a launch's arguments; steps this shape cannot honour are turned into plain in-order launches
 static void attn_bind(AttnArgs& a, ChainStep*& chain, int64_t L, const int32_t* cu, int64_t heads) {
     a.chain = ChainLink{nullptr, nullptr, nullptr, 0, 0};
-    if (cu == nullptr && uh::xcd_affinity()) a.chain.pad = 1;           // plain launches only: contiguous units per XCD (common.cuh: affine_block)
     if (chain == nullptr) return;
     if (!attention_chainable(L, cu)) { chain->anyorder = 0; chain->produced = 0; return; }
     a.chain = chain->link;

@@ -167,13 +167,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return start + loc;
 }
-// XCD affinity of a kernel chain (UNITER_AMD_XCD_AFFINITY=1; bit 0 of ChainLink.pad): every kernel of
-// the encoder gives XCD x the x-th contiguous eighth of its rows (attention units of an example, LayerNorm rows, GEMM row
-// blocks through the 8-row XCD grid of tile_of_block), so that what a kernel reads from its predecessor's output was written
-// on its own XCD and is still in that L2 (tests/native/l2_carry_probe.cpp: 0.68 us against 2.3 us per 64 KiB).
-__device__ __forceinline__ int affine_block(const ChainLink& c) {
-    return (c.pad & 1u) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-}
 
 // output stores of a kernel that may run inside a chain: write-through when it signals, the kernel's usual policy otherwise
 __device__ __forceinline__ void out_store16c(void* p, const u32x4 v, const bool wt) {

@@ -35,6 +35,18 @@
 namespace {
 
 constexpr bool g_aux_early_dev = UNITER_AUX_EARLY;
+#ifndef UNITER_GEMM_PIPE
+#define UNITER_GEMM_PIPE 1
+#endif
+#ifndef UNITER_GEMM_EPI_ALL
+#define UNITER_GEMM_EPI_ALL 1
+#endif
+constexpr bool g_gemm_epi_all = UNITER_GEMM_EPI_ALL;   // wave-specialised tiles: the loader waves take their share of the epilogue's rows
+#ifndef UNITER_GEMM_DMA_SADDR
+#define UNITER_GEMM_DMA_SADDR 1
+#endif
+constexpr bool g_gemm_dma_saddr = UNITER_GEMM_DMA_SADDR;   // LDS-DMA as scalar origin + loop-invariant 32-bit lane offsets (plan_kc / plan_ks)
+constexpr bool g_gemm_pipe = UNITER_GEMM_PIPE;     // fragment reads one K half ahead of their MFMAs (gemm_tile: pipe_body)
 // GemmArgs, the epilogue kinds and the blockIdx -> tile maps: gemm_args.cuh
 
 // ---- LDS layouts and fragment reads: gemm_lds.cuh ---------------------------------------------------
@@ -112,6 +124,39 @@ __device__ __forceinline__ void glds_ks(bf16_t* tile, const bf16_t* base, int64_
         const int r = RPI * j + lane / CPR;
         const int c = (lane % CPR) ^ (ks_swz<W>(r) << 1);
         glds16(base + (int64_t)(k0 + r) * ld + col0 + c * 8, tile + j * 512);
+    }
+}
+
+// ---- LDS-DMA with a scalar origin (UNITER_GEMM_DMA_SADDR) ----------------------------------------------------------------
+// glds_kc / glds_ks hand the builtin a flat 64-bit pointer per lane: two 64-bit VALU adds, a v_readfirstlane for M0 and ONE
+// address register pair per instruction, re-used by the next one — so every instruction waits until the texture addresser
+// has taken the previous one's address (ISA of the loader waves; a loader wave issued one 1 KiB piece per ~140 cycles, four
+// loader waves = 29 B/clk per CU = the 840 cycles a 96 x 96 K step took: profiles/r05_chain_gemm_roofs.json).  The lane's
+// position inside an operand tile does not depend on the K tile, so its byte offset from the K tile's origin is computed once
+// (32 bits: the launcher checks the operand spans) and an instruction is  s_mov m0 ; global_load_lds_dwordx4 voff, s[origin].
+// Same lanes, same addresses, same LDS image as glds_kc / glds_ks (instruction index j = it * 4 + issuing wave).
+template <int ROWS>
+__device__ __forceinline__ void plan_kc(int it, int iw, int lane, int64_t ld, int row0, int rows_total, uint32_t& voff, uint32_t& loff) {
+    const int j = it * 4 + iw;
+    const int r = 8 * j + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int gr = row0 + r;
+    gr = gr < rows_total ? gr : rows_total - 1;
+    voff = (uint32_t)(((int64_t)gr * ld + c * 8) * 2);
+    loff = (uint32_t)j * 1024u;
+}
+template <int W>
+__device__ __forceinline__ void plan_ks(int it, int iw, int lane, int64_t ld, int col0, uint32_t& voff, uint32_t& loff) {
+    if constexpr (W == 192) {                                // [64][128] sub-tile (4 instructions per wave), then [64][64] (2)
+        if (it < 4) plan_ks<128>(it, iw, lane, ld, col0, voff, loff);
+        else { plan_ks<64>(it - 4, iw, lane, ld, col0 + 128, voff, loff); loff += 64u * 128u * 2u; }
+    } else {
+        constexpr int RPI = 1024 / (2 * W), CPR = W / 8;
+        const int j = it * 4 + iw;
+        const int r = RPI * j + lane / CPR;
+        const int c = (lane % CPR) ^ (ks_swz<W>(r) << 1);
+        voff = (uint32_t)(((int64_t)r * ld + col0 + c * 8) * 2);
+        loff = (uint32_t)j * 1024u;
     }
 }
 
@@ -201,7 +246,41 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         sr.store(smem + buf * STAGE, t);
         sc.store(smem + buf * STAGE + TILE_R, t);
     };
+    // LDS-DMA plan of this wave (the compute waves of a wave-specialised tile never issue DMA)
+    constexpr int GR = BM / 32, GC = BN / 32;
+    uint32_t dvoR[GR], dloR[GR], dvoC[GC], dloC[GC];
+    const char* dgR = reinterpret_cast<const char*>(p.R + (TRA ? (int64_t)k_begin * p.ldr : (int64_t)k_begin));
+    const char* dgC = reinterpret_cast<const char*>(p.Cc + (TRB ? (int64_t)k_begin * p.ldcc : (int64_t)k_begin));
+    const int64_t dstepR = (TRA ? 64 * p.ldr : (int64_t)64) * 2, dstepC = (TRB ? 64 * p.ldcc : (int64_t)64) * 2;   // bytes per K tile
+    typedef __attribute__((address_space(3))) char lds_char_t;
+    const uint32_t dlds0 = (uint32_t)(size_t)(lds_char_t*)smem_raw;
+    if constexpr (g_gemm_dma_saddr) {
+        // (unconditional: a branch on the wave index would make the LDS offsets divergent values in the compiler's eyes, and they
+        //  must be scalars for M0; the compute waves of a wave-specialised tile compute a plan they never use, once)
+        const int iw = __builtin_amdgcn_readfirstlane(WS ? (wid - WG::NCW) & 3 : wid);
+#pragma unroll
+        for (int it = 0; it < GR; ++it) {
+            if constexpr (TRA) plan_ks<BM>(it, iw, lane, p.ldr, m0, dvoR[it], dloR[it]);
+            else               plan_kc<BM>(it, iw, lane, p.ldr, m0, p.M, dvoR[it], dloR[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < GC; ++it) {
+            if constexpr (TRB) plan_ks<BN>(it, iw, lane, p.ldcc, n0, dvoC[it], dloC[it]);
+            else               plan_kc<BN>(it, iw, lane, p.ldcc, n0, p.N, dvoC[it], dloC[it]);
+            dloC[it] += (uint32_t)TILE_R * 2u;
+        }
+    }
+    auto dma_tile = [&](int kt, int buf) {
+        const char* oR = dgR + (int64_t)kt * dstepR;
+        const char* oC = dgC + (int64_t)kt * dstepC;
+        const uint32_t sb = dlds0 + (uint32_t)buf * (uint32_t)(STAGE * 2);
+#pragma unroll
+        for (int it = 0; it < GR; ++it) g8_glds16(dvoR[it], oR, (uint32_t)__builtin_amdgcn_readfirstlane((int)(sb + dloR[it])));
+#pragma unroll
+        for (int it = 0; it < GC; ++it) g8_glds16(dvoC[it], oC, (uint32_t)__builtin_amdgcn_readfirstlane((int)(sb + dloC[it])));
+    };
     auto do_glds = [&](int kt, int buf) {       // direct-to-LDS path (full K tiles)
+        if constexpr (g_gemm_dma_saddr) { dma_tile(kt, buf); return; }
         const int k0 = k_begin + kt * 64;
         bf16_t* tr_ = smem + buf * STAGE;
         bf16_t* tc_ = tr_ + TILE_R;
@@ -220,7 +299,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     // EPI_WGRAD with a bias-gradient output: the first tile column also sums its M-side operand (dy) over the
     // contraction — one extra MFMA per fragment against a fragment of ones, on operands that are in registers anyway —
     // so the separate column-sum kernels over dy disappear.  All four rows of the result tile are the same sum.
-    const bool rowsum = (EPI == EPI_WGRAD) && p.C2 != nullptr && tn == 0 && wn == 0;
+    const bool rowsum = (EPI == EPI_WGRAD) && p.C2 != nullptr && tn == 0 && wn == 0 && (WS == 0 || wid < WG::NCW);
     f32x4 bacc[MI];
     bf16x8 ones;
 #pragma unroll
@@ -228,39 +307,83 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 #pragma unroll
     for (int b = 0; b < MI; ++b) bacc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int buf) {
+    // One K half (32 deep) of a tile: the fragment reads and the MFMAs are separate so that the main loops can keep the reads of
+    // the NEXT half in flight under the MFMAs of the current one (UNITER_GEMM_PIPE, below).
+    auto frag_read = [&](int buf, int ks, bf16x8 (&fr)[MI], bf16x8 (&fc)[NI]) {
         const bf16_t* tr = smem + buf * STAGE;
         const bf16_t* tc = tr + TILE_R;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fr[MI], fc[NI];
+        for (int b = 0; b < MI; ++b) {
+            if constexpr (TRA) fr[b] = frag_ks<BM>(tr, wm * WM + b * 16, ks, g, i);
+            else               fr[b] = frag_kc(tr, wm * WM + b * 16 + i, ks, g);
+        }
 #pragma unroll
-            for (int b = 0; b < MI; ++b) {
-                if constexpr (TRA) fr[b] = frag_ks<BM>(tr, wm * WM + b * 16, ks, g, i);
-                else               fr[b] = frag_kc(tr, wm * WM + b * 16 + i, ks, g);
-            }
-            if constexpr (EPI == EPI_WGRAD) {
-                if (rowsum) {
-#pragma unroll
-                    for (int b = 0; b < MI; ++b)
-                        bacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fr[b], bacc[b], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < NI; ++a) {
-                if constexpr (TRB) fc[a] = frag_ks<BN>(tc, wn * WN + a * 16, ks, g, i);
-                else               fc[a] = frag_kc(tc, wn * WN + a * 16 + i, ks, g);
-            }
-#pragma unroll
-            for (int a = 0; a < NI; ++a)
+        for (int a = 0; a < NI; ++a) {
+            if constexpr (TRB) fc[a] = frag_ks<BN>(tc, wn * WN + a * 16, ks, g, i);
+            else               fc[a] = frag_kc(tc, wn * WN + a * 16 + i, ks, g);
+        }
+    };
+    auto frag_mma = [&](const bf16x8 (&fr)[MI], const bf16x8 (&fc)[NI]) {
+        if constexpr (EPI == EPI_WGRAD) {
+            if (rowsum) {
 #pragma unroll
                 for (int b = 0; b < MI; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[a], fr[b], acc[a][b], 0, 0, 0);
+                    bacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fr[b], bacc[b], 0, 0, 0);
+            }
         }
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+            for (int b = 0; b < MI; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[a], fr[b], acc[a][b], 0, 0, 0);
+    };
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fr[MI], fc[NI];
+            frag_read(buf, ks, fr, fc);
+            frag_mma(fr, fc);
+        }
+    };
+    // UNITER_GEMM_PIPE: the fragment reads of a K half are issued one half ahead of the MFMAs that consume them, through the
+    // barrier of the next tile (tile kt+1's first half is read right after the barrier that proves it has landed, under the
+    // MFMAs of tile kt's second half).  The unpipelined loop — barrier, reads, s_waitcnt lgkmcnt(0), MFMAs — exposes the LDS
+    // latency (~128 cycles per batch of reads) five times per K step on a wave that has its SIMD to itself (the wave-specialised
+    // tiles: ISA of the 96 x 96 tile, 62 VGPRs, ~840 cycles per step for 288 cycles of MFMAs; profiles/r05_chain_gemm_roofs.json).
+    // Per accumulator the MFMAs run in the same order (K half 0, then 1, tile after tile): results are bit-identical.
+    // (only where a wave has its SIMD to itself — the wave-specialised tiles; the plain tiles run two or three workgroups per CU,
+    //  which cover each other's LDS latency, and measured 5 % slower with the extra registers — and only where accumulators + two
+    //  fragment sets stay inside the register budget of the tile's launch bounds: a spill inside the K loop costs 3x)
+    constexpr bool PIPE = g_gemm_pipe && WS != 0 && (MI * NI * 4 + 2 * (MI + NI) * 4 + 28 <= (WS == 2 ? 168 : (WS == 5 ? 248 : 128)));
+    bf16x8 pfr[2][MI], pfc[2][NI];                         // (dead, hence register-free, where !PIPE)
+    // (the last tile is peeled off the loop instead of guarded inside it: with a guard the second MFMA block is reached on two
+    //  paths, with and without the next tile's reads in flight, and the compiler's single wait for both covers the new reads too)
+    auto pipe_step = [&](int buf, int nbuf, auto&& at_tile_boundary) {       // a tile that is followed by another
+        frag_read(buf, 1, pfr[1], pfc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        frag_mma(pfr[0], pfc[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every LDS read of this tile is back: its buffer may be re-filled
+        at_tile_boundary();                                          // wait / barrier / next DMA: the next tile has landed for every wave
+        frag_read(nbuf, 0, pfr[0], pfc[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        frag_mma(pfr[1], pfc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto pipe_last = [&](auto buf) {                                         // (generic like pipe_step: only instantiated where PIPE)
+        frag_read(buf, 1, pfr[1], pfc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        frag_mma(pfr[0], pfc[0]);
+        frag_mma(pfr[1], pfc[1]);
     };
 
     // ---- epilogue geometry, and the global operands the epilogue combines with the accumulators --------------------------
-    constexpr int NT = WG::NCW * 64;                        // the compute waves (loader waves have exited by then)
+    // Wave-specialised tiles: the loader waves are idle after the last tile, and one wave per SIMD runs the element-wise tail
+    // (erf GELU, Philox dropout: ~25 dependent VALU operations per element) at half the VALU rate two waves reach — so the
+    // loaders stay and take their share of every pass's rows (they read the staged accumulators from LDS like everyone else).
+    constexpr bool EPI_ALL = g_gemm_epi_all && WS != 0;
+    constexpr int NT = EPI_ALL ? WG::THREADS : WG::NCW * 64; // threads that walk the staged rows
+    const bool is_cw = WS == 0 || wid < WG::NCW;             // this wave owns accumulators
     constexpr int SROW = BN + 4;                            // fp32 row stride of the staging block (+4 spreads banks)
     constexpr int PASS_ROWS = WG::GM * 16;                  // one 16-row MFMA block of every wave row per pass
     constexpr int CPR = BN / 8;                             // 16-byte output chunks per tile row
@@ -271,7 +394,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     // passes of the epilogue at once, before the last K step's MFMAs, instead of one exposed round trip per 16-row pass.
     // (early only where accumulators + fragments + these registers stay inside the wave's register budget: the 128x128 tiles
     //  would spill ~100 registers otherwise; they fetch at the start of the epilogue, where the fragments are dead)
-    constexpr bool AUX_EARLY = g_aux_early_dev && HAS_AUX && (MI * NI * 4 + (MI + NI) * 4 + MI * ITERS * 4 + 24 <= (WS == 2 ? 168 : 128));
+    constexpr int REG_BUDGET = WS == 2 ? 168 : (WS == 5 ? 248 : 128);      // what the launch bounds leave a wave
+    constexpr bool AUX_EARLY = g_aux_early_dev && HAS_AUX && (MI * NI * 4 + (PIPE ? 2 : 1) * (MI + NI) * 4 + MI * ITERS * 4 + 24 <= REG_BUDGET);
     u32x4 auxr[HAS_AUX ? MI : 1][ITERS];
     constexpr bool HAS_BIAS = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RES);
     u32x4 biasr[ITERS];                                     // the bias chunk of a thread's column does not depend on the pass
@@ -310,11 +434,19 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     // every wave's share visible and also proves that all waves are done reading the buffer tile kt+NSTAGE-1 is
     // about to overwrite (it held tile kt-1).  No __syncthreads() here: its fence would drain the DMA queue.
     const int nfull = (k_end > k_begin) ? ((k_end - k_begin) >> 6) : 0;
+    // Every kernel argument the epilogue will want, consumed once HERE: the compiler hoists their scalar loads (s_load) in front
+    // of the K loop but waits for them at the first use — inside or behind the loop — and while a scalar load is pending the
+    // LGKM counter is shared with the LDS reads and returns out of order, so every `s_waitcnt lgkmcnt(n)` of the loop degrades
+    // to lgkmcnt(0) (seen in the ISA: the fragment reads issued one K half ahead were waited for at once).
+    asm volatile("" ::"s"(p.C), "s"(p.C2), "s"(p.ldc), "s"(p.bias), "s"(p.aux), "s"(p.ldaux), "s"(p.partial));
+    asm volatile("" ::"s"(p.M), "s"(p.N), "s"(p.accumulate), "s"(p.relu), "s"(p.drop.p), "s"(p.drop.scale), "s"(p.drop.thresh));
+    asm volatile("" ::"s"(p.drop.seed_lo), "s"(p.drop.seed_hi), "s"(p.drop.off_lo), "s"(p.drop.off_hi), "s"(p.drop.off_ptr), "s"(p.chain.signal), "s"(p.chain.expect));
     if constexpr (WS != 0) {
         if (wid >= WG::NCW) {
             // ---- loader waves: one barrier per tile, shared with the compute waves ----
             const int lw = wid - WG::NCW;
             auto ws_glds = [&](int kt, int b) {
+                if constexpr (g_gemm_dma_saddr) { dma_tile(kt, b); return; }
                 const int k0 = k_begin + kt * 64;
                 bf16_t* tr_ = smem + b * STAGE;
                 bf16_t* tc_ = tr_ + TILE_R;
@@ -333,8 +465,26 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 if (kt + NSTAGE - 1 < nfull) ws_glds(kt + NSTAGE - 1, pre);
                 pre = (pre + 1 == NSTAGE) ? 0 : pre + 1;
             }
-            return;
-        }
+            if constexpr (!EPI_ALL) return;
+        } else {
+        if constexpr (PIPE) {
+            // compute waves, pipelined: the loaders' barrier kt is passed right before the first read of tile kt
+            if (nfull > 0) {
+                __builtin_amdgcn_s_barrier();
+                frag_read(0, 0, pfr[0], pfc[0]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            int buf = 0;
+            for (int kt = 0; kt + 1 < nfull; ++kt) {
+                const int nbuf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+                pipe_step(buf, nbuf, [&] { __builtin_amdgcn_s_barrier(); });
+                buf = nbuf;
+            }
+            if (nfull > 0) {
+                if (AUX_EARLY) aux_fetch();
+                pipe_last(buf);
+            }
+        } else {
         int buf = 0;
         for (int kt = 0; kt < nfull; ++kt) {
 #ifdef UNITER_GEMM_PROBE
@@ -353,10 +503,39 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 #endif
             buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
         }
+        }
+        }
     } else {
 #pragma unroll
         for (int d = 0; d < NSTAGE - 1; ++d)
             if (d < nfull) do_glds(d, d);
+        if constexpr (PIPE) {
+            int buf = 0, pre = NSTAGE - 1;
+            if (nfull > 0) {
+                wait_tile<NSTAGE, G>(nfull - 1);
+                __builtin_amdgcn_s_barrier();
+                if (NSTAGE - 1 < nfull) do_glds(NSTAGE - 1, pre);
+                pre = (pre + 1 == NSTAGE) ? 0 : pre + 1;
+                frag_read(0, 0, pfr[0], pfc[0]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            for (int kt = 0; kt + 1 < nfull; ++kt) {
+                const int nbuf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+                pipe_step(buf, nbuf, [&] {
+                    // tile kt+1: my share has landed, then everyone's; the DMA of tile kt+NSTAGE goes into tile kt's buffer, which
+                    // every wave has finished reading (the lgkmcnt(0) in front of this barrier)
+                    wait_tile<NSTAGE, G>(nfull - 2 - kt);
+                    __builtin_amdgcn_s_barrier();
+                    if (kt + NSTAGE < nfull) do_glds(kt + NSTAGE, pre);
+                    pre = (pre + 1 == NSTAGE) ? 0 : pre + 1;
+                });
+                buf = nbuf;
+            }
+            if (nfull > 0) {
+                if (AUX_EARLY) aux_fetch();
+                pipe_last(buf);
+            }
+        } else {
         int buf = 0;                  // kt % NSTAGE
         int pre = NSTAGE - 1;         // (kt + NSTAGE - 1) % NSTAGE
         for (int kt = 0; kt < nfull; ++kt) {
@@ -384,6 +563,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 #endif
             buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
             pre = (pre + 1 == NSTAGE) ? 0 : pre + 1;
+        }
         }
     }
     // ---- partial K tile (contraction length not a multiple of 64): zero-filled register staging --------------------
@@ -417,6 +597,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     if ((EPI == EPI_WGRAD || EPI == EPI_RES) && p.partial != nullptr) {   // split-K partials: already 16-byte fp32 stores
 #pragma unroll
         for (int b = 0; b < MI; ++b) {
+            if (!is_cw) continue;                           // (loader waves hold no accumulators)
             const int m = m0 + wm * WM + b * 16 + i;
             if (m >= p.M) continue;
 #pragma unroll
@@ -436,9 +617,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 #pragma unroll
         for (int b = 0; b < MI; ++b) {
             float* sb = stage + (b & 1) * PASS_ROWS * SROW;
+            if (is_cw) {
 #pragma unroll
-            for (int a = 0; a < NI; ++a)
-                *reinterpret_cast<f32x4*>(sb + (wm * 16 + i) * SROW + wn * WN + a * 16 + 4 * g) = acc[a][b];
+                for (int a = 0; a < NI; ++a)
+                    *reinterpret_cast<f32x4*>(sb + (wm * 16 + i) * SROW + wn * WN + a * 16 + 4 * g) = acc[a][b];
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                   // (also orders the reads of pass b-1 before the writes of b+1)
 #pragma unroll HAS_AUX ? ITERS : 1                          // unrolled only where the prefetched aux registers need static indices (the GELU body is big)
@@ -524,7 +707,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 }
 
 template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, int WS>
-__global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS == 2 ? 3 : 1)) void gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS == 2 ? 3 : (WS == 5 ? 2 : 1))) void gemm_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     gemm_tile<BM, BN, TRA, TRB, EPI, NSTAGE, WS>(p, (int)blockIdx.x, (int)blockIdx.y, smem_raw);
 }
@@ -547,7 +730,7 @@ struct GemmGroupArgs {
     int per;
 };
 template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, int WS>
-__global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS == 2 ? 3 : 1)) void gemm_group_kernel(const GemmGroupArgs ga) {
+__global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS == 2 ? 3 : (WS == 5 ? 2 : 1))) void gemm_group_kernel(const GemmGroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     int b = (int)blockIdx.x;
     if (ga.compact) {
@@ -663,7 +846,6 @@ int launch_g8(const GemmArgs& a_in, int splits, hipStream_t st) {
     if (EPI == EPI_WGRAD && a.C2 != nullptr) { uh_set_error("gemm: the eight-phase tile does not produce the bias gradient"); return -1; }
     const int tiles_m = (a.M + 255) / 256, tiles_n = a.N / 256;
     a.xr = pick_xr(tiles_m, tiles_n, 256, 256);
-    if (!TRA && uh::xcd_affinity() && tiles_m % 8 == 0) a.xr = 8;
     a.pair = nullptr;
     if (EPI == EPI_WGRAD && splits == 2 && a.partial != nullptr) {
         a.pair = g8_pair_counters(tiles_m * tiles_n);
@@ -700,7 +882,6 @@ int launch_g6(const GemmArgs& a_in, int splits, hipStream_t st) {
     if (EPI == EPI_WGRAD && a.C2 != nullptr) { uh_set_error("gemm: the three-phase tile does not produce the bias gradient"); return -1; }
     const int tiles_m = (a.M + 191) / 192, tiles_n = a.N / 192;
     a.xr = pick_xr(tiles_m, tiles_n, 192, 192);
-    if (!TRA && uh::xcd_affinity() && tiles_m % 8 == 0) a.xr = 8;
     a.pair = nullptr;
     static bool attr_done = false;
     if (!attr_done) {
@@ -728,7 +909,14 @@ int launch_cfg(const GemmArgs& a_in, int splits, hipStream_t st) {
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
     a.xr = pick_xr(tiles_m, tiles_n, BM, BN);
-    if (!TRA && uh::xcd_affinity() && tiles_m % 8 == 0) a.xr = 8;      // whole row blocks per XCD (common.cuh: affine_block)
+    if (g_gemm_dma_saddr) {                                  // per-lane LDS-DMA offsets are 32-bit byte offsets from a K tile's origin
+        const int64_t span_r = TRA ? (int64_t)64 * a.ldr + a.M : (int64_t)a.M * a.ldr;
+        const int64_t span_c = TRB ? (int64_t)64 * a.ldcc + a.N : (int64_t)a.N * a.ldcc;
+        if (span_r * 2 >= ((int64_t)1 << 32) || span_c * 2 >= ((int64_t)1 << 32)) {
+            uh_set_error("gemm: operand larger than 4 GiB (M=%d N=%d K=%d ld %lld / %lld)", a.M, a.N, a.K, (long long)a.ldr, (long long)a.ldcc);
+            return -1;
+        }
+    }
 #ifdef UNITER_GEMM_PROBE
     a.probe = g_probe;
 #endif
@@ -774,14 +962,18 @@ constexpr TileShape kTiles[] = {{128, 128, 2, 0}, {128, 64, 2, 0}, {64, 128, 2, 
                                 // ws = 3: the eight-phase 256 x 256 tile (gemm8.cuh): 8 waves, two wave groups one barrier apart
                                 {256, 256, 2, 3},
                                 // ws = 4: its 192 x 192 sibling (three phases per K tile, three LDS buffers): 256 tiles for a 3072 x 3072 output
-                                {192, 192, 3, 4}};
+                                {192, 192, 3, 4},
+                                // ws = 5: 4 compute + 4 loader waves with ONE workgroup per CU (256 registers per wave): wave tiles of
+                                // 48 x 96 ... 96 x 96 with the fragment reads pipelined (pipe_step), three-stage rings
+                                {96, 192, 3, 5}, {192, 96, 3, 5}, {192, 192, 2, 5}, {192, 192, 3, 5}, {128, 192, 3, 5}, {192, 128, 3, 5},
+                                {128, 128, 4, 5}};
 constexpr int kTileG8 = 58, kTileG6 = 59;
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <bool TRA, bool TRB>
 constexpr bool tile_ok(int idx) {
     const int bm = kTiles[idx].bm, bn = kTiles[idx].bn;
-    if (kTiles[idx].ws >= 3) return true;
+    if (kTiles[idx].ws == 3 || kTiles[idx].ws == 4) return true;
     if (TRA && !(bm == 64 || bm == 128)) return false;
     if (TRB && !(bn == 64 || bn == 128 || bn == 192)) return false;
     return true;
@@ -860,6 +1052,13 @@ int launch_gemm(const GemmArgs& a, int cfg, int splits, hipStream_t st) {
         case 57: return launch_idx<TRA, TRB, EPI, 57>(a, splits, st);
         case 58: return launch_idx<TRA, TRB, EPI, 58>(a, splits, st);
         case 59: return launch_idx<TRA, TRB, EPI, 59>(a, splits, st);
+        case 60: return launch_idx<TRA, TRB, EPI, 60>(a, splits, st);
+        case 61: return launch_idx<TRA, TRB, EPI, 61>(a, splits, st);
+        case 62: return launch_idx<TRA, TRB, EPI, 62>(a, splits, st);
+        case 63: return launch_idx<TRA, TRB, EPI, 63>(a, splits, st);
+        case 64: return launch_idx<TRA, TRB, EPI, 64>(a, splits, st);
+        case 65: return launch_idx<TRA, TRB, EPI, 65>(a, splits, st);
+        case 66: return launch_idx<TRA, TRB, EPI, 66>(a, splits, st);
         default: uh_set_error("gemm: bad tile index %d", cfg); return -1;
     }
 }

@@ -30,12 +30,6 @@ inline void chain_launch(const ChainStep* cs, K kernel, dim3 grid, dim3 block, s
     else hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
 }
 
-// UNITER_AMD_XCD_AFFINITY=1 (experiment, default off): one row-block -> XCD map for all kernels of the encoder chain (common.cuh: affine_block)
-inline bool xcd_affinity() {
-    static const bool on = [] { const char* e = getenv("UNITER_AMD_XCD_AFFINITY"); return e != nullptr && atoi(e) != 0; }();
-    return on;
-}
-
 // ---- capi.hip: optional per-launch timing (uniter_hip_timing_begin / _end) ----
 // Kinds of timed launches; (kind, M, N, K) identifies one row of the report.
 enum { TIME_GEMM_FWD_BIAS = 0, TIME_GEMM_FWD_GELU = 1, TIME_GEMM_FWD_DROP_RES = 2, TIME_GEMM_DGRAD = 3,

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      int rows, int H, float eps, const DropoutCfg drop, const ChainLink chain) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int blk = affine_block(chain);
+    const int blk = (int)blockIdx.x;
     const int row = blk * ROWS_PER_BLOCK + wid;
     chain_wait(chain, blk * ROWS_PER_BLOCK, ROWS_PER_BLOCK);      // overlapped chain (common.cuh): z rows of this block
     if (row < rows) ln_fwd_row<NC, false>(z, gamma, beta, y, mean_out, rstd_out, row, H, eps, drop, lane, chain.signal != nullptr);
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const bf16_t* __restri
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int nch = H >> 2;
     // overlapped chain (common.cuh): such launches cover all rows in one pass of the grid, so a block owns rows 4b .. 4b+3
-    const int blk = affine_block(chain);
+    const int blk = (int)blockIdx.x;
     chain_wait(chain, blk * 4, 4);
     const bool wt = chain.signal != nullptr;
     float gv[NC][4];
@@ -413,7 +413,6 @@ int layernorm_fwd(const void* z, const void* gamma, const void* beta, void* y, f
         if (rows % 32 == 0) { link = chain->link; chain->produced = 32 / ROWS_PER_BLOCK; }
         else { chain->anyorder = 0; chain->produced = 0; }
     }
-    if (link.signal == nullptr && link.wait == nullptr && uh::xcd_affinity()) link.pad = 1;
 #define LN_FWD(NCV)                                                                                         \
     chain_launch(chain, ln_fwd_kernel<NCV>, grid, block, 0, st, (const bf16_t*)z, (const bf16_t*)gamma,     \
                  (const bf16_t*)beta, (bf16_t*)y, mean, rstd, (int)rows, (int)H, eps, drop, link)
@@ -456,7 +455,6 @@ int layernorm_bwd_rows(const void* dy, const void* dy_extra, const void* z, cons
         else { chain->anyorder = 0; chain->produced = 0; }
     }
     if (link.signal == nullptr && link.wait == nullptr && nb > 4096) nb = 4096;
-    if (link.signal == nullptr && link.wait == nullptr && uh::xcd_affinity() && nb * 4 == rows) link.pad = 1;   // (one pass of the grid: XCD-contiguous rows)
 #define LN_ROWS(NCV)                                                                                                   \
     chain_launch(chain, ln_bwd_rows_kernel<NCV>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)dy,             \
                  (const bf16_t*)dy_extra, (const bf16_t*)z, mean, rstd, (const bf16_t*)gamma, (bf16_t*)dz,             \
