@@ -22,9 +22,12 @@ def bench(cache, steps):
     env = dict(os.environ, UNITER_AMD_TUNE_CACHE=cache, UNITER_AMD_FACTORY_TUNE="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-kernel-timing", "--config", CONFIG,
                           "--steps", str(steps)],
-                         env=env, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
-    line = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")][-1]
-    return json.loads(line)["ms_per_step"]
+                         env=env, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
+    if not lines:
+        sys.stderr.write(out.stderr.decode()[-3000:])
+        raise RuntimeError("bench.py printed no result line (rc %d)" % out.returncode)
+    return json.loads(lines[-1])["ms_per_step"]
 
 
 def main():

@@ -73,7 +73,7 @@ def family(name):
     if m:
         return "%s  [tile %sx%s st%s %s]" % (EPI_KIND[int(m.group(5))], m.group(1), m.group(2), m.group(6),
                                                {"0": "plain", "false": "plain", "1": "ws4+4", "true": "ws4+4", "2": "ws8+4",
-                                                "3": "deep 8-phase", "4": "deep 3-phase", "5": "ws4+4, one per CU"}.get(m.group(7), m.group(7)))
+                                                "3": "deep 8-phase", "4": "deep 3-phase"}.get(m.group(7), m.group(7)))
     if n.startswith("Cijk_"):
         return "rocBLAS/hipBLASLt GEMM (task heads, torch)"
     if "at::native" in n:
@@ -203,7 +203,7 @@ def pmc_traffic(fetch_csv, write_csv, dst):
             M, cfg, splits = e["M"], e["cfg"], e["splits"]
             bm, bn, st, ws = tiles[cfg]
             rows, cols = (M, N) if kind == 0 else ((M, K) if kind == 1 else (N, K))      # output of the launch
-            threads = 256 if ws == 0 else (512 if ws in (1, 3, 4, 5) else 768)
+            threads = 256 if ws == 0 else (512 if ws in (1, 3, 4) else 768)
             grid = ((rows + bm - 1) // bm) * (cols // bn) * threads * splits
             layout = {0: "false, false", 1: "false, true", 2: "true, true"}[kind]
             if ws >= 3:

@@ -261,7 +261,7 @@ static const int kTileBM[] = {128, 128, 64, 64, 96, 192, 192, 128, 96, 128, 96, 
                               128, 128, 192, 96, 192, 128, 192, 128, 64, 192,
                               96, 96, 128, 128,
                               256, 192,
-                              96, 192, 192, 192, 128, 192, 128};
+                              192, 96, 192};
 static const int kTileBN[] = {128, 64, 128, 64, 192, 96, 128, 192, 128, 96, 96, 64, 64, 64, 128, 64, 96, 64, 128, 96,
                               128, 192, 96, 64, 128, 96, 64, 128, 96, 64,
                               64, 128, 96, 128, 64, 64, 64, 128, 96, 64,
@@ -269,8 +269,8 @@ static const int kTileBN[] = {128, 64, 128, 64, 192, 96, 128, 192, 128, 96, 96, 
                               128, 128, 192, 192, 96, 192, 128, 64, 128, 64,
                               128, 128, 96, 96,
                               256, 192,
-                              192, 96, 192, 192, 192, 128, 128};
-static const int kNumTiles = 67;     // 13..19 are 3-stage rings, 20..29 wave-specialised (4 compute + 4 loader waves), 58 the eight-phase 256x256 tile
+                              192, 192, 96};
+static const int kNumTiles = 63;     // 13..19 are 3-stage rings, 20..29 wave-specialised (4 compute + 4 loader waves), 58 the eight-phase 256x256 tile
 static const int kTileG8 = 58, kTileG6 = 59;   // the deep-pipelined 256x256 / 192x192 tiles
 
 static void test_gemm(int M, int N, int K, int cfg, int splits) {

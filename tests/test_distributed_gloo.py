@@ -146,11 +146,9 @@ def _case_sparse_word_rows(rank, world, D):
             reducer.begin()
             for l in reversed(range(len(model.uniter.encoder.layer))):
                 model.uniter.encoder.grad_ready_hook(l)
-            if sparse and big_vocab:
-                os.environ["UNITER_AMD_DP_WORD_COMPACT"] = "1"
+            reducer.word_compact = bool(sparse and big_vocab)
             os.environ["UNITER_AMD_DP_SPARSE_WORD"] = "1"         # the row exchange is opt-in at every world size
             scale = reducer.finish(word_ids=ids if sparse else None)
-            os.environ.pop("UNITER_AMD_DP_WORD_COMPACT", None)
             os.environ.pop("UNITER_AMD_DP_SPARSE_WORD", None)
             assert scale == 1.0 / world
             results.append(arena.grad.clone())

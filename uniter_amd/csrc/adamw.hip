@@ -55,8 +55,9 @@ struct Plan {
 // `zero_grads`: the gradient element is overwritten with zero once it has been read — optimizer.zero_grad() folded into
 // the update (same bytes written as the separate memset, one pass and one launch fewer).
 // NT = the update's streams (every byte is touched exactly once) are loaded and stored with the non-temporal hint, so that they
-// do not displace what the next forward pass wants to find in the L2s / the Infinity Cache (UNITER_AMD_ADAMW_NT=1; experiment,
-// default off).  Same arithmetic either way.
+// do not displace what the next forward pass wants to find in the L2s / the Infinity Cache.  Same arithmetic either way; the
+// step ends on bit-identical parameters (tests/test_gpu_parity.py digest test) and is 1.3-1.5 % shorter (round 5, one box, A/B:
+// 4.53 / 4.52 ms default policy, 4.46 ms non-temporal), so NT is what runs (the template parameter stays for an A/B build).
 // (the table hands the kernel generic pointers; named as global at the access they become global_load / global_store
 //  instead of flat instructions, like every other kernel of the library — common.cuh: ldg16)
 template <bool NT, typename V>
@@ -322,18 +323,10 @@ static int fill_hyper(const UniterAdamGroup* groups, int32_t n_groups, HyperTabl
 static int adamw_step_impl(void* plan, const UniterAdamGroup* groups, int32_t n_groups, const float* clip_coef, int zero_grads,
                            void* stream);
 
-static bool adamw_nt() {
-    static const bool on = [] { const char* e = getenv("UNITER_AMD_ADAMW_NT"); return e != nullptr && atoi(e) != 0; }();
-    return on;
-}
 static void adamw_launch(int64_t blocks, hipStream_t st, const DevTensor* tensors, const ChunkRef* chunks, int64_t begin, int64_t end,
                          const HyperTable& ht, const GroupHyper* dev_hyper, const float* clip_coef, int zero_grads) {
-    if (adamw_nt())
-        hipLaunchKernelGGL(adamw_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, tensors, chunks, begin, end, ht, dev_hyper,
-                           clip_coef, zero_grads);
-    else
-        hipLaunchKernelGGL(adamw_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, tensors, chunks, begin, end, ht, dev_hyper,
-                           clip_coef, zero_grads);
+    hipLaunchKernelGGL(adamw_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, tensors, chunks, begin, end, ht, dev_hyper,
+                       clip_coef, zero_grads);
 }
 
 int uniter_adamw_step(void* plan, const UniterAdamGroup* groups, int32_t n_groups,
@@ -452,12 +445,8 @@ int uniter_adamw_step_async(void* plan, const UniterAdamGroup* groups, int32_t n
         const int64_t end = ends[(size_t)sgm];
         if (end == begin) continue;
         const int64_t n = end - begin;
-        // the first segments gate the start of the forward pass and run flat out; later ones only have to stay ahead of
-        // a forward pass that takes ~100 us per layer, and a throttled grid leaves the memory system to that pass
-        static const int throttle = [] { const char* e = getenv("UNITER_AMD_ADAMW_BLOCKS"); return e ? atoi(e) : 0; }();
-        static const int full_segs = [] { const char* e = getenv("UNITER_AMD_ADAMW_FULL_SEGS"); return e ? atoi(e) : 2; }();
-        int64_t blocks = n < 8192 ? n : 8192;
-        if (throttle > 0 && sgm >= full_segs && blocks > throttle) blocks = throttle;
+        // (throttled grids for the later segments were measured worse than flat-out ones, DESIGN.md / EXPERIMENTS.md round 2)
+        const int64_t blocks = n < 8192 ? n : 8192;
         {
             uh::LaunchTimer lt(uh::TIME_ADAMW, n, 0, 0, side);
             adamw_launch(blocks, side, (const DevTensor*)p->d_tensors, (const ChunkRef*)p->d_chunks, begin, end, ht,

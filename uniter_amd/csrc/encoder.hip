@@ -91,7 +91,7 @@ ScratchLayout scratch_layout(const UniterEncoderShape& s) {
 // previous launch's flags, signal a fresh slot, drop the queue barrier); done() records what that launcher reported.  A
 // launcher that cannot take part (packed attention, split-K) clears produced: it has then run as an ordinary in-order kernel
 // without flags, and so does the kernel after it.
-int g_chain = [] { const char* e = getenv("UNITER_AMD_CHAIN"); return e ? atoi(e) : 0; }();     // (opt-in: measured neutral to -1 % at 32 x 96 tokens)
+int g_chain = 0;     // overlapped kernel chains: a test / harness hook (uniter_encoder_debug_chain); measured neutral to -1 % at 32 x 96 tokens (EXPERIMENTS.md, round 4)
 struct Chain {
     bool on = false;
     uint32_t* flags = nullptr;
@@ -209,7 +209,7 @@ int side_init() {
 // tiles = five full rounds of the chip).  The per-layer grouped launch is a half-filled kernel that fights the data-gradient
 // chain for CUs for ~70 us per layer; nothing needs a weight gradient before the optimizer / the bucket's
 // allreduce.  A stage of twice the call's sets lets consecutive calls (gradient buckets) alternate halves, so the next range
-// does not wait for the previous range's launch.  UNITER_AMD_WGRAD_MULTI=0 keeps the per-layer launches.
+// does not wait for the previous range's launch.  (Without a registered stage the per-layer grouped launches run.)
 struct WgradStage {
     char* buf = nullptr;
     size_t bytes = 0;
@@ -219,7 +219,6 @@ struct WgradStage {
     bool pending[2] = {false, false};
 };
 thread_local WgradStage g_stage;
-int g_wgrad_multi = [] { const char* e = getenv("UNITER_AMD_WGRAD_MULTI"); return e ? atoi(e) : 1; }();
 struct StageSet { size_t dd, dd1, dqkv, dpre, dy2, dy1, dz2, dz1, dctx, total; };
 StageSet stage_set(const UniterEncoderShape& s) {
     const size_t T = tokens(s), H = s.H, I = s.I;
@@ -283,15 +282,10 @@ int buckets_init() {
 int g_use_side_stream = 1;
 int g_tune_in_situ = 1;
 int g_group_wgrad = 1;      // 1: the four weight gradients of a layer go out as one grouped launch
-// How many main-stream kernels after a layer's attention backward the grouped launch is released to the side stream
-// (0 = immediately, 1 = after the layer's last dgrad, 2 = after the next layer's first LayerNorm row kernel, ...).
-// The grouped kernel shares the CUs with whatever the main stream runs meanwhile; which neighbours it slows least is
-// an empirical question.  UNITER_AMD_WGRAD_DEFER overrides it.
-// 1: LayerNorm backward as ONE kernel on the caller's stream (rows + per-block column partials in the same pass over dy / z)
-// with only the tiny finalize on the side stream; 0: row kernel on the caller's stream + column kernel (re-reads dy, z) on
-// the side stream.  UNITER_AMD_LN_FUSED overrides.
-int g_ln_fused = [] { const char* e = getenv("UNITER_AMD_LN_FUSED"); return e ? atoi(e) : 0; }();
-int g_group_defer = [] { const char* e = getenv("UNITER_AMD_WGRAD_DEFER"); return e ? atoi(e) : 0; }();
+// (The grouped launch of a layer is released to the side stream right after that layer's attention backward; releasing it one
+//  to three main-stream kernels later, and LayerNorm backward as one kernel with a side-stream finalize, were measured neutral
+//  in rounds 2 and 3 and removed in round 5: EXPERIMENTS.md.)
+constexpr int g_group_defer = 0;
 
 int check_shape(const UniterEncoderShape* s) {
     if (s == nullptr) { uh_set_error("encoder: null shape"); return -1; }
@@ -394,7 +388,6 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
     void* red = S + sl.red;
     void* red2 = S + sl.red2;
     void* wg = S + sl.wg;
-    const bool hdrop = s->p_hidden > 0.f;
     const bool side = g_use_side_stream != 0;
     const bool grouped = g_group_wgrad != 0;
     // deferred weight gradients: every layer of this call gets its own set of dy buffers in the registered stage
@@ -402,7 +395,7 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
     const StageSet sset = stage_set(*s);
     bool defer_wg = false;
     int stage_half = 0;
-    if (grouped && side && g_wgrad_multi != 0 && g_stage.buf != nullptr && g_stage.bytes >= (size_t)nl * sset.total &&
+    if (grouped && side && g_stage.buf != nullptr && g_stage.bytes >= (size_t)nl * sset.total &&
         H % 256 == 0 && I % 256 == 0 && T % 64 == 0 && T >= 64) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) defer_wg = true;
@@ -510,17 +503,6 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         // (dgamma, dbeta and the dense bias gradient) go to the side stream.  dd is always materialised (a copy of dz
         // when there is no dropout) so that the weight-gradient work can read it after bufA has moved on.
         RC(before_overwrite(par));                 // weight gradients of layer l+2 used this buffer set
-        const bool lnf = g_ln_fused != 0 && grouped && !defer_wg;
-        if (lnf) {
-            int nbp = 0;
-            RC(before_overwrite(4));               // the finalize of the previous LayerNorm still reads `red`
-            RC(uh::layernorm_bwd_fused_rows(dyl, A + al.z2, (const float*)(A + al.mean2), (const float*)(A + al.rstd2), P.ln2_g, bufA,
-                                            ddb2, T, H, d_h2, red, sl.red_bytes, &nbp, st));
-            RC(tick());
-            RC(fork(4));
-            RC(uh::layernorm_bwd_fused_finalize(red, nbp, P.g_ln2_g, P.g_ln2_b, H, 1, ss));
-            RC(joined(4));
-        } else {
         CH(uh::layernorm_bwd_rows(dyl, nullptr, A + al.z2, (const float*)(A + al.mean2), (const float*)(A + al.rstd2),
                                   P.ln2_g, dz2b, ddb2, T, H, d_h2, 0, st, cs));
         RC(tick());
@@ -530,7 +512,6 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
                                   dz2b, ddb2, P.g_ln2_g, P.g_ln2_b, grouped ? nullptr : P.g_b2, T, H, 1, d_h2, 0,
                                   side ? red2 : red, sl.red_bytes, ss));
         RC(joined(4));                         // dyl (bufB below the top layer) has been read
-        }
         }
         if (!grouped) {
             RC(uh::gemm_wgrad(ddb2, A + al.g, P.g_w2, T, H, I, 1, wg, sl.wg_bytes, ss));
@@ -549,16 +530,6 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         CH(uh::gemm_dgrad(uh::GEMM_EPI_RES, dpre, P.w1, dz2b, dab, T, I, H, st, 0, 0, cs));           // da = dpre*W1 + dz2
         RC(tick());
         // ---- BertSelfOutput backward (model/layer.py:111-115) ----
-        if (lnf) {
-            int nbp = 0;
-            RC(before_overwrite(5));               // the finalize of the previous LayerNorm still reads `red2`
-            RC(uh::layernorm_bwd_fused_rows(bufB, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1), P.ln1_g, bufA,
-                                            ddb1, T, H, d_h1, red2, sl.red_bytes, &nbp, st));
-            RC(tick());
-            RC(fork(5));
-            RC(uh::layernorm_bwd_fused_finalize(red2, nbp, P.g_ln1_g, P.g_ln1_b, H, 1, ss));
-            RC(joined(5));
-        } else {
         CH(uh::layernorm_bwd_rows(dab, nullptr, A + al.z1, (const float*)(A + al.mean1), (const float*)(A + al.rstd1),
                                   P.ln1_g, dz1b, ddb1, T, H, d_h1, 0, st, cs));
         RC(tick());
@@ -568,7 +539,6 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
                                   dz1b, ddb1, P.g_ln1_g, P.g_ln1_b, grouped ? nullptr : P.g_bo, T, H, 1, d_h1, 0,
                                   side ? red2 : red, sl.red_bytes, ss));
         RC(joined(5));                         // bufB (da) has been read
-        }
         }
         if (!grouped) {
             RC(uh::gemm_wgrad(ddb1, A + al.ctx, P.g_wo, T, H, H, 1, wg, sl.wg_bytes, ss));
@@ -814,7 +784,7 @@ int uniter_encoder_autotune(const UniterEncoderShape* s, void* stream) {
     // the stack is timed the way training runs it: with the weight gradients deferred to one launch per call when a stage
     // would be registered (the data-gradient chain then has the chip to itself, which changes its best tiles)
     char* tune_stage = nullptr;
-    if (g_group_wgrad && g_wgrad_multi && H % 256 == 0 && I % 256 == 0 && T % 64 == 0 && T >= 64) {
+    if (g_group_wgrad && H % 256 == 0 && I % 256 == 0 && T % 64 == 0 && T >= 64) {
         const size_t stb = (size_t)NL * stage_set(*s).total;
         TN_HIP(hipMalloc((void**)&tune_stage, stb));
         g_stage = WgradStage{};
@@ -898,7 +868,7 @@ int uniter_encoder_debug_tune_in_situ(int enable) {
 
 // test / tuning hook: 0 = run the weight-gradient GEMMs on the caller's stream, 1 = on the library's side stream
 // test / measurement hook: 0 = every kernel of the encoder calls in queue order (barrier between dependent kernels; the default),
-// 1 = the overlapped chains (UNITER_AMD_CHAIN=1 in the environment is the same switch)
+// 1 = the overlapped chains (tests / harness)
 int uniter_encoder_debug_chain(int enable) { g_chain = enable; return 0; }
 // the status word of the last chained call whose flags lived in `scratch`: 0 = no wait timed out.  Synchronises the device.
 int uniter_encoder_chain_status(const UniterEncoderShape* s, const void* scratch, int32_t* status_out) {

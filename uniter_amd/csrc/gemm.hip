@@ -354,7 +354,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     // (only where a wave has its SIMD to itself — the wave-specialised tiles; the plain tiles run two or three workgroups per CU,
     //  which cover each other's LDS latency, and measured 5 % slower with the extra registers — and only where accumulators + two
     //  fragment sets stay inside the register budget of the tile's launch bounds: a spill inside the K loop costs 3x)
-    constexpr bool PIPE = g_gemm_pipe && WS != 0 && (MI * NI * 4 + 2 * (MI + NI) * 4 + 28 <= (WS == 2 ? 168 : (WS == 5 ? 248 : 128)));
+    constexpr bool PIPE = g_gemm_pipe && WS != 0 && (MI * NI * 4 + 2 * (MI + NI) * 4 + 28 <= (WS == 2 ? 168 : 128));
     bf16x8 pfr[2][MI], pfc[2][NI];                         // (dead, hence register-free, where !PIPE)
     // (the last tile is peeled off the loop instead of guarded inside it: with a guard the second MFMA block is reached on two
     //  paths, with and without the next tile's reads in flight, and the compiler's single wait for both covers the new reads too)
@@ -394,7 +394,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     // passes of the epilogue at once, before the last K step's MFMAs, instead of one exposed round trip per 16-row pass.
     // (early only where accumulators + fragments + these registers stay inside the wave's register budget: the 128x128 tiles
     //  would spill ~100 registers otherwise; they fetch at the start of the epilogue, where the fragments are dead)
-    constexpr int REG_BUDGET = WS == 2 ? 168 : (WS == 5 ? 248 : 128);      // what the launch bounds leave a wave
+    constexpr int REG_BUDGET = WS == 2 ? 168 : 128;      // what the launch bounds leave a wave
     constexpr bool AUX_EARLY = g_aux_early_dev && HAS_AUX && (MI * NI * 4 + (PIPE ? 2 : 1) * (MI + NI) * 4 + MI * ITERS * 4 + 24 <= REG_BUDGET);
     u32x4 auxr[HAS_AUX ? MI : 1][ITERS];
     constexpr bool HAS_BIAS = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RES);
@@ -460,9 +460,24 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 if (d < nfull) ws_glds(d, d);
             int pre = NSTAGE - 1;
             for (int kt = 0; kt < nfull; ++kt) {
+#ifdef UNITER_GEMM_PROBE
+                // loader wave 0: [0] before the wait for its share of tile kt, [1] landed, [2] released by the barrier, [3] next tile issued
+                unsigned long long* lp = (p.probe && lw == 0 && lane == 0 && bx < 4096)
+                                             ? p.probe + (size_t)4096 * 64 * 5 + (size_t)4096 * 2 + ((size_t)bx * 64 + (kt < 63 ? kt : 63)) * 4 : nullptr;
+                if (lp) lp[0] = __builtin_readcyclecounter();
+#endif
                 wait_tile<NSTAGE, G>(nfull - 1 - kt);
+#ifdef UNITER_GEMM_PROBE
+                if (lp) lp[1] = __builtin_readcyclecounter();
+#endif
                 __builtin_amdgcn_s_barrier();
+#ifdef UNITER_GEMM_PROBE
+                if (lp) lp[2] = __builtin_readcyclecounter();
+#endif
                 if (kt + NSTAGE - 1 < nfull) ws_glds(kt + NSTAGE - 1, pre);
+#ifdef UNITER_GEMM_PROBE
+                if (lp) lp[3] = __builtin_readcyclecounter();
+#endif
                 pre = (pre + 1 == NSTAGE) ? 0 : pre + 1;
             }
             if constexpr (!EPI_ALL) return;
@@ -477,7 +492,21 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
             int buf = 0;
             for (int kt = 0; kt + 1 < nfull; ++kt) {
                 const int nbuf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+#ifdef UNITER_GEMM_PROBE
+                // wave 0: [0] step begins (second-half reads issued next), [1] arrives at the tile boundary (first-half MFMAs issued,
+                // reads of this tile retired), [2] released by the barrier, [3] = [2], [4] step ends (second-half MFMAs issued)
+                unsigned long long* pr = p.probe ? p.probe + ((size_t)bx * 64 + (kt < 63 ? kt : 63)) * 5 : nullptr;
+                const bool rec = pr != nullptr && t == 0;
+                if (rec) pr[0] = __builtin_readcyclecounter();
+                pipe_step(buf, nbuf, [&] {
+                    if (rec) pr[1] = __builtin_readcyclecounter();
+                    __builtin_amdgcn_s_barrier();
+                    if (rec) pr[2] = pr[3] = __builtin_readcyclecounter();
+                });
+                if (rec) { asm volatile("s_nop 0" ::: "memory"); pr[4] = __builtin_readcyclecounter(); }
+#else
                 pipe_step(buf, nbuf, [&] { __builtin_amdgcn_s_barrier(); });
+#endif
                 buf = nbuf;
             }
             if (nfull > 0) {
@@ -707,7 +736,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 }
 
 template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, int WS>
-__global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS == 2 ? 3 : (WS == 5 ? 2 : 1))) void gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS == 2 ? 3 : 1)) void gemm_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     gemm_tile<BM, BN, TRA, TRB, EPI, NSTAGE, WS>(p, (int)blockIdx.x, (int)blockIdx.y, smem_raw);
 }
@@ -730,7 +759,7 @@ struct GemmGroupArgs {
     int per;
 };
 template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, int WS>
-__global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS == 2 ? 3 : (WS == 5 ? 2 : 1))) void gemm_group_kernel(const GemmGroupArgs ga) {
+__global__ __launch_bounds__((WaveGrid<BM, BN, WS>::THREADS), WS == 1 ? 4 : (WS == 2 ? 3 : 1)) void gemm_group_kernel(const GemmGroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     int b = (int)blockIdx.x;
     if (ga.compact) {
@@ -963,10 +992,8 @@ constexpr TileShape kTiles[] = {{128, 128, 2, 0}, {128, 64, 2, 0}, {64, 128, 2, 
                                 {256, 256, 2, 3},
                                 // ws = 4: its 192 x 192 sibling (three phases per K tile, three LDS buffers): 256 tiles for a 3072 x 3072 output
                                 {192, 192, 3, 4},
-                                // ws = 5: 4 compute + 4 loader waves with ONE workgroup per CU (256 registers per wave): wave tiles of
-                                // 48 x 96 ... 96 x 96 with the fragment reads pipelined (pipe_step), three-stage rings
-                                {96, 192, 3, 5}, {192, 96, 3, 5}, {192, 192, 2, 5}, {192, 192, 3, 5}, {128, 192, 3, 5}, {192, 128, 3, 5},
-                                {128, 128, 4, 5}};
+                                // round 5 (after the LDS-DMA issue fix the big 8 + 4 tiles win the wide outputs): deeper rings of those
+                                {192, 192, 3, 2}, {96, 192, 4, 2}, {192, 96, 4, 2}};
 constexpr int kTileG8 = 58, kTileG6 = 59;
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -1055,18 +1082,14 @@ int launch_gemm(const GemmArgs& a, int cfg, int splits, hipStream_t st) {
         case 60: return launch_idx<TRA, TRB, EPI, 60>(a, splits, st);
         case 61: return launch_idx<TRA, TRB, EPI, 61>(a, splits, st);
         case 62: return launch_idx<TRA, TRB, EPI, 62>(a, splits, st);
-        case 63: return launch_idx<TRA, TRB, EPI, 63>(a, splits, st);
-        case 64: return launch_idx<TRA, TRB, EPI, 64>(a, splits, st);
-        case 65: return launch_idx<TRA, TRB, EPI, 65>(a, splits, st);
-        case 66: return launch_idx<TRA, TRB, EPI, 66>(a, splits, st);
         default: uh_set_error("gemm: bad tile index %d", cfg); return -1;
     }
 }
 
 // ---- grouped weight-gradient launch ------------------------------------------------------------------------------
-// 1 (default): compact per-XCD tile segments (GemmGroupArgs); 0: every problem spread over all XCDs with its own 2-D
-// blocking.  UNITER_AMD_GROUP_COMPACT overrides.
-int g_group_compact = [] { const char* e = getenv("UNITER_AMD_GROUP_COMPACT"); return e ? atoi(e) : 1; }();
+// Compact per-XCD tile segments (GemmGroupArgs).  (The alternative — every problem spread over all XCDs with its own 2-D
+// blocking — read 239 MB instead of 132 slabs' worth per layer and was removed in round 5; profiles/r02_wgrad_group_fetch_ab.txt.)
+constexpr int g_group_compact = 1;
 template <int IDX>
 int launch_group_idx(GemmGroupArgs& ga, hipStream_t st) {
     if constexpr (tile_ok<true, true>(IDX)) {
@@ -1159,7 +1182,7 @@ bool cfg_legal(int kind, int cfg, int64_t M, int64_t N, int64_t K, int splits) {
     const TileShape& t = kTiles[cfg];
     const int64_t contraction = kind == 0 ? K : (kind == 1 ? N : M);
     const int64_t out_m = kind == 2 ? N : M, out_n = kind == 0 ? N : K;
-    if (t.ws >= 3) {                                        // the deep-pipelined tiles: 256 x 256 (3) and 192 x 192 (4)
+    if (t.ws == 3 || t.ws == 4) {                           // the deep-pipelined tiles: 256 x 256 (3) and 192 x 192 (4)
         if (out_n % t.bn != 0 || contraction % 64 != 0 || contraction < (int64_t)64 * splits) return false;
         return kind != 2 || out_m % t.bm == 0;
     }
@@ -1456,7 +1479,7 @@ int gemm_wgrad(const void* dy, const void* x, void* dw, int64_t M, int64_t N, in
     if (g_force_cfg < 0 && g_force_splits < 0 && tuned_lookup(2, M, N, K, &tn)) { cfg = tn.cfg; splits = tn.splits; }
     if (db != nullptr) {
         splits = 1;
-        if (kTiles[cfg].ws >= 3) cfg = pick_cfg((int)N, (int)K, true, true, M % 64 == 0);   // those tiles have no bias-gradient output
+        if (kTiles[cfg].ws == 3 || kTiles[cfg].ws == 4) cfg = pick_cfg((int)N, (int)K, true, true, M % 64 == 0);   // those tiles have no bias-gradient output
     }
     while (splits > 1 && (size_t)splits * N * K * sizeof(float) > ws_bytes) splits >>= 1;
     const bool in_launch = kTiles[cfg].ws == 3 && splits == 2;     // two K slices combined by the tile's own workgroups
@@ -1479,7 +1502,7 @@ int gemm_wgrad(const void* dy, const void* x, void* dw, int64_t M, int64_t N, in
 static const int kGroupCfgs[] = {0, 1, 2, 3, 13, 14, 15, 20, 23, 24, 26, 27, 29, 33, 34, 36, 37, 43, 44, 45, 49, 51, 52};
 static bool group_g8_ok(int n, int64_t M, const int64_t* N, const int64_t* K, int splits, int edge);
 static bool group_cfg_ok(int cfg, int n, int64_t M, const int64_t* N, const int64_t* K) {
-    if (kTiles[cfg].ws >= 3) return group_g8_ok(n, M, N, K, 1, kTiles[cfg].bm);
+    if (kTiles[cfg].ws == 3 || kTiles[cfg].ws == 4) return group_g8_ok(n, M, N, K, 1, kTiles[cfg].bm);
     const int bm = kTiles[cfg].bm, bn = kTiles[cfg].bn;
     if (kTiles[cfg].ws && M % 64 != 0) return false;
     for (int q = 0; q < n; ++q)
@@ -1568,10 +1591,7 @@ int gemm_wgrad_group(int n, const void* const* dy, const void* const* x, void* c
     int splits = splits_override > 0 ? splits_override : 1;
     if (cfg < 0) {
         Tuned tn;
-        static const int env_cfg = [] { const char* e = getenv("UNITER_AMD_GROUP_CFG"); return e ? atoi(e) : -1; }();   // experiment hook
-        static const int env_sp = [] { const char* e = getenv("UNITER_AMD_GROUP_SPLITS"); return e ? atoi(e) : 1; }();
-        if (env_cfg >= 0 && env_cfg < kNumTiles && group_cfg_ok(env_cfg, n, M, N, K)) { cfg = env_cfg; splits = env_sp; }
-        else if (tuned_lookup(3, M, group_sum(n, N), group_sum(n, K), &tn) && group_cfg_ok(tn.cfg, n, M, N, K)) { cfg = tn.cfg; splits = tn.splits; }
+        if (tuned_lookup(3, M, group_sum(n, N), group_sum(n, K), &tn) && group_cfg_ok(tn.cfg, n, M, N, K)) { cfg = tn.cfg; splits = tn.splits; }
         else {
             const int prefer[] = {33, 29, 0, 3};                      // 128x128 ws, 64x64 ws, then the plain tiles
             for (int c : prefer)
@@ -1747,9 +1767,8 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
     unsigned* tail_pairs = nullptr;
     float* tail_slabs = nullptr;
     {
-        static const bool split_tail = [] { const char* e = getenv("UNITER_AMD_MULTI_TAIL_SPLIT"); return e == nullptr || atoi(e) != 0; }();
         const int tail = per % 32;
-        if (split_tail && buckets == nullptr && per > 32 && tail > 0 && tail <= kMultiTailMax && M >= 256 && dev >= 0 && dev < 16) {
+        if (buckets == nullptr && per > 32 && tail > 0 && tail <= kMultiTailMax && M >= 256 && dev >= 0 && dev < 16) {
             if (g_multi.tail_slabs[dev] == nullptr &&
                 hipMalloc(&g_multi.tail_slabs[dev], (size_t)8 * kMultiTailMax * 256 * 256 * sizeof(float)) != hipSuccess)
                 g_multi.tail_slabs[dev] = nullptr;
@@ -1759,16 +1778,12 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
         }
     }
     const int gemm_blocks = (full + 2 * (per - full)) * 8;
-    // The staggered start (see the kernel): some CUs begin with a tile, the others with one or two LayerNorm strips, when the
-    // launch is long enough for it to matter.  UNITER_AMD_MULTI_STAGGER="tiles,strips,strips2" overrides (0,128,0 = round 3).
+    // The staggered start (see the kernel): some CUs begin with a tile, the others with a LayerNorm strip, when the launch is long
+    // enough for it to matter: 0 leading tiles, 128 leading strips, no second strip group (three phases, 64 / 192 / 64, took 15 us off
+    // the step but added 17 us and 18 % of fabric reads to this launch: EXPERIMENTS.md, round 4).
     int lead_strips = 0, lead_tiles = 0, lead_strips2 = 0;
     {
-        static int cfg[3] = {-1, -1, -1};
-        if (cfg[0] < 0) {
-            cfg[0] = 0; cfg[1] = 128; cfg[2] = 0;         // (64,192,64 = three phases: the step -15 us, this launch +17 us and +18 % HBM-side reads — DESIGN 10.5)
-            const char* e = getenv("UNITER_AMD_MULTI_STAGGER");
-            if (e != nullptr) { int a = 0, b2 = 0, c = 0; if (sscanf(e, "%d,%d,%d", &a, &b2, &c) == 3 && a >= 0 && b2 >= 0 && c >= 0) { cfg[0] = a; cfg[1] = b2; cfg[2] = c; } }
-        }
+        constexpr int cfg[3] = {0, 128, 0};
         const int n_ln_strips = n_ln * ln_strips_per_job;
         if (per > 64) {
             lead_strips = std::min(cfg[1], n_ln_strips) & ~7;

@@ -481,7 +481,7 @@ class _EncoderFn(torch.autograd.Function):
             if defer:
                 want_defer = begin > 0
             else:
-                defer_only = bool(getattr(hook, "defer_wgrad_join", False)) and os.environ.get("UNITER_AMD_DEFER_WGRAD_JOIN", "1") != "0"
+                defer_only = bool(getattr(hook, "defer_wgrad_join", False))
                 want_defer = defer_only
             C.uniter_encoder_defer_side_join(1 if want_defer else 0)
             # gradient buckets of a data-parallel reducer (one call, flags per bucket): per thread and sticky, so stated every time
@@ -592,7 +592,7 @@ def wgrad_group(dys, lddys, xs_, ldxs, dws, dbs, M, Ns, Ks, training=True):
     C.uniter_gemm_wgrad_group(n, PA(*dys), IA(*lddys), PA(*xs_), IA(*ldxs), PA(*dws), PA(*dbs), M, Na, Ka, 1, st)
 
 
-_HEAD_GROUP = os.environ.get("UNITER_AMD_HEAD_GROUP", "1") != "0"
+_HEAD_GROUP = True          # (False: one launch per problem — the A/B of round 4, kept as a module attribute for tests)
 
 
 def fwd_group(xs_, ldxs, ws, biases, ys, ldys, M, Ns, K):

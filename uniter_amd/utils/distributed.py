@@ -252,6 +252,7 @@ class GradientReducer(object):
 
     def __init__(self, arena, encoder=None, layers_per_bucket=3, word_embeddings=None, word_ids_cap=None):
         self.arena = arena
+        self.word_compact = False             # tests: segment sums on the gathered rows even for a small vocabulary
         self.word_ids_cap = word_ids_cap      # most word ids (batch x padded text length) any rank hands to finish(); None: agreed per step
         self.encoder = encoder
         self.buckets = []          # (lo, hi) element ranges
@@ -283,7 +284,7 @@ class GradientReducer(object):
                 # backward only has to hand control back at the layers that complete a bucket (ops._EncoderFn.backward cuts
                 # the stack there instead of after every layer)
                 encoder.grad_ready_hook = _LayerHook(self._on_layer, set(self.layer_bucket.keys()),
-                                                     joins_side_stream=bool(arena.grad.is_cuda) and os.environ.get("UNITER_AMD_DEFER_JOIN", "1") != "0")
+                                                     joins_side_stream=bool(arena.grad.is_cuda))
         covered.sort()
         pos = 0
         for lo, hi in covered:
@@ -378,7 +379,7 @@ class GradientReducer(object):
         dist.all_gather_into_tensor(all_rows, rows)
         # rows of the union, summed over ranks in fp32 and rounded once; every touched row is rewritten by every rank alike
         uniq_ids = all_ids                       # (duplicates carry zero rows or the same id from another rank: index_add sums them)
-        compact = V * H > (1 << 22) or os.environ.get("UNITER_AMD_DP_WORD_COMPACT") == "1"
+        compact = V * H > (1 << 22) or self.word_compact
         acc = None if compact else torch.zeros(V, H, dtype=torch.float32, device=g.device)
         if acc is not None:
             acc.index_add_(0, uniq_ids, all_rows.float())
