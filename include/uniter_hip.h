@@ -473,7 +473,7 @@ int uniter_encoder_debug_side_stream(int enable);
  * uniter_encoder_backward dispatch the dependent kernels of all their layers WITHOUT the queue barrier between them
  * (hipExtLaunchKernel, hipExtAnyOrderLaunch) and order them through per-32-row flags in the scratch buffer instead: a consumer
  * tile starts when the row block it reads is complete, not when the slowest tile of the producer has drained
- * (csrc/common.cuh "Overlapped kernel chains").  Same kernels, same arithmetic: results are bit-identical
+ * (csrc/common.cuh "Overlapped kernel chains", EXPERIMENTS.md section 10).  Same kernels, same arithmetic: results are bit-identical
  * to the in-order launches, which uniter_encoder_debug_chain(0) (or UNITER_AMD_CHAIN=0) selects.  A flag wait that does not
  * complete within 50 ms gives up and sets a status word instead of hanging; uniter_encoder_chain_status reads it
  * (synchronising the device): 0 = clean.  (model/model.py:282-292 has no counterpart.) */

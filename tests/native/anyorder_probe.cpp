@@ -1,4 +1,4 @@
-// Feasibility probe for overlapped kernel chains: can dependent kernels of ONE stream be dispatched
+// Feasibility probe for overlapped kernel chains (EXPERIMENTS.md section 10): can dependent kernels of ONE stream be dispatched
 // without the barrier between them (hipExtLaunchKernel + hipExtAnyOrderLaunch) and synchronise through row-block flags
 // instead — and which store / load flavours make the hand-off coherent across XCDs without a kernel boundary's cache
 // write-back / invalidate?  Measures, on one MI355X:

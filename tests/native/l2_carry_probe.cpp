@@ -1,5 +1,5 @@
 // l2_carry_probe.cpp — does an XCD's L2 keep what a kernel wrote for the NEXT kernel on the same stream?
-// (a row-block -> XCD affinity across the kernel chain only pays if it does.)
+// (EXPERIMENTS.md section 10.7 item 1: a row-block -> XCD affinity across the kernel chain only pays if it does.)
 // Kernel W: workgroup b (256 of them; hardware block b runs on XCD b % 8) writes slice b (64 KiB) with the default store policy
 // , write-through (sc1) or non-temporal.  Kernel R: workgroup b reads slice (b + shift) % 256 and stamps the wall clock around the read.
 // shift 0: the reader sits where the writer sat; shift 8: another CU of the same XCD; shift 1: the neighbouring XCD.

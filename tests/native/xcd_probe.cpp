@@ -1,4 +1,4 @@
-// Feasibility probe for a persistent per-XCD layer kernel: measures, on one MI355X,
+// Feasibility probe for a persistent per-XCD layer kernel (EXPERIMENTS.md section 8): measures, on one MI355X,
 //   E1  the latency of a barrier among the workgroups that share one XCD (L2-resident counter, L1-bypassing poll),
 //   E2  the observed blockIdx -> XCD / CU placement of a 256-workgroup, one-per-CU grid,
 //   E3  whether a tile written with plain stores by one CU is read correctly by another CU of the SAME XCD

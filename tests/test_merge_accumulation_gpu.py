@@ -55,7 +55,7 @@ def test_merged_micro_batches_give_the_accumulation_loops_gradients(workload):
         l1, g1 = out[True][task]
         assert abs(l1 - l0) <= 5e-3 * max(1.0, abs(l0)), (task, l0, l1)
         assert sorted(g0) == sorted(g1), task
-        worst = (0.0, None)
+        worst = (-1.0, "")
         for n in g0:
             a, b = g1[n].double().flatten(), g0[n].double().flatten()
             if float(b.norm()) == 0.0:

@@ -104,7 +104,7 @@ __device__ __forceinline__ void out_store8(void* p, const u32x2 v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Overlapped kernel chains (feasibility: tests/native/anyorder_probe.cpp, profiles/r04_anyorder_probe.log)
+// Overlapped kernel chains (EXPERIMENTS.md section 10; feasibility: tests/native/anyorder_probe.cpp, profiles/r04_anyorder_probe.log)
 // ---------------------------------------------------------------------------------------------
 // The kernels of an encoder forward / backward call form a dependent chain in which every operation is local to a block of
 // rows (tokens) — attention to an example, which at L % 32 == 0 is a whole number of 32-row units.  Launched in order, each

@@ -86,7 +86,7 @@ ScratchLayout scratch_layout(const UniterEncoderShape& s) {
     return l;
 }
 
-// ---- overlapped kernel chain (common.cuh) --------------------------------------------------------------
+// ---- overlapped kernel chain (common.cuh, EXPERIMENTS.md section 10) --------------------------------------------------------------
 // One per uniter_encoder_forward / _backward call.  next() hands the launcher of the following kernel its step (wait on the
 // previous launch's flags, signal a fresh slot, drop the queue barrier); done() records what that launcher reported.  A
 // launcher that cannot take part (packed attention, split-K) clears produced: it has then run as an ordinary in-order kernel
@@ -207,7 +207,7 @@ int side_init() {
 // (dd2, dpre, dd1, dqkv: one "set" per layer) instead of recycling two sets by layer parity, and the weight + bias gradients of
 // ALL layers of the call go out as ONE launch at its end (uh::gemm_wgrad_multi, 256 x 256 eight-phase tile: 12 layers = 1 296
 // tiles = five full rounds of the chip).  The per-layer grouped launch is a half-filled kernel that fights the data-gradient
-// chain for CUs for ~70 us per layer; nothing needs a weight gradient before the optimizer / the bucket's
+// chain for CUs for ~70 us per layer (EXPERIMENTS.md section 9.3); nothing needs a weight gradient before the optimizer / the bucket's
 // allreduce.  A stage of twice the call's sets lets consecutive calls (gradient buckets) alternate halves, so the next range
 // does not wait for the previous range's launch.  (Without a registered stage the per-layer grouped launches run.)
 struct WgradStage {

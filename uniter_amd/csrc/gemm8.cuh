@@ -2,7 +2,7 @@
 //
 // Why a second tile family.  The 64...192-wide tiles of gemm.hip run one or two barriers per K step with every wave
 // doing the same thing at the same time; that structure tops out near 36 % of the MFMA peak however its ring is tuned
-// (DESIGN §7/§8).  This one follows the schedule cdna_hip_programming.md §5 "256² 8-phase template" describes:
+// (EXPERIMENTS.md §7/§8).  This one follows the schedule cdna_hip_programming.md §5 "256² 8-phase template" describes:
 //
 //   * tile 256 x 256, K step 64, 8 waves as 2 (M) x 4 (N): a wave owns four 64 x 32 quadrants (mq, nq) of the output,
 //     rows mq*128 + wr*64 + [0,64), columns nq*128 + wc*32 + [0,32) — 128 accumulator registers;

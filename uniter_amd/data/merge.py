@@ -4,7 +4,7 @@ The reference accumulates because a 16 / 32 GB GPU cannot hold the batch (`gradi
 config/pretrain-*.json, config/train-vqa-large-8gpu.json; loop: pretrain.py:264-312, train_vqa.py:183-206): the micro-steps of a
 step draw the same task (data/loader.py:42-47), each does `loss.mean().backward()` and the gradients add up.  On a 288 GB
 MI355X the micro-batches fit side by side, and one forward / backward over 4 x 32 sequences runs the same arithmetic in GEMMs
-four times as tall — the shape this chip is efficient at.  Two pieces:
+four times as tall — the shape this chip is efficient at (EXPERIMENTS.md section 11).  Two pieces:
 
   merge_batches(batches)         collated micro-batches of one task -> the batch the task's collate function would have built
                                  from all their examples at once (same keys, padding values, gather / scatter indices)

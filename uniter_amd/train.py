@@ -119,7 +119,7 @@ class StepRunner(object):
             self.optimizer.fuse_zero_grad = True
         if reducer_layers_per_bucket is None:
             # 4-layer buckets: a backward range's deferred weight-gradient launch is 432 tiles (1.7 rounds of 256 CUs); with 3
-            # layers it is 324 (1.3 rounds) and the one-rank RCCL step measures 5.49 ms against 5.26
+            # layers it is 324 (1.3 rounds) and the one-rank RCCL step measures 5.49 ms against 5.26 (EXPERIMENTS.md section 5)
             reducer_layers_per_bucket = int(os.environ.get("UNITER_AMD_LAYERS_PER_BUCKET", "4"))
         self.reducer = (D.GradientReducer(self.arena, self.model.uniter.encoder, layers_per_bucket=reducer_layers_per_bucket,
                                           word_embeddings=self.model.uniter.embeddings.word_embeddings.weight,

@@ -409,7 +409,7 @@ class GradientReducer(object):
             # Called on autograd's thread right after the one backward call of the stack.  Only note the bucket's flag here; the
             # waits and collectives are enqueued by finish(), after backward() has returned: the ~0.3 ms of host work they cost
             # would otherwise sit between the encoder's backward and the embedding backward, whose kernels then reach the GPU
-            # when the deferred launch already owns every CU and do not run until it ends (rocprofv3 trace).
+            # when the deferred launch already owns every CU and do not run until it ends (rocprofv3 trace, EXPERIMENTS.md section 5).
             from .. import _lib
             lib = _lib.load()
             if self._chain_done is None:
