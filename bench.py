@@ -155,6 +155,66 @@ def pmc_step_traffic():
             "note": "FETCH_SIZE (x2: the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE per kernel family, separate --pmc passes"}
 
 
+def measured_step_traffic(config, timeout_s=150):
+    """Fabric-side bytes per optimizer step, MEASURED in this run: two `rocprofv3 --pmc` passes (FETCH_SIZE, then WRITE_SIZE — never
+    in one pass, never with another trace domain; MI355X_MICROARCH.md "HBM" / "rocprofv3 PMC slots") over a short child run of
+    this very script (same workload, same kernels: 1 warm-up + 2 steps, no timing legs), summed per kernel and divided by the
+    child's optimizer steps (= its adamw_kernel launches).  FETCH_SIZE is doubled (gfx950 tallies the 128-B requests of wide
+    coalesced reads at 64 B), both counters are KiB.  Returns None when rocprofv3 is not on the box or a pass fails — the line then
+    falls back to the committed passes (traffic_source says which)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--config", config, "--steps", "2", "--warmup", "1", "--windows", "1",
+             "--no-cpu-baseline", "--no-kernel-timing", "--no-traffic"]
+    per = {}
+    steps = None
+    tmp = tempfile.mkdtemp(prefix="uniter_pmc_")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--"] + child,
+                                   capture_output=True, text=True, timeout=timeout_s, env=env, cwd="/tmp")
+            except subprocess.TimeoutExpired:
+                return None
+            files = glob.glob(os.path.join(out, "*", "*counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None
+            fam = {}
+            n_adam = 0
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if row["Counter_Name"] != counter:
+                        continue
+                    name = row["Kernel_Name"]
+                    key = "optimizer" if ("adamw_kernel" in name or "gradsq_kernel" in name) else "fwd_bwd"
+                    n_adam += 1 if "adamw_kernel" in name else 0
+                    fam[key] = fam.get(key, 0.0) + float(row["Counter_Value"]) * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
+            if n_adam == 0:
+                return None
+            # the child runs warm-up + timed steps (+ the dummy first optimizer step of the reference's loop, which launches
+            # no AdamW kernel): every AdamW launch closes one step
+            steps = n_adam
+            per[counter] = {k: v / n_adam for k, v in fam.items()}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    rd, wr = per["FETCH_SIZE"], per["WRITE_SIZE"]
+    return {"fwd_bwd_bytes_per_step": int(rd.get("fwd_bwd", 0.0) + wr.get("fwd_bwd", 0.0)),
+            "fwd_bwd_read_bytes_per_step": int(rd.get("fwd_bwd", 0.0)), "fwd_bwd_write_bytes_per_step": int(wr.get("fwd_bwd", 0.0)),
+            "optimizer_bytes_per_step": int(rd.get("optimizer", 0.0) + wr.get("optimizer", 0.0)),
+            "steps_in_pass": steps, "source": "measured in this run",
+            "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over a 3-step child run of "
+                    "this command; FETCH_SIZE x 2 (gfx950), KiB -> bytes; the counters sit on the L2's fabric side, so "
+                    "Infinity-Cache hits are included"}
+
+
 def usable_cores():
     """Host cores this process may actually use: affinity mask and cgroup CPU quota, not the raw host count."""
     try:
@@ -391,6 +451,8 @@ def main():
                          "configurations as one GPU's share of the job (uniter_amd/train.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the in-run PMC passes (rocprofv3 child runs, ~1.5 min) behind roofline.traffic; the committed passes are used")
     ap.add_argument("--overlap", action="store_true",
                     help="run the optimizer update asynchronously under the next forward pass (AdamW.enable_overlap)")
     ap.add_argument("--graph", action="store_true",
@@ -549,7 +611,13 @@ def main():
                                            "avg_launch_us": dom["us"], "launches_per_step": dom["launches_per_step"],
                                            "traffic": None if traffic is None else traffic["hbm_bytes"], "traffic_detail": traffic,
                                            "measured": "HIP events around every launch on its own stream during %d extra optimizer steps; %s" % (tsteps, note)}
-            step_traffic = pmc_step_traffic()
+            step_traffic = None
+            if world == 1 and not args.no_traffic and not args.no_cpu_baseline:
+                # (after the timed region and the timing legs, with this process's GPU work finished: the child has the GPU to itself)
+                torch.cuda.synchronize()
+                step_traffic = measured_step_traffic(args.config)
+            if step_traffic is None:
+                step_traffic = pmc_step_traffic()
             if step_traffic is not None:
                 roofline["traffic"] = step_traffic["fwd_bwd_bytes_per_step"]
                 roofline["traffic_detail"] = step_traffic
@@ -574,8 +642,9 @@ def main():
             "roofline": roofline,
             # `roofline.achieved` / `avg_launch_us` are measured in THIS run (HIP events); `roofline.traffic` is not: it is the
             # per-launch PMC figure of the committed rocprofv3 passes (profiles/*_pmc_traffic.json, separate --pmc runs)
-            "traffic_source": None if roofline.get("traffic") is None else
-                              "committed (%s; not measured in this run)" % roofline["traffic_detail"].get("source", "profiles/*_pmc_traffic.json"),
+            "traffic_source": None if roofline.get("traffic") is None else (
+                "measured in this run (rocprofv3 --pmc child passes)" if roofline["traffic_detail"].get("source") == "measured in this run"
+                else "committed (%s; not measured in this run)" % roofline["traffic_detail"].get("source", "profiles/*_pmc_traffic.json")),
             "timed_windows": {"n": len(window_s), "steps_each": args.steps, "reported": "median",
                               "ms_per_step": [round(x / args.steps * 1e3, 3) for x in window_s],
                               "ms_per_step_min": round(min(window_s) / args.steps * 1e3, 3),
