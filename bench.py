@@ -615,7 +615,11 @@ def main():
             if world == 1 and not args.no_traffic and not args.no_cpu_baseline:
                 # (after the timed region and the timing legs, with this process's GPU work finished: the child has the GPU to itself)
                 torch.cuda.synchronize()
-                step_traffic = measured_step_traffic(args.config)
+                try:
+                    step_traffic = measured_step_traffic(args.config)
+                except Exception as e:                          # profiling must never cost the line
+                    sys.stderr.write("in-run PMC traffic pass failed (%s: %s); using the committed passes\n" % (type(e).__name__, e))
+                    step_traffic = None
             if step_traffic is None:
                 step_traffic = pmc_step_traffic()
             if step_traffic is not None:
