@@ -155,7 +155,7 @@ def pmc_step_traffic():
             "note": "FETCH_SIZE (x2: the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE per kernel family, separate --pmc passes"}
 
 
-def measured_step_traffic(config, timeout_s=150):
+def measured_step_traffic(config, timeout_s=150, extra_args=()):
     """Fabric-side bytes per optimizer step, MEASURED in this run: two `rocprofv3 --pmc` passes (FETCH_SIZE, then WRITE_SIZE — never
     in one pass, never with another trace domain; MI355X_MICROARCH.md "HBM" / "rocprofv3 PMC slots") over a short child run of
     this very script (same workload, same kernels: 1 warm-up + 2 steps, no timing legs), summed per kernel and divided by the
@@ -171,7 +171,7 @@ def measured_step_traffic(config, timeout_s=150):
     if exe is None:
         return None
     child = [sys.executable, os.path.abspath(__file__), "--config", config, "--steps", "2", "--warmup", "1", "--windows", "1",
-             "--no-cpu-baseline", "--no-kernel-timing", "--no-traffic"]
+             "--no-cpu-baseline", "--no-kernel-timing", "--no-traffic"] + list(extra_args)
     per = {}
     steps = None
     tmp = tempfile.mkdtemp(prefix="uniter_pmc_")
@@ -209,7 +209,7 @@ def measured_step_traffic(config, timeout_s=150):
     return {"fwd_bwd_bytes_per_step": int(rd.get("fwd_bwd", 0.0) + wr.get("fwd_bwd", 0.0)),
             "fwd_bwd_read_bytes_per_step": int(rd.get("fwd_bwd", 0.0)), "fwd_bwd_write_bytes_per_step": int(wr.get("fwd_bwd", 0.0)),
             "optimizer_bytes_per_step": int(rd.get("optimizer", 0.0) + wr.get("optimizer", 0.0)),
-            "steps_in_pass": steps, "source": "measured in this run",
+            "steps_in_pass": steps, "source": "measured in this run", "child_argv": child[1:],
             "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over a 3-step child run of "
                     "this command; FETCH_SIZE x 2 (gfx950), KiB -> bytes; the counters sit on the L2's fabric side, so "
                     "Infinity-Cache hits are included"}
@@ -438,6 +438,137 @@ def gpu_parity_probe(runner, path):
     set_dropout(model, runner.w['dropout'])
     torch.cuda.synchronize()
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# N > 1: launching, rendezvous, start-up self-check of the data-parallel mode
+# ------------------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(gpus):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: replace this process by
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same args>`
+    (one rank per GPU, the reference's `horovodrun -np N` of pretrain.py:169-173 / utils/distributed.py).  Does not return."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL's peer mappings need it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    argv = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execve(sys.executable, argv, env)
+
+
+def init_group(backend):
+    """Join the process group.  First incarnation: the env:// rendezvous of torch.distributed.run.  After a watchdog re-exec
+    (UNITER_BENCH_INCARNATION > 0) the ranks meet again on the same TCP store under a fresh key prefix, so that nothing the first
+    incarnation left in the store (its ncclUniqueId, its barrier counters) is read by the second."""
+    import torch.distributed as dist
+    inc = int(os.environ.get("UNITER_BENCH_INCARNATION", "0"))
+    if inc == 0 or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        from uniter_amd.utils import distributed as D
+        D.init(backend)
+        return
+    import datetime
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "False") == "True"
+    store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"]), world,
+                          is_master=(rank == 0 and not agent_store), timeout=datetime.timedelta(seconds=120))
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend=backend, store=dist.PrefixStore("uniter_bench_inc%d" % inc, store), rank=rank, world_size=world)
+
+
+def reexec_with_fallback(reason):
+    """Watchdog action: the self-check of the single-launch data-parallel mode did not come back.  A stream that waits for a flag
+    nobody raises cannot be recovered inside the process, so every rank (all of them sit behind the same stuck collective and time
+    out together) replaces itself by a fresh bench.py with the per-bucket mode forced; torch.distributed.run keeps seeing the same
+    PIDs.  Never returns."""
+    env = dict(os.environ)
+    env["UNITER_AMD_DP_SINGLE_LAUNCH"] = "0"
+    env["UNITER_BENCH_DP_FALLBACK"] = reason
+    env["UNITER_BENCH_INCARNATION"] = str(int(os.environ.get("UNITER_BENCH_INCARNATION", "0")) + 1)
+    sys.stderr.write("bench.py rank %s: %s -> re-exec with UNITER_AMD_DP_SINGLE_LAUNCH=0\n" % (os.environ.get("RANK", "0"), reason))
+    sys.stderr.flush()
+    os.execve(sys.executable, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env)
+
+
+def dp_self_check(run_mode, watchdog_s=30.0, steps=2):
+    """Start-up self-check of the data-parallel gradient exchange (N > 1), before anything is timed.
+
+    run_mode(single_launch: bool) -> int digest of the reduced gradient arena after one forward + backward + exchange of the same
+    batch on the same (untouched) parameters, dropout off.  The default mode (ONE deferred weight-gradient launch whose buckets go out
+    behind flags, `hipStreamWaitValue32` on the communication stream: uniter_amd/utils/distributed.py) must give, `steps` times, the
+    digest of the conservative mode (one backward call and one event-ordered collective per bucket), and all ranks must agree.  A
+    mismatch selects the conservative mode for the run; a check that does not return within `watchdog_s` seconds re-execs every
+    rank with that mode forced.  Returns (mode, note): mode in {"single_launch_flags", "per_bucket"}."""
+    import threading
+    import torch.distributed as dist
+    forced = os.environ.get("UNITER_BENCH_DP_FALLBACK")
+    if os.environ.get("UNITER_AMD_DP_SINGLE_LAUNCH", "1") == "0":
+        return "per_bucket", (forced or "UNITER_AMD_DP_SINGLE_LAUNCH=0 in the environment")
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(watchdog_s):
+            reexec_with_fallback("self-check of the single-launch data-parallel mode did not return within %.0f s" % watchdog_s)
+    t = threading.Thread(target=watchdog, daemon=True)
+    t.start()
+    try:
+        ref = [run_mode(False) for _ in range(steps)]
+        got = [run_mode(True) for _ in range(steps)]
+        ok = int(got == ref)
+        # every rank must have seen the same digests (the exchange leaves identical gradients everywhere) and the same verdict
+        box = [None] * dist.get_world_size()
+        dist.all_gather_object(box, (ok, ref, got))
+    finally:
+        done.set()
+    agree = all(b[1] == box[0][1] for b in box)
+    if all(b[0] for b in box) and agree:
+        return "single_launch_flags", "digests of %d step(s) equal to the per-bucket mode on all %d ranks" % (steps, len(box))
+    why = "single-launch digests differ from the per-bucket mode on rank(s) %s" % [i for i, b in enumerate(box) if not b[0]]
+    if not agree:
+        why += "; per-bucket digests differ between ranks"
+    return "per_bucket", why
+
+
+def dry_launch(args, world):
+    """--dry-launch: everything of the N > 1 start-up that needs no GPU — rendezvous (gloo), the self-check protocol with its
+    watchdog and re-exec, the barrier / MAX-over-ranks timing bracket — with a stand-in for the model.  Rank 0 prints one JSON line."""
+    import torch.distributed as dist
+    init_group("gloo")
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    hang = os.environ.get("UNITER_BENCH_SELFTEST_HANG") == "1" and int(os.environ.get("UNITER_BENCH_INCARNATION", "0")) == 0
+    diverge = os.environ.get("UNITER_BENCH_SELFTEST_DIVERGE") == "1"
+
+    def run_mode(single):
+        if single and hang and rank == world - 1:
+            time.sleep(3600)                      # a rank whose flag never comes: the others block in the collective below
+        g = torch.Generator().manual_seed(1234 + rank)
+        x = torch.randint(-1000, 1000, (4096,), generator=g, dtype=torch.int64)
+        if single and diverge and rank == 0:
+            x[7] += 1
+        if world > 1:
+            dist.all_reduce(x)
+        return int((x * torch.arange(1, 4097)).sum().item())
+    mode, note = ("single_process", "world 1")
+    if world > 1:
+        mode, note = dp_self_check(run_mode, watchdog_s=float(os.environ.get("UNITER_BENCH_WATCHDOG_S", "30")))
+        dist.barrier()
+    t0 = time.perf_counter()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "backend": "gloo", "dp_mode": mode, "dp_mode_note": note,
+                          "incarnation": int(os.environ.get("UNITER_BENCH_INCARNATION", "0"))}), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -465,6 +596,8 @@ def main():
     ap.add_argument("--merge-accum", action="store_true",
                     help="c3 / c4 / c5: run the micro-batches of an optimizer step as ONE batch (uniter_amd/data/merge.py: same "
                          "examples, loss and gradients as the accumulation loop); the line says so in config.micro_batches_merged")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="N > 1 start-up only, on the CPU with gloo: self-launch, rendezvous, data-parallel self-check, no model (tests)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--parity-file", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -474,18 +607,20 @@ def main():
 
     from uniter_amd.utils import distributed as D
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)                    # python bench.py --gpus N: becomes torch.distributed.run with N ranks
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                             "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ..." % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.dry_launch:
+        dry_launch(args, world)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the encoder path has no CPU fallback")
     local = D.local_rank()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    D.init("nccl")
+    init_group("nccl")
     rank = D.rank()
 
     cfg_path = os.path.join("/tmp", "uniter_bench_%d.json" % os.getpid())
@@ -493,6 +628,12 @@ def main():
     overlap = bool(args.overlap and not args.graph)
     runner = StepRunner(args.config, device, rank=rank, world=world, seed=77, ragged=args.ragged, pack=args.pack,
                         overlap=overlap, cfg_path=cfg_path, reducer_layers_per_bucket=lpb, merge_accum=args.merge_accum)
+    dp_mode, dp_note = ("single_process", None)
+    if runner.reducer is not None:
+        dp_mode, dp_note = dp_self_check(runner.dp_check_step, watchdog_s=float(os.environ.get("UNITER_BENCH_WATCHDOG_S", "30")))
+        runner.set_dp_mode(dp_mode == "single_launch_flags")
+        if rank == 0:
+            sys.stderr.write("data-parallel mode: %s (%s)\n" % (dp_mode, dp_note))
     first_batch = next(iter(runner.batches.values()))
     real_tokens = int(first_batch['attn_masks'].sum().item())
 
@@ -612,11 +753,12 @@ def main():
                                            "traffic": None if traffic is None else traffic["hbm_bytes"], "traffic_detail": traffic,
                                            "measured": "HIP events around every launch on its own stream during %d extra optimizer steps; %s" % (tsteps, note)}
             step_traffic = None
-            if world == 1 and not args.no_traffic and not args.no_cpu_baseline:
+            if world == 1 and not args.no_traffic:
                 # (after the timed region and the timing legs, with this process's GPU work finished: the child has the GPU to itself)
                 torch.cuda.synchronize()
                 try:
-                    step_traffic = measured_step_traffic(args.config)
+                    step_traffic = measured_step_traffic(args.config, extra_args=[f for f, on in (
+                        ("--merge-accum", args.merge_accum), ("--overlap", args.overlap), ("--ragged", args.ragged), ("--pack", args.pack)) if on])
                 except Exception as e:                          # profiling must never cost the line
                     sys.stderr.write("in-run PMC traffic pass failed (%s: %s); using the committed passes\n" % (type(e).__name__, e))
                     step_traffic = None
@@ -637,7 +779,7 @@ def main():
             "config": {"workload": "%s: %s" % (args.config, w['desc']),
                        "global_batch": B * world, "micro_batch": w['batch'], "grad_accumulation": w['accum'], "seq_len": L,
                        "micro_batches_merged": bool(runner.merge_accum),
-                       "parallelism": "dp%d" % world, "launch": mode, "optimizer_overlap": overlap,
+                       "parallelism": "dp%d" % world, "dp_mode": dp_mode, "dp_mode_note": dp_note, "launch": mode, "optimizer_overlap": overlap,
                        "ragged": bool(args.ragged), "pack_padding": bool(args.pack),
                        "real_token_fraction": round(real_tokens / float(first_batch['attn_masks'].numel()), 3),
                        "examples": "encoder sequences per optimizer step" + (" (32/GPU = 16 NLVR2 pairs)" if args.config == 'c2' else ""),

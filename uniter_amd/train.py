@@ -121,9 +121,10 @@ class StepRunner(object):
             # 4-layer buckets: a backward range's deferred weight-gradient launch is 432 tiles (1.7 rounds of 256 CUs); with 3
             # layers it is 324 (1.3 rounds) and the one-rank RCCL step measures 5.49 ms against 5.26 (EXPERIMENTS.md section 5)
             reducer_layers_per_bucket = int(os.environ.get("UNITER_AMD_LAYERS_PER_BUCKET", "4"))
-        self.reducer = (D.GradientReducer(self.arena, self.model.uniter.encoder, layers_per_bucket=reducer_layers_per_bucket,
-                                          word_embeddings=self.model.uniter.embeddings.word_embeddings.weight,
-                                          word_ids_cap=int(w['batch']) * int(w['max_txt_len']) * (int(w['accum']) if self.merge_accum else 1))     # (every rank's text is padded to at most this)
+        self._reducer_args = dict(layers_per_bucket=reducer_layers_per_bucket,
+                                  word_embeddings=self.model.uniter.embeddings.word_embeddings.weight,
+                                  word_ids_cap=int(w['batch']) * int(w['max_txt_len']) * (int(w['accum']) if self.merge_accum else 1))     # (every rank's text is padded to at most this)
+        self.reducer = (D.GradientReducer(self.arena, self.model.uniter.encoder, **self._reducer_args)
                         if (world > 1 or D._on()) else None)
         self.model.uniter.pack_padding = bool(pack)
         # each rank trains on its own shard (data/data.py:222): different synthetic batches per rank, resident in HBM
@@ -203,6 +204,37 @@ class StepRunner(object):
                 return itm_loss + self.w['itm_ot_lambda'] * ot
             return itm_loss
         return loss.mean() if micro is None else accumulated_loss(loss, micro)
+
+    def set_dp_mode(self, single_launch):
+        """Data-parallel exchange mode of the following steps: True = ONE deferred weight-gradient launch whose gradient buckets go
+        out behind flags (default), False = one backward call and one event-ordered collective per bucket (utils/distributed.py)."""
+        from .utils import distributed as D
+        if self.reducer is None or bool(self.reducer.single_launch) == bool(single_launch):
+            return
+        self.reducer = D.GradientReducer(self.arena, self.model.uniter.encoder, single_launch=bool(single_launch), **self._reducer_args)
+
+    def dp_check_step(self, single_launch):
+        """bench.py's start-up self-check (N > 1): forward + backward + gradient exchange of the first resident batch with dropout
+        off in the given exchange mode; returns an order-sensitive 64-bit digest of the reduced bf16 gradient arena.  Parameters and
+        optimizer state are not touched; the gradients are zero again on return and the runner keeps the mode."""
+        from . import _lib
+        from .utils.misc import set_dropout
+        self.set_dp_mode(single_launch)
+        task, batch = next(iter(self.batches.items()))
+        set_dropout(self.model, 0.0)
+        try:
+            self.reducer.begin()
+            loss = self._loss(task, batch)
+            loss.backward()
+            self.reducer.finish(word_ids=None)
+            _lib.join_wgrads()
+            g = self.arena.grad.view(torch.int16).to(torch.int64)
+            w = torch.arange(g.numel(), device=g.device, dtype=torch.int64).remainder_(8191).add_(1)
+            digest = int((g * w).sum().item())
+        finally:
+            set_dropout(self.model, self.w['dropout'])
+            self.arena.grad.zero_()
+        return digest
 
     def warm_up_tasks(self):
         """One untimed optimizer step per task of the mix, so that one-off work (tile selection for a task's head shapes,

@@ -250,7 +250,7 @@ class GradientReducer(object):
     the tokens in its batch (all-gather of ids and rows, <= B*Lt x H per rank instead of a vocab x H allreduce).
     """
 
-    def __init__(self, arena, encoder=None, layers_per_bucket=3, word_embeddings=None, word_ids_cap=None):
+    def __init__(self, arena, encoder=None, layers_per_bucket=3, word_embeddings=None, word_ids_cap=None, single_launch=None):
         self.arena = arena
         self.word_compact = False             # tests: segment sums on the gathered rows even for a small vocabulary
         self.word_ids_cap = word_ids_cap      # most word ids (batch x padded text length) any rank hands to finish(); None: agreed per step
@@ -262,8 +262,9 @@ class GradientReducer(object):
         self._stream = None
         self._pending = []
         self.layers_per_bucket = int(layers_per_bucket)
-        self.single_launch = (encoder is not None and bool(arena.grad.is_cuda)
-                              and os.environ.get("UNITER_AMD_DP_SINGLE_LAUNCH", "1") != "0"
+        if single_launch is None:              # default: on, unless the environment (or bench.py's start-up self-check) says otherwise
+            single_launch = os.environ.get("UNITER_AMD_DP_SINGLE_LAUNCH", "1") != "0"
+        self.single_launch = (encoder is not None and bool(arena.grad.is_cuda) and bool(single_launch)
                               and (len(list(encoder.layer)) + self.layers_per_bucket - 1) // self.layers_per_bucket <= 24)
         covered = []
         if encoder is not None:
