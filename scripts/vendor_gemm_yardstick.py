@@ -28,7 +28,7 @@ SHAPES = [  # name, flavour, Linear out features N, Linear in features K  (M = t
     ("qkv_dgrad", "dgrad", 2304, 768)]
 
 
-def fold(trace_dir, out):
+def fold(trace_dir, out, skip=0, iters=20):
     files = glob.glob(os.path.join(trace_dir, "**", "*kernel_trace.csv"), recursive=True)
     if not files:
         raise SystemExit("no *kernel_trace.csv under " + trace_dir)
@@ -44,14 +44,21 @@ def fold(trace_dir, out):
         if cur is not None:
             cur.append((name, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3))
     lines = []
+    phases = phases[skip:]
     labels = [s[0] + " hot" for s in SHAPES] + ["chain forward", "chain data-gradient"]
+    flop = {s[0] + " hot": 2.0 * 3072 * s[2] * s[3] for s in SHAPES}
     for label, ph in zip(labels, phases):
         by = {}
         for name, us in ph:
-            by.setdefault(name, []).append(us)
+            if name.startswith("Cijk_"):               # Tensile GEMM kernels only (the phase also holds the next shape's set-up)
+                by.setdefault(name, []).append(us)
         for name, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+            if len(v) < iters and "hot" in label:      # (< iters launches: the NEXT shape's three warm-up launches)
+                continue
             v2 = sorted(v)
-            lines.append("%-22s x%-4d avg %7.2f us  med %7.2f  min %7.2f  %s" % (label, len(v), sum(v) / len(v), v2[len(v2) // 2], v2[0], name[:200]))
+            avg = sum(v) / len(v)
+            tf = ("%7.1f TF" % (flop[label] / avg * 1e-6)) if label in flop else "          "
+            lines.append("%-22s x%-4d avg %7.2f us  med %7.2f  min %7.2f  %s  %s" % (label, len(v), avg, v2[len(v2) // 2], v2[0], tf, name))
     txt = "\n".join(lines)
     print(txt)
     if out:
@@ -65,10 +72,11 @@ def main():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--tokens", type=int, default=3072)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--skip", type=int, default=0, help="--fold: marker phases to drop at the front")
     ap.add_argument("--fold", default=None, help="fold the kernel trace under this rocprofv3 output directory")
     a = ap.parse_args()
     if a.fold:
-        fold(a.fold, a.out)
+        fold(a.fold, a.out, a.skip, a.iters)
         return
     import torch
     import torch.nn.functional as F
@@ -80,7 +88,7 @@ def main():
     def rnd(*shape, scale=1.0):
         return (torch.rand(*shape, device=dev, generator=g, dtype=torch.float32) * 2 - 1).mul_(scale).to(torch.bfloat16)
 
-    marker = torch.zeros(64, dtype=torch.int32, device=dev)
+    marker = torch.empty(64, dtype=torch.int32, device=dev)      # (empty, not zeros: its fill kernel is the phase fence)
 
     def timed(fn, n):
         torch.cuda.synchronize()

@@ -1502,7 +1502,7 @@ static int run_g8(int argc, char** argv, int at) {
 
 // --roofs [iters] [M] : the eight GEMMs of a UNITER-base layer's forward / data-gradient chain, each alone on hot operands with the
 // tile the shipped table picks (or UNITER_ROOFS_CFG=<tile> for all of them), `iters` launches each.  Prints one TIME line per
-// shape; meant to run under `rocprofv3 --pmc ... --kernel-trace` (scripts/gpu_r5_roofs.sh), where the dispatches of the CSV
+// shape; meant to run under `rocprofv3 --pmc ... --kernel-trace` (scripts/gpu_r5_record.sh), where the dispatches of the CSV
 // appear in this order, 3 warm-up + iters per shape.
 static int run_roofs(int argc, char** argv, int at) {
     const int iters = at < argc ? atoi(argv[at]) : 10;
@@ -1517,7 +1517,8 @@ static int run_roofs(int argc, char** argv, int at) {
     uint16_t *dO = dalloc<uint16_t>((size_t)M * I), *dO2 = dalloc<uint16_t>((size_t)M * I);
     struct Shape { const char* name; int kind; int64_t N, K; } shapes[] = {
         {"qkv_fwd", 0, 3 * H, H}, {"out_fwd", 1, H, H}, {"ffn1_fwd_gelu", 2, I, H}, {"ffn2_fwd", 1, H, I},
-        {"ffn2_dgrad_gelu", 3, H, I}, {"ffn1_dgrad", 4, I, H}, {"out_dgrad", 5, H, H}, {"qkv_dgrad", 4, 3 * H, H}};
+        {"ffn2_dgrad_gelu", 3, H, I}, {"ffn1_dgrad", 4, I, H}, {"out_dgrad", 5, H, H}, {"qkv_dgrad", 4, 3 * H, H},
+        {"ffn2_dgrad_plain", 5, H, I}};        // (not a launch of the model: the x gelu' shape without its epilogue, beside the vendor yardstick)
     Timer tm;
     for (const Shape& s : shapes) {
         const int64_t N = s.N, K = s.K;
