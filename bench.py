@@ -586,9 +586,6 @@ def main():
                     help="skip the in-run PMC passes (rocprofv3 child runs, ~1.5 min) behind roofline.traffic; the committed passes are used")
     ap.add_argument("--overlap", action="store_true",
                     help="run the optimizer update asynchronously under the next forward pass (AdamW.enable_overlap)")
-    ap.add_argument("--graph", action="store_true",
-                    help="capture the whole optimizer step into a hipGraph and replay it (N=1, c2 only); measured slower than "
-                         "eager issue on ROCm 7.2, so it is opt-in")
     ap.add_argument("--ragged", action="store_true",
                     help="NOT the headline config: ragged synthetic batch (10-60 text tokens, 10-36 regions per sequence) "
                          "to measure padding-free execution (SURVEY.md section 8 f-3)")
@@ -625,7 +622,7 @@ def main():
 
     cfg_path = os.path.join("/tmp", "uniter_bench_%d.json" % os.getpid())
     lpb = int(os.environ["UNITER_BENCH_LAYERS_PER_BUCKET"]) if "UNITER_BENCH_LAYERS_PER_BUCKET" in os.environ else None
-    overlap = bool(args.overlap and not args.graph)
+    overlap = bool(args.overlap)
     runner = StepRunner(args.config, device, rank=rank, world=world, seed=77, ragged=args.ragged, pack=args.pack,
                         overlap=overlap, cfg_path=cfg_path, reducer_layers_per_bucket=lpb, merge_accum=args.merge_accum)
     dp_mode, dp_note = ("single_process", None)
@@ -644,31 +641,8 @@ def main():
         parity_file = os.path.join("/tmp", "uniter_bench_parity_%d.pt" % os.getpid())
         gpu_parity_probe(runner, parity_file)
 
-    # --graph (N == 1): the whole step is captured once into a hipGraph and replayed.  Default is eager issue.
-    mode = "eager"
+    mode = "eager"              # (whole-step hipGraph replay was measured and removed in round 6: profiles/r06_hipgraph_vs_eager.txt)
     train_step = runner.train_step
-    if world == 1 and args.graph and args.config == 'c2':
-        from uniter_amd.optim import clip_grad_norm_
-        from uniter_amd.utils.graph import GraphedStep
-        runner.optimizer.fuse_zero_grad = False
-
-        def device_step():
-            loss = runner.model(first_batch, compute_loss=True).mean()
-            loss.backward()
-            clip_grad_norm_(runner.optimizer, runner.opts.grad_norm)
-            runner.optimizer.step()
-            runner.optimizer.zero_grad()
-            return loss
-        try:
-            train_step = GraphedStep(device_step, runner.optimizer, device, warmup=3, pre_step=runner._schedule_lr).capture()
-            mode = "hipgraph"
-        except Exception as e:                                  # pragma: no cover - depends on the runtime
-            sys.stderr.write("hipGraph capture failed (%s: %s); falling back to eager steps\n" % (type(e).__name__, e))
-            from uniter_amd import ops as _ops
-            _ops.disable_graph_rng()
-            runner.optimizer._graph = None
-            train_step = runner.train_step
-
     if len(runner.batches) > 1:
         runner.warm_up_tasks()                # every task of the mix once, untimed (on top of the W warm-up steps)
     for _ in range(args.warmup):
@@ -702,7 +676,7 @@ def main():
     # ranks these steps contain the gradient collectives, so EVERY rank runs them (only rank 0 reports).
     kernels = None
     segments = None
-    if not args.no_kernel_timing and mode == "eager":
+    if not args.no_kernel_timing:
         tsteps = max(1, min(args.steps, 5))
         segments = segment_pass(runner, train_step, max(tsteps, min(args.steps, 10)))
         kernels = timed_pass(train_step, tsteps)

@@ -674,101 +674,6 @@ def test_adamw_state_dict_roundtrip_keeps_fp32_state(golden):
         assert torch.equal(a, b), n
 
 
-# --------------------------------------------------------------------------------------------------------------
-# whole-step hipGraph capture
-# --------------------------------------------------------------------------------------------------------------
-def test_graphed_step_matches_eager(golden):
-    """3 optimizer steps replayed from a captured hipGraph == 3 eager steps (dropout 0, LR schedule active), and with
-    dropout on, consecutive replays draw different masks (device-side Philox counter)."""
-    from uniter_amd import ops
-    from uniter_amd.model.pretrain import UniterForPretraining
-    from uniter_amd.optim import build_optimizer, clip_grad_norm_
-    from uniter_amd.utils.arena import flatten_model
-    from uniter_amd.utils.graph import GraphedStep
-    from uniter_amd.utils.misc import Struct, set_dropout
-    # ITM: no boolean-mask row selection (a device->host sync, not capturable) in the head
-    batch = _to_dev(golden.batch('itm'))
-    opts = Struct(dict(optim='adamw', learning_rate=1e-3, betas=(0.9, 0.98), weight_decay=0.01))
-    results = []
-    try:
-        for graphed in (False, True):
-            model = _prep(UniterForPretraining.from_pretrained(TINY_CONFIG, golden.pretrain_sd(), img_dim=IMG_DIM,
-                                                               img_label_dim=LABEL_DIM))
-            flatten_model(model)
-            opt = build_optimizer(model, opts)
-            n = [0]
-
-            def sched():
-                n[0] += 1
-                for grp in opt.param_groups:
-                    grp['lr'] = 1e-3 * n[0] / 4.0
-
-            def dev_step():
-                loss = model(batch, task='itm', compute_loss=True)[0].mean()
-                loss.backward()
-                clip_grad_norm_(opt, 1.0)
-                opt.step()
-                opt.zero_grad()
-                return loss
-
-            if graphed:
-                # GraphedStep's warm-up steps would already train the model: snapshot / restore around it
-                snap = {k: v.detach().clone() for k, v in model.state_dict().items()}
-                step = GraphedStep(dev_step, opt, _dev(), warmup=2, pre_step=sched).capture()
-                model.load_state_dict(snap)
-                for p in model.parameters():
-                    st = opt.state[p]
-                    if st:
-                        st['step'] = 0
-                        st['exp_avg'].zero_(); st['exp_avg_sq'].zero_()
-                        if 'master' in st:
-                            st['master'].copy_(p.data)
-                n[0] = 0
-                losses = [float(step()) for _ in range(3)]
-            else:
-                losses = []
-                for _ in range(3):
-                    sched()
-                    losses.append(float(dev_step()))
-            results.append((losses, {k: v.detach().float().cpu().clone() for k, v in model.named_parameters()}))
-        for a, b in zip(results[0][0], results[1][0]):
-            assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (results[0][0], results[1][0])
-        for k in results[0][1]:
-            if k.endswith('attention.self.key.bias'):
-                # softmax is invariant to a key bias: its true gradient is identically zero, what the kernels produce is the
-                # rounding noise of dK's column sums, and Adam turns noise into full-size steps of arbitrary sign.  Replay
-                # computes the weight / bias gradients layer by layer, eager in the deferred launch (another summation
-                # order), so the two may walk apart by at most the sum of the learning rates of the three steps, each way.
-                assert (results[1][1][k] - results[0][1][k]).abs().max().item() <= 2 * 1e-3 * (0.25 + 0.5 + 0.75) + 1e-6, k
-                continue
-            assert rel_l2(results[1][1][k], results[0][1][k]) < 2e-3, k
-        # dropout under replay: fresh masks every replay
-        model = _prep(UniterForPretraining.from_pretrained(TINY_CONFIG, golden.pretrain_sd(), img_dim=IMG_DIM, img_label_dim=LABEL_DIM))
-        set_dropout(model, 0.3)
-        opt = build_optimizer(model, Struct(dict(optim='adamw', learning_rate=0.0, betas=(0.9, 0.98), weight_decay=0.0)))
-
-        def dev_step2():
-            loss = model(batch, task='itm', compute_loss=True)[0].mean()
-            loss.backward()
-            opt.step()
-            opt.zero_grad()
-            return loss
-
-        step = GraphedStep(dev_step2, opt, _dev(), warmup=2).capture()
-        vals = [float(step()) for _ in range(4)]                   # lr = 0: weights frozen, only the masks change
-        assert len(set(round(v, 4) for v in vals)) >= 3, vals
-    finally:
-        ops.disable_graph_rng()
-
-
-# --------------------------------------------------------------------------------------------------------------
-# (5) the other configs of SURVEY.md §8d as parity cases: uniter-large shapes, L = 128 + 50, VQA with 4 parameter groups
-# --------------------------------------------------------------------------------------------------------------
-LARGE_CFG = dict(vocab_size=28996, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
-                 hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
-                 max_position_embeddings=512, type_vocab_size=2, initializer_range=0.02)
-
-
 def test_large_config_vqa_l178_vs_oracle(tmp_path):
     """config/uniter-large.json widths (H=1024, 16 heads, I=4096) with 2 layers, ragged text up to 128 tokens + up to 50
     regions (the large-178 shape, config/pretrain-alldata-large-16gpu.json), VQA head; then one clipped AdamW step with
@@ -1651,10 +1556,12 @@ def test_long_sequences_up_to_512_dense_and_packed_vs_oracle(tmp_path):
 
 
 @pytest.mark.parametrize("act", ["relu", "swish"])
-def test_hidden_act_relu_and_swish_vs_oracle(tmp_path, act):
-    """config.hidden_act other than gelu (model/layer.py:44 ACT2FN): the FFN epilogues switch activation, the MLM head's
-    transform falls back to the module path."""
+def test_hidden_act_relu_and_swish_vs_oracle(tmp_path, act, monkeypatch):
+    """config.hidden_act other than gelu (model/layer.py:44 ACT2FN): the FFN epilogues switch activation; the MLM head's HIP path
+    covers the erf-GELU transform only, so its PyTorch module path has to be asked for (UNITER_AMD_HEAD_TORCH=1) — without the
+    switch the head raises instead of degrading silently."""
     import json
+    monkeypatch.setenv("UNITER_AMD_HEAD_TORCH", "1")
     from uniter_amd.model.pretrain import UniterForPretraining
     from uniter_amd.utils.synthetic import make_batch
     cfg = dict(BASE_CFG, num_hidden_layers=2, hidden_size=256, num_attention_heads=4, intermediate_size=512, hidden_act=act)

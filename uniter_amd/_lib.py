@@ -18,6 +18,17 @@ class UniterHipError(RuntimeError):
     pass
 
 
+def head_torch_path(what, why):
+    """The task heads run on HIP kernels (include/uniter_hip.h head / pool / OT entry points).  Their plain PyTorch module path
+    (the reference's op sequence) is a comparison path for tests and scripts: it is taken only when UNITER_AMD_HEAD_TORCH=1 is set.
+    Otherwise an input the kernels do not cover RAISES, like the encoder does — a mis-typed run (fp32 weights, CPU tensors, an
+    unsupported width) must not degrade silently to eager PyTorch."""
+    if os.environ.get("UNITER_AMD_HEAD_TORCH") == "1":
+        return True
+    raise UniterHipError("%s: %s — the HIP head path does not cover this input and UNITER_AMD_HEAD_TORCH=1 (PyTorch module path, "
+                         "tests / comparisons only) is not set" % (what, why))
+
+
 class UniterLayerParams(Structure):
     _fields_ = [(n, c_void_p) for n in (
         "wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2", "ln2_g", "ln2_b",

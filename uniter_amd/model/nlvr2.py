@@ -12,6 +12,7 @@ from torch.nn import functional as F
 
 from .attention import MultiheadAttention
 from .model import UniterModel, UniterPreTrainedModel
+from .. import _lib
 
 
 class _Nlvr2Base(UniterPreTrainedModel):
@@ -91,6 +92,8 @@ class AttentionPool(nn.Module):
                 and input_.size(2) % 8 == 0 and self.fc[0].weight.dtype == torch.bfloat16):
             from .. import ops
             return ops.attention_pool(input_, mask, self.fc[0], self.dropout.p, self.training)   # one fused kernel
+        if not self.force_module_path:              # (force_module_path is the explicit per-module form of the switch)
+            _lib.head_torch_path("AttentionPool", "needs a bf16 CUDA input with T <= 512, D <= 1024, D % 8 == 0")
         score = self.fc(input_).squeeze(-1)
         if mask is not None:
             score = score + mask.to(dtype=input_.dtype) * -1e4
@@ -134,6 +137,7 @@ class UniterForNlvr2PairedAttn(_Nlvr2Base):
             att = ops.paired_cross_attention(xs, valid.flip(0).reshape(bs, tl), self.attn1, self.attn2,
                                              self.attn1.dropout, self.training)
         else:
+            _lib.head_torch_path("NLVR2 paired cross attention", "needs a bf16 CUDA sequence, 64-wide heads, L <= 512")
             valid = batch['attn_masks'].contiguous().view(n, 2, tl).transpose(0, 1)     # [2, n, L]
             pad = (valid == 0).reshape(bs, tl)
             left, right = xs[0].transpose(0, 1), xs[1].transpose(0, 1)                  # (L, N, E) module layout
@@ -148,6 +152,7 @@ class UniterForNlvr2PairedAttn(_Nlvr2Base):
             # Linear(2H, H) + ReLU + Dropout as one GEMM with a fused epilogue
             hidden = ops.linear_relu_dropout(cat.view(bs * tl, 2 * d), self.fc[0], self.fc[2].p, self.training).view(bs, tl, d)
         else:
+            _lib.head_torch_path("NLVR2 fc (Linear + ReLU + Dropout)", "needs the fused pair attention path, hidden size % 64 == 0, bf16 weights")
             hidden = self.fc(cat).view(bs, tl, d)
         pooled = self.attn_pool(hidden, pad)                                            # [2n, H]
         pooled = pooled.view(2, n, d).transpose(0, 1).reshape(n, 2 * d)

@@ -14,7 +14,7 @@ from torch.nn import functional as F
 
 from .layer import GELU, BertLayerNorm as LayerNorm, BertOnlyMLMHead, gelu
 from .model import UniterModel, UniterPreTrainedModel
-from .ot import optimal_transport_dist
+from .. import _lib
 
 
 class RegionFeatureRegression(nn.Module):
@@ -99,7 +99,9 @@ class UniterForPretraining(UniterPreTrainedModel):
             from .. import ops
             # transform + tied 28996-way decoder + cross entropy without an fp32 logits tensor (ops._HeadCeFn)
             return ops.mlm_head_loss(rows, txt_labels[picked], self.cls.predictions)
-        prediction_scores = self.cls(rows)
+        if compute_loss:
+            _lib.head_torch_path("MLM head loss", "needs bf16 CUDA rows, erf-GELU transform, hidden size % 64 == 0")
+        prediction_scores = self.cls(rows)           # (scores for inference: the reference's modules, as they are)
         if not compute_loss:
             return prediction_scores
         return F.cross_entropy(prediction_scores.float(), txt_labels[picked], reduction='none')
@@ -138,6 +140,8 @@ class UniterForPretraining(UniterPreTrainedModel):
                 ot_dist = ops.optimal_transport_dist(sequence_output, ot_inputs['ot_scatter'], ot_inputs['txt_pad'],
                                                      ot_inputs['img_pad'])
             else:
+                _lib.head_torch_path("optimal-transport (IPOT) loss", "needs a bf16 CUDA sequence and hidden size <= 1024")
+                from .ot import optimal_transport_dist
                 # undo the compaction: scatter the joint sequence back to [txt(max_tl) ; img] slots
                 b = sequence_output.size(0)
                 max_l = max(ot_inputs['scatter_max'] + 1, tl + il)
@@ -167,6 +171,8 @@ class UniterForPretraining(UniterPreTrainedModel):
                 return ops.head_kl_div(rows, label_targets, net[0], net[2], net[3].weight, net[3].bias)
             hard = torch.max(label_targets[:, 1:], dim=-1)[1] + 1           # never 0, so ignore_index=0 is moot
             return ops.head_cross_entropy(rows, hard, net[0], net[2], net[3].weight, net[3].bias)
+        if compute_loss:
+            _lib.head_torch_path("MRC head loss", "needs bf16 CUDA rows and bf16 classifier weights")
         prediction_soft_label = self.region_classifier(rows)
         if not compute_loss:
             return prediction_soft_label

@@ -27,35 +27,9 @@ class _Rng(threading.local):
     def __init__(self):
         self.seed = None
         self.offset = 0
-        self.counter = None        # device uint64 step counter (hipGraph mode), see enable_graph_rng
 
 
 _rng = _Rng()
-GRAPH_RNG_STRIDE = 1 << 24         # offsets reserved per training step in graph mode
-
-
-def enable_graph_rng(device):
-    """hipGraph-friendly dropout stream: host offsets restart at 0 every step (so a captured step replays with
-    identical kernel arguments) and a DEVICE counter, advanced by `graph_rng_step()` inside the captured step,
-    is added by the kernels at run time — every replay draws fresh masks without touching kernel arguments."""
-    if _rng.counter is None or _rng.counter.device != torch.device(device):
-        _rng.counter = torch.zeros(1, dtype=torch.int64, device=device)
-    C.uniter_hip_set_dropout_offset_ptr(_rng.counter.data_ptr())
-    return _rng.counter
-
-
-def disable_graph_rng():
-    C.uniter_hip_set_dropout_offset_ptr(None)
-    _rng.counter = None
-
-
-def graph_rng_step():
-    """Call once at the start of every (captured or eager) training step while graph RNG is enabled."""
-    if _rng.counter is None:
-        return
-    _rng.offset = 0
-    C.uniter_hip_counter_add(_rng.counter.data_ptr(), GRAPH_RNG_STRIDE, _lib.stream_ptr())
-
 
 def manual_seed(seed):
     """Reset the dropout stream (utils.misc.set_random_seed calls this)."""

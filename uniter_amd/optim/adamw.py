@@ -58,7 +58,6 @@ class AdamW(Optimizer):
         self._keep = None
         self._clip = None             # device tensor [norm, coef] left by clip_grad_norm_
         self._norm_buf = None
-        self._graph = None            # (ring of pinned hyper tables, device hyper table) in hipGraph mode
         self._overlap = None          # ctypes array of segment boundaries (parameter addresses) or None
         self._grads_zeroed = False    # the last step zeroed the gradients itself (fused), zero_grad() has nothing to do
         self.fuse_zero_grad = False   # True: step() zeroes every gradient once read and the next zero_grad() is a no-op —
@@ -270,48 +269,6 @@ class AdamW(Optimizer):
         self._grads_zeroed = False        # gradients have been produced since a fused zeroing: a later zero_grad() is real work
         return self._norm_buf[0]
 
-    # ---- hipGraph mode ----------------------------------------------------------------------------------
-    def enable_graph_mode(self):
-        """Make step() capturable: hyper-parameters travel through a device table instead of kernel arguments.
-        Protocol per training step: `graph_prepare()` on the host (advances state['step'], folds the current
-        param_groups' lr / betas / ... into the next slot of a ring of pinned staging tables and enqueues its upload on
-        the current stream), then step() — eagerly, under capture, or as part of a graph replay.  The upload is NOT part
-        of the captured graph and every step has its own staging slot (recycled only after the upload that read it has
-        completed), so a host that runs several replays ahead cannot overwrite hyper-parameters a queued step has yet
-        to read."""
-        if not self._ensure_plan():
-            raise _lib.UniterHipError("enable_graph_mode needs gradients to exist (run one eager backward first)")
-        dev = self._plan_groups[0][1][0].device
-        n_slots = 8
-        slots = [torch.zeros(16, 6, dtype=torch.float32).pin_memory() for _ in range(n_slots)]
-        self._graph = (slots, torch.zeros(16, 6, dtype=torch.float32, device=dev))
-        self._graph_events = [None] * n_slots
-        self._graph_slot = -1
-
-    def graph_prepare(self):
-        slots, dev = self._graph
-        self._graph_slot = (self._graph_slot + 1) % len(slots)
-        ev = self._graph_events[self._graph_slot]
-        if ev is not None:
-            ev.synchronize()                  # the upload that last read this slot (len(slots) steps ago) is done
-        host = slots[self._graph_slot]
-        for ig, (gi, plist) in enumerate(self._plan_groups):
-            group = self.param_groups[gi]
-            for p in plist:
-                self.state[p]['step'] += 1
-            t = int(self.state[plist[0]]['step'])
-            b1, b2 = float(group['betas'][0]), float(group['betas'][1])
-            lr = float(group['lr'])
-            step_size = lr
-            if group['correct_bias']:
-                step_size = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
-            host[ig, 0], host[ig, 1], host[ig, 2] = lr, b1, b2
-            host[ig, 3], host[ig, 4], host[ig, 5] = float(group['eps']), float(group['weight_decay']), step_size
-        dev.copy_(host, non_blocking=True)    # stream-ordered, ahead of the step that reads it
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev.device))
-        self._graph_events[self._graph_slot] = ev
-
     def step(self, closure=None):
         """One optimisation step over every parameter that has a gradient."""
         loss = None
@@ -321,13 +278,6 @@ class AdamW(Optimizer):
         if not self._ensure_plan(in_step=True):
             return loss           # nothing has a gradient: no-op, like the reference's dummy first step (pretrain.py:261-263)
         self._grads_zeroed = False    # whatever an earlier fused step zeroed has been written again by the backward in between
-        if self._graph is not None:
-            dev = self._graph[1]              # uploaded by graph_prepare()
-            clip = self._clip
-            self._clip = None
-            C.uniter_adamw_step_dev(self._plan, ptr(dev), len(self._plan_groups), ptr(clip[1:]) if clip is not None else None,
-                                    _lib.stream_ptr())
-            return loss
         hyper = (UniterAdamGroup * len(self._plan_groups))()
         for ig, (gi, plist) in enumerate(self._plan_groups):
             group = self.param_groups[gi]
