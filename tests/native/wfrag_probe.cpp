@@ -1,0 +1,281 @@
+// wfrag_probe.cpp — go / no-go of "weights in MFMA-fragment order"  on ONE shape:
+//   Y[3072, 3072] = X[3072, 768] . W[3072, 768]^T + bias     (FFN1 forward of UNITER-base at 32 x 96 tokens, model/layer.py:139-142)
+// The shipped tiles (uniter_amd/csrc/gemm.hip) stage BOTH operands through LDS; round 5's port model says the K loop is bound by the
+// CU's LDS port (DMA fill ~64 B/clk + fragment reads).  Here the weight operand never touches LDS: a packed copy of W in
+// v_mfma_f32_16x16x32_bf16 fragment order (block (n/16, k/32) = 1 KiB, lane (g, i) owns W[16 nb + i][32 kb + 8 g .. + 8]) is loaded
+// global -> VGPR with one coalesced 1 KiB wave instruction per fragment, two K tiles ahead of its MFMAs; only the activations go
+// through a 3-stage LDS-DMA ring.  192 x 192 tile, 4 waves (1 x 4: every wave owns all 192 rows and 48 columns, so no weight
+// fragment is loaded twice), one workgroup per CU, 256 tiles.
+// Per K tile (64 deep) and CU, on paper: MFMA 1 152 cycles; LDS port 24 KiB fill / 64 + 96 KiB reads / 256 = 768; vector memory
+// 24 KiB DMA + 24 KiB weights = 768 at 64 B/clk.  The LDS-staged 8 + 4-wave 192 x 192 tile: fill 48 KiB + reads 144 KiB = 1 344.
+// Checks the result bit for bit against uniter_gemm_bias_fwd (same MFMA order per accumulator) and times both alone on hot operands.
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip tests/native/wfrag_probe.cpp -o aux_bin/wfrag_probe -Iinclude
+//        -Luniter_amd/csrc/build -luniter_hip -Wl,-rpath,$ORIGIN/../uniter_amd/csrc/build
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include "uniter_hip.h"
+extern "C" int uniter_gemm_debug_force(int32_t cfg, int32_t splits);
+
+#define CHK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("%s -> %s\n", #e, hipGetErrorString(_e)); return 1; } } while (0)
+typedef uint16_t bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int kc_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void global_void_t;
+__device__ __forceinline__ void glds16(const bf16_t* src, bf16_t* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((global_void_t*)src, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+    ua += 0x7FFFu + ((ua >> 16) & 1u);             // round to nearest even (finite inputs)
+    ub += 0x7FFFu + ((ub >> 16) & 1u);
+    return (ua >> 16) | (ub & 0xFFFF0000u);
+}
+__host__ __device__ inline float bf2f(bf16_t v) { unsigned u = (unsigned)v << 16; float f; __builtin_memcpy(&f, &u, 4); return f; }
+
+// W [N, K] row-major -> fragment order: block (nb, kb) at ((nb * (K / 32) + kb) * 512) elements, lane l = 16 g + i at + 8 l
+__global__ void pack_w(const bf16_t* __restrict__ w, bf16_t* __restrict__ wp, int N, int K) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one 16-byte chunk
+    if (idx >= (int64_t)N * K / 8) return;
+    const int l = (int)(idx & 63);
+    const int64_t blk = idx >> 6;
+    const int kb = (int)(blk % (K / 32)), nb = (int)(blk / (K / 32));
+    const int g = l >> 4, i = l & 15;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(w + (int64_t)(nb * 16 + i) * K + kb * 32 + g * 8);
+    *reinterpret_cast<u32x4*>(wp + idx * 8) = v;
+}
+
+constexpr int BM = 192, BN = 192, NW = 4, WN = BN / NW, NI = WN / 16, MI = BM / 16;
+constexpr int TILE = BM * 64;                                   // elements per X tile
+constexpr int GD = BM / 8 / NW;                                 // DMA instructions per wave per K tile (8 rows each)
+
+struct Args { const bf16_t* x; const bf16_t* wp; const bf16_t* bias; bf16_t* y; int M, N, K; int store; };
+
+template <int DEPTH>
+__global__ __launch_bounds__(NW * 64, 1) void wfrag_gemm(const Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+    constexpr int NSTAGE = DEPTH + 1;                           // ring slots: DEPTH tiles in flight + the one being read
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int tiles_n = p.N / BN;
+    // XCD-aware map: consecutive blocks go to different XCDs; give each XCD a compact set of tile rows (they share X panels)
+    const int nb_total = gridDim.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int lin = xcd * (nb_total >> 3) + slot;
+    const int tm = lin / tiles_n, tn = lin % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk = p.K >> 6;
+
+    // X DMA plan: instruction j = it * NW + wid covers rows 8j .. 8j+7 of the tile
+    const bf16_t* xsrc[GD];
+#pragma unroll
+    for (int it = 0; it < GD; ++it) {
+        const int j = it * NW + wid;
+        const int r = 8 * j + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        xsrc[it] = p.x + (int64_t)(m0 + r) * p.K + c * 8;
+    }
+    auto dma = [&](int kt, int buf) {
+#pragma unroll
+        for (int it = 0; it < GD; ++it) glds16(xsrc[it] + kt * 64, smem + buf * TILE + (it * NW + wid) * 512);
+    };
+    // weight fragments of this wave: n blocks (n0 + wid * WN) / 16 + a, consecutive k blocks are 1 KiB apart.  The loads are inline
+    // asm (scalar base + 32-bit lane offset): the compiler must not put its own (conservative, loop-carried) s_waitcnt vmcnt(0) in
+    // front of their use — the counted waits in front of the tile barriers below cover them (VMEM returns in issue order).
+    const int wid_u = __builtin_amdgcn_readfirstlane(wid);
+    const char* wsb = reinterpret_cast<const char*>(p.wp) + ((int64_t)((n0 + wid_u * WN) >> 4) * (p.K >> 5)) * 1024;
+    const int64_t wnb = (int64_t)(p.K >> 5) * 1024;                                 // bytes between n blocks
+    const unsigned wvoff = (unsigned)lane * 16u;
+    u32x4 wf[DEPTH + 1][2][NI];
+    auto wload = [&](int kt, int s) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < NI; ++a)
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wf[s][ks][a]) : "v"(wvoff), "s"(wsb + a * wnb + (int64_t)(kt * 2 + ks) * 1024) : "memory");
+    };
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 fr[2][MI];
+    auto xread = [&](int buf, int ks, bf16x8 (&f)[MI]) {
+        const bf16_t* tr = smem + buf * TILE;
+#pragma unroll
+        for (int b = 0; b < MI; ++b) f[b] = *reinterpret_cast<const bf16x8*>(tr + kc_off(b * 16 + i, ks * 4 + g));
+    };
+    auto mma = [&](const bf16x8 (&f)[MI], int s, int ks) {
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+            for (int b = 0; b < MI; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[s][ks][a]), f[b], acc[a][b], 0, 0, 0);
+    };
+    // tile boundary in front of tile kt: this wave's share of X tile kt has landed (younger tiles stay in flight) and its W
+    // fragments are in registers (VMEM returns in issue order), then everyone's share; every wave is done reading tile kt - 1,
+    // whose ring slot the DMA of tile kt + DEPTH refills
+    // (the W fragments of tile kt + DEPTH go into the register stage tile kt - 1 used: they are issued AFTER that tile's last MFMA,
+    //  at the end of its step — the boundary sits in the middle of the step, between the MFMAs of its two K halves)
+    auto boundary = [&](int kt) {
+        if (kt + DEPTH <= nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * (GD + 2 * NI)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + DEPTH < nk) dma(kt + DEPTH, (kt + DEPTH) % NSTAGE);
+    };
+    // prologue: DEPTH tiles in flight (X by DMA, W into registers)
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < nk) { dma(d, d % NSTAGE); wload(d, d); }
+    boundary(0);
+    if (DEPTH < nk) wload(DEPTH, DEPTH);
+    xread(0, 0, fr[0]);
+    // main loop, unrolled by DEPTH + 1 so that register stage indices are static (the host checks nk % (DEPTH + 1) == 0).  The X
+    // fragments of the next K half are read under the MFMAs of the current one, through the tile boundary.
+    for (int kt0 = 0; kt0 < nk; kt0 += DEPTH + 1) {
+#pragma unroll
+        for (int u = 0; u <= DEPTH; ++u) {
+            const int kt = kt0 + u;
+            xread(kt % NSTAGE, 1, fr[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fr[0], u, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every read of tile kt is back: its slot may be refilled
+            if (kt + 1 < nk) {
+                boundary(kt + 1);
+                xread((kt + 1) % NSTAGE, 0, fr[0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fr[1], u, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 + DEPTH < nk) wload(kt + 1 + DEPTH, u);         // stage u is free: tile kt's MFMAs have all been issued
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // epilogue: bias, bf16, 8-byte stores (lane holds Y[m0 + 16 b + i][n .. n + 3], n = n0 + wid * WN + 16 a + 4 g)
+    if (p.store) {
+#pragma unroll
+        for (int a = 0; a < NI; ++a) {
+            const int n = n0 + wid * WN + a * 16 + 4 * g;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) { const u32x2 q = *reinterpret_cast<const u32x2*>(p.bias + n); bv[0] = __builtin_bit_cast(float, q[0] << 16); bv[1] = __builtin_bit_cast(float, q[0] & 0xFFFF0000u); bv[2] = __builtin_bit_cast(float, q[1] << 16); bv[3] = __builtin_bit_cast(float, q[1] & 0xFFFF0000u); }
+#pragma unroll
+            for (int b = 0; b < MI; ++b) {
+                const int m = m0 + b * 16 + i;
+                u32x2 o;
+                o[0] = pack2(acc[a][b][0] + bv[0], acc[a][b][1] + bv[1]);
+                o[1] = pack2(acc[a][b][2] + bv[2], acc[a][b][3] + bv[3]);
+                *reinterpret_cast<u32x2*>(p.y + (int64_t)m * p.N + n) = o;
+            }
+        }
+    } else if (acc[0][0][0] == 12345.678f) {
+        p.y[0] = 1;                                          // keep the accumulators alive
+    }
+}
+
+static float frand(uint32_t& s) { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xFFFF) / 32768.0f - 1.0f; }
+static bf16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return (bf16_t)(u >> 16); }
+
+template <int DEPTH>
+static int run(const Args& a, int iters, const char* label, hipEvent_t e0, hipEvent_t e1) {
+    const size_t lds = (size_t)(DEPTH + 1) * TILE * 2;
+    CHK(hipFuncSetAttribute((const void*)wfrag_gemm<DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = (a.M / BM) * (a.N / BN);
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(wfrag_gemm<DEPTH>, dim3(grid), dim3(NW * 64), lds, 0, a);
+    CHK(hipDeviceSynchronize());
+    CHK(hipEventRecord(e0, 0));
+    for (int w = 0; w < iters; ++w) hipLaunchKernelGGL(wfrag_gemm<DEPTH>, dim3(grid), dim3(NW * 64), lds, 0, a);
+    CHK(hipEventRecord(e1, 0));
+    CHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / iters;
+    printf("  %-58s %7.2f us  %7.1f TF\n", label, us, 2.0 * a.M * a.N * a.K / us * 1e-6);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 20;
+    const int M = 3072, N = 3072, K = 768;
+    std::vector<bf16_t> hx((size_t)M * K), hw((size_t)N * K), hb(N);
+    uint32_t s = 7;
+    for (auto& v : hx) v = f2bf(frand(s));
+    for (auto& v : hw) v = f2bf(frand(s) * 0.05f);
+    for (auto& v : hb) v = f2bf(frand(s) * 0.1f);
+    bf16_t *dx, *dw, *dwp, *db, *dy, *dyr, *dy2;
+    CHK(hipMalloc(&dx, hx.size() * 2)); CHK(hipMalloc(&dw, hw.size() * 2)); CHK(hipMalloc(&dwp, hw.size() * 2));
+    CHK(hipMalloc(&db, hb.size() * 2)); CHK(hipMalloc(&dy, (size_t)M * N * 2)); CHK(hipMalloc(&dyr, (size_t)M * N * 2)); CHK(hipMalloc(&dy2, (size_t)M * N * 2));
+    CHK(hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+    CHK(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    CHK(hipMemcpy(db, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(pack_w, dim3((unsigned)(((size_t)N * K / 8 + 255) / 256)), dim3(256), 0, 0, dw, dwp, N, K);
+    CHK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    printf("FFN1 forward 3072 x 3072 x 768, bias epilogue, alone on hot operands, %d launches each\n", iters);
+    // reference: the shipped LDS-staged path (tile from the tuned table / cost model)
+    for (int w = 0; w < 3; ++w) if (uniter_gemm_bias_fwd(dx, dw, db, dyr, M, N, K, nullptr)) { printf("library call failed: %s\n", uniter_hip_last_error()); return 1; }
+    CHK(hipDeviceSynchronize());
+    CHK(hipEventRecord(e0, 0));
+    for (int w = 0; w < iters; ++w) uniter_gemm_bias_fwd(dx, dw, db, dyr, M, N, K, nullptr);
+    CHK(hipEventRecord(e1, 0));
+    CHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    printf("  %-58s %7.2f us  %7.1f TF\n", "library uniter_gemm_bias_fwd (both operands through LDS)", ms * 1e3 / iters, 2.0 * M * N * K / (ms * 1e3 / iters) * 1e-6);
+    for (int cfg : {46, 21, 59, 4}) {          // 192x192 8+4 waves, 96x192 4+4, 192x192 three-phase, 96x192 plain
+        uniter_gemm_debug_force(cfg, 1);
+        if (uniter_gemm_bias_fwd(dx, dw, db, dyr, M, N, K, nullptr)) { printf("  library tile %d: %s\n", cfg, uniter_hip_last_error()); CHK(hipDeviceSynchronize()); continue; }
+        CHK(hipDeviceSynchronize());
+        CHK(hipEventRecord(e0, 0));
+        for (int w = 0; w < iters; ++w) uniter_gemm_bias_fwd(dx, dw, db, dyr, M, N, K, nullptr);
+        CHK(hipEventRecord(e1, 0));
+        CHK(hipEventSynchronize(e1));
+        CHK(hipEventElapsedTime(&ms, e0, e1));
+        char lab[96]; snprintf(lab, sizeof lab, "library, tile %d forced", cfg);
+        printf("  %-58s %7.2f us  %7.1f TF\n", lab, ms * 1e3 / iters, 2.0 * M * N * K / (ms * 1e3 / iters) * 1e-6);
+    }
+    uniter_gemm_debug_force(-1, -1);
+    uniter_gemm_bias_fwd(dx, dw, db, dyr, M, N, K, nullptr);
+    CHK(hipDeviceSynchronize());
+    Args a{dx, dwp, db, dy, M, N, K, 1};
+    if (run<2>(a, iters, "fragment-order W -> VGPR, 2 K tiles ahead", e0, e1)) return 1;
+    Args a3 = a; a3.y = dy2;
+    if (run<3>(a3, iters, "fragment-order W -> VGPR, 3 K tiles ahead", e0, e1)) return 1;
+    Args an = a; an.store = 0;
+    if (run<2>(an, iters, "  same (2 ahead), no output stores", e0, e1)) return 1;
+    Args ab = a; ab.bias = nullptr; ab.store = 0;
+    // bit-identity against the library
+    std::vector<bf16_t> y((size_t)M * N), yr((size_t)M * N), y2((size_t)M * N);
+    CHK(hipMemcpy(y.data(), dy, y.size() * 2, hipMemcpyDeviceToHost));
+    CHK(hipMemcpy(y2.data(), dy2, y2.size() * 2, hipMemcpyDeviceToHost));
+    CHK(hipMemcpy(yr.data(), dyr, yr.size() * 2, hipMemcpyDeviceToHost));
+    size_t diff = 0, diff2 = 0; double maxd = 0;
+    for (size_t k = 0; k < y.size(); ++k) {
+        if (y[k] != yr[k]) { ++diff; const double d = fabs((double)bf2f(y[k]) - (double)bf2f(yr[k])); if (d > maxd) maxd = d; }
+        if (y2[k] != yr[k]) ++diff2;
+    }
+    // and a host fp32 spot check of 64 elements
+    double worst = 0;
+    for (int q = 0; q < 64; ++q) {
+        const int m = (q * 977) % M, n = (q * 7919) % N;
+        double acc = 0;
+        for (int k = 0; k < K; ++k) acc += (double)bf2f(hx[(size_t)m * K + k]) * (double)bf2f(hw[(size_t)n * K + k]);
+        acc += bf2f(hb[n]);
+        const double d = fabs(acc - (double)bf2f(y[(size_t)m * N + n]));
+        if (d > worst) worst = d;
+    }
+    printf("  vs the library: %zu of %zu elements differ (2 ahead), %zu (3 ahead), max |d| %.3g ; vs host fp64 on 64 samples: max |d| %.3g\n", diff, y.size(), diff2, maxd, worst);
+    return (diff == 0 && diff2 == 0 && worst < 0.05) ? 0 : 2;
+}

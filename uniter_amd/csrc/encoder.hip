@@ -186,20 +186,8 @@ int side_init() {
     int dev = 0;
     UH_CHECK_HIP(hipGetDevice(&dev));
     if (g_side.stream != nullptr && g_side.device == dev) return 0;
-    {
-        // The weight-gradient stream carries ONE long launch per backward call (1 296 tiles, ~0.5 ms) beside which the caller's
-        // stream runs the embedding backward: ~20 short kernels that would otherwise wait for CUs behind the long launch's
-        // next round of workgroups.  Lowest priority for the long launch lets their workgroups in as soon as any CU frees a
-        // slot (UNITER_AMD_WGRAD_STREAM_PRIO=0 keeps the default priority; profiles/r06_wgrad_stream_priority_ab.txt).
-        int least = 0, greatest = 0;
-        const char* e = getenv("UNITER_AMD_WGRAD_STREAM_PRIO");
-        const bool low = e == nullptr || e[0] != '0';
-        if (low && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
-            UH_CHECK_HIP(hipStreamCreateWithPriority(&g_side.stream, hipStreamNonBlocking, least));
-        } else {
-            UH_CHECK_HIP(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));
-        }
-    }
+    // (lowest stream priority for the long deferred launch was measured in round 6: no difference — profiles/r06_wgrad_stream_priority_ab.txt)
+    UH_CHECK_HIP(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));
     for (int i = 0; i < 6; ++i) {
         UH_CHECK_HIP(hipEventCreateWithFlags(&g_side.main_ev[i], hipEventDisableTiming));
         UH_CHECK_HIP(hipEventCreateWithFlags(&g_side.side_ev[i], hipEventDisableTiming));
