@@ -54,40 +54,46 @@ __global__ void pack_w(const bf16_t* __restrict__ w, bf16_t* __restrict__ wp, in
     *reinterpret_cast<u32x4*>(wp + idx * 8) = v;
 }
 
-constexpr int BM = 192, BN = 192, NW = 4, WN = BN / NW, NI = WN / 16, MI = BM / 16;
-constexpr int TILE = BM * 64;                                   // elements per X tile
-constexpr int GD = BM / 8 / NW;                                 // DMA instructions per wave per K tile (8 rows each)
-
 struct Args { const bf16_t* x; const bf16_t* wp; const bf16_t* bias; bf16_t* y; int M, N, K; int store; };
 
-template <int DEPTH>
-__global__ __launch_bounds__(NW * 64, 1) void wfrag_gemm(const Args p) {
+// BM x BN tile, NW waves side by side along N (every wave owns all BM rows and BN / NW columns: no weight fragment is loaded twice),
+// DEPTH K tiles in flight.  256 tiles, one workgroup per CU.
+template <int BM, int BN, int NW, int DEPTH>
+__global__ __launch_bounds__(NW * 64, NW / 4) void wfrag_gemm(const Args p) {
+    constexpr int WN = BN / NW, NI = WN / 16, MI = BM / 16;
+    constexpr int TILE = BM * 64;                                   // elements per X tile
+    constexpr int GROUPS = BM / 8;                                  // 8-row groups = LDS-DMA instructions per X tile
+    constexpr int GD = (GROUPS + NW - 1) / NW;                      // per wave (a wave without a group re-loads one into a scratch KiB:
+                                                                    //  every wave issues the same number, so that vmcnt counts alike)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
     constexpr int NSTAGE = DEPTH + 1;                           // ring slots: DEPTH tiles in flight + the one being read
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int g = lane >> 4, i = lane & 15;
-    const int tiles_n = p.N / BN;
-    // XCD-aware map: consecutive blocks go to different XCDs; give each XCD a compact set of tile rows (they share X panels)
-    const int nb_total = gridDim.x;
+    // XCD-aware map (block b runs on XCD b % 8): XCD x owns a compact (TM / 2) x (TN / 4) block of tiles = 32 of them, so that its
+    // X panels + W slabs (3.5 MB) stay in its 4 MiB L2
+    const int TM = p.M / BM, TN = p.N / BN;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int lin = xcd * (nb_total >> 3) + slot;
-    const int tm = lin / tiles_n, tn = lin % tiles_n;
+    const int tm = (xcd & 1) * (TM / 2) + slot / (TN / 4), tn = (xcd >> 1) * (TN / 4) + slot % (TN / 4);
     const int m0 = tm * BM, n0 = tn * BN;
     const int nk = p.K >> 6;
 
     // X DMA plan: instruction j = it * NW + wid covers rows 8j .. 8j+7 of the tile
     const bf16_t* xsrc[GD];
+    int xdst[GD];
 #pragma unroll
     for (int it = 0; it < GD; ++it) {
-        const int j = it * NW + wid;
+        const int j0 = it * NW + wid;
+        const int j = j0 < GROUPS ? j0 : j0 % GROUPS;
         const int r = 8 * j + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         xsrc[it] = p.x + (int64_t)(m0 + r) * p.K + c * 8;
+        xdst[it] = j0 < GROUPS ? j * 512 : -(1 + wid);              // (negative: this wave's scratch KiB behind the ring)
     }
     auto dma = [&](int kt, int buf) {
 #pragma unroll
-        for (int it = 0; it < GD; ++it) glds16(xsrc[it] + kt * 64, smem + buf * TILE + (it * NW + wid) * 512);
+        for (int it = 0; it < GD; ++it)
+            glds16(xsrc[it] + kt * 64, xdst[it] >= 0 ? smem + buf * TILE + xdst[it] : smem + NSTAGE * TILE + (-xdst[it] - 1) * 512);
     };
     // weight fragments of this wave: n blocks (n0 + wid * WN) / 16 + a, consecutive k blocks are 1 KiB apart.  The loads are inline
     // asm (scalar base + 32-bit lane offset): the compiler must not put its own (conservative, loop-carried) s_waitcnt vmcnt(0) in
@@ -187,15 +193,17 @@ __global__ __launch_bounds__(NW * 64, 1) void wfrag_gemm(const Args p) {
 static float frand(uint32_t& s) { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xFFFF) / 32768.0f - 1.0f; }
 static bf16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return (bf16_t)(u >> 16); }
 
-template <int DEPTH>
+template <int BM, int BN, int NW, int DEPTH>
 static int run(const Args& a, int iters, const char* label, hipEvent_t e0, hipEvent_t e1) {
-    const size_t lds = (size_t)(DEPTH + 1) * TILE * 2;
-    CHK(hipFuncSetAttribute((const void*)wfrag_gemm<DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = (size_t)(DEPTH + 1) * BM * 64 * 2 + (size_t)NW * 1024;
+    auto kern = wfrag_gemm<BM, BN, NW, DEPTH>;
+    CHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = (a.M / BM) * (a.N / BN);
-    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(wfrag_gemm<DEPTH>, dim3(grid), dim3(NW * 64), lds, 0, a);
+    if (grid != 256 || (a.K >> 6) % (DEPTH + 1) != 0) { printf("  %s: unsupported geometry\n", label); return 1; }
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, 0, a);
     CHK(hipDeviceSynchronize());
     CHK(hipEventRecord(e0, 0));
-    for (int w = 0; w < iters; ++w) hipLaunchKernelGGL(wfrag_gemm<DEPTH>, dim3(grid), dim3(NW * 64), lds, 0, a);
+    for (int w = 0; w < iters; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, 0, a);
     CHK(hipEventRecord(e1, 0));
     CHK(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -250,12 +258,14 @@ int main(int argc, char** argv) {
     uniter_gemm_bias_fwd(dx, dw, db, dyr, M, N, K, nullptr);
     CHK(hipDeviceSynchronize());
     Args a{dx, dwp, db, dy, M, N, K, 1};
-    if (run<2>(a, iters, "fragment-order W -> VGPR, 2 K tiles ahead", e0, e1)) return 1;
-    Args a3 = a; a3.y = dy2;
-    if (run<3>(a3, iters, "fragment-order W -> VGPR, 3 K tiles ahead", e0, e1)) return 1;
+    if (run<192, 192, 4, 2>(a, iters, "W -> VGPR, 192x192 tile, 4 waves (1/SIMD), 2 ahead", e0, e1)) return 1;
     Args an = a; an.store = 0;
-    if (run<2>(an, iters, "  same (2 ahead), no output stores", e0, e1)) return 1;
-    Args ab = a; ab.bias = nullptr; ab.store = 0;
+    if (run<192, 192, 4, 2>(an, iters, "  same, no output stores", e0, e1)) return 1;
+    Args a3 = a; a3.y = dy2;
+    if (run<96, 384, 8, 2>(a3, iters, "W -> VGPR, 96x384 tile, 8 waves (2/SIMD), 2 ahead", e0, e1)) return 1;
+    Args a3n = a3; a3n.store = 0;
+    if (run<96, 384, 8, 2>(a3n, iters, "  same, no output stores", e0, e1)) return 1;
+    if (run<96, 384, 8, 3>(a3n, iters, "  3 ahead, no output stores", e0, e1)) return 1;
     // bit-identity against the library
     std::vector<bf16_t> y((size_t)M * N), yr((size_t)M * N), y2((size_t)M * N);
     CHK(hipMemcpy(y.data(), dy, y.size() * 2, hipMemcpyDeviceToHost));
@@ -276,6 +286,6 @@ int main(int argc, char** argv) {
         const double d = fabs(acc - (double)bf2f(y[(size_t)m * N + n]));
         if (d > worst) worst = d;
     }
-    printf("  vs the library: %zu of %zu elements differ (2 ahead), %zu (3 ahead), max |d| %.3g ; vs host fp64 on 64 samples: max |d| %.3g\n", diff, y.size(), diff2, maxd, worst);
+    printf("  vs the library: %zu of %zu elements differ (192x192), %zu (96x384), max |d| %.3g ; vs host fp64 on 64 samples: max |d| %.3g\n", diff, y.size(), diff2, maxd, worst);
     return (diff == 0 && diff2 == 0 && worst < 0.05) ? 0 : 2;
 }
