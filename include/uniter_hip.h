@@ -186,6 +186,13 @@ int uniter_gemm_wgrad_ld(const void* dy, int64_t lddy, const void* x, int64_t ld
 int uniter_attention_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse,
                          int64_t B, int64_t L, int64_t heads,
                          float p_drop, uint64_t seed, uint64_t offset, void* stream);
+/* BertSelfAttention.forward in ONE launch (model/layer.py:75-101: the three nn.Linear(H, H) as one [3H, H] projection, then the
+ * attention above): qkv[B*L, 3H] = x wqkv^T + bqkv (stored: the backward reads it), ctx, lse.  For dense batches of L == 96 tokens
+ * (60 text + 36 regions, the shipped finetune / pretrain shape) and 64-wide heads tile (example, head) of a 96 x 192 GEMM tile keeps
+ * its Q, K, V in LDS and runs the unit's attention in its epilogue; other shapes run the two launches inside the call.  Bit-identical
+ * to uniter_gemm_bias_fwd + uniter_attention_fwd with the same (p_drop, seed, offset). */
+int uniter_qkv_attention_fwd(const void* x, const void* wqkv, const void* bqkv, const float* mask_bias, void* qkv, void* ctx, float* lse,
+                             int64_t B, int64_t L, int64_t heads, float p_drop, uint64_t seed, uint64_t offset, void* stream);
 /* dqkv[B*L,3H] from dctx[B*L,H]; needs the forward's qkv, ctx, lse and the same (seed, offset). */
 int uniter_attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, const float* lse,
                          const void* dctx, void* dqkv,

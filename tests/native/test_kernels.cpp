@@ -1653,6 +1653,52 @@ static int run_attn(int argc, char** argv, int at) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// fused QKV projection + attention forward (uniter_qkv_attention_fwd) against the two launches it replaces: qkv, ctx and lse must be
+// the same BITS (same MFMA order in the projection, same attention body); --qkvattn [B heads p] also times both forms
+// ---------------------------------------------------------------------------------------------
+static int test_qkv_attention(int B, int heads, float p, bool timing) {
+    const int L = 96, H = heads * 64;
+    const size_t T = (size_t)B * L;
+    HostBf X, W, Bq;
+    X.fill(T * H, 1.f); W.fill((size_t)3 * H * H, 0.05f); Bq.fill((size_t)3 * H, 0.1f);
+    std::vector<float> mask((size_t)B * L, 0.f);
+    for (int b = 0; b < B; ++b)
+        for (int k = L - (b % 7) * 5; k < L; ++k) mask[(size_t)b * L + k] = -10000.f;      // ragged key padding
+    uint16_t *dX = upload(X), *dW = upload(W), *dB = upload(Bq);
+    float* dMask = dalloc<float>((size_t)B * L);
+    HIPCHK(hipMemcpy(dMask, mask.data(), mask.size() * 4, hipMemcpyHostToDevice));
+    uint16_t *dQ1 = dalloc<uint16_t>(T * 3 * H), *dQ2 = dalloc<uint16_t>(T * 3 * H), *dC1 = dalloc<uint16_t>(T * H), *dC2 = dalloc<uint16_t>(T * H);
+    float *dL1 = dalloc<float>((size_t)B * heads * L), *dL2 = dalloc<float>((size_t)B * heads * L);
+    HIPCHK(hipMemset(dQ2, 0xFF, T * 3 * H * 2)); HIPCHK(hipMemset(dC2, 0xFF, T * H * 2)); HIPCHK(hipMemset(dL2, 0xFF, (size_t)B * heads * L * 4));
+    UHCHK(uniter_gemm_bias_fwd(dX, dW, dB, dQ1, (int64_t)T, 3 * H, H, 0));
+    UHCHK(uniter_attention_fwd(dQ1, dMask, dC1, dL1, B, L, heads, p, 99, 5, 0));
+    UHCHK(uniter_qkv_attention_fwd(dX, dW, dB, dMask, dQ2, dC2, dL2, B, L, heads, p, 99, 5, 0));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<uint16_t> q1(T * 3 * H), q2(T * 3 * H), c1(T * H), c2(T * H);
+    std::vector<float> l1((size_t)B * heads * L), l2((size_t)B * heads * L);
+    HIPCHK(hipMemcpy(q1.data(), dQ1, q1.size() * 2, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(q2.data(), dQ2, q2.size() * 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(c1.data(), dC1, c1.size() * 2, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(c2.data(), dC2, c2.size() * 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(l1.data(), dL1, l1.size() * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(l2.data(), dL2, l2.size() * 4, hipMemcpyDeviceToHost));
+    size_t dq = 0, dc = 0, dl = 0;
+    for (size_t k = 0; k < q1.size(); ++k) dq += q1[k] != q2[k];
+    for (size_t k = 0; k < c1.size(); ++k) dc += c1[k] != c2[k];
+    for (size_t k = 0; k < l1.size(); ++k) dl += memcmp(&l1[k], &l2[k], 4) != 0;
+    const bool ok = dq == 0 && dc == 0 && dl == 0;
+    printf("[%s] fused qkv + attention fwd B%d heads%d p=%.2f vs two launches: differing qkv %zu / %zu, ctx %zu / %zu, lse %zu / %zu\n",
+           ok ? " OK " : "FAIL", B, heads, p, dq, q1.size(), dc, c1.size(), dl, l1.size());
+    if (!ok) ++g_fail;
+    if (timing) {
+        Timer tm;
+        const double two = tm.run([&] { UHCHK(uniter_gemm_bias_fwd(dX, dW, dB, dQ1, (int64_t)T, 3 * H, H, 0)); UHCHK(uniter_attention_fwd(dQ1, dMask, dC1, dL1, B, L, heads, p, 99, 5, 0)); }, 3, 20);
+        const double one = tm.run([&] { UHCHK(uniter_qkv_attention_fwd(dX, dW, dB, dMask, dQ2, dC2, dL2, B, L, heads, p, 99, 5, 0)); }, 3, 20);
+        const double gem = tm.run([&] { UHCHK(uniter_gemm_bias_fwd(dX, dW, dB, dQ1, (int64_t)T, 3 * H, H, 0)); }, 3, 20);
+        printf("  TIME qkv projection + attention fwd, B%d x 96 tokens, %d heads, p=%.2f: two launches %.2f us (projection alone %.2f), fused %.2f us\n", B, heads, p, two, gem, one);
+    }
+    for (void* q : {(void*)dX, (void*)dW, (void*)dB, (void*)dMask, (void*)dQ1, (void*)dQ2, (void*)dC1, (void*)dC2, (void*)dL1, (void*)dL2}) HIPCHK(hipFree(q));
+    return 0;
+}
+
 int main(int argc, char** argv) {
     setvbuf(stdout, nullptr, _IONBF, 0);   // keep the log complete if a later test dies
     signal(SIGSEGV, on_segv);
@@ -1683,6 +1729,16 @@ int main(int argc, char** argv) {
             int32_t inf[4];
             UHCHK(uniter_hip_device_info(inf));
             return run_attn(argc, argv, i + 1);
+        }
+        if (!strcmp(argv[i], "--qkvattn")) {
+            int32_t inf[4];
+            UHCHK(uniter_hip_device_info(inf));
+            load_tuned_json(getenv("UNITER_TUNED_JSON") ? getenv("UNITER_TUNED_JSON") : "uniter_amd/tuned/gfx950.json");
+            const int B = i + 1 < argc ? atoi(argv[i + 1]) : 32, heads = i + 2 < argc ? atoi(argv[i + 2]) : 12;
+            const float p = i + 3 < argc ? (float)atof(argv[i + 3]) : 0.1f;
+            test_qkv_attention(B, heads, p, true);
+            printf("== %d check(s) failed ==\n", g_fail);
+            return g_fail;
         }
         if (!strcmp(argv[i], "--sweep")) {
             int32_t inf[4];
@@ -1733,6 +1789,11 @@ int main(int argc, char** argv) {
     test_attention(2, 260, 2, 0.1f);          // 60 text + 2 x 100 regions (the NLVR2 triplet format): the split backward
     test_attention(1, 384, 1, 0.f);
     test_attention(1, 512, 2, 0.1f);
+    printf("== fused qkv projection + attention forward ==\n");
+    test_qkv_attention(2, 2, 0.f, false);
+    test_qkv_attention(5, 4, 0.2f, false);
+    test_qkv_attention(32, 12, 0.1f, false);          // the benchmark shape (UNITER-base, 32 x 96 tokens)
+    test_qkv_attention(16, 16, 0.1f, false);          // UNITER-large heads
     printf("== layernorm ==\n");
     printf("== grouped weight gradients ==\n");
     test_wgrad_group(320);

@@ -129,67 +129,22 @@ __device__ __forceinline__ void attn_chain_signal(const AttnArgs& p) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-// One (example, head) unit, run by all waves of the calling workgroup; the caller owns Lp*64*2*2 + Lp*4 bytes of LDS at
-// smem_raw and must put a __syncthreads() between two units that share it.  COH: the unit's qkv rows were written by
-// another CU of this XCD inside the same launch (persistent per-XCD forward, xcd_forward.hip) — loads must not be
-// served from this CU's L1 (nt loads are L2-served), and the outputs are stored with the default policy so that the
-// consuming CU finds them in the XCD's L2.
-template <int MAXKT, bool COH>
-__device__ __forceinline__ void attn_fwd_unit(const AttnArgs& p, const int bh, char* smem_raw) {
-#pragma clang fp contract(off)          // the same bits from every kernel this is inlined into
-    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);
-    bf16_t* Vs = Ks + p.Lp * 64;
-    float* mb = reinterpret_cast<float*>(Vs + p.Lp * 64);
-
-    const int b = bh / p.heads, h = bh % p.heads;
-    const int H = p.heads * DH;
-    const int Lm = p.L, Lp = p.Lp;
-    const int64_t row0 = p.cu ? (int64_t)p.cu[b] : (int64_t)b * Lm;
-    const int L = p.cu ? (p.cu[b + 1] - p.cu[b]) : Lm;         // real rows of this example
-    const int64_t ld = 3 * (int64_t)H;
-    const bf16_t* base = p.qkv + row0 * ld + h * DH;
-
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int g = lane >> 4, i = lane & 15;
+// The query sweep of one (example, head) unit: K, V (swizzled [Lp x 64] tiles) and the additive key mask are in LDS, wave `wid` of
+// `nw` takes query tiles wid, wid + nw, ...; fetch_q(qt, qf) supplies a tile's two Q fragments — from global memory (attn_fwd_unit
+// below; the first tile's are prefetched with the prologue loads) or from an LDS tile (the fused QKV projection + attention of
+// gemm.hip, whose epilogue leaves Q, K, V of its unit in LDS).  ctx_base = first output element of the unit (row 0, column h * 64);
+// lse is indexed [bh * Lm + q].  One body for both callers: the same bits from either.
+template <int MAXKT, bool COH, typename FetchQ>
+__device__ __forceinline__ void attn_fwd_core(const bf16_t* Ks, const bf16_t* Vs, const float* mb, FetchQ&& fetch_q, bf16x8 (&qf)[2],
+                                              const bool q_prefetched, const int L, const int Lm, const int Lp, const int bh, const int H,
+                                              const DropoutCfg& dcfg, float* lse, bf16_t* ctx_base, const bool wt,
+                                              const int wid, const int nw, const int g, const int i) {
+#pragma clang fp contract(off)
     const int nkt = Lp >> 4;           // key tiles (even)
     const int nqt = (L + 15) >> 4;
-
-    // prologue: the wave's first Q fragment, the K and V tiles and the mask all leave in one burst
-    auto fetch_q = [&](int qt, bf16x8 (&qf)[2]) {
-        const int q = qt * 16 + i;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (q < L) v = ldg16<COH>(base + (int64_t)q * ld + ks * 32 + g * 8);
-            qf[ks] = __builtin_bit_cast(bf16x8, v);
-        }
-    };
-    bf16x8 qf[2] = {};
-    if (wid < nqt) fetch_q(wid, qf);
-    {
-        constexpr int NIT = MAXKT > 16 ? 2 * TILE_IT : TILE_IT;
-        u32x4 rk[NIT], rv[NIT];
-        tile_fetch<NIT, COH>(rk, base + H, ld, L, Lp);
-        tile_fetch<NIT, COH>(rv, base + 2 * H, ld, L, Lp);
-        float mbv[2];
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int k = threadIdx.x + it * blockDim.x;
-            mbv[it] = (k < L) ? (p.mask_bias ? p.mask_bias[(int64_t)b * Lm + k] : 0.f) : -INFINITY;
-        }
-        tile_commit(Ks, rk, Lp);
-        tile_commit(Vs, rv, Lp);
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int k = threadIdx.x + it * blockDim.x;
-            if (k < Lp) mb[k] = mbv[it];
-        }
-    }
-    __syncthreads();
-
     for (int qt = wid; qt < nqt; qt += nw) {
         const int q = qt * 16 + i;
-        if (qt != wid) fetch_q(qt, qf);
+        if (!(q_prefetched && qt == wid)) fetch_q(qt, qf);
         // S^T tiles: lane holds keys kt*16+4g+{0..3} of query i
         f32x4 s[MAXKT];
 #pragma unroll
@@ -230,17 +185,17 @@ __device__ __forceinline__ void attn_fwd_unit(const AttnArgs& p, const int bh, c
         sum += __shfl_xor(sum, 16, WAVE);
         sum += __shfl_xor(sum, 32, WAVE);
         const float inv = 1.0f / sum;
-        if (g == 0 && q < L && p.lse != nullptr) p.lse[(int64_t)bh * Lm + q] = mx + __logf(sum);
+        if (g == 0 && q < L && lse != nullptr) lse[(int64_t)bh * Lm + q] = mx + __logf(sum);
 
         // dropout: one Philox call covers this lane's 4 keys in BOTH tiles of a key-tile pair (element group
         // ((b,h,q) * 8 + pair) * 4 + g; fields 0-3 = tile 2u, 4-7 = tile 2u+1) — the backward pass indexes the same way
-        const bool drop = p.drop.p > 0.f;
+        const bool drop = dcfg.p > 0.f;
         const uint64_t drow = ((uint64_t)bh * (uint64_t)Lm + (uint64_t)q) * (uint64_t)pair_stride(Lm);
 #pragma unroll
         for (int u = 0; u < MAXKT / 2; ++u) {
             if (2 * u < nkt) {
                 float mult[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-                if (drop) dropout_mult8(p.drop, (drow + (uint64_t)u) * 4 + (uint64_t)g, mult);
+                if (drop) dropout_mult8(dcfg, (drow + (uint64_t)u) * 4 + (uint64_t)g, mult);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     s[2 * u][r] = s[2 * u][r] * inv * mult[r];
@@ -264,15 +219,76 @@ __device__ __forceinline__ void attn_fwd_unit(const AttnArgs& p, const int bh, c
             }
         }
         if (q < L) {
-            bf16_t* dst = p.ctx + (row0 + q) * H + h * DH + 4 * g;
+            bf16_t* dst = ctx_base + (int64_t)q * H + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const float v[4] = {o[dt][0], o[dt][1], o[dt][2], o[dt][3]};
                 if constexpr (COH) stg8<true>(dst + dt * 16, pack4(v));
-                else out_store8c(dst + dt * 16, pack4(v), p.chain.signal != nullptr);
+                else out_store8c(dst + dt * 16, pack4(v), wt);
             }
         }
     }
+}
+
+// One (example, head) unit, run by all waves of the calling workgroup; the caller owns Lp*64*2*2 + Lp*4 bytes of LDS at
+// smem_raw and must put a __syncthreads() between two units that share it.  COH: the unit's qkv rows were written by
+// another CU of this XCD inside the same launch (persistent per-XCD forward, xcd_forward.hip) — loads must not be
+// served from this CU's L1 (nt loads are L2-served), and the outputs are stored with the default policy so that the
+// consuming CU finds them in the XCD's L2.
+template <int MAXKT, bool COH>
+__device__ __forceinline__ void attn_fwd_unit(const AttnArgs& p, const int bh, char* smem_raw) {
+#pragma clang fp contract(off)          // the same bits from every kernel this is inlined into
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* Vs = Ks + p.Lp * 64;
+    float* mb = reinterpret_cast<float*>(Vs + p.Lp * 64);
+
+    const int b = bh / p.heads, h = bh % p.heads;
+    const int H = p.heads * DH;
+    const int Lm = p.L, Lp = p.Lp;
+    const int64_t row0 = p.cu ? (int64_t)p.cu[b] : (int64_t)b * Lm;
+    const int L = p.cu ? (p.cu[b + 1] - p.cu[b]) : Lm;         // real rows of this example
+    const int64_t ld = 3 * (int64_t)H;
+    const bf16_t* base = p.qkv + row0 * ld + h * DH;
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int nqt = (L + 15) >> 4;
+
+    // prologue: the wave's first Q fragment, the K and V tiles and the mask all leave in one burst
+    auto fetch_q = [&](int qt, bf16x8 (&qf)[2]) {
+        const int q = qt * 16 + i;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (q < L) v = ldg16<COH>(base + (int64_t)q * ld + ks * 32 + g * 8);
+            qf[ks] = __builtin_bit_cast(bf16x8, v);
+        }
+    };
+    bf16x8 qf[2] = {};
+    if (wid < nqt) fetch_q(wid, qf);
+    {
+        constexpr int NIT = MAXKT > 16 ? 2 * TILE_IT : TILE_IT;
+        u32x4 rk[NIT], rv[NIT];
+        tile_fetch<NIT, COH>(rk, base + H, ld, L, Lp);
+        tile_fetch<NIT, COH>(rv, base + 2 * H, ld, L, Lp);
+        float mbv[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int k = threadIdx.x + it * blockDim.x;
+            mbv[it] = (k < L) ? (p.mask_bias ? p.mask_bias[(int64_t)b * Lm + k] : 0.f) : -INFINITY;
+        }
+        tile_commit(Ks, rk, Lp);
+        tile_commit(Vs, rv, Lp);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int k = threadIdx.x + it * blockDim.x;
+            if (k < Lp) mb[k] = mbv[it];
+        }
+    }
+    __syncthreads();
+
+    attn_fwd_core<MAXKT, COH>(Ks, Vs, mb, fetch_q, qf, true, L, Lm, Lp, bh, H, p.drop, p.lse, p.ctx + row0 * H + h * DH,
+                              p.chain.signal != nullptr, wid, nw, g, i);
 }
 
 }  // namespace

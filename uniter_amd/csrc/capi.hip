@@ -302,6 +302,19 @@ int uniter_attention_fwd(const void* qkv, const float* mask_bias, void* ctx, flo
     return uh::attention_fwd(qkv, mask_bias, ctx, lse, B, L, heads, make_dropout(p_drop, seed, offset), (hipStream_t)stream);
 }
 
+int uniter_qkv_attention_fwd(const void* x, const void* wqkv, const void* bqkv, const float* mask_bias, void* qkv, void* ctx, float* lse,
+                             int64_t B, int64_t L, int64_t heads, float p_drop, uint64_t seed, uint64_t offset, void* stream) {
+    UH_CHECK_ARG(x && wqkv && mask_bias && qkv && ctx, "null pointer");
+    UH_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "dropout probability must be in [0,1)");
+    const int rc = uh::qkv_attention_fwd(x, wqkv, bqkv, mask_bias, qkv, ctx, lse, B, L, heads, make_dropout(p_drop, seed, offset), (hipStream_t)stream);
+    if (rc != 1) return rc;
+    // shapes the fused tile does not cover: the two launches it replaces
+    const int64_t H = heads * 64;
+    const int r1 = uh::gemm_fwd(uh::GEMM_EPI_BIAS, x, wqkv, bqkv, nullptr, qkv, nullptr, B * L, 3 * H, H, make_dropout(0.f, 0, 0), (hipStream_t)stream);
+    if (r1) return r1;
+    return uh::attention_fwd(qkv, mask_bias, ctx, lse, B, L, heads, make_dropout(p_drop, seed, offset), (hipStream_t)stream);
+}
+
 int uniter_attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, const float* lse,
                          const void* dctx, void* dqkv, int64_t B, int64_t L, int64_t heads,
                          float p_drop, uint64_t seed, uint64_t offset, void* stream) {

@@ -91,6 +91,8 @@ ScratchLayout scratch_layout(const UniterEncoderShape& s) {
 // previous launch's flags, signal a fresh slot, drop the queue barrier); done() records what that launcher reported.  A
 // launcher that cannot take part (packed attention, split-K) clears produced: it has then run as an ordinary in-order kernel
 // without flags, and so does the kernel after it.
+// fused QKV projection + attention forward (gemm.hip EPI_QKV_ATTN); UNITER_AMD_FUSED_QKV_ATTN=0 keeps the two launches (A/B, tests)
+const bool g_fused_qkv_attn = [] { const char* e = getenv("UNITER_AMD_FUSED_QKV_ATTN"); return e == nullptr || e[0] != '0'; }();
 int g_chain = 0;     // overlapped kernel chains: a test / harness hook (uniter_encoder_debug_chain); measured neutral to -1 % at 32 x 96 tokens (EXPERIMENTS.md, round 4)
 struct Chain {
     bool on = false;
@@ -347,10 +349,16 @@ int uniter_encoder_forward(const UniterEncoderShape* s, const UniterLayerParams*
         const DropoutCfg d_h2 = tr ? make_dropout(s->p_hidden, seed, off + 2) : nodrop;
         RC(uniter_params_wait(P.wqkv, stream));        // an asynchronous optimizer step may still be writing this layer
         // model/layer.py:76-78  (three Linear(H,H) fused into one [3H,H] GEMM)
+        // and model/layer.py:80-100: ONE launch where the fused tile applies (dense batches of 96 tokens, 64-wide heads: the
+        // attention of an (example, head) unit runs in the epilogue of the GEMM tile that produced its Q, K, V), two otherwise
+        if (g_fused_qkv_attn && !g_chain && s->total_tokens == 0 && uh::qkv_attention_fused_ok(s->B, s->L, s->heads, H)) {
+            RC(uh::qkv_attention_fwd(x, P.wqkv, P.bqkv, mask_bias, A + al.qkv, A + al.ctx, (float*)(A + al.lse), s->B, s->L, s->heads, d_attn, st));
+        } else {
         CH(uh::gemm_fwd(uh::GEMM_EPI_BIAS, x, P.wqkv, P.bqkv, nullptr, A + al.qkv, nullptr, T, 3 * H, H, nodrop, st, 0, 0, 0, cs));
         // model/layer.py:80-100
         CH(uh::attention_fwd(A + al.qkv, s->total_tokens > 0 ? nullptr : mask_bias, A + al.ctx, (float*)(A + al.lse), s->B, s->L, s->heads, d_attn, st,
                              s->total_tokens > 0 ? s->cu_seqlens : nullptr, cs));
+        }
         // model/layer.py:112-114  dense + dropout + residual
         CH(uh::gemm_fwd(uh::GEMM_EPI_BIAS_DROP_RES, A + al.ctx, P.wo, P.bo, x, A + al.z1, nullptr, T, H, H, d_h1, st, 0, 0, 0, cs));
         CH(uh::layernorm_fwd(A + al.z1, P.ln1_g, P.ln1_b, A + al.a, (float*)(A + al.mean1), (float*)(A + al.rstd1),

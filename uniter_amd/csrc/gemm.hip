@@ -21,6 +21,7 @@
 #include "gemm_args.cuh"
 #include "gemm_lds.cuh"
 #include "gemm8.cuh"
+#include "attention_fwd.cuh"   // attn_fwd_core: the fused QKV projection + attention tile (EPI_QKV_ATTN)
 #ifndef UNITER_AUX_EARLY
 #define UNITER_AUX_EARLY 1
 #endif
@@ -221,6 +222,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     int tm, tn;
     tile_of_block(p.xr, bx, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
+    // EPI_QKV_ATTN: tile (tm, tn) = (example, head); tile column c stands for column qa_col(c) of the fused [3H] projection: the
+    // head's 64 query, 64 key, 64 value columns.  Everything that addresses the N side (weight rows, bias, output columns) goes
+    // through it; everything else is the plain forward tile.
+    constexpr bool QA = (EPI == EPI_QKV_ATTN);
+    static_assert(!QA || (BM == 96 && BN == 192 && !TRA && !TRB && WS == 1 && g_gemm_dma_saddr && g_gemm_epi_all),
+                  "the fused QKV + attention tile is the 96 x 192 wave-specialised forward tile");
+    const int qa_h = p.N / 3;                                // hidden size H (EPI_QKV_ATTN)
+    auto qa_col = [&](int c) { return (c >> 6) * qa_h + tn * 64 + (c & 63); };
 
     const int k_begin = by * p.k_per_split;
     const int k_end = min(p.K, k_begin + p.k_per_split);
@@ -265,7 +274,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         }
 #pragma unroll
         for (int it = 0; it < GC; ++it) {
-            if constexpr (TRB) plan_ks<BN>(it, iw, lane, p.ldcc, n0, dvoC[it], dloC[it]);
+            if constexpr (QA) {                              // plan_kc with the head's gathered weight rows
+                const int j = it * 4 + iw;
+                const int r = 8 * j + (lane >> 3);
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                dvoC[it] = (uint32_t)(((int64_t)qa_col(r) * p.ldcc + c * 8) * 2);
+                dloC[it] = (uint32_t)j * 1024u;
+            } else if constexpr (TRB) plan_ks<BN>(it, iw, lane, p.ldcc, n0, dvoC[it], dloC[it]);
             else               plan_kc<BN>(it, iw, lane, p.ldcc, n0, p.N, dvoC[it], dloC[it]);
             dloC[it] += (uint32_t)TILE_R * 2u;
         }
@@ -397,7 +412,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     constexpr int REG_BUDGET = WS == 2 ? 168 : 128;      // what the launch bounds leave a wave
     constexpr bool AUX_EARLY = g_aux_early_dev && HAS_AUX && (MI * NI * 4 + (PIPE ? 2 : 1) * (MI + NI) * 4 + MI * ITERS * 4 + 24 <= REG_BUDGET);
     u32x4 auxr[HAS_AUX ? MI : 1][ITERS];
-    constexpr bool HAS_BIAS = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RES);
+    constexpr bool HAS_BIAS = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RES || EPI == EPI_QKV_ATTN);
     u32x4 biasr[ITERS];                                     // the bias chunk of a thread's column does not depend on the pass
     bool aux_fetched = false;
     auto aux_fetch = [&]() {
@@ -408,7 +423,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 const int c = t + it * NT;
                 const int c8 = c % CPR;
                 biasr[it] = u32x4{0u, 0u, 0u, 0u};
-                if (p.bias != nullptr && c < PASS_ROWS * CPR) biasr[it] = *reinterpret_cast<const u32x4*>(p.bias + n0 + c8 * 8);
+                if (p.bias != nullptr && c < PASS_ROWS * CPR) biasr[it] = *reinterpret_cast<const u32x4*>(p.bias + (QA ? qa_col(c8 * 8) : n0 + c8 * 8));
             }
         }
         if constexpr (HAS_AUX) {
@@ -441,6 +456,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     asm volatile("" ::"s"(p.C), "s"(p.C2), "s"(p.ldc), "s"(p.bias), "s"(p.aux), "s"(p.ldaux), "s"(p.partial));
     asm volatile("" ::"s"(p.M), "s"(p.N), "s"(p.accumulate), "s"(p.relu), "s"(p.drop.p), "s"(p.drop.scale), "s"(p.drop.thresh));
     asm volatile("" ::"s"(p.drop.seed_lo), "s"(p.drop.seed_hi), "s"(p.drop.off_lo), "s"(p.drop.off_hi), "s"(p.drop.off_ptr), "s"(p.chain.signal), "s"(p.chain.expect));
+    if constexpr (QA) asm volatile("" ::"s"(p.attn_mask), "s"(p.attn_lse));
     if constexpr (WS != 0) {
         if (wid >= WG::NCW) {
             // ---- loader waves: one barrier per tile, shared with the compute waves ----
@@ -640,12 +656,21 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 #pragma clang fp contract(off)                              // bias, dropout, residual: three roundings, the same in every kernel that has this epilogue (xcd_forward.hip)
         static_assert(2 * PASS_ROWS * SROW * 4 <= NSTAGE * STAGE * 2, "staging blocks must fit the LDS ring");
         float* stage = reinterpret_cast<float*>(smem_raw);
+        // EPI_QKV_ATTN: ONE staging block (an extra barrier per pass instead of two alternating blocks), and behind it the unit's
+        // Q, K, V as three swizzled [96 x 64] bf16 tiles + the additive key mask — all inside the (now idle) ring, so that the
+        // tile still shares a CU with a second workgroup
+        constexpr int QA_STAGE_B = PASS_ROWS * SROW * 4;
+        static_assert(!QA || QA_STAGE_B + 3 * BM * 64 * 2 + BM * 4 <= NSTAGE * STAGE * 2, "Q, K, V tiles must fit the LDS ring");
+        bf16_t* qa_tiles = reinterpret_cast<bf16_t*>(smem_raw + QA_STAGE_B);
         if (!aux_fetched) aux_fetch();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                       // every wave is done reading the ring
 #pragma unroll
         for (int b = 0; b < MI; ++b) {
-            float* sb = stage + (b & 1) * PASS_ROWS * SROW;
+            float* sb = stage + (QA ? 0 : (b & 1)) * PASS_ROWS * SROW;
+            if constexpr (QA) {
+                if (b > 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }   // pass b-1 has been read
+            }
             if (is_cw) {
 #pragma unroll
                 for (int a = 0; a < NI; ++a)
@@ -664,7 +689,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(sb + r * SROW + c8 * 8);
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(sb + r * SROW + c8 * 8 + 4);
                 float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RES) {
+                if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RES || EPI == EPI_QKV_ATTN) {
                     if (p.bias != nullptr) {
                         float bv[8];
                         u32x4 bq = biasr[0];                 // select chain instead of a dynamic register index (the loop may stay rolled)
@@ -675,7 +700,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                         for (int e = 0; e < 8; ++e) v[e] += bv[e];
                     }
                 }
-                bf16_t* cptr = p.C + (int64_t)m * p.ldc + n;
+                bf16_t* cptr = p.C + (int64_t)m * p.ldc + (QA ? qa_col(c8 * 8) : n);
+                if constexpr (QA) {
+                    // the bf16 chunk goes to qkv (saved for the backward) and into the unit's LDS tile: block c8 / 8 of {Q, K, V},
+                    // row = token of the example, 16-byte chunk c8 % 8 (attention_fwd.cuh layout)
+                    const u32x4 bits = pack8(v);
+                    const int trow = (r >> 4) * WM + b * 16 + (r & 15);
+                    *reinterpret_cast<u32x4*>(qa_tiles + (c8 >> 3) * (BM * 64) + at_off8(trow, 2 * (c8 & 7))) = bits;
+                    out_store16c(cptr, bits, wt);
+                    continue;
+                }
                 if (EPI == EPI_BIAS_GELU) {
                     const u32x4 uq_bits = pack8(v);
                     out_store16c(cptr, uq_bits, wt);   // u (pre-activation)
@@ -728,6 +762,24 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 out_store16c(cptr, pack8(v), wt);    // consumed by a later kernel from MALL/HBM, never from this L2
             }
         }
+    }
+    if constexpr (QA) {
+        // ---- the attention forward of unit (example tm, head tn) on the Q, K, V the epilogue left in LDS (model/layer.py:75-101) ----
+        bf16_t* Qs = reinterpret_cast<bf16_t*>(smem_raw + PASS_ROWS * SROW * 4);
+        bf16_t* Ks = Qs + BM * 64;
+        bf16_t* Vs = Ks + BM * 64;
+        float* mb = reinterpret_cast<float*>(Vs + BM * 64);
+        if (t < BM) mb[t] = p.attn_mask[(int64_t)tm * BM + t];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        auto fetch_q = [&](int qt, bf16x8 (&qf)[2]) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) qf[ks] = at_frag(Qs, qt * 16 + i, ks, g);
+        };
+        bf16x8 qf[2] = {};
+        const int heads = tiles_n, Hd = heads * 64;
+        attn_fwd_core<BM / 16, false>(Ks, Vs, mb, fetch_q, qf, false, BM, BM, BM, tm * heads + tn, Hd, p.drop, p.attn_lse,
+                                      p.C2 + (int64_t)m0 * Hd + tn * 64, wt, wid, (int)(WG::THREADS >> 6), g, i);
     }
     if constexpr (!TRA) chain_signal(p.chain, m0, min(BM, p.M - m0));
 #ifdef UNITER_GEMM_PROBE
@@ -1337,6 +1389,38 @@ int gemm_dgrad(int epi, const void* dy, const void* w, const void* aux, void* dx
 }
 
 // y_q[M, N_q] = x_q[M, K] w_q[N_q, K]^T + bias_q for q < n <= 4, one launch; 1 = no grouped tile fits these shapes (nothing launched)
+// Fused Q / K / V projection + self-attention forward (model/layer.py:75-101): qkv[B*L, 3H] = x wqkv^T + bqkv, then per (example, head)
+// ctx = dropout(softmax(Q K^T / 8 + mask)) V with lse, in ONE launch — tile (b, h) of the 96 x 192 wave-specialised forward tile
+// computes the head's query | key | value columns for the example's 96 tokens, stores them (qkv is saved for the backward) and runs
+// the unit's attention on the copies its epilogue leaves in LDS: no second launch, no re-read of qkv.  Results are bit-identical to
+// gemm_fwd(EPI_BIAS) followed by attention_fwd (same MFMA order, same attention body: attention_fwd.cuh attn_fwd_core).
+// Only for dense batches of L == 96 tokens and 64-wide heads; returns 1 (nothing launched) for any other shape.
+bool qkv_attention_fused_ok(int64_t B, int64_t L, int64_t heads, int64_t H) {
+    return L == 96 && heads > 0 && H == heads * 64 && H % 64 == 0 && B > 0 && B * L <= INT32_MAX && 3 * H <= INT32_MAX &&
+           (int64_t)B * L * H * 2 < ((int64_t)1 << 32) && (int64_t)3 * H * H * 2 < ((int64_t)1 << 32);
+}
+int qkv_attention_fwd(const void* x, const void* wqkv, const void* bqkv, const float* mask_bias, void* qkv, void* ctx, float* lse,
+                      int64_t B, int64_t L, int64_t heads, const DropoutCfg& drop, hipStream_t st) {
+    const int64_t H = heads * 64;
+    if (!qkv_attention_fused_ok(B, L, heads, H)) return 1;
+    if (x == nullptr || wqkv == nullptr || mask_bias == nullptr || qkv == nullptr || ctx == nullptr) { uh_set_error("qkv_attention_fwd: null pointer"); return -1; }
+    const int64_t M = B * L, N = 3 * H, K = H;
+    LaunchTimer lt(TIME_GEMM_FWD_BIAS, M, N, K, st);
+    GemmArgs a{};
+    a.R = (const bf16_t*)x; a.ldr = (int)K;
+    a.Cc = (const bf16_t*)wqkv; a.ldcc = K;
+    a.C = (bf16_t*)qkv; a.C2 = (bf16_t*)ctx; a.ldc = (int)N;
+    a.bias = (const bf16_t*)bqkv;
+    a.aux = nullptr; a.ldaux = N;
+    a.partial = nullptr;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.k_per_split = (int)K;
+    a.accumulate = 0; a.relu = 0;
+    a.drop = drop;                              // the attention-probability dropout (the projection has none)
+    a.attn_mask = mask_bias; a.attn_lse = lse;
+    return launch_cfg<96, 192, false, false, EPI_QKV_ATTN, 2, 1>(a, 1, st);
+}
+
 int gemm_fwd_group(int n, const void* const* x, const int64_t* ldx, const void* const* w, const void* const* bias, void* const* y,
                    const int64_t* ldy, int64_t M, const int64_t* N, int64_t K, hipStream_t st) {
     if (n < 1 || n > 4) { uh_set_error("gemm_fwd_group: 1..4 problems"); return -1; }

@@ -4,7 +4,12 @@
 
 namespace {
 
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_DROP_RES = 2, EPI_RES = 3, EPI_GELU_BWD = 4, EPI_WGRAD = 5 };
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_DROP_RES = 2, EPI_RES = 3, EPI_GELU_BWD = 4, EPI_WGRAD = 5,
+       // fused Q / K / V projection + self-attention of one (example, head) unit per 96 x 192 tile (gemm.hip, round 6): the tile's
+       // columns are the head's query | key | value columns of the fused [3H, H] weight, its rows one example's 96 tokens; the
+       // epilogue stores qkv (+ bias) as EPI_BIAS does AND keeps the three [96 x 64] blocks in LDS, where the attention forward of
+       // the unit runs at once (C2 = ctx, attn_mask, attn_lse, drop = the attention dropout)
+       EPI_QKV_ATTN = 6 };
 
 //   C[M,N] = sum_k R(m,k) * Cc(n,k)
 //     fwd   : R = x  [M][K]   (k contiguous)          Cc = w  [N][K]   (k contiguous)
@@ -34,6 +39,8 @@ struct GemmArgs {
 #endif
     DropoutCfg drop;
     ChainLink chain;      // overlapped kernel chain (common.cuh): wait for the M-side rows' producer, signal the output rows
+    const float* attn_mask;   // EPI_QKV_ATTN: additive key mask [B, L] fp32 (model/model.py:342-345)
+    float* attn_lse;          // EPI_QKV_ATTN: log-sum-exp of the score rows [B * heads, L] fp32 (saved for the backward)
 };
 
 // blockIdx -> (tile row, tile column) for a tiles_m x tiles_n grid: the caller's choice (xr < 0), 2-D XCD blocking

@@ -55,6 +55,10 @@ int gemm_fwd(int epi, const void* x, const void* w, const void* bias, const void
              int relu = 0, ChainStep* chain = nullptr);
 int gemm_dgrad(int epi, const void* dy, const void* w, const void* aux, void* dx,
                int64_t M, int64_t N, int64_t K, hipStream_t st, int64_t lddy = 0, int act = 0, ChainStep* chain = nullptr);
+// fused Q / K / V projection + self-attention forward in one launch (dense L == 96, 64-wide heads); 1 = shape not covered (nothing launched)
+bool qkv_attention_fused_ok(int64_t B, int64_t L, int64_t heads, int64_t H);
+int qkv_attention_fwd(const void* x, const void* wqkv, const void* bqkv, const float* mask_bias, void* qkv, void* ctx, float* lse,
+                      int64_t B, int64_t L, int64_t heads, const DropoutCfg& drop, hipStream_t st);
 // up to four forward / data-gradient problems over the same rows in one launch; 1 = no grouped tile fits (nothing was launched)
 int gemm_fwd_group(int n, const void* const* x, const int64_t* ldx, const void* const* w, const void* const* bias, void* const* y,
                    const int64_t* ldy, int64_t M, const int64_t* N, int64_t K, hipStream_t st);
