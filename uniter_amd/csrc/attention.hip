@@ -197,14 +197,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const AttnArgs p) {
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) dq[dt][r] = fmaf(-shift, pk[dt][r], dq[dt][r]);
-        if (q < L && !((ATTN_DBG(p) & 1) && dq[0][0] != 12345.f)) {
-            bf16_t* dst = p.dqkv + (row0 + q) * ld + h * DH + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const float v[4] = {dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]};
-                out_store8c(dst + dt * 16, pack4(v), wt);
-            }
-        }
+        store_rows64(p.dqkv + (row0 + q) * ld + h * DH, dq, g, q < L && !((ATTN_DBG(p) & 1) && dq[0][0] != 12345.f), wt);
     }
 
     if (stamp && lane == 0) { asm volatile("s_nop 0" ::: "memory"); stamp[3] = __builtin_readcyclecounter(); }
@@ -251,15 +244,11 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const AttnArgs p) {
                 dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Qs, u, dt, g, i), dsf, dk[dt], 0, 0, 0);
             }
         }
-        if (key < L && !((ATTN_DBG(p) & 1) && dk[0][0] != 12345.f)) {
-            bf16_t* dst = p.dqkv + (row0 + key) * ld + h * DH + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const float kv[4] = {dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]};
-                const float vv[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
-                out_store8c(dst + H + dt * 16, pack4(kv), wt);
-                out_store8c(dst + 2 * H + dt * 16, pack4(vv), wt);
-            }
+        {
+            const bool st_ok = key < L && !((ATTN_DBG(p) & 1) && dk[0][0] != 12345.f);
+            bf16_t* dst = p.dqkv + (row0 + key) * ld + h * DH;
+            store_rows64(dst + H, dk, g, st_ok, wt);
+            store_rows64(dst + 2 * H, dv, g, st_ok, wt);
         }
         if (stamp && lane == 0) { asm volatile("s_nop 0" ::: "memory"); stamp[5] = __builtin_readcyclecounter(); }
     }
@@ -420,14 +409,7 @@ __global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_share_kernel(con
                     dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Ks, u, dt, g, i), dsf, dq[dt], 0, 0, 0);
             }
         }
-        if (q < L) {
-            bf16_t* dst = p.dqkv + (row0 + q) * ld + h * DH + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const float v[4] = {dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]};
-                out_store8c(dst + dt * 16, pack4(v), wt);
-            }
-        }
+        store_rows64(p.dqkv + (row0 + q) * ld + h * DH, dq, g, q < L, wt);
     }
     if (stamp && lane == 0) { asm volatile("s_nop 0" ::: "memory"); stamp[3] = __builtin_readcyclecounter(); }
     __syncthreads();                       // nobody reads K or V any more
@@ -470,15 +452,10 @@ __global__ __launch_bounds__(HP == 2 ? 768 : 512) void attn_bwd_share_kernel(con
                 }
             }
         }
-        if (key < L) {
-            bf16_t* dst = p.dqkv + (row0 + key) * ld + h * DH + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const float kv[4] = {dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]};
-                const float vv[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
-                out_store8c(dst + H + dt * 16, pack4(kv), wt);
-                out_store8c(dst + 2 * H + dt * 16, pack4(vv), wt);
-            }
+        {
+            bf16_t* dst = p.dqkv + (row0 + key) * ld + h * DH;
+            store_rows64(dst + H, dk, g, key < L, wt);
+            store_rows64(dst + 2 * H, dv, g, key < L, wt);
         }
     }
     if (stamp && lane == 0) { asm volatile("s_nop 0" ::: "memory"); stamp[5] = __builtin_readcyclecounter(); }

@@ -39,6 +39,28 @@ __device__ __forceinline__ bf16x8 pack_frag(const float (&a)[4], const float (&b
     return __builtin_bit_cast(bf16x8, w);
 }
 
+// A wave holds a [16 rows x 64 columns] fp32 block of one head as o[dt][r] = column 16 dt + 4 g + r of row i.  Stored as it sits that
+// is 8 bytes per lane: four store instructions, each 16 row pieces of 32 bytes — and the store tail of these kernels is issue-bound
+// (MI355X_MICROARCH.md, "attention epilogue store tail").  Lanes g and g ^ 1 of a row swap one packed half per block pair, so that
+// every lane stores 16 bytes: two instructions of 16 x 64-byte row pieces, the same bits at the same addresses.
+// row = column 0 of this lane's row (of this head); all 64 lanes must call (the exchange is a wave operation), `valid` gates the store.
+__device__ __forceinline__ void store_rows64(bf16_t* row, const f32x4 (&o)[4], const int g, const bool valid, const bool wt) {
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        const float va[4] = {o[2 * pr][0], o[2 * pr][1], o[2 * pr][2], o[2 * pr][3]};
+        const float vb[4] = {o[2 * pr + 1][0], o[2 * pr + 1][1], o[2 * pr + 1][2], o[2 * pr + 1][3]};
+        const u32x2 a = pack4(va), b = pack4(vb);
+        const bool odd = (g & 1) != 0;
+        const u32x2 send = odd ? a : b;                      // even g keeps block 2 pr (and takes the partner's), odd g block 2 pr + 1
+        u32x2 recv;
+        recv[0] = (unsigned)__shfl_xor((int)send[0], 16, WAVE);
+        recv[1] = (unsigned)__shfl_xor((int)send[1], 16, WAVE);
+        const u32x4 w = odd ? u32x4{recv[0], recv[1], b[0], b[1]} : u32x4{a[0], a[1], recv[0], recv[1]};
+        const int col = odd ? (2 * pr + 1) * 16 + 4 * (g - 1) : (2 * pr) * 16 + 4 * g;
+        if (valid) out_store16c(row + col, w, wt);
+    }
+}
+
 // copy rows [0,Lp) x 64 columns starting at src (row stride ld) into an LDS tile, zero beyond L
 __device__ __forceinline__ void load_tile(bf16_t* tile, const bf16_t* src, int64_t ld, int L, int Lp) {
     for (int idx = threadIdx.x; idx < Lp * 8; idx += blockDim.x) {
@@ -218,14 +240,17 @@ __device__ __forceinline__ void attn_fwd_core(const bf16_t* Ks, const bf16_t* Vs
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_frag_tr(Vs, u, dt, g, i), pf, o[dt], 0, 0, 0);
             }
         }
-        if (q < L) {
-            bf16_t* dst = ctx_base + (int64_t)q * H + 4 * g;
+        if constexpr (COH) {
+            if (q < L) {
+                bf16_t* dst = ctx_base + (int64_t)q * H + 4 * g;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const float v[4] = {o[dt][0], o[dt][1], o[dt][2], o[dt][3]};
-                if constexpr (COH) stg8<true>(dst + dt * 16, pack4(v));
-                else out_store8c(dst + dt * 16, pack4(v), wt);
+                for (int dt = 0; dt < 4; ++dt) {
+                    const float v[4] = {o[dt][0], o[dt][1], o[dt][2], o[dt][3]};
+                    stg8<true>(dst + dt * 16, pack4(v));
+                }
             }
+        } else {
+            store_rows64(ctx_base + (int64_t)q * H, o, g, q < L, wt);
         }
     }
 }

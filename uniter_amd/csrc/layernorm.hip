@@ -4,6 +4,7 @@
 // model/model.py:229,252,253,258 — biased variance, eps inside the sqrt, affine, fp32 statistics.
 // One wave64 owns a row; every lane keeps its slice of the row in registers (8-byte bf16x4 loads,
 // row fully coalesced), statistics by wave-level reductions, no LDS on the forward path.
+#include <cstdlib>
 #include "common.cuh"
 #include "kernels.h"
 #include "layernorm_fwd.cuh"
@@ -236,6 +237,178 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const bf16_t* __restri
     chain_signal(chain, blk * 4, 4);
 }
 
+// ---- 16-byte forms (H % 8 == 0, H <= 2048): a lane owns 8-column chunks lane, lane + 64, ... of its wave's row --------------------
+// The 8-byte forms above move one row with three 512-byte wave instructions per tensor; 8-byte accesses run at 0.54-0.70 of the
+// 16-byte rate (MI355X_MICROARCH.md) and these kernels are latency chains of loads -> two reductions -> stores.  Same arithmetic per
+// element, same dropout element groups (4 columns per Philox field group); only the partial sums a lane forms before the wave
+// reduction cover 8 columns instead of 4.
+template <int NC8>
+__global__ __launch_bounds__(256) void ln_fwd_kernel8(const bf16_t* __restrict__ z, const bf16_t* __restrict__ gamma,
+                                                      const bf16_t* __restrict__ beta, bf16_t* __restrict__ y,
+                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                      int rows, int H, float eps, const DropoutCfg drop, const ChainLink chain) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int blk = (int)blockIdx.x;
+    const int row = blk * ROWS_PER_BLOCK + wid;
+    chain_wait(chain, blk * ROWS_PER_BLOCK, ROWS_PER_BLOCK);
+    const bool wt = chain.signal != nullptr;
+    if (row < rows) {
+        const int nch = H >> 3;
+        const bf16_t* zr = z + (int64_t)row * H;
+        float x[NC8][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC8; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                unpack8(*reinterpret_cast<const u32x4*>(zr + ch * 8), x[c]);
+                s += ((x[c][0] + x[c][1]) + (x[c][2] + x[c][3])) + ((x[c][4] + x[c][5]) + (x[c][6] + x[c][7]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[c][e] = 0.f;
+            }
+        }
+        const float mean = wave_sum(s) / (float)H;
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC8; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = x[c][e] - mean; v += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(v) / (float)H + eps);
+        if (lane == 0) {
+            if (mean_out) mean_out[row] = mean;
+            if (rstd_out) rstd_out[row] = rstd;
+        }
+        bf16_t* yr = y + (int64_t)row * H;
+#pragma unroll
+        for (int c = 0; c < NC8; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                float gv[8], bv[8], o[8];
+                unpack8(*reinterpret_cast<const u32x4*>(gamma + ch * 8), gv);
+                unpack8(*reinterpret_cast<const u32x4*>(beta + ch * 8), bv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (x[c][e] - mean) * rstd * gv[e] + bv[e];
+                if (drop.p > 0.f) {
+                    // the dropped value is the bf16-rounded LN output (what a separate dropout kernel would see)
+                    float oq[8], m0[4], m1[4];
+                    unpack8(pack8(o), oq);
+                    const uint64_t grp = ((uint64_t)row * (uint64_t)H + (uint64_t)ch * 8) >> 2;
+                    dropout_mult4(drop, grp, m0);
+                    dropout_mult4(drop, grp + 1, m1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] = oq[e] * m0[e]; o[4 + e] = oq[4 + e] * m1[e]; }
+                }
+                out_store16c(yr + ch * 8, pack8(o), wt);
+            }
+        }
+    }
+    chain_signal(chain, blk * ROWS_PER_BLOCK, ROWS_PER_BLOCK);
+}
+
+template <int NC8>
+__global__ __launch_bounds__(256) void ln_bwd_rows_kernel8(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dy_extra,
+                                                           const bf16_t* __restrict__ z, const float* __restrict__ mean_in,
+                                                           const float* __restrict__ rstd_in, const bf16_t* __restrict__ gamma,
+                                                           bf16_t* __restrict__ dz, bf16_t* __restrict__ dd, int rows, int H,
+                                                           int post_drop, const DropoutCfg drop, const ChainLink chain) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nch = H >> 3;
+    const int blk = (int)blockIdx.x;
+    chain_wait(chain, blk * 4, 4);
+    const bool wt = chain.signal != nullptr;
+    float gv[NC8][8];
+#pragma unroll
+    for (int c = 0; c < NC8; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) unpack8(*reinterpret_cast<const u32x4*>(gamma + ch * 8), gv[c]);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gv[c][e] = 0.f;
+        }
+    }
+    const bool use_drop = drop.p > 0.f && !post_drop;
+    const bool use_post = drop.p > 0.f && post_drop;
+    for (int row = blk * 4 + wid; row < rows; row += gridDim.x * 4) {
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        const int64_t ro = (int64_t)row * H;
+        float xh[NC8][8], gy[NC8][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC8; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                float zv[8], dv[8];
+                unpack8(*reinterpret_cast<const u32x4*>(z + ro + ch * 8), zv);
+                unpack8(*reinterpret_cast<const u32x4*>(dy + ro + ch * 8), dv);
+                if (dy_extra != nullptr) {
+                    float ev[8];
+                    unpack8(*reinterpret_cast<const u32x4*>(dy_extra + ro + ch * 8), ev);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dv[e] += ev[e];
+                }
+                if (use_post) {
+                    float m0[4], m1[4];
+                    const uint64_t grp = ((uint64_t)row * (uint64_t)H + (uint64_t)ch * 8) >> 2;
+                    dropout_mult4(drop, grp, m0);
+                    dropout_mult4(drop, grp + 1, m1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { dv[e] *= m0[e]; dv[4 + e] *= m1[e]; }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xh[c][e] = (zv[e] - mean) * rstd;
+                    gy[c][e] = dv[e] * gv[c][e];
+                    s1 += gy[c][e];
+                    s2 += gy[c][e] * xh[c][e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xh[c][e] = 0.f; gy[c][e] = 0.f; }
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)H;
+        const float c2 = wave_sum(s2) / (float)H;
+#pragma unroll
+        for (int c = 0; c < NC8; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rstd * (gy[c][e] - c1 - xh[c][e] * c2);
+                const u32x4 packed = pack8(o);
+                out_store16c(dz + ro + ch * 8, packed, wt);
+                if (dd != nullptr) {            // dd = dropout-masked dz (a plain copy when there is no dropout)
+                    u32x4 dpk = packed;
+                    if (use_drop) {
+                        float oq[8], m0[4], m1[4];
+                        unpack8(packed, oq);
+                        const uint64_t grp = ((uint64_t)row * (uint64_t)H + (uint64_t)ch * 8) >> 2;
+                        dropout_mult4(drop, grp, m0);
+                        dropout_mult4(drop, grp + 1, m1);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { oq[e] *= m0[e]; oq[4 + e] *= m1[e]; }
+                        dpk = pack8(oq);
+                    }
+                    out_store16c(dd + ro + ch * 8, dpk, wt);
+                }
+            }
+        }
+    }
+    chain_signal(chain, blk * 4, 4);
+}
+
+// UNITER_AMD_LN_WIDE=0 keeps the 8-byte forms (A/B: profiles/r06_layernorm_wide_ab.txt)
+static bool ln_wide() {
+    static const bool on = [] { const char* e = getenv("UNITER_AMD_LN_WIDE"); return e == nullptr || e[0] != '0'; }();
+    return on;
+}
+
 // Column part: per-block partial sums over rows of (dy*xhat, dy, d) with d = `dsrc` (the bf16 dd / dz the row kernel
 // wrote; masked on the fly when `mask_dsrc`).  Grid (strips of 512 columns, row blocks); partial [gridDim.y][3][H].
 __global__ __launch_bounds__(1024) void ln_bwd_cols_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dy_extra,
@@ -416,6 +589,19 @@ int layernorm_fwd(const void* z, const void* gamma, const void* beta, void* y, f
 #define LN_FWD(NCV)                                                                                         \
     chain_launch(chain, ln_fwd_kernel<NCV>, grid, block, 0, st, (const bf16_t*)z, (const bf16_t*)gamma,     \
                  (const bf16_t*)beta, (bf16_t*)y, mean, rstd, (int)rows, (int)H, eps, drop, link)
+    if (ln_wide() && H % 8 == 0 && H <= 2048) {
+        const int nc8 = (int)((H / 8 + 63) / 64);
+#define LN_FWD8(NCV)                                                                                        \
+    chain_launch(chain, ln_fwd_kernel8<NCV>, grid, block, 0, st, (const bf16_t*)z, (const bf16_t*)gamma,    \
+                 (const bf16_t*)beta, (bf16_t*)y, mean, rstd, (int)rows, (int)H, eps, drop, link)
+        if (nc8 <= 1) LN_FWD8(1);
+        else if (nc8 == 2) LN_FWD8(2);
+        else if (nc8 == 3) LN_FWD8(3);
+        else LN_FWD8(4);
+#undef LN_FWD8
+        UH_LAUNCH_CHECK();
+        return 0;
+    }
     if (nc <= 1) LN_FWD(1);
     else if (nc == 2) LN_FWD(2);
     else if (nc == 3) LN_FWD(3);
@@ -459,6 +645,20 @@ int layernorm_bwd_rows(const void* dy, const void* dy_extra, const void* z, cons
     chain_launch(chain, ln_bwd_rows_kernel<NCV>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)dy,             \
                  (const bf16_t*)dy_extra, (const bf16_t*)z, mean, rstd, (const bf16_t*)gamma, (bf16_t*)dz,             \
                  (bf16_t*)dd, (int)rows, (int)H, post_drop, drop, link)
+    if (ln_wide()) {                                           // (H % 8 == 0 and H <= 2048 were checked above)
+        const int nc8 = (int)((H / 8 + 63) / 64);
+#define LN_ROWS8(NCV)                                                                                                  \
+    chain_launch(chain, ln_bwd_rows_kernel8<NCV>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)dy,            \
+                 (const bf16_t*)dy_extra, (const bf16_t*)z, mean, rstd, (const bf16_t*)gamma, (bf16_t*)dz,             \
+                 (bf16_t*)dd, (int)rows, (int)H, post_drop, drop, link)
+        if (nc8 <= 1) LN_ROWS8(1);
+        else if (nc8 == 2) LN_ROWS8(2);
+        else if (nc8 == 3) LN_ROWS8(3);
+        else LN_ROWS8(4);
+#undef LN_ROWS8
+        UH_LAUNCH_CHECK();
+        return 0;
+    }
     if (nc <= 1) LN_ROWS(1);
     else if (nc == 2) LN_ROWS(2);
     else if (nc == 3) LN_ROWS(3);
