@@ -108,6 +108,7 @@ SIGNATURES = {
     "uniter_encoder_side_join_all": (c_int, [_P]),
     "uniter_gemm_wgrad_group_ws": (c_int, [c_int32, _P, _P, _P, _P, _P, _P, _I, _P, _P, c_int, _P, c_size_t, c_int, c_int, _P]),
     "uniter_attention_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
+    "uniter_qkv_attention_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
     "uniter_attention_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P]),
     "uniter_attention_bwd_workspace_bytes": (c_size_t, [_I, _I, _I]),
     "uniter_attention_bwd_ws": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, c_float, c_uint64, c_uint64, _P, c_size_t, _P]),

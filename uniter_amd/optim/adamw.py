@@ -342,9 +342,9 @@ class AdamW(Optimizer):
         self._flat_grads = bases if (all_flat and bases) else None
 
 
-def overlap_boundaries(model):
-    """Segment boundaries for `AdamW.enable_overlap`: the first parameter of every BertLayer and of whatever follows the
-    last layer in module order.  With the parameters in a flat arena (utils.arena.flatten_model) these addresses ascend in
+def overlap_boundaries(model, layers_per_segment=None):
+    """Segment boundaries for `AdamW.enable_overlap`: the first parameter of every `layers_per_segment`-th BertLayer (default 1,
+    UNITER_AMD_OVERLAP_LAYERS) and of whatever follows the last layer in module order.  With the parameters in a flat arena (utils.arena.flatten_model) these addresses ascend in
     the order the forward pass consumes them.  The arena is REQUIRED: the encoder waits for a layer's segment through the
     address of its fused query/key/value weight only (csrc/encoder.hip), which covers the layer's other parameters — and the
     fused weight itself, a view of the arena rather than a re-stacked copy — only when all of them sit in one arena segment."""
@@ -355,8 +355,11 @@ def overlap_boundaries(model):
                                   "(uniter_amd.utils.arena.flatten_model) that is still intact; the asynchronous optimizer step "
                                   "orders a layer behind its update through one address per layer")
     layers = [m for m in model.modules() if isinstance(m, BertLayer)]
+    if layers_per_segment is None:
+        import os
+        layers_per_segment = int(os.environ.get("UNITER_AMD_OVERLAP_LAYERS", "1"))
     out = []
-    for lay in layers:
+    for lay in layers[::max(1, int(layers_per_segment))]:
         ps = [p.data_ptr() for p in lay.parameters()]
         if ps:
             out.append(min(ps))
