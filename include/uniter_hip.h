@@ -65,10 +65,6 @@ typedef struct {
 int uniter_hip_timing_begin(void);
 int uniter_hip_timing_end(UniterTimingRecord* out, int32_t cap, int32_t* n_out);
 
-/* Test / tuning hook: force the GEMM tile (0=128x128, 1=128x64, 2=64x128, 3=64x64; -1 = heuristic)
- * and the wgrad split-K factor (-1 = heuristic). */
-int uniter_gemm_debug_force(int cfg, int splits);
-
 /* ------------------------------------------------------------------------------------------------
  * GEMM family — bf16 operands, fp32 MFMA accumulation, fused epilogues.
  * Replaces the cuBLAS calls behind nn.Linear in model/layer.py:76-78,112,140,153 (forward) and the
@@ -422,7 +418,7 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
  * nn.Linear of model/layer.py:64-66,112,140,153 and the inputs of the two LayerNorm backward passes) and computes all their weight
  * + bias gradients and the LayerNorm weight / bias gradients in ONE launch at the end of the call (which also reads the caller's
  * dy: keep it valid until the weight-gradient stream has been joined) (hidden and intermediate sizes must be multiples of 256, the token count a multiple of 64; otherwise — and during
- * stream capture, or with UNITER_AMD_WGRAD_MULTI=0 — the per-layer grouped launches run as before).  A stage of twice that size
+ * stream capture — the per-layer grouped launches run as before).  A stage of twice that size
  * lets consecutive calls (layer ranges of one backward) alternate halves instead of waiting for each other's launch.  The
  * registration is per calling thread (autograd runs backward on its own thread) and is read at the start of each call;
  * buf = NULL unregisters. */
@@ -473,22 +469,16 @@ int uniter_encoder_side_stream(void** stream_out);
  * call once per shape at set-up time (the Python side does it on the first forward of a new shape). */
 int uniter_encoder_autotune(const UniterEncoderShape* s, void* stream);
 
-/* Test / tuning hook: backward runs the weight-gradient GEMMs and bias column sums on an internal side stream
- * (ordered against `stream` purely by events) unless disabled with 0. */
-int uniter_encoder_debug_side_stream(int enable);
 /* Overlapped kernel chains (ABI v7).  With a scratch buffer, uniter_encoder_forward and (in the deferred-weight-gradient flow)
  * uniter_encoder_backward dispatch the dependent kernels of all their layers WITHOUT the queue barrier between them
  * (hipExtLaunchKernel, hipExtAnyOrderLaunch) and order them through per-32-row flags in the scratch buffer instead: a consumer
  * tile starts when the row block it reads is complete, not when the slowest tile of the producer has drained
  * (csrc/common.cuh "Overlapped kernel chains", EXPERIMENTS.md section 10).  Same kernels, same arithmetic: results are bit-identical
- * to the in-order launches, which uniter_encoder_debug_chain(0) (or UNITER_AMD_CHAIN=0) selects.  A flag wait that does not
- * complete within 50 ms gives up and sets a status word instead of hanging; uniter_encoder_chain_status reads it
- * (synchronising the device): 0 = clean.  (model/model.py:282-292 has no counterpart.) */
-int uniter_encoder_debug_chain(int enable);
+ * to the in-order launches.  Chains are OFF by default (measured neutral at 32 x 96 tokens, EXPERIMENTS.md section 10.2); the
+ * switch is a test hook (include/uniter_hip_test.h).  A flag wait that does not complete within 50 ms gives up and sets a status word
+ * instead of hanging; uniter_encoder_chain_status reads it (synchronising the device): 0 = clean.  (model/model.py:282-292 has no
+ * counterpart.) */
 int uniter_encoder_chain_status(const UniterEncoderShape* s, const void* scratch, int32_t* status_out);
-/* 0 = uniter_encoder_autotune keeps the isolated per-GEMM winners; 1 (default) = it then re-picks every GEMM's tile among
- * its fastest candidates by timing a short forward+backward stack (cold weights, wgrad side stream running). */
-int uniter_encoder_debug_tune_in_situ(int enable);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused multi-tensor AdamW + global gradient norm / clipping.                 optim/adamw.py:40-103

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/uniter_hip.h"
+#include "../../include/uniter_hip_test.h"
 
 #define HIPCHK(x)                                                                        \
     do {                                                                                 \

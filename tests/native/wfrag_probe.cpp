@@ -19,7 +19,7 @@
 #include <cmath>
 #include <vector>
 #include "uniter_hip.h"
-extern "C" int uniter_gemm_debug_force(int32_t cfg, int32_t splits);
+#include "uniter_hip_test.h"
 
 #define CHK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("%s -> %s\n", #e, hipGetErrorString(_e)); return 1; } } while (0)
 typedef uint16_t bf16_t;

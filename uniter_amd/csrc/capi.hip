@@ -3,6 +3,7 @@
 #include "common.cuh"
 #include "kernels.h"
 #include "../../include/uniter_hip.h"
+#include "../../include/uniter_hip_test.h"
 
 #include <cstdarg>
 #include <cstdio>

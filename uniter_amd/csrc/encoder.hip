@@ -12,6 +12,7 @@
 #include <atomic>
 #include "kernels.h"
 #include "../../include/uniter_hip.h"
+#include "../../include/uniter_hip_test.h"
 
 namespace {
 

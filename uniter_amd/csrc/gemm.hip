@@ -554,33 +554,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 #pragma unroll
         for (int d = 0; d < NSTAGE - 1; ++d)
             if (d < nfull) do_glds(d, d);
-        if constexpr (PIPE) {
-            int buf = 0, pre = NSTAGE - 1;
-            if (nfull > 0) {
-                wait_tile<NSTAGE, G>(nfull - 1);
-                __builtin_amdgcn_s_barrier();
-                if (NSTAGE - 1 < nfull) do_glds(NSTAGE - 1, pre);
-                pre = (pre + 1 == NSTAGE) ? 0 : pre + 1;
-                frag_read(0, 0, pfr[0], pfc[0]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            for (int kt = 0; kt + 1 < nfull; ++kt) {
-                const int nbuf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
-                pipe_step(buf, nbuf, [&] {
-                    // tile kt+1: my share has landed, then everyone's; the DMA of tile kt+NSTAGE goes into tile kt's buffer, which
-                    // every wave has finished reading (the lgkmcnt(0) in front of this barrier)
-                    wait_tile<NSTAGE, G>(nfull - 2 - kt);
-                    __builtin_amdgcn_s_barrier();
-                    if (kt + NSTAGE < nfull) do_glds(kt + NSTAGE, pre);
-                    pre = (pre + 1 == NSTAGE) ? 0 : pre + 1;
-                });
-                buf = nbuf;
-            }
-            if (nfull > 0) {
-                if (AUX_EARLY) aux_fetch();
-                pipe_last(buf);
-            }
-        } else {
+        {   // (PIPE is only ever true for the wave-specialised tiles: the unspecialised loop has no pipelined form)
         int buf = 0;                  // kt % NSTAGE
         int pre = NSTAGE - 1;         // (kt + NSTAGE - 1) % NSTAGE
         for (int kt = 0; kt < nfull; ++kt) {
@@ -976,6 +950,20 @@ int launch_g6(const GemmArgs& a_in, int splits, hipStream_t st) {
     return 0;
 }
 
+// Per-lane LDS-DMA offsets (plan_kc / plan_ks) are 32-bit byte offsets from a K tile's origin: every launcher of gemm_tile — the plain
+// one and the grouped ones — checks the operand spans through this.
+template <bool TRA, bool TRB>
+bool dma_spans_ok(const GemmArgs& a) {
+    if (!g_gemm_dma_saddr) return true;
+    const int64_t span_r = TRA ? (int64_t)64 * a.ldr + a.M : (int64_t)a.M * a.ldr;
+    const int64_t span_c = TRB ? (int64_t)64 * a.ldcc + a.N : (int64_t)a.N * a.ldcc;
+    if (span_r * 2 >= ((int64_t)1 << 32) || span_c * 2 >= ((int64_t)1 << 32)) {
+        uh_set_error("gemm: operand larger than 4 GiB (M=%d N=%d K=%d ld %lld / %lld)", a.M, a.N, a.K, (long long)a.ldr, (long long)a.ldcc);
+        return false;
+    }
+    return true;
+}
+
 template <int BM, int BN, bool TRA, bool TRB, int EPI, int NSTAGE, int WS>
 int launch_cfg(const GemmArgs& a_in, int splits, hipStream_t st) {
     if constexpr (WS == 3) {
@@ -990,14 +978,7 @@ int launch_cfg(const GemmArgs& a_in, int splits, hipStream_t st) {
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
     a.xr = pick_xr(tiles_m, tiles_n, BM, BN);
-    if (g_gemm_dma_saddr) {                                  // per-lane LDS-DMA offsets are 32-bit byte offsets from a K tile's origin
-        const int64_t span_r = TRA ? (int64_t)64 * a.ldr + a.M : (int64_t)a.M * a.ldr;
-        const int64_t span_c = TRB ? (int64_t)64 * a.ldcc + a.N : (int64_t)a.N * a.ldcc;
-        if (span_r * 2 >= ((int64_t)1 << 32) || span_c * 2 >= ((int64_t)1 << 32)) {
-            uh_set_error("gemm: operand larger than 4 GiB (M=%d N=%d K=%d ld %lld / %lld)", a.M, a.N, a.K, (long long)a.ldr, (long long)a.ldcc);
-            return -1;
-        }
-    }
+    if (!dma_spans_ok<TRA, TRB>(a)) return -1;
 #ifdef UNITER_GEMM_PROBE
     a.probe = g_probe;
 #endif
@@ -1153,6 +1134,7 @@ int launch_group_idx(GemmGroupArgs& ga, hipStream_t st) {
                 uh_set_error("gemm group: tile %dx%d does not divide problem %d", BM, BN, q);
                 return -1;
             }
+            if (!dma_spans_ok<true, true>(a)) return -1;
             const int tiles_m = a.M / BM, tiles_n = a.N / BN;
             a.xr = g_group_compact ? -1 : pick_xr(tiles_m, tiles_n, BM, BN);
             a.k_per_split = (a.K + 63) / 64 * 64;
@@ -1203,6 +1185,7 @@ int launch_group_layout(GemmGroupArgs& ga, hipStream_t st) {
     for (int q = 0; q < ga.n; ++q) {
         GemmArgs& a = ga.g[q];
         if (a.N % BN != 0 || (WS && a.K % 64 != 0) || (TRA && a.M % BM != 0)) return 1;      // 1 = this tile does not fit: caller falls back
+        if (!dma_spans_ok<TRA, TRB>(a)) return -1;
         const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
         a.xr = -1;
         a.k_per_split = (a.K + 63) / 64 * 64;

@@ -65,10 +65,10 @@ __device__ __forceinline__ void g8_sc1_store16(void* p, const f32x4 v) {
 
 // LDS-DMA of 64 lanes x 16 bytes: global address = uniform 64-bit origin (scalar registers) + per-lane 32-bit offset, LDS
 // destination = lds_addr (uniform, through M0) + lane * 16.  Inline asm: the builtin takes a flat 64-bit per-lane pointer,
-// which costs a 64-bit VALU add and a register pair per instruction in a kernel that has neither to spare; nothing else in
-// the kernel uses M0.  The loads are invisible to the compiler's vmcnt bookkeeping — every wait on them is written by hand.
+// which costs a 64-bit VALU add and a register pair per instruction in a kernel that has neither to spare; M0 is declared
+// clobbered, so the compiler keeps its own uses of it (movrel, the LDS-DMA builtin) apart.  The loads are invisible to the compiler's vmcnt bookkeeping — every wait on them is written by hand.
 __device__ __forceinline__ void g8_glds16(uint32_t voff, const void* origin, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(origin), "s"(lds_addr) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(origin), "s"(lds_addr) : "memory", "m0");
 }
 
 // ---- epilogue pieces shared by the tile shapes ------------------------------------------------------------------------------

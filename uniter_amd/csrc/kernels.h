@@ -115,10 +115,6 @@ int layernorm_bwd(const void* dy, const void* dy_extra, const void* z, const flo
                   const void* gamma, void* dz, void* dd, void* dgamma, void* dbeta, void* dbias,
                   int64_t rows, int64_t H, int accumulate, const DropoutCfg& drop, int post_drop,
                   void* workspace, size_t ws_bytes, hipStream_t st);
-int layernorm_bwd_fused_rows(const void* dy, const void* z, const float* mean, const float* rstd, const void* gamma, void* dz,
-                             void* dd, int64_t rows, int64_t H, const DropoutCfg& drop, void* workspace, size_t ws_bytes,
-                             int* nb_out, hipStream_t st);
-int layernorm_bwd_fused_finalize(const void* workspace, int nb, void* dgamma, void* dbeta, int64_t H, int accumulate, hipStream_t st);
 int layernorm_bwd_rows(const void* dy, const void* dy_extra, const void* z, const float* mean, const float* rstd,
                        const void* gamma, void* dz, void* dd, int64_t rows, int64_t H, const DropoutCfg& drop,
                        int post_drop, hipStream_t st, ChainStep* chain = nullptr);

@@ -697,41 +697,6 @@ int layernorm_bwd_cols(const void* dy, const void* dy_extra, const void* z, cons
     return 0;
 }
 
-// One-kernel form: rows (dz, dd) and the per-block column partial sums in the same pass over dy / z (the split form's
-// column kernel reads both again); `fin` = stream of the small finalize kernel (may differ from st: only parameter
-// gradients depend on it).  Returns the number of partial blocks through *nb_out.
-int layernorm_bwd_fused_rows(const void* dy, const void* z, const float* mean, const float* rstd, const void* gamma, void* dz,
-                             void* dd, int64_t rows, int64_t H, const DropoutCfg& drop, void* workspace, size_t ws_bytes,
-                             int* nb_out, hipStream_t st) {
-    if (ln_bwd_check(rows, H)) return -1;
-    if (ws_bytes < layernorm_bwd_workspace_bytes(rows, H)) { uh_set_error("layernorm_bwd: workspace too small"); return -1; }
-    LaunchTimer lt(TIME_LN_BWD, rows, H, 0, st);
-    const int nc = (int)((H / 4 + 63) / 64);
-    const int nw = ln_bwd_waves(nc);
-    const int nb = ln_bwd_blocks(rows, nw);
-    float* partial = (float*)workspace;
-#define LN_BWDF(NCV, NWV)                                                                                             \
-    hipLaunchKernelGGL((ln_bwd_kernel2<NCV, NWV>), dim3(nb), dim3(64 * NWV), 0, st, (const bf16_t*)dy, (const bf16_t*)nullptr, \
-                       (const bf16_t*)z, mean, rstd, (const bf16_t*)gamma, (bf16_t*)dz, (bf16_t*)dd, partial,     \
-                       (int)rows, (int)H, 0, 0, drop)
-    if (nc <= 1) LN_BWDF(1, 16);
-    else if (nc == 2) LN_BWDF(2, 16);
-    else if (nc == 3) LN_BWDF(3, 16);
-    else if (nc == 4) LN_BWDF(4, 8);
-    else LN_BWDF(8, 4);
-#undef LN_BWDF
-    UH_LAUNCH_CHECK();
-    *nb_out = nb;
-    return 0;
-}
-int layernorm_bwd_fused_finalize(const void* workspace, int nb, void* dgamma, void* dbeta, int64_t H, int accumulate, hipStream_t st) {
-    LaunchTimer lt(TIME_LN_BWD_COLS, nb, H, 0, st);
-    hipLaunchKernelGGL(finalize_cols_kernel, dim3((unsigned)((3 * H + 63) / 64)), dim3(1024), 0, st,
-                       (const float*)workspace, nb, 3, (int)H, (bf16_t*)dgamma, (bf16_t*)dbeta, (bf16_t*)nullptr, accumulate);
-    UH_LAUNCH_CHECK();
-    return 0;
-}
-
 int layernorm_bwd(const void* dy, const void* dy_extra, const void* z, const float* mean, const float* rstd,
                   const void* gamma, void* dz, void* dd, void* dgamma, void* dbeta, void* dbias,
                   int64_t rows, int64_t H, int accumulate, const DropoutCfg& drop, int post_drop,
