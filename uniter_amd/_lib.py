@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
                     c_uint64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "build", "libuniter_hip.so")
+LIB_PATH = os.environ.get("UNITER_AMD_LIB") or os.path.join(_HERE, "csrc", "build", "libuniter_hip.so")   # (UNITER_AMD_LIB: a variant build, A/B runs)
 ABI_VERSION = 7          # UNITER_HIP_ABI_VERSION of include/uniter_hip.h (struct layouts below must match it)
 
 

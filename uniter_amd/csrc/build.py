@@ -15,7 +15,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-BUILD = os.path.join(HERE, "build")
+# (variant builds for A/B runs: UNITER_BUILD_DIR=build_b UNITER_EXTRA_FLAGS="-DUNITER_STORE_POLICY=2" python build.py; a process picks
+#  a variant up through UNITER_AMD_LIB=<path to its libuniter_hip.so> / LD_LIBRARY_PATH for the native harness)
+BUILD = os.path.join(HERE, os.environ.get("UNITER_BUILD_DIR", "build"))
 LIB = os.path.join(BUILD, "libuniter_hip.so")
 SOURCES = ["capi.hip", "gemm.hip", "attention.hip", "layernorm.hip", "embed.hip", "adamw.hip", "encoder.hip", "comm.hip", "ot.hip", "pool.hip", "lmhead.hip", "head.hip"]
 HEADERS = [os.path.join(HERE, h) for h in ("common.cuh", "kernels.h", "gemm_lds.cuh", "gemm_args.cuh", "gemm8.cuh", "attention_fwd.cuh", "layernorm_fwd.cuh")] + \
@@ -41,7 +43,7 @@ def build(force=False, verbose=False):
     hipcc = find_hipcc()
     os.makedirs(BUILD, exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
-             "-DNDEBUG"]
+             "-DNDEBUG"] + os.environ.get("UNITER_EXTRA_FLAGS", "").split()
     jobs = []
     objs = []
     for src in SOURCES:
