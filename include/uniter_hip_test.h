@@ -11,6 +11,10 @@ extern "C" {
 /* Force the GEMM tile (index into the build's tile table, uniter_gemm_tile_count(); -1 = tuned table / cost model) and the weight-
  * gradient split-K factor (-1 = heuristic) for every following GEMM call of the process. */
 int uniter_gemm_debug_force(int cfg, int splits);
+/* 0x100: uniter_gemm_bias_gelu_fwd writes gelu'(u) where it documents u, and uniter_gemm_dgrad_gelu takes that tensor as its `u`
+ * argument and multiplies by it — the form uniter_encoder_forward / _backward use between FFN1 and the FFN2 data gradient
+ * (csrc/common.cuh, UH_ACT_SAVE_GRAD); 0 (default): the documented forms. */
+int uniter_gemm_debug_act_flags(int flags);
 /* 0: uniter_encoder_backward runs the weight-gradient GEMMs and bias column sums on the caller's stream instead of the library's
  * weight-gradient stream (default 1). */
 int uniter_encoder_debug_side_stream(int enable);

@@ -42,7 +42,7 @@ def gemm_match(name):
         return _M((edge, edge, d.group(2), d.group(3), d.group(4), "2" if d.group(1) == "8" else "3", "3" if d.group(1) == "8" else "4"))
     return None
 EPI_KIND = {0: "gemm fwd +bias", 1: "gemm fwd +bias+gelu", 2: "gemm fwd +bias+dropout+residual", 3: "gemm dgrad",
-            4: "gemm dgrad x gelu'", 5: "gemm wgrad"}
+            4: "gemm dgrad x gelu'", 5: "gemm wgrad", 6: "gemm fwd QKV + self-attention (one launch)"}
 
 
 def short(name):

@@ -307,6 +307,17 @@ static void test_gemm(int M, int N, int K, int cfg, int splits) {
         check(tag, gu, ref, 0.05f, 0.01f);
         snprintf(tag, sizeof tag, "gemm_bias_gelu_fwd(g=gelu(u)) cfg%d", cfg);
         check(tag, gg, rg, 0.01f, 0.01f);
+        // the encoder's form: the first output is gelu'(u) of the same rounded u, the second output keeps its bits
+        uniter_gemm_debug_act_flags(0x100);
+        UHCHK(uniter_gemm_bias_gelu_fwd(dX, dW, dB, dY, dY2, M, N, K, 0));
+        HIPCHK(hipDeviceSynchronize());
+        uniter_gemm_debug_act_flags(0);
+        std::vector<float> gd = download_bf(dY, (size_t)M * N), gg2 = download_bf(dY2, (size_t)M * N), rd((size_t)M * N);
+        for (size_t i = 0; i < rd.size(); ++i) rd[i] = gelu_grad_h(gu[i]);
+        snprintf(tag, sizeof tag, "gemm_bias_gelu_fwd(d=gelu'(u)) cfg%d", cfg);
+        check(tag, gd, rd, 0.006f, 0.005f);
+        snprintf(tag, sizeof tag, "gemm_bias_gelu_fwd(g, saved-derivative form) bit-identical cfg%d", cfg);
+        check(tag, gg2, gg, 0.f, 0.f);
     }
     // --- fwd bias + dropout + residual ---
     for (float p : {0.0f, 0.25f}) {
@@ -350,6 +361,13 @@ static void test_gemm(int M, int N, int K, int cfg, int splits) {
         HIPCHK(hipDeviceSynchronize());
         for (size_t i = 0; i < r2.size(); ++i) r2[i] = dxr[i] * gelu_grad_h(U.v[i]);
         snprintf(tag, sizeof tag, "gemm_dgrad_gelu cfg%d", cfg);
+        check(tag, download_bf(dDX, (size_t)M * K), r2, 0.05f, 0.01f);
+        uniter_gemm_debug_act_flags(0x100);                      // `u` holds the derivative itself
+        UHCHK(uniter_gemm_dgrad_gelu(dDY, dW, dU, dDX, M, N, K, 0));
+        HIPCHK(hipDeviceSynchronize());
+        uniter_gemm_debug_act_flags(0);
+        for (size_t i = 0; i < r2.size(); ++i) r2[i] = dxr[i] * U.v[i];
+        snprintf(tag, sizeof tag, "gemm_dgrad_gelu (saved derivative) cfg%d", cfg);
         check(tag, download_bf(dDX, (size_t)M * K), r2, 0.05f, 0.01f);
         HIPCHK(hipFree(dDX)); HIPCHK(hipFree(dRX)); HIPCHK(hipFree(dU));
     }
@@ -1519,7 +1537,8 @@ static int run_roofs(int argc, char** argv, int at) {
     struct Shape { const char* name; int kind; int64_t N, K; } shapes[] = {
         {"qkv_fwd", 0, 3 * H, H}, {"out_fwd", 1, H, H}, {"ffn1_fwd_gelu", 2, I, H}, {"ffn2_fwd", 1, H, I},
         {"ffn2_dgrad_gelu", 3, H, I}, {"ffn1_dgrad", 4, I, H}, {"out_dgrad", 5, H, H}, {"qkv_dgrad", 4, 3 * H, H},
-        {"ffn2_dgrad_plain", 5, H, I}};        // (not a launch of the model: the x gelu' shape without its epilogue, beside the vendor yardstick)
+        {"ffn2_dgrad_plain", 5, H, I},         // (not a launch of the model: the x gelu' shape without its epilogue, beside the vendor yardstick)
+        {"ffn1_fwd_gelu_d", 6, I, H}, {"ffn2_dgrad_saved_d", 7, H, I}};   // the encoder's forms: FFN1 saves gelu'(u), the data gradient multiplies by it
     Timer tm;
     for (const Shape& s : shapes) {
         const int64_t N = s.N, K = s.K;
@@ -1530,12 +1549,16 @@ static int run_roofs(int argc, char** argv, int at) {
                 case 2: UHCHK(uniter_gemm_bias_gelu_fwd(dA, dW, dB, dO, dO2, M, N, K, 0)); break;
                 case 3: UHCHK(uniter_gemm_dgrad_gelu(dA, dW, dR, dO, M, N, K, 0)); break;
                 case 4: UHCHK(uniter_gemm_dgrad(dA, dW, dR, dO, M, N, K, 0)); break;
+                case 6: UHCHK(uniter_gemm_bias_gelu_fwd(dA, dW, dB, dO, dO2, M, N, K, 0)); break;
+                case 7: UHCHK(uniter_gemm_dgrad_gelu(dA, dW, dR, dO, M, N, K, 0)); break;
                 default: UHCHK(uniter_gemm_dgrad(dA, dW, nullptr, dO, M, N, K, 0)); break;
             }
         };
+        uniter_gemm_debug_act_flags(s.kind >= 6 ? 0x100 : 0);
         const double us = tm.run(fn, 3, iters);
+        uniter_gemm_debug_act_flags(0);
         int32_t ch[2] = {-1, -1};
-        uniter_gemm_tuned_choice(s.kind == 0 || s.kind == 1 || s.kind == 2 ? 0 : 1, M, N, K, ch);
+        uniter_gemm_tuned_choice(s.kind == 0 || s.kind == 1 || s.kind == 2 || s.kind == 6 ? 0 : 1, M, N, K, ch);
         printf("  ROOF %-16s M%lld N%lld K%lld tile %d : %7.2f us  %7.1f TF\n", s.name, (long long)M, (long long)N, (long long)K, fc ? atoi(fc) : ch[0], us,
                2.0 * M * N * K / us * 1e-6);
     }

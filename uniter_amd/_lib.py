@@ -75,6 +75,7 @@ SIGNATURES = {
     "uniter_hip_timing_begin": (c_int, []),
     "uniter_hip_timing_end": (c_int, [POINTER(UniterTimingRecord), c_int32, POINTER(c_int32)]),
     "uniter_gemm_debug_force": (c_int, [c_int, c_int]),
+    "uniter_gemm_debug_act_flags": (c_int, [c_int]),
     "uniter_gemm_autotune": (c_int, [c_int, _I, _I, _I, _P]),
     "uniter_gemm_set_tuned": (c_int, [c_int, _I, _I, _I, c_int32, c_int32]),
     "uniter_gemm_tuned_choice": (c_int, [c_int, _I, _I, _I, POINTER(c_int32)]),

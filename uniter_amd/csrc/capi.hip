@@ -204,10 +204,14 @@ int uniter_gemm_dgrad_group(int32_t n, const void* const* dy, const int64_t* ldd
     return 0;
 }
 
+static int g_debug_act_flags = 0;      // test hook (include/uniter_hip_test.h): the encoder's saved-derivative mode through the two entry points below
+int uniter_gemm_debug_act_flags(int flags) { g_debug_act_flags = flags & UH_ACT_SAVE_GRAD; return 0; }
+
 int uniter_gemm_bias_gelu_fwd(const void* x, const void* w, const void* bias, void* u, void* g,
                               int64_t M, int64_t N, int64_t K, void* stream) {
     UH_CHECK_ARG(x && w && u && g, "null pointer");
-    return uh::gemm_fwd(uh::GEMM_EPI_BIAS_GELU, x, w, bias, nullptr, u, g, M, N, K, make_dropout(0.f, 0, 0), (hipStream_t)stream);
+    return uh::gemm_fwd(uh::GEMM_EPI_BIAS_GELU, x, w, bias, nullptr, u, g, M, N, K, make_dropout(0.f, 0, 0), (hipStream_t)stream,
+                        0, 0, UH_ACT_GELU | g_debug_act_flags);
 }
 
 int uniter_gemm_bias_dropout_residual_fwd(const void* x, const void* w, const void* bias,
@@ -234,7 +238,7 @@ int uniter_gemm_dgrad_ld(const void* dy, int64_t lddy, const void* w, const void
 int uniter_gemm_dgrad_gelu(const void* dy, const void* w, const void* u, void* dpre,
                            int64_t M, int64_t N, int64_t K, void* stream) {
     UH_CHECK_ARG(dy && w && u && dpre, "null pointer");
-    return uh::gemm_dgrad(uh::GEMM_EPI_GELU_BWD, dy, w, u, dpre, M, N, K, (hipStream_t)stream);
+    return uh::gemm_dgrad(uh::GEMM_EPI_GELU_BWD, dy, w, u, dpre, M, N, K, (hipStream_t)stream, 0, UH_ACT_GELU | g_debug_act_flags);
 }
 
 size_t uniter_gemm_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K) {

@@ -376,6 +376,24 @@ __device__ __forceinline__ f32x2_t act_grad2(int act, const f32x2_t x) {
     return f32x2_t{act_grad(act, x.x), act_grad(act, x.y)};
 }
 
+// The encoder's FFN1 epilogue saves act'(u) in place of u (UH_ACT_SAVE_GRAD or-ed into the activation code): the normal cdf and
+// pdf that GELU needs give the derivative for one more fused multiply-add, and the backward's "x act'(u)" epilogue (FFN2 data
+// gradient, model/layer.py:139-142) becomes one multiply per element instead of an exponential, a reciprocal and a degree-5
+// polynomial (29.1 -> 21.2 us alone at 3072 x 3072 x 768, profiles/r06a_native_roofs.txt).  y has the bits of act_fwd2.
+enum { UH_ACT_SAVE_GRAD = 0x100, UH_ACT_MASK = 0xff };
+__device__ __forceinline__ void act_fwd_grad2(int act, const f32x2_t x, f32x2_t& y, f32x2_t& dy) {
+    if (act == UH_ACT_GELU) {
+#pragma clang fp contract(off)
+        f32x2_t cdf, pdf;
+        normal_cdf_pdf2(x, cdf, pdf);
+        y = x * cdf;
+        dy = __builtin_elementwise_fma(x, pdf, cdf);
+        return;
+    }
+    y = f32x2_t{act_fwd(act, x.x), act_fwd(act, x.y)};
+    dy = f32x2_t{act_grad(act, x.x), act_grad(act, x.y)};
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side status plumbing for the C ABI
 // ---------------------------------------------------------------------------------------------

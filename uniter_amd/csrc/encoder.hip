@@ -93,6 +93,9 @@ ScratchLayout scratch_layout(const UniterEncoderShape& s) {
 // launcher that cannot take part (packed attention, split-K) clears produced: it has then run as an ordinary in-order kernel
 // without flags, and so does the kernel after it.
 // fused QKV projection + attention forward (gemm.hip EPI_QKV_ATTN); UNITER_AMD_FUSED_QKV_ATTN=0 keeps the two launches (A/B, tests)
+// FFN1's epilogue saves act'(u) in the layer's `u` slot and the FFN2 data gradient multiplies by it (common.cuh, UH_ACT_SAVE_GRAD);
+// UNITER_AMD_SAVE_ACT_GRAD=0 keeps u and re-evaluates the derivative in the backward (the A/B of profiles/r06_save_act_grad_ab.txt)
+const int g_act_flags = [] { const char* e = getenv("UNITER_AMD_SAVE_ACT_GRAD"); return (e == nullptr || e[0] != '0') ? (int)UH_ACT_SAVE_GRAD : 0; }();
 const bool g_fused_qkv_attn = [] { const char* e = getenv("UNITER_AMD_FUSED_QKV_ATTN"); return e == nullptr || e[0] != '0'; }();
 int g_chain = 0;     // overlapped kernel chains: a test / harness hook (uniter_encoder_debug_chain); measured neutral to -1 % at 32 x 96 tokens (EXPERIMENTS.md, round 4)
 struct Chain {
@@ -365,7 +368,7 @@ int uniter_encoder_forward(const UniterEncoderShape* s, const UniterLayerParams*
         CH(uh::layernorm_fwd(A + al.z1, P.ln1_g, P.ln1_b, A + al.a, (float*)(A + al.mean1), (float*)(A + al.rstd1),
                              T, H, s->ln_eps, nodrop, st, cs));
         // model/layer.py:140-141  dense + erf-GELU
-        CH(uh::gemm_fwd(uh::GEMM_EPI_BIAS_GELU, A + al.a, P.w1, P.b1, nullptr, A + al.u, A + al.g, T, I, H, nodrop, st, 0, 0, s->hidden_act, cs));
+        CH(uh::gemm_fwd(uh::GEMM_EPI_BIAS_GELU, A + al.a, P.w1, P.b1, nullptr, A + al.u, A + al.g, T, I, H, nodrop, st, 0, 0, s->hidden_act | g_act_flags, cs));
         // model/layer.py:153-155
         CH(uh::gemm_fwd(uh::GEMM_EPI_BIAS_DROP_RES, A + al.g, P.w2, P.b2, A + al.a, A + al.z2, nullptr, T, H, I, d_h2, st, 0, 0, 0, cs));
         CH(uh::layernorm_fwd(A + al.z2, P.ln2_g, P.ln2_b, A + al.y, (float*)(A + al.mean2), (float*)(A + al.rstd2),
@@ -527,7 +530,7 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
             RC(uh::gemm_wgrad(ddb2, A + al.g, P.g_w2, T, H, I, 1, wg, sl.wg_bytes, ss));
             RC(joined(par));
         }
-        CH(uh::gemm_dgrad(uh::GEMM_EPI_GELU_BWD, ddb2, P.w2, A + al.u, dpre, T, H, I, st, 0, s->hidden_act, cs));
+        CH(uh::gemm_dgrad(uh::GEMM_EPI_GELU_BWD, ddb2, P.w2, A + al.u, dpre, T, H, I, st, 0, s->hidden_act | g_act_flags, cs));
         RC(tick());
         // ---- BertIntermediate backward (model/layer.py:139-142) ----
         if (!grouped) {

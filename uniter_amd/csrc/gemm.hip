@@ -686,10 +686,22 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 }
                 if (EPI == EPI_BIAS_GELU) {
                     const u32x4 uq_bits = pack8(v);
-                    out_store16c(cptr, uq_bits, wt);   // u (pre-activation)
                     // activation is applied to the bf16-rounded u so that backward (which only has u) is consistent
                     float uq[8], gq[8];
                     unpack8(uq_bits, uq);
+                    if (p.relu & UH_ACT_SAVE_GRAD) {       // C <- act'(u) instead of u (common.cuh, act_fwd_grad2)
+                        float dq[8];
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            f32x2_t gp, dp;
+                            act_fwd_grad2(p.relu & UH_ACT_MASK, f32x2_t{uq[e], uq[e + 1]}, gp, dp);
+                            gq[e] = gp.x; gq[e + 1] = gp.y; dq[e] = dp.x; dq[e + 1] = dp.y;
+                        }
+                        out_store16c(cptr, pack8(dq), wt);
+                        out_store16c(p.C2 + (int64_t)m * p.ldc + n, pack8(gq), wt);
+                        continue;
+                    }
+                    out_store16c(cptr, uq_bits, wt);   // u (pre-activation)
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
                         const f32x2_t gp = act_fwd2(p.relu, f32x2_t{uq[e], uq[e + 1]});
@@ -721,10 +733,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 if (EPI == EPI_GELU_BWD) {
                     float uv[8];
                     unpack8(auxr[b][it], uv);
+                    if (p.relu & UH_ACT_SAVE_GRAD) {       // aux holds act'(u) already
 #pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
-                        const f32x2_t gp = act_grad2(p.relu, f32x2_t{uv[e], uv[e + 1]});
-                        v[e] *= gp.x; v[e + 1] *= gp.y;
+                        for (int e = 0; e < 8; ++e) v[e] *= uv[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            const f32x2_t gp = act_grad2(p.relu, f32x2_t{uv[e], uv[e + 1]});
+                            v[e] *= gp.x; v[e + 1] *= gp.y;
+                        }
                     }
                 }
                 if (EPI == EPI_WGRAD && p.accumulate) {

@@ -170,6 +170,18 @@ struct G8Epi {
             float uq[W], gq[W];
 #pragma unroll
             for (int e = 0; e < W; ++e) uq[e] = bf2f(f2bf(v[e]));
+            if (p.relu & UH_ACT_SAVE_GRAD) {               // C <- act'(u) instead of u (common.cuh, act_fwd_grad2)
+                float dq[W];
+#pragma unroll
+                for (int e = 0; e < W; e += 2) {
+                    f32x2_t gp, dp;
+                    act_fwd_grad2(p.relu & UH_ACT_MASK, f32x2_t{uq[e], uq[e + 1]}, gp, dp);
+                    gq[e] = gp.x; gq[e + 1] = gp.y; dq[e] = dp.x; dq[e + 1] = dp.y;
+                }
+                store<W>(cptr, dq);
+                store<W>(p.C2 + (int64_t)m * p.ldc + n, gq);
+                return;
+            }
             store<W>(cptr, v);
 #pragma unroll
             for (int e = 0; e < W; e += 2) {
@@ -198,8 +210,11 @@ struct G8Epi {
                 for (int e = 0; e < W / 2; ++e) {
                     const float lo = bits2f_lo(auxw[e]), hi = bits2f_hi(auxw[e]);
                     if constexpr (EPI == EPI_GELU_BWD) {
-                        const f32x2_t gp = act_grad2(p.relu, f32x2_t{lo, hi});
-                        v[2 * e] *= gp.x; v[2 * e + 1] *= gp.y;
+                        if (p.relu & UH_ACT_SAVE_GRAD) { v[2 * e] *= lo; v[2 * e + 1] *= hi; }     // aux holds act'(u) already
+                        else {
+                            const f32x2_t gp = act_grad2(p.relu, f32x2_t{lo, hi});
+                            v[2 * e] *= gp.x; v[2 * e + 1] *= gp.y;
+                        }
                     }
                     else { v[2 * e] += lo; v[2 * e + 1] += hi; }
                 }
