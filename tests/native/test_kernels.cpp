@@ -1575,9 +1575,13 @@ static int run_sweep(int argc, char** argv, int at) {
     A.fill((size_t)M * I, 1.f); W.fill((size_t)I * I, 0.05f); Bv.fill((size_t)I, 0.1f);
     uint16_t *dA = upload(A), *dW = upload(W), *dB = upload(Bv), *dR = upload(A);
     uint16_t *dO = dalloc<uint16_t>((size_t)M * I), *dO2 = dalloc<uint16_t>((size_t)M * I);
-    struct Shape { const char* name; int kind; int64_t N, K; } shapes[] = {
+    struct Shape { const char* name; int kind; int64_t N, K; };
+    std::vector<Shape> shapes = {
         {"qkv_fwd", 0, 3 * H, H}, {"out_fwd", 1, H, H}, {"ffn1_fwd_gelu", 2, I, H}, {"ffn2_fwd", 1, H, I},
         {"ffn2_dgrad_gelu", 3, H, I}, {"ffn1_dgrad", 4, I, H}, {"out_dgrad", 5, H, H}, {"qkv_dgrad", 4, 3 * H, H}};
+    // `--sweep iters head`: the two un-grouped GEMMs of the NLVR2 paired-attention head instead (Linear(2H, H) + ReLU + Dropout,
+    // model/nlvr2.py:138-141): forward 3072 x 768 x 1536, data gradient 3072 x 1536 from a 768-wide dy
+    if (at + 1 < argc && !strcmp(argv[at + 1], "head")) shapes = {{"head_fc_fwd", 1, H, 2 * H}, {"head_fc_dgrad", 5, H, 2 * H}};
     Timer tm;
     for (const Shape& s : shapes) {
         const int64_t N = s.N, K = s.K;

@@ -204,7 +204,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     static_assert(WM % 16 == 0 && WN % 16 == 0, "wave tile must be a multiple of the 16x16 MFMA tile");
     constexpr int TILE_R = BM * 64, TILE_C = BN * 64;   // elements per LDS tile
     constexpr int STAGE = TILE_R + TILE_C;               // elements per pipeline stage
+#if defined(UNITER_GEMM_FEED_PROBE) && UNITER_GEMM_FEED_PROBE == 2
+    constexpr int G = BM / 32;
+#else
     constexpr int G = BM / 32 + BN / 32;                 // LDS-DMA instructions per wave per K tile
+#endif
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);                 // NSTAGE x STAGE bf16, sized at launch
 
     const int t = threadIdx.x;
@@ -291,8 +295,20 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         const uint32_t sb = dlds0 + (uint32_t)buf * (uint32_t)(STAGE * 2);
 #pragma unroll
         for (int it = 0; it < GR; ++it) g8_glds16(dvoR[it], oR, (uint32_t)__builtin_amdgcn_readfirstlane((int)(sb + dloR[it])));
+#if defined(UNITER_GEMM_FEED_PROBE) && UNITER_GEMM_FEED_PROBE == 2
+        // feed probe, variant builds only (WRONG results): the N-side operand is never fetched — the LDS-DMA instructions (and the
+        // bytes landing in LDS) of a step halve; G, the per-tile instruction count of the vmcnt bookkeeping, is reduced to match
+        (void)oC;
+#elif defined(UNITER_GEMM_FEED_PROBE) && UNITER_GEMM_FEED_PROBE == 3
+        // feed probe (WRONG results): same instruction count and LDS bytes, but the N-side pieces all come from ONE hot 1 KB piece
+        // of the M-side operand — the source side (L2 / fabric) of that operand costs nothing
+#pragma unroll
+        for (int it = 0; it < GC; ++it) g8_glds16(dvoR[0], oR, (uint32_t)__builtin_amdgcn_readfirstlane((int)(sb + dloC[it])));
+        (void)oC;
+#else
 #pragma unroll
         for (int it = 0; it < GC; ++it) g8_glds16(dvoC[it], oC, (uint32_t)__builtin_amdgcn_readfirstlane((int)(sb + dloC[it])));
+#endif
     };
     auto do_glds = [&](int kt, int buf) {       // direct-to-LDS path (full K tiles)
         if constexpr (g_gemm_dma_saddr) { dma_tile(kt, buf); return; }
@@ -334,8 +350,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         }
 #pragma unroll
         for (int a = 0; a < NI; ++a) {
+#if defined(UNITER_GEMM_FEED_PROBE) && UNITER_GEMM_FEED_PROBE == 1
+            // feed probe, variant builds only (WRONG results; profiles/r06_gemm_feed_probe.txt): no N-side fragment reads — what does
+            // the K loop gain when the LDS read bytes of a step halve?
+            fc[a] = fr[a % MI];
+            (void)tc;
+#else
             if constexpr (TRB) fc[a] = frag_ks<BN>(tc, wn * WN + a * 16, ks, g, i);
             else               fc[a] = frag_kc(tc, wn * WN + a * 16 + i, ks, g);
+#endif
         }
     };
     auto frag_mma = [&](const bf16x8 (&fr)[MI], const bf16x8 (&fc)[NI]) {
