@@ -843,6 +843,48 @@ def test_paired_cross_attention_fused_equals_module_path(tmp_path, long_seq, mon
         assert rel_l2(g_f[name], g_m[name]) <= 1e-1, (name, rel_l2(g_f[name], g_m[name]))
 
 
+def test_paired_cross_attention_cat_node_is_bit_identical_to_three_nodes(tmp_path, monkeypatch):
+    """ops._PairedCrossAttnCatFn (regroup + both cross attentions + cat([attended, own]) written in place, round 6) against the
+    round-4 form it replaces (regroup copy, _PairedCrossAttnFn, torch.cat: UNITER_AMD_NLVR2_CAT_TORCH=1): same kernels on the same
+    values through different row strides, dropout active with the same Philox offsets — loss and every gradient bit for bit."""
+    import json
+    from uniter_amd import ops
+    from uniter_amd.model.nlvr2 import UniterForNlvr2PairedAttn
+    from uniter_amd.utils.misc import set_dropout
+    from uniter_amd.utils.synthetic import make_batch
+    cfg = dict(BASE_CFG, num_hidden_layers=1)
+    path = tmp_path / "pa.json"
+    path.write_text(json.dumps(cfg))
+    torch.manual_seed(5)
+    model = UniterForNlvr2PairedAttn.from_pretrained(str(path), {}, img_dim=2048)
+    model.init_type_embedding()
+    _prep(model)
+    set_dropout(model, 0.1)
+    model.attn1.dropout = model.attn2.dropout = 0.1
+    model.train()
+    batch = _to_dev(make_batch('nlvr2', 8, seed=6, ragged=True))
+
+    def run(three_nodes):
+        if three_nodes:
+            monkeypatch.setenv("UNITER_AMD_NLVR2_CAT_TORCH", "1")
+        else:
+            monkeypatch.delenv("UNITER_AMD_NLVR2_CAT_TORCH", raising=False)
+        ops.manual_seed(1234)
+        for p in model.parameters():
+            p.grad = None
+        loss = model(batch, compute_loss=True)
+        loss.float().mean().backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    loss_a, g_a = run(False)
+    loss_b, g_b = run(True)
+    assert torch.equal(loss_a, loss_b)
+    assert set(g_a) == set(g_b) and len(g_a) > 30
+    for name in g_a:
+        assert torch.equal(g_a[name], g_b[name]), name
+
+
 def test_timing_records_tuned_choice_and_cache(tmp_path, monkeypatch):
     """uniter_hip_timing_{begin,end}, uniter_gemm_set_tuned legality and the UNITER_AMD_TUNE_CACHE round trip."""
     import ctypes

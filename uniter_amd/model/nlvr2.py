@@ -4,6 +4,7 @@ All three share the encoder call and the token-type table growth (2 -> 3 rows, `
 model/nlvr2.py:26-34), factored into a base class here; public class names, constructor signatures and
 sub-module names (state_dict keys) are the reference's.
 """
+import os
 from collections import defaultdict
 
 import torch
@@ -122,6 +123,19 @@ class UniterForNlvr2PairedAttn(_Nlvr2Base):
         bs, tl, d = seq.size()
         n = bs // 2
         # rows 2i / 2i+1 are the left / right image of pair i (model/nlvr2.py:172-176): regroup as [side, pair, L, H]
+        fused = self._fused_pair_attention(seq) and d % 64 == 0 and self.fc[0].weight.dtype == torch.bfloat16
+        if fused and batch['attn_masks'].dtype == torch.int64 and os.environ.get("UNITER_AMD_NLVR2_CAT_TORCH") != "1":
+            from .. import ops
+            # the shipped path: masks from one kernel; regrouping, both cross attentions and cat([attended, own]) as one autograd
+            # node that writes the fc input in place (no torch.cat, no regrouped copy of its own) — ops._PairedCrossAttnCatFn
+            pad, partner_bias = ops.nlvr2_pair_masks(batch['attn_masks'])
+            cat = ops.paired_cross_attention_cat(seq, partner_bias, self.attn1, self.attn2, self.attn1.dropout, self.training)
+            hidden = ops.linear_relu_dropout(cat.view(bs * tl, 2 * d), self.fc[0], self.fc[2].p, self.training).view(bs, tl, d)
+            pooled = self.attn_pool(hidden, pad)                                        # [2n, H]
+            pooled = pooled.view(2, n, d).transpose(0, 1).reshape(n, 2 * d)
+            if compute_loss and self.nlvr2_output.weight.dtype == torch.bfloat16:
+                return ops.linear_cross_entropy(pooled, self.nlvr2_output, batch['targets'])
+            return self._finish(self.nlvr2_output(pooled), batch, compute_loss)
         xs = seq.contiguous().view(n, 2, tl, d).transpose(0, 1).contiguous()
         if self._fused_pair_attention(seq) and batch['attn_masks'].dtype == torch.int64:
             from .. import ops

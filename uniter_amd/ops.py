@@ -910,6 +910,139 @@ class _PairedCrossAttnFn(torch.autograd.Function):
         return (dxs if ctx.needs_input_grad[0] else None, None, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 6)
 
 
+class _PairedCrossAttnCatFn(torch.autograd.Function):
+    """cat([attn_i(own, partner, partner), own], -1) of UniterForNlvr2PairedAttn (model/nlvr2.py:172-184) as ONE autograd node.
+
+    seq [2n, L, H] is the encoder output in (pair, side) row order.  The node regroups it to [side, pair] order straight into the
+    right half of the result `cat` [2, n, L, 2H] (one strided copy), runs _PairedCrossAttnFn's launches with that half as their
+    input (row stride 2H) and lets the two output projections write the left half (row stride 2H): the torch.cat launch and its
+    backward (slice copy, add, regroup copy) disappear — the backward reads d cat through row strides and ends in one elementwise
+    kernel that adds the direct path and undoes the regrouping.
+    """
+
+    @staticmethod
+    def forward(ctx, seq, mask_bias_p, attn1, attn2, p_drop, training, *anchor):
+        bs, L, H = seq.shape
+        n = bs // 2
+        heads = attn1.num_heads
+        T2 = n * L
+        T = 2 * T2
+        dev = seq.device
+        st = _lib.stream_ptr()
+        es = 2
+        cat = torch.empty(2, n, L, 2 * H, dtype=_BF16, device=dev)
+        cat[..., H:].copy_(seq.view(n, 2, L, H).transpose(0, 1))        # rows 2i / 2i+1 -> [left block; right block]
+        P = torch.empty(T, 3 * H, dtype=_BF16, device=dev)
+        cx = torch.empty(T, H, dtype=_BF16, device=dev)
+        lse = torch.empty(2 * n * heads * L, dtype=torch.float32, device=dev)
+        side = T2 * 2 * H * es                                             # bytes of one side block of cat
+        x_l, x_r = cat.data_ptr() + H * es, cat.data_ptr() + side + H * es
+        w1, w2 = attn1.in_proj_weight, attn2.in_proj_weight
+        b1, b2 = attn1.in_proj_bias, attn2.in_proj_bias
+        bp = lambda b, o: None if b is None else b.data_ptr() + o * es
+        p0, p1 = P.data_ptr(), P.data_ptr() + T2 * 3 * H * es
+        fwd_group([x_l, x_r, x_r, x_l], [2 * H] * 4,
+                  [w1.data_ptr(), w1.data_ptr() + H * H * es, w2.data_ptr(), w2.data_ptr() + H * H * es],
+                  [bp(b1, 0), bp(b1, H), bp(b2, 0), bp(b2, H)],
+                  [p0, p0 + H * es, p1, p1 + H * es], [3 * H] * 4, T2, [H, 2 * H, H, 2 * H], H)
+        p = float(p_drop) if training else 0.0
+        seed, off = _next_offsets(1) if p > 0.0 else (0, 0)
+        C.uniter_attention_fwd(ptr(P), ptr(mask_bias_p), ptr(cx), ptr(lse), 2 * n, L, heads, p, seed, off, st)
+        c0, c1 = cx.data_ptr(), cx.data_ptr() + T2 * H * es
+        fwd_group([c0, c1], [0, 0], [ptr(attn1.out_proj.weight), ptr(attn2.out_proj.weight)],
+                  [ptr(attn1.out_proj.bias), ptr(attn2.out_proj.bias)], [cat.data_ptr(), cat.data_ptr() + side], [2 * H] * 2,
+                  T2, [H, H], H)
+        ctx.mods = (attn1, attn2)
+        ctx.p, ctx.seed, ctx.off = p, seed, off
+        ctx.save_for_backward(cat, mask_bias_p, P, cx, lse)
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        cat, mask_bias_p, P, cx, lse = ctx.saved_tensors
+        attn1, attn2 = ctx.mods
+        two, n, L, H2 = cat.shape
+        H = H2 // 2
+        heads = attn1.num_heads
+        T2 = n * L
+        T = 2 * T2
+        dev = cat.device
+        st = _lib.stream_ptr()
+        es = 2
+        dcat = dcat.contiguous()
+        dcx = torch.empty(T, H, dtype=_BF16, device=dev)
+        dP = torch.empty(T, 3 * H, dtype=_BF16, device=dev)
+        dxs = torch.empty(2, n, L, H, dtype=_BF16, device=dev)
+        wsb = max(C.uniter_gemm_wgrad_workspace_bytes(T2, 2 * H, H), C.uniter_colsum_workspace_bytes(T2, 3 * H))
+        _scratch(("pca", dev.index), wsb, dev)
+        pool = {}
+
+        def grad_of(prm):
+            if prm is None:
+                return None
+            return ensure_grad(prm) if prm.requires_grad else _dummy_grad_like(prm, pool)
+
+        half = T2 * H * es
+        side = T2 * 2 * H * es
+        do_l, do_r = dcat.data_ptr(), dcat.data_ptr() + side               # d(attended) = left half of d cat, row stride 2H
+        # ---- out_proj (model/attention.py:257) ----
+        dgrad_group([do_l, do_r], [2 * H] * 2, [ptr(attn1.out_proj.weight), ptr(attn2.out_proj.weight)],
+                    [None, None], [dcx.data_ptr(), dcx.data_ptr() + half], T2, [H, H], H)
+        wgrad_group([do_l, do_r], [2 * H] * 2, [cx.data_ptr(), cx.data_ptr() + half], [0, 0],
+                    [ptr(grad_of(attn1.out_proj.weight)), ptr(grad_of(attn2.out_proj.weight))],
+                    [ptr(grad_of(attn1.out_proj.bias)), ptr(grad_of(attn2.out_proj.bias))], T2, [H, H], [H, H])
+        # ---- attention core ----
+        awb = C.uniter_attention_bwd_workspace_bytes(2 * n, L, heads)
+        aws = _scratch(("pca_attn", dev.index), max(awb, 16), dev)
+        C.uniter_attention_bwd_ws(ptr(P), ptr(mask_bias_p), None, ptr(cx), ptr(lse), ptr(dcx), ptr(dP), 2 * n, L, heads,
+                                  ctx.p, ctx.seed, ctx.off, ptr(aws), awb, st)
+        # ---- in_proj (model/attention.py:103-127, the kv_same branch) ----
+        x_l, x_r = cat.data_ptr() + H * es, cat.data_ptr() + side + H * es
+        dx_l, dx_r = dxs.data_ptr(), dxs.data_ptr() + half
+        d0, d1 = dP.data_ptr(), dP.data_ptr() + T2 * 3 * H * es
+        w1, w2 = attn1.in_proj_weight, attn2.in_proj_weight
+        wq1, wkv1 = w1.data_ptr(), w1.data_ptr() + H * H * es
+        wq2, wkv2 = w2.data_ptr(), w2.data_ptr() + H * H * es
+        dgrad_group([d0, d1], [3 * H, 3 * H], [wq1, wq2], [None, None], [dx_l, dx_r], T2, [H, H], H)
+        dgrad_group([d1 + H * es, d0 + H * es], [3 * H, 3 * H], [wkv2, wkv1], [dx_l, dx_r], [dx_l, dx_r], T2, [2 * H, 2 * H], H)
+        g1, g2 = grad_of(w1), grad_of(w2)
+        gb1, gb2 = grad_of(attn1.in_proj_bias), grad_of(attn2.in_proj_bias)
+        bq1, bkv1 = (gb1.data_ptr(), gb1.data_ptr() + H * es) if gb1 is not None else (None, None)
+        bq2, bkv2 = (gb2.data_ptr(), gb2.data_ptr() + H * es) if gb2 is not None else (None, None)
+        wgrad_group([d0, d0 + H * es, d1, d1 + H * es], [3 * H] * 4, [x_l, x_r, x_r, x_l], [2 * H] * 4,
+                    [g1.data_ptr(), g1.data_ptr() + H * H * es, g2.data_ptr(), g2.data_ptr() + H * H * es],
+                    [bq1, bkv1, bq2, bkv2], T2, [H, 2 * H, H, 2 * H], [H, H, H, H])
+        dseq = None
+        if ctx.needs_input_grad[0]:
+            # d seq = regroup^-1(d(own via the projections) + d(own via the right half of cat)), one elementwise launch
+            # (explicit contiguous output: an elementwise op on two equally permuted inputs would keep their permuted layout)
+            dseq = torch.empty(n, 2, L, H, dtype=_BF16, device=dev)
+            torch.add(dxs.transpose(0, 1), dcat[..., H:].transpose(0, 1), out=dseq)
+            dseq = dseq.view(2 * n, L, H)
+        return (dseq, None, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 6)
+
+
+def paired_cross_attention_cat(seq, partner_bias, attn1, attn2, p_drop, training):
+    """seq [2n, L, H] bf16, rows 2i / 2i+1 = the two sequences of pair i; partner_bias [2n, L] fp32 from nlvr2_pair_masks.
+    Returns cat([attended, own], -1) as [2, n, L, 2H] (left block, right block): the input of UniterForNlvr2PairedAttn.fc."""
+    _check_dev(seq, "paired sequences")
+    if seq.dim() != 3 or seq.size(0) % 2:
+        raise _lib.UniterHipError("paired sequences must be [2n, L, H]")
+    H = seq.size(2)
+    for mod in (attn1, attn2):
+        if mod.embed_dim != H or mod.head_dim != 64 or mod.out_proj.bias is None:
+            raise _lib.UniterHipError("fused paired attention needs embed_dim == H, head_dim 64 and an out_proj bias")
+        for prm in (mod.in_proj_weight, mod.in_proj_bias, mod.out_proj.weight, mod.out_proj.bias):
+            if prm is not None:
+                _check_dev(prm, "attention parameter")
+    seq = seq.contiguous()
+    if not torch.is_grad_enabled():
+        return _PairedCrossAttnCatFn.apply(seq, partner_bias, attn1, attn2, p_drop, training)
+    anchor = next((p for m in (attn1, attn2) for p in m.parameters() if p.requires_grad), None)
+    extra = () if anchor is None else (anchor,)
+    return _PairedCrossAttnCatFn.apply(seq, partner_bias, attn1, attn2, p_drop, training, *extra)
+
+
 def nlvr2_pair_masks(attn_masks):
     """attn_masks [2n, L] int64, rows in (pair, side) order -> (pad [2n, L] uint8, rows regrouped [left block; right block];
     partner key-mask bias [2n, L] fp32) in one launch (uniter_nlvr2_pair_masks)."""
