@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UNITER_HIP_ABI_VERSION 7
+#define UNITER_HIP_ABI_VERSION 8
 
 /* ------------------------------------------------------------------------------------------------
  * Library
@@ -433,6 +433,14 @@ int uniter_encoder_set_wgrad_stage(void* buf, size_t bytes);
  * uniter_encoder_defer_side_join(0) before the last range restores the default, whose end-of-call wait covers everything.
  * (model/model.py:282-292 has no counterpart: the reference's autograd runs layer by layer on one stream.) */
 int uniter_encoder_defer_side_join(int enable);
+
+/* Gradient overwrite (round 6; torch's zero_grad(set_to_none=True) semantics for the encoder's parameter gradients).
+ * uniter_encoder_set_grad_overwrite(1) makes the NEXT uniter_encoder_backward call of this thread REPLACE the contents of g_w*, g_b*,
+ * g_ln* of the layers it covers instead of adding to them (the flag is consumed by that call): the deferred launch neither reads the old
+ * gradients nor needs them zeroed, so a fused optimizer step can leave them alone (uniter_adamw_plan_keep_grads).  Flows without the
+ * deferred launch zero the tensors first and accumulate — same result, no saving.  Gradient accumulation over several backward calls
+ * (pretrain.py:298-312): state it for the first call of an optimizer step only. */
+int uniter_encoder_set_grad_overwrite(int32_t enable);
 int uniter_encoder_side_join(void* stream);
 /* The same from ANY thread: makes `stream` wait for the weight-gradient streams of every thread of this process that left a
  * backward call un-joined on the current device (autograd runs backward on its own thread, the optimizer runs on the caller's).
@@ -503,6 +511,10 @@ typedef struct UniterAdamGroup {
 /* Opaque plan: the tensor table lives on the device; build once, reuse every step. */
 int uniter_adamw_plan_create(const UniterAdamTensor* tensors, int64_t n_tensors, void** plan_out);
 int uniter_adamw_plan_destroy(void* plan);
+/* keep[i] != 0: uniter_adamw_step_zero / _step_async leave the gradient of tensor i of the plan as it is (its producer overwrites it in
+ * the next backward pass, uniter_encoder_set_grad_overwrite) — 2 bytes per parameter less written by the update.  One flag per tensor,
+ * in the order of uniter_adamw_plan_create's table; all zero restores the default. */
+int uniter_adamw_plan_keep_grads(void* plan, const uint8_t* keep, int64_t n_tensors);
 
 /* norm_out[0] = sqrt(sum g^2) * grad_scale ; norm_out[1] = clip coefficient
  *   coef = grad_scale * min(1, max_norm / (norm + 1e-6))     (max_norm <= 0: coef = grad_scale)

@@ -18,7 +18,7 @@ def _declared(header="uniter_hip.h"):
 def test_library_is_built_and_loads():
     assert os.path.exists(_lib.LIB_PATH), "run `python -c 'import __graft_entry__ as g; g.build()'` first"
     lib = _lib.load()
-    assert lib.uniter_hip_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.uniter_hip_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_every_declared_symbol_is_exported_and_bound():

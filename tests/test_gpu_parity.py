@@ -663,11 +663,67 @@ def test_overlapped_adamw_step_is_bit_identical_and_skips_untouched_params(golde
         assert model.uniter.pooler.dense.weight.grad is None
         assert torch.equal(model.uniter.pooler.dense.weight, pool0)
         assert len(opt.state[model.uniter.pooler.dense.weight]) == 0
+        from uniter_amd import _lib as L
+        L.lazy_resolve()     # (lazy_zero: the encoder's gradients are left for the next backward to replace; a reader gets zeros this way)
         assert float(arena.grad.float().abs().max()) == 0.0            # zero_grad happened (fused or memset)
         results.append({n: p.detach().clone() for n, p in model.named_parameters()})
     for n in results[0]:
         assert torch.equal(results[0][n], results[1][n]), n
         assert torch.equal(results[0][n], results[2][n]), n
+
+
+def test_lazy_zero_grad_is_bit_identical_over_steps(tmp_path):
+    """AdamW.lazy_zero (round 6): the fused step leaves the encoder's parameter gradients un-zeroed and the next backward REPLACES
+    them through the deferred launch (base width: the flow uniter_encoder_set_grad_overwrite is for).  Four optimizer steps, the
+    second with two accumulated micro-batches and one without any backward in between (the kept gradients must read as zeros):
+    parameters and the optimizer's moments bit for bit those of the eager zero_grad."""
+    import json
+    from uniter_amd import _lib as L, ops
+    from uniter_amd.model.nlvr2 import UniterForNlvr2PairedAttn
+    from uniter_amd.optim import build_optimizer, clip_grad_norm_
+    from uniter_amd.utils.arena import flatten_model
+    from uniter_amd.utils.misc import Struct, set_dropout
+    from uniter_amd.utils.synthetic import make_batch
+    cfg = dict(BASE_CFG, num_hidden_layers=2)
+    path = tmp_path / "lz.json"
+    path.write_text(json.dumps(cfg))
+    batches = [_to_dev(make_batch('nlvr2', 8, seed=20 + k)) for k in range(2)]
+    opts = Struct(dict(optim='adamw', learning_rate=1e-3, betas=(0.9, 0.98), weight_decay=0.01))
+    out = []
+    for lazy in (False, True):
+        torch.manual_seed(11)
+        model = UniterForNlvr2PairedAttn.from_pretrained(str(path), {}, img_dim=2048)
+        model.init_type_embedding()
+        _prep(model)
+        set_dropout(model, 0.1)
+        model.train()
+        flatten_model(model)
+        opt = build_optimizer(model, opts)
+        opt.fuse_zero_grad = True
+        opt.lazy_zero = lazy
+        ops.manual_seed(99)
+        seen_overwrite = []
+        for step in range(4):
+            if step != 2:                                          # step 2: an optimizer step with no backward before it
+                for b in (batches if step == 1 else batches[:1]):  # step 1: two accumulated micro-batches
+                    seen_overwrite.append(L.lazy_undefined)
+                    model(b, compute_loss=True).mean().backward()
+            clip_grad_norm_(opt, 1.0)
+            opt.step()
+            opt.zero_grad()
+        torch.cuda.synchronize()
+        assert seen_overwrite == ([False, True, False, True] if lazy else [False] * 4), seen_overwrite
+        assert L.lazy_undefined == lazy
+        L.lazy_resolve()
+        state = {n: p.detach().clone() for n, p in model.named_parameters()}
+        for n, p in model.named_parameters():
+            if 'exp_avg' in opt.state[p]:
+                state[n + '/m'] = opt.state[p]['exp_avg'].clone()
+                state[n + '/v'] = opt.state[p]['exp_avg_sq'].clone()
+        out.append(state)
+    assert set(out[0]) == set(out[1]) and len(out[0]) > 100
+    for n in out[0]:
+        assert torch.equal(out[0][n], out[1][n]), n
 
 
 def test_adamw_state_dict_roundtrip_keeps_fp32_state(golden):

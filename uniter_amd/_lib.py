@@ -11,7 +11,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UNITER_AMD_LIB") or os.path.join(_HERE, "csrc", "build", "libuniter_hip.so")   # (UNITER_AMD_LIB: a variant build, A/B runs)
-ABI_VERSION = 7          # UNITER_HIP_ABI_VERSION of include/uniter_hip.h (struct layouts below must match it)
+ABI_VERSION = 8          # UNITER_HIP_ABI_VERSION of include/uniter_hip.h (struct layouts below must match it)
 
 
 class UniterHipError(RuntimeError):
@@ -143,6 +143,7 @@ SIGNATURES = {
     "uniter_encoder_autotune": (c_int, [POINTER(UniterEncoderShape), _P]),
     "uniter_encoder_debug_side_stream": (c_int, [c_int]),
     "uniter_encoder_defer_side_join": (c_int, [c_int]),
+    "uniter_encoder_set_grad_overwrite": (c_int, [c_int32]),
     "uniter_encoder_side_join": (c_int, [c_void_p]),
     "uniter_encoder_side_stream": (c_int, [POINTER(c_void_p)]),
     "uniter_encoder_set_grad_buckets": (c_int, [c_int32]),
@@ -159,6 +160,7 @@ SIGNATURES = {
     "uniter_cls_ce_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "uniter_adamw_plan_create": (c_int, [POINTER(UniterAdamTensor), _I, POINTER(c_void_p)]),
     "uniter_adamw_plan_destroy": (c_int, [_P]),
+    "uniter_adamw_plan_keep_grads": (c_int, [_P, _P, c_int64]),
     "uniter_adamw_grad_norm": (c_int, [_P, c_float, c_float, _P, _P]),
     "uniter_adamw_step": (c_int, [_P, POINTER(UniterAdamGroup), c_int32, _P, _P]),
     "uniter_adamw_step_dev": (c_int, [_P, _P, c_int32, _P, _P]),
@@ -322,6 +324,24 @@ def grad_attach_epoch():
 # record_stream on that stream: their memory is not given out again before the launch is through, but no Python reference
 # outlives the backward call (round 3 parked the tensors in a list until the join — with gradient accumulation 4 on
 # UNITER-large that was four micro-steps' activation arenas alive at once).
+# Lazy zero_grad (AdamW.lazy_zero, round 6): the encoder's backward REPLACES the parameter gradients of its layers when they are
+# marked undefined, so the fused optimizer step need not zero them and the deferred launch need not read them.
+#   lazy_ranges      {(first byte, byte length)} of the gradient storages the last encoder backward wrote (per layer, fused q|k|v once)
+#   lazy_undefined   True between a fused step that skipped those storages and the backward that overwrites them
+lazy_ranges = frozenset()
+lazy_tensors = []        # the gradient tensors behind lazy_ranges (zeroed explicitly when an undefined state has to be resolved)
+lazy_undefined = False
+
+
+def lazy_resolve():
+    """Give the undefined gradient storages the zeros a zero_grad() promises (someone is about to read them before a backward
+    pass has replaced them: a gradient norm, an optimizer step, a set_to_none)."""
+    global lazy_undefined
+    if lazy_undefined:
+        for t in lazy_tensors:
+            t.zero_()
+        lazy_undefined = False
+
 _wgrads_pending = False
 _side_streams = {}
 

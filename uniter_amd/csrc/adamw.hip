@@ -29,8 +29,10 @@ struct DevTensor {
     float* v;
     int64_t numel;
     int32_t group;
-    int32_t is_bf16;
+    int32_t is_bf16;     // bit 0: bf16 parameter / gradient; bit 1 (DT_KEEP_GRAD): the fused zero_grad leaves this gradient alone — its
+                         // producer overwrites it in the next backward pass (uniter_adamw_plan_keep_grads)
 };
+constexpr int32_t DT_BF16 = 1, DT_KEEP_GRAD = 2;
 struct ChunkRef {
     int32_t tensor;
     int32_t chunk;     // chunk index inside the tensor
@@ -81,7 +83,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(const DevTensor* __restrict_
     const float coef = clip_coef ? *clip_coef : 1.0f;
     for (int64_t ci = chunk_begin + blockIdx.x; ci < n_chunks; ci += gridDim.x) {
         const ChunkRef cr = chunks[ci];
-        const DevTensor t = tensors[cr.tensor];
+        DevTensor t = tensors[cr.tensor];
+        const bool zero_this = zero_grads && !(t.is_bf16 & DT_KEEP_GRAD);
+        t.is_bf16 &= DT_BF16;
         const GroupHyper h = hyp_dev ? hyp_dev[t.group] : hyp.g[t.group];
         const int64_t base = (int64_t)cr.chunk * CHUNK;
 #pragma unroll
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const DevTensor* __restrict_
                 // (the bf16 weights are what the next forward pass reads, the zeroed gradients what the next backward pass
                 //  accumulates into: both keep the default policy)
                 if (t.is_bf16) adam_st<false>(reinterpret_cast<u32x2*>((bf16_t*)t.param + idx), pack4(p));
-                if (zero_grads) {
+                if (zero_this) {
                     if (t.is_bf16) adam_st<false>(reinterpret_cast<u32x2*>((bf16_t*)t.grad + idx), u32x2{0u, 0u});
                     else adam_st<false>(reinterpret_cast<f32x4*>((float*)t.grad + idx), f32x4{0.f, 0.f, 0.f, 0.f});
                 }
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const DevTensor* __restrict_
                 for (int e = 0; e < n; ++e) {
                     pm[idx + e] = p[e]; t.m[idx + e] = m[e]; t.v[idx + e] = v[e];
                     if (t.is_bf16) ((bf16_t*)t.param)[idx + e] = f2bf(p[e]);
-                    if (zero_grads) {
+                    if (zero_this) {
                         if (t.is_bf16) ((bf16_t*)t.grad)[idx + e] = f2bf(0.f);
                         else ((float*)t.grad)[idx + e] = 0.f;
                     }
@@ -154,12 +158,12 @@ __global__ __launch_bounds__(256) void gradsq_kernel(const DevTensor* __restrict
     int64_t ci = blockIdx.x;
     ChunkRef cr{};
     DevTensor t{};
-    if (ci < n_chunks) { cr = chunks[ci]; t = tensors[cr.tensor]; }
+    if (ci < n_chunks) { cr = chunks[ci]; t = tensors[cr.tensor]; t.is_bf16 &= DT_BF16; }
     while (ci < n_chunks) {
         const int64_t nci = ci + gridDim.x;
         ChunkRef ncr{};
         DevTensor nt{};
-        if (nci < n_chunks) { ncr = chunks[nci]; nt = tensors[ncr.tensor]; }
+        if (nci < n_chunks) { ncr = chunks[nci]; nt = tensors[ncr.tensor]; nt.is_bf16 &= DT_BF16; }
         const int64_t base = (int64_t)cr.chunk * CHUNK;
         if (t.is_bf16) {
             u32x2 raw[CHUNK / (256 * 4)];
@@ -241,7 +245,7 @@ int uniter_adamw_plan_create(const UniterAdamTensor* tensors, int64_t n_tensors,
         UH_CHECK_ARG(((uintptr_t)t.param % (t.param_is_bf16 ? 8 : 16) == 0) && ((uintptr_t)t.grad % (t.param_is_bf16 ? 8 : 16) == 0),
                      "param / grad pointers must be 8-byte (bf16) / 16-byte (fp32) aligned");
         UH_CHECK_ARG(!t.param_is_bf16 || ((uintptr_t)t.master % 16 == 0), "master copy must be 16-byte aligned");
-        dt[(size_t)i] = DevTensor{t.param, (void*)t.grad, t.master, t.exp_avg, t.exp_avg_sq, t.numel, t.group, t.param_is_bf16};
+        dt[(size_t)i] = DevTensor{t.param, (void*)t.grad, t.master, t.exp_avg, t.exp_avg_sq, t.numel, t.group, t.param_is_bf16 ? DT_BF16 : 0};
     }
     // chunks in ascending parameter-address order: with the parameters in one arena laid out in module order
     // (utils/arena.py) that is the order the next forward pass needs them in, which is what the segmented asynchronous
@@ -279,6 +283,18 @@ int uniter_adamw_plan_create(const UniterAdamTensor* tensors, int64_t n_tensors,
         return (int)e;
     }
     *plan_out = p;
+    return 0;
+}
+
+int uniter_adamw_plan_keep_grads(void* plan, const uint8_t* keep, int64_t n_tensors) {
+    UH_CHECK_ARG(plan != nullptr && keep != nullptr, "null pointer");
+    Plan* p = (Plan*)plan;
+    UH_CHECK_ARG(n_tensors == p->n_tensors, "one flag per tensor of the plan");
+    std::vector<DevTensor> dt((size_t)n_tensors);
+    UH_CHECK_HIP(hipMemcpy(dt.data(), p->d_tensors, dt.size() * sizeof(DevTensor), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n_tensors; ++i)
+        dt[(size_t)i].is_bf16 = (dt[(size_t)i].is_bf16 & DT_BF16) | (keep[i] ? DT_KEEP_GRAD : 0);
+    UH_CHECK_HIP(hipMemcpy(p->d_tensors, dt.data(), dt.size() * sizeof(DevTensor), hipMemcpyHostToDevice));
     return 0;
 }
 

@@ -96,6 +96,7 @@ ScratchLayout scratch_layout(const UniterEncoderShape& s) {
 // FFN1's epilogue saves act'(u) in the layer's `u` slot and the FFN2 data gradient multiplies by it (common.cuh, UH_ACT_SAVE_GRAD);
 // UNITER_AMD_SAVE_ACT_GRAD=0 keeps u and re-evaluates the derivative in the backward (the A/B of profiles/r06_save_act_grad_ab.txt)
 const int g_act_flags = [] { const char* e = getenv("UNITER_AMD_SAVE_ACT_GRAD"); return (e == nullptr || e[0] != '0') ? (int)UH_ACT_SAVE_GRAD : 0; }();
+thread_local bool g_grad_overwrite = false;       // uniter_encoder_set_grad_overwrite: consumed by the next backward call of this thread
 const bool g_fused_qkv_attn = [] { const char* e = getenv("UNITER_AMD_FUSED_QKV_ATTN"); return e == nullptr || e[0] != '0'; }();
 int g_chain = 0;     // overlapped kernel chains: a test / harness hook (uniter_encoder_debug_chain); measured neutral to -1 % at 32 x 96 tokens (EXPERIMENTS.md, round 4)
 struct Chain {
@@ -419,6 +420,20 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         ss = g_side.stream;
     }
     g_buckets.last_nb = 0;                      // (set again below when this call's deferred launch runs with buckets)
+    // uniter_encoder_set_grad_overwrite(1) before this call: the caller does not promise zeroed (or meaningful) parameter gradients —
+    // this call's results REPLACE them.  The deferred launch then writes instead of accumulating (no read of the old gradient, and the
+    // fused zero_grad of the optimizer skips these tensors); every other flow zeroes them first and accumulates as always.
+    const int grad_acc = g_grad_overwrite ? 0 : 1;
+    if (g_grad_overwrite && !defer_wg) {
+        for (int l = layer_begin; l < layer_end; ++l) {
+            const UniterLayerParams& Pz = layers[l];
+            void* gp[12] = {Pz.g_wqkv, Pz.g_bqkv, Pz.g_wo, Pz.g_bo, Pz.g_ln1_g, Pz.g_ln1_b, Pz.g_w1, Pz.g_b1, Pz.g_w2, Pz.g_b2, Pz.g_ln2_g, Pz.g_ln2_b};
+            const int64_t gn[12] = {3 * H * H, 3 * H, H * H, H, H, H, I * H, I, H * I, H, H, H};
+            for (int q = 0; q < 12; ++q)
+                if (gp[q] != nullptr) UH_CHECK_HIP(hipMemsetAsync(gp[q], 0, (size_t)gn[q] * sizeof(bf16_t), st));
+        }
+    }
+    g_grad_overwrite = 0;                       // (per call: the caller states it before every call that wants it)
     if (defer_wg) {
         for (int k = 0; k < 2; ++k)
             if (g_stage.busy[k] == nullptr) UH_CHECK_HIP(hipEventCreateWithFlags(&g_stage.busy[k], hipEventDisableTiming));
@@ -636,7 +651,7 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
             }
         }
         RC(fork(3));
-        const int mrc = uh::gemm_wgrad_multi((int)vdy.size(), vdy.data(), vx.data(), vdw.data(), vdb.data(), T, vN.data(), vK.data(), 1, ss,
+        const int mrc = uh::gemm_wgrad_multi((int)vdy.size(), vdy.data(), vx.data(), vdw.data(), vdb.data(), T, vN.data(), vK.data(), grad_acc, ss,
                                              (int)ln.size(), ln.data(), mbp);
         if (mrc != 0) {
             if (mrc == 1) uh_set_error("encoder backward: the deferred weight-gradient launch does not fit these shapes");
@@ -668,6 +683,11 @@ size_t uniter_encoder_wgrad_stage_bytes(const UniterEncoderShape* s, int32_t n_l
 int uniter_encoder_set_wgrad_stage(void* buf, size_t bytes) {
     g_stage.buf = (char*)buf;
     g_stage.bytes = buf != nullptr ? bytes : 0;
+    return 0;
+}
+
+int uniter_encoder_set_grad_overwrite(int32_t enable) {
+    g_grad_overwrite = enable != 0;
     return 0;
 }
 

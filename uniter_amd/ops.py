@@ -243,6 +243,23 @@ def _layer_table(layers, with_grads):
     return table, keep
 
 
+_range_cache = {}
+
+
+def _layer_grad_ranges(layers, keep):
+    """(frozenset of (first byte, byte length), [tensors]) of the parameter-gradient storages an encoder backward over `layers`
+    writes — what AdamW.lazy_zero may leave un-zeroed.  `keep` is _layer_table(layers, True)[1]; cached per table."""
+    key = (id(layers[0]) if layers else 0, len(layers), id(keep))
+    hit = _range_cache.get(key)
+    if hit is not None and hit[0] is keep:
+        return hit[1], hit[2]
+    tensors = [g for _, gs in keep for g in gs]
+    ranges = frozenset((g.data_ptr(), g.numel() * g.element_size()) for g in tensors)
+    _range_cache.clear()
+    _range_cache[key] = (keep, ranges, tensors)
+    return ranges, tensors
+
+
 def _shape(cfg_like, B, L, training):
     s = UniterEncoderShape()
     s.B, s.L, s.H, s.heads, s.I = B, L, cfg_like["H"], cfg_like["heads"], cfg_like["I"]
@@ -415,6 +432,18 @@ class _EncoderFn(torch.autograd.Function):
         scr_bytes = C.uniter_encoder_scratch_bytes(ctypes.byref(s))
         scratch = _scratch(("enc", xc.device.index), scr_bytes, xc.device)
         table, keep = _layer_table(layers, with_grads=True)
+        # lazy zero_grad (optim.AdamW.lazy_zero): after a fused step that left exactly these gradient storages alone, this backward
+        # REPLACES their contents (uniter_encoder_set_grad_overwrite); anything else that is marked undefined is zeroed first
+        g_ranges, g_tensors = _layer_grad_ranges(layers, keep)
+        overwrite = False
+        if _lib.lazy_undefined:
+            if g_ranges == _lib.lazy_ranges:
+                overwrite = True
+            else:
+                for t in _lib.lazy_tensors:
+                    t.zero_()
+            _lib.lazy_undefined = False
+        _lib.lazy_ranges, _lib.lazy_tensors = g_ranges, g_tensors
         # split the stack where an intermediate layer output received a gradient of its own
         if ctx.need_all:
             extra = [g for g in grads]
@@ -474,6 +503,7 @@ class _EncoderFn(torch.autograd.Function):
                 C.uniter_encoder_set_wgrad_stage(ptr(stage), st_bytes)
             else:
                 C.uniter_encoder_set_wgrad_stage(None, 0)       # (the registration is per thread and outlives a call)
+            C.uniter_encoder_set_grad_overwrite(1 if overwrite else 0)       # (per call: the library consumes it)
             C.uniter_encoder_backward(ctypes.byref(s), table, begin, end, x_in,
                                       None if ctx.packed is not None else ptr(mask_bias), ptr(dy), ptr(dx),
                                       ptr(ctx.acts), ptr(scratch), ctx.seed, ctx.off, st)

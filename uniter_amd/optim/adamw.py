@@ -21,6 +21,7 @@ MI355X specifics:
     stream for code that reads parameters / optimizer state some other way.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -62,6 +63,14 @@ class AdamW(Optimizer):
         self._grads_zeroed = False    # the last step zeroed the gradients itself (fused), zero_grad() has nothing to do
         self.fuse_zero_grad = False   # True: step() zeroes every gradient once read and the next zero_grad() is a no-op —
                                       # for loops that call zero_grad() right after step() (pretrain.py:332-334)
+        # lazy_zero (with a fused zero_grad only): the gradients the encoder's backward produces are NOT zeroed by the step — the next
+        # backward replaces them (uniter_encoder_set_grad_overwrite), so the update writes 2 bytes per parameter less and the deferred
+        # weight-gradient launch does not read the old values.  Like zero_grad(set_to_none=True): between step() and the next
+        # backward those `.grad` tensors hold stale values, not zeros; every reader inside this package (grad_norm, step, the
+        # allreduce — all after a backward) sees finished gradients, and an optimizer call without a backward in between zeroes
+        # them first (_lib.lazy_resolve).  UNITER_AMD_LAZY_ZERO=0 switches it off.
+        self.lazy_zero = os.environ.get("UNITER_AMD_LAZY_ZERO", "1") != "0"
+        self._keep_ranges = None      # the _lib.lazy_ranges the plan's keep flags were computed from
 
     # ---- plan management ------------------------------------------------------------------------------
     def _active(self):
@@ -137,6 +146,27 @@ class AdamW(Optimizer):
         handle = ctypes.c_void_p()
         C.uniter_adamw_plan_create(table, len(active), ctypes.byref(handle))
         self._plan, self._plan_groups = handle, groups
+        self._plan_grads = [(int(table[k].grad), int(table[k].numel) * (2 if table[k].param_is_bf16 else 4)) for k in range(len(active))]
+        self._keep_ranges = None      # (a new device table: no keep flags yet)
+        self._keep_any = False
+
+    def _sync_keep_flags(self):
+        """Mark the plan's tensors whose gradient storage lies inside what the encoder's backward overwrites (lazy_zero)."""
+        ranges = _lib.lazy_ranges if self.lazy_zero else frozenset()
+        if ranges is self._keep_ranges or ranges == self._keep_ranges:
+            return self._keep_any
+        spans = sorted(ranges)
+        import bisect
+        starts = [a for a, _ in spans]
+        flags = (ctypes.c_uint8 * len(self._plan_grads))()
+        for k, (g, nbytes) in enumerate(self._plan_grads):
+            j = bisect.bisect_right(starts, g) - 1
+            if j >= 0 and g + nbytes <= spans[j][0] + spans[j][1]:
+                flags[k] = 1
+        C.uniter_adamw_plan_keep_grads(self._plan, flags, len(self._plan_grads))
+        self._keep_ranges = ranges
+        self._keep_any = any(flags)
+        return self._keep_any
 
     def _destroy_plan(self):
         if self._plan is not None:
@@ -257,6 +287,7 @@ class AdamW(Optimizer):
         """Global L2 norm of all gradients times `grad_scale`, as a 0-dim device tensor (no sync), and arm the fused
         clipping coefficient `grad_scale * min(1, max_norm / (norm + 1e-6))` for the next step()."""
         _lib.join_wgrads()                # weight gradients a training loop left in flight (ops.defer_wgrad_join)
+        _lib.lazy_resolve()               # (no backward since a lazy step: the kept gradients become the zeros zero_grad() promised)
         if not self._ensure_plan():
             return torch.zeros((), device='cuda')
         dev = self._plan_groups[0][1][0].device
@@ -275,6 +306,7 @@ class AdamW(Optimizer):
         if closure is not None:
             loss = closure()
         _lib.join_wgrads()
+        _lib.lazy_resolve()
         if not self._ensure_plan(in_step=True):
             return loss           # nothing has a gradient: no-op, like the reference's dummy first step (pretrain.py:261-263)
         self._grads_zeroed = False    # whatever an earlier fused step zeroed has been written again by the backward in between
@@ -292,15 +324,19 @@ class AdamW(Optimizer):
         self._clip = None
         if self._overlap is not None and not torch.cuda.is_current_stream_capturing():
             arr, n, fuse = self._overlap
+            kept = self._sync_keep_flags() if fuse else False
             C.uniter_adamw_step_async(self._plan, hyper, len(self._plan_groups), ptr(clip[1:]) if clip is not None else None,
                                       arr, n, 1 if fuse else 0, _lib.stream_ptr())
             self._grads_zeroed = fuse
+            _lib.lazy_undefined = bool(kept)
             _lib.set_async_pending(True)
             return loss
         if self.fuse_zero_grad:
+            kept = self._sync_keep_flags()
             C.uniter_adamw_step_zero(self._plan, hyper, len(self._plan_groups), ptr(clip[1:]) if clip is not None else None,
                                      _lib.stream_ptr())
             self._grads_zeroed = True
+            _lib.lazy_undefined = bool(kept)      # the kept gradients are stale until the next encoder backward replaces them
             return loss
         C.uniter_adamw_step(self._plan, hyper, len(self._plan_groups), ptr(clip[1:]) if clip is not None else None,
                             _lib.stream_ptr())
@@ -311,6 +347,7 @@ class AdamW(Optimizer):
         one flat arena (utils.arena), which must survive the step."""
         _lib.join_wgrads()
         if set_to_none:
+            _lib.lazy_resolve()
             self.synchronize()
             self._grads_zeroed = False
             self._flat_grads = None
