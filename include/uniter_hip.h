@@ -441,6 +441,15 @@ int uniter_encoder_defer_side_join(int enable);
  * deferred launch zero the tensors first and accumulate — same result, no saving.  Gradient accumulation over several backward calls
  * (pretrain.py:298-312): state it for the first call of an optimizer step only. */
 int uniter_encoder_set_grad_overwrite(int32_t enable);
+
+/* Gradient-norm partials (round 6).  After uniter_encoder_set_grad_sq(1) (per thread, sticky) a uniter_encoder_backward call whose
+ * parameter gradients go out as the one deferred launch — and not as data-parallel buckets, whose gradients are reduced across ranks
+ * before their norm is taken — also leaves one float per 256 x 256 weight-gradient tile: the sum of squares of the bf16 values it stored
+ * (old gradient included when it accumulated).  uniter_encoder_last_grad_sq returns that device array (library-owned, valid until the
+ * next backward call of this thread; written on the weight-gradient stream: join it first) and its length, or NULL / 0 when the last
+ * call produced none.  Together the floats are sum g^2 over the wqkv, wo, w1, w2 gradients of the layers of that call. */
+int uniter_encoder_set_grad_sq(int32_t enable);
+int uniter_encoder_last_grad_sq(void** partials_out, int32_t* n_out);
 int uniter_encoder_side_join(void* stream);
 /* The same from ANY thread: makes `stream` wait for the weight-gradient streams of every thread of this process that left a
  * backward call un-joined on the current device (autograd runs backward on its own thread, the optimizer runs on the caller's).
@@ -511,16 +520,25 @@ typedef struct UniterAdamGroup {
 /* Opaque plan: the tensor table lives on the device; build once, reuse every step. */
 int uniter_adamw_plan_create(const UniterAdamTensor* tensors, int64_t n_tensors, void** plan_out);
 int uniter_adamw_plan_destroy(void* plan);
-/* keep[i] != 0: uniter_adamw_step_zero / _step_async leave the gradient of tensor i of the plan as it is (its producer overwrites it in
- * the next backward pass, uniter_encoder_set_grad_overwrite) — 2 bytes per parameter less written by the update.  One flag per tensor,
- * in the order of uniter_adamw_plan_create's table; all zero restores the default. */
-int uniter_adamw_plan_keep_grads(void* plan, const uint8_t* keep, int64_t n_tensors);
+/* Per-tensor flags of a plan (one byte per tensor, in the order of uniter_adamw_plan_create's table; all zero = the default):
+ *   UNITER_ADAM_KEEP_GRAD  uniter_adamw_step_zero / _step_async leave this tensor's gradient as it is — its producer overwrites it in
+ *                          the next backward pass (uniter_encoder_set_grad_overwrite): 2 bytes per parameter less written by the update;
+ *   UNITER_ADAM_SKIP_NORM  uniter_adamw_grad_norm_ex does not read this tensor's gradient: the caller passes sums of squares that stand
+ *                          for it (uniter_encoder_last_grad_sq). */
+#define UNITER_ADAM_KEEP_GRAD 1
+#define UNITER_ADAM_SKIP_NORM 2
+int uniter_adamw_plan_set_flags(void* plan, const uint8_t* flags, int64_t n_tensors);
 
 /* norm_out[0] = sqrt(sum g^2) * grad_scale ; norm_out[1] = clip coefficient
  *   coef = grad_scale * min(1, max_norm / (norm + 1e-6))     (max_norm <= 0: coef = grad_scale)
  * = torch.nn.utils.clip_grad_norm_ as called at pretrain.py:329-331, with the 1/world averaging of
  * the allreduce (utils/distributed.py:35) foldable into grad_scale.  No host synchronisation. */
 int uniter_adamw_grad_norm(void* plan, float grad_scale, float max_norm, float* norm_out, void* stream);
+/* The same with `n_extra` partial sums of squares (device floats) added to the total in place of the tensors flagged
+ * UNITER_ADAM_SKIP_NORM, whose gradients are then not read: the weights' share of pretrain.py:329-331's norm comes out of the launch
+ * that produced those gradients (uniter_encoder_last_grad_sq) instead of a second pass over 170 MB.  n_extra == 0: uniter_adamw_grad_norm. */
+int uniter_adamw_grad_norm_ex(void* plan, float grad_scale, float max_norm, float* norm_out, const float* extra, int32_t n_extra,
+                              void* stream);
 
 /* One AdamW update of every tensor of the plan.  clip_coef (device pointer, may be NULL = 1.0)
  * multiplies every gradient element on the fly (fused clipping). */

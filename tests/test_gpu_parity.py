@@ -726,6 +726,57 @@ def test_lazy_zero_grad_is_bit_identical_over_steps(tmp_path):
         assert torch.equal(out[0][n], out[1][n]), n
 
 
+def test_folded_gradient_norm_equals_the_full_reduction(tmp_path, monkeypatch):
+    """AdamW.fold_norm (round 6): the encoder weights' share of sum g^2 comes out of the deferred weight-gradient launch
+    (uniter_encoder_last_grad_sq -> uniter_adamw_grad_norm_ex).  Same gradients, folded vs full reduction: equal to fp32 summation
+    order; after a second accumulated micro-batch still equal; after an in-place edit of one gradient the fold must notice
+    (version counters) and give the full reduction's number; with the lazy zero_grad in between as well."""
+    import json
+    from uniter_amd import _lib as L, ops
+    from uniter_amd.model.nlvr2 import UniterForNlvr2PairedAttn
+    from uniter_amd.optim import build_optimizer, clip_grad_norm_
+    from uniter_amd.utils.arena import flatten_model
+    from uniter_amd.utils.misc import Struct
+    from uniter_amd.utils.synthetic import make_batch
+    monkeypatch.setattr(ops, "_FOLD_NORM", True)              # (opt-in: the backward is asked for the per-tile sums)
+    cfg = dict(BASE_CFG, num_hidden_layers=2)
+    path = tmp_path / "fn.json"
+    path.write_text(json.dumps(cfg))
+    torch.manual_seed(12)
+    model = UniterForNlvr2PairedAttn.from_pretrained(str(path), {}, img_dim=2048)
+    model.init_type_embedding()
+    _prep(model)
+    flatten_model(model)
+    opt = build_optimizer(model, Struct(dict(optim='adamw', learning_rate=1e-3, betas=(0.9, 0.98), weight_decay=0.01)))
+    opt.fuse_zero_grad = True
+    batches = [_to_dev(make_batch('nlvr2', 8, seed=30 + k)) for k in range(2)]
+
+    def both():
+        opt.fold_norm = True
+        folded_used = L.sq_state is not None
+        a = float(clip_grad_norm_(opt, 1.0))
+        opt.fold_norm = False
+        b = float(clip_grad_norm_(opt, 1.0))
+        opt.fold_norm = True
+        return a, b, folded_used
+
+    for step in range(3):
+        model(batches[0], compute_loss=True).mean().backward()
+        a, b, used = both()
+        assert used and b > 0 and abs(a - b) <= 2e-5 * b, (step, a, b)
+        model(batches[1], compute_loss=True).mean().backward()          # accumulation: the sums are those of the running total
+        a, b, used = both()
+        assert used and abs(a - b) <= 2e-5 * b, (step, a, b)
+        if step == 1:
+            w = model.uniter.encoder.layer[0].output.dense.weight
+            w.grad.mul_(3.0)                                            # someone edits a gradient in place
+            a, b, _ = both()
+            assert a == b, (a, b)                                       # the fold stood down: the very same reduction
+        opt.step()
+        opt.zero_grad()
+    torch.cuda.synchronize()
+
+
 def test_adamw_state_dict_roundtrip_keeps_fp32_state(golden):
     """save -> load -> step for bf16 parameters: torch would cast the fp32 moments / master weights to bf16 on load."""
     from uniter_amd.model.pretrain import UniterForPretraining

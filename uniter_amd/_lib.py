@@ -144,6 +144,8 @@ SIGNATURES = {
     "uniter_encoder_debug_side_stream": (c_int, [c_int]),
     "uniter_encoder_defer_side_join": (c_int, [c_int]),
     "uniter_encoder_set_grad_overwrite": (c_int, [c_int32]),
+    "uniter_encoder_set_grad_sq": (c_int, [c_int32]),
+    "uniter_encoder_last_grad_sq": (c_int, [POINTER(c_void_p), POINTER(c_int32)]),
     "uniter_encoder_side_join": (c_int, [c_void_p]),
     "uniter_encoder_side_stream": (c_int, [POINTER(c_void_p)]),
     "uniter_encoder_set_grad_buckets": (c_int, [c_int32]),
@@ -160,7 +162,8 @@ SIGNATURES = {
     "uniter_cls_ce_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "uniter_adamw_plan_create": (c_int, [POINTER(UniterAdamTensor), _I, POINTER(c_void_p)]),
     "uniter_adamw_plan_destroy": (c_int, [_P]),
-    "uniter_adamw_plan_keep_grads": (c_int, [_P, _P, c_int64]),
+    "uniter_adamw_plan_set_flags": (c_int, [_P, _P, c_int64]),
+    "uniter_adamw_grad_norm_ex": (c_int, [_P, c_float, c_float, _P, _P, c_int32, _P]),
     "uniter_adamw_grad_norm": (c_int, [_P, c_float, c_float, _P, _P]),
     "uniter_adamw_step": (c_int, [_P, POINTER(UniterAdamGroup), c_int32, _P, _P]),
     "uniter_adamw_step_dev": (c_int, [_P, _P, c_int32, _P, _P]),
@@ -328,6 +331,11 @@ def grad_attach_epoch():
 # marked undefined, so the fused optimizer step need not zero them and the deferred launch need not read them.
 #   lazy_ranges      {(first byte, byte length)} of the gradient storages the last encoder backward wrote (per layer, fused q|k|v once)
 #   lazy_undefined   True between a fused step that skipped those storages and the backward that overwrites them
+# Folded gradient norm (AdamW.fold_norm, round 6): the deferred weight-gradient launch of the last encoder backward left per-tile sums of
+# squares of the gradients it stored; grad_norm() adds them instead of re-reading those tensors — as long as nothing has touched the
+# tensors since (torch's version counters: an in-place op, an allreduce) and the optimizer's plan holds exactly these tensors.
+#   sq_state   None or dict(ptr, n, ranges = frozenset of (first byte, byte length) of the weight gradients covered, tensors, versions)
+sq_state = None
 lazy_ranges = frozenset()
 lazy_tensors = []        # the gradient tensors behind lazy_ranges (zeroed explicitly when an undefined state has to be resolved)
 lazy_undefined = False

@@ -32,7 +32,7 @@ struct DevTensor {
     int32_t is_bf16;     // bit 0: bf16 parameter / gradient; bit 1 (DT_KEEP_GRAD): the fused zero_grad leaves this gradient alone — its
                          // producer overwrites it in the next backward pass (uniter_adamw_plan_keep_grads)
 };
-constexpr int32_t DT_BF16 = 1, DT_KEEP_GRAD = 2;
+constexpr int32_t DT_BF16 = 1, DT_KEEP_GRAD = 2, DT_SKIP_NORM = 4;   // (bits 1, 2: uniter_adamw_plan_set_flags)
 struct ChunkRef {
     int32_t tensor;
     int32_t chunk;     // chunk index inside the tensor
@@ -52,6 +52,9 @@ struct Plan {
     int64_t n_tensors = 0;
     int64_t n_chunks = 0;
     int norm_blocks = 0;
+    std::vector<ChunkRef> h_chunks;  // host copy of d_chunks (uniter_adamw_plan_set_flags builds the filtered list from it)
+    ChunkRef* d_norm_chunks = nullptr;   // the chunks of the tensors NOT flagged UNITER_ADAM_SKIP_NORM (nullptr: no tensor is flagged)
+    int64_t n_norm_chunks = 0;
 };
 
 // `zero_grads`: the gradient element is overwritten with zero once it has been read — optimizer.zero_grad() folded into
@@ -207,10 +210,12 @@ __global__ __launch_bounds__(256) void gradsq_kernel(const DevTensor* __restrict
 
 // norm_out[0] = sqrt(sum)*grad_scale ; norm_out[1] = grad_scale * min(1, max_norm/(norm+1e-6))
 __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restrict__ partial, int n,
-                                                            float grad_scale, float max_norm, float* __restrict__ out) {
+                                                            float grad_scale, float max_norm, float* __restrict__ out,
+                                                            const float* __restrict__ extra, int n_extra) {
     __shared__ float red[4];
     float acc = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    for (int i = threadIdx.x; i < n_extra; i += 256) acc += extra[i];      // per-tile sums a producer kernel left (grad_norm_ex)
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -266,6 +271,7 @@ int uniter_adamw_plan_create(const UniterAdamTensor* tensors, int64_t n_tensors,
     }
     Plan* p = new Plan();
     p->chunk_addr = chunk_addr;
+    p->h_chunks = ch;
     p->n_tensors = n_tensors;
     p->n_chunks = (int64_t)ch.size();
     p->norm_blocks = (int)(p->n_chunks < 1024 ? p->n_chunks : 1024);
@@ -286,15 +292,29 @@ int uniter_adamw_plan_create(const UniterAdamTensor* tensors, int64_t n_tensors,
     return 0;
 }
 
-int uniter_adamw_plan_keep_grads(void* plan, const uint8_t* keep, int64_t n_tensors) {
-    UH_CHECK_ARG(plan != nullptr && keep != nullptr, "null pointer");
+int uniter_adamw_plan_set_flags(void* plan, const uint8_t* flags, int64_t n_tensors) {
+    UH_CHECK_ARG(plan != nullptr && flags != nullptr, "null pointer");
     Plan* p = (Plan*)plan;
-    UH_CHECK_ARG(n_tensors == p->n_tensors, "one flag per tensor of the plan");
+    UH_CHECK_ARG(n_tensors == p->n_tensors, "one flag byte per tensor of the plan");
     std::vector<DevTensor> dt((size_t)n_tensors);
     UH_CHECK_HIP(hipMemcpy(dt.data(), p->d_tensors, dt.size() * sizeof(DevTensor), hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < n_tensors; ++i)
-        dt[(size_t)i].is_bf16 = (dt[(size_t)i].is_bf16 & DT_BF16) | (keep[i] ? DT_KEEP_GRAD : 0);
+    bool any_skip = false;
+    for (int64_t i = 0; i < n_tensors; ++i) {
+        dt[(size_t)i].is_bf16 = (dt[(size_t)i].is_bf16 & DT_BF16) | ((flags[i] & UNITER_ADAM_KEEP_GRAD) ? DT_KEEP_GRAD : 0) |
+                                ((flags[i] & UNITER_ADAM_SKIP_NORM) ? DT_SKIP_NORM : 0);
+        any_skip = any_skip || (flags[i] & UNITER_ADAM_SKIP_NORM);
+    }
     UH_CHECK_HIP(hipMemcpy(p->d_tensors, dt.data(), dt.size() * sizeof(DevTensor), hipMemcpyHostToDevice));
+    if (p->d_norm_chunks != nullptr) { (void)hipFree(p->d_norm_chunks); p->d_norm_chunks = nullptr; }
+    p->n_norm_chunks = 0;
+    if (any_skip) {
+        std::vector<ChunkRef> sel;
+        for (const ChunkRef& c : p->h_chunks)
+            if (!(flags[c.tensor] & UNITER_ADAM_SKIP_NORM)) sel.push_back(c);
+        UH_CHECK_HIP(hipMalloc(&p->d_norm_chunks, std::max<size_t>(sel.size(), 1) * sizeof(ChunkRef)));
+        if (!sel.empty()) UH_CHECK_HIP(hipMemcpy(p->d_norm_chunks, sel.data(), sel.size() * sizeof(ChunkRef), hipMemcpyHostToDevice));
+        p->n_norm_chunks = (int64_t)sel.size();
+    }
     return 0;
 }
 
@@ -304,21 +324,33 @@ int uniter_adamw_plan_destroy(void* plan) {
     (void)hipFree(p->d_tensors);
     (void)hipFree(p->d_chunks);
     (void)hipFree(p->d_partial);
+    if (p->d_norm_chunks != nullptr) (void)hipFree(p->d_norm_chunks);
     delete p;
     return 0;
 }
 
-int uniter_adamw_grad_norm(void* plan, float grad_scale, float max_norm, float* norm_out, void* stream) {
+int uniter_adamw_grad_norm_ex(void* plan, float grad_scale, float max_norm, float* norm_out, const float* extra, int32_t n_extra,
+                              void* stream) {
     UH_CHECK_ARG(plan != nullptr && norm_out != nullptr, "null pointer");
+    UH_CHECK_ARG(n_extra >= 0 && (n_extra == 0 || extra != nullptr), "bad list of extra partial sums");
     Plan* p = (Plan*)plan;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gradsq_kernel, dim3(p->norm_blocks), dim3(256), 0, st,
-                       (const DevTensor*)p->d_tensors, (const ChunkRef*)p->d_chunks, p->n_chunks, p->d_partial);
+    // extra partial sums stand for the tensors flagged UNITER_ADAM_SKIP_NORM: the reduction then walks the other tensors' chunks only
+    const bool folded = n_extra > 0 && p->d_norm_chunks != nullptr;
+    UH_CHECK_ARG(n_extra == 0 || folded, "extra partial sums need tensors flagged UNITER_ADAM_SKIP_NORM (uniter_adamw_plan_set_flags)");
+    const ChunkRef* chunks = folded ? p->d_norm_chunks : p->d_chunks;
+    const int64_t n_chunks = folded ? p->n_norm_chunks : p->n_chunks;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, p->norm_blocks));
+    hipLaunchKernelGGL(gradsq_kernel, dim3(blocks), dim3(256), 0, st, (const DevTensor*)p->d_tensors, chunks, n_chunks, p->d_partial);
     UH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)p->d_partial, p->norm_blocks,
-                       grad_scale, max_norm, norm_out);
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)p->d_partial, blocks,
+                       grad_scale, max_norm, norm_out, extra, (int)n_extra);
     UH_LAUNCH_CHECK();
     return 0;
+}
+
+int uniter_adamw_grad_norm(void* plan, float grad_scale, float max_norm, float* norm_out, void* stream) {
+    return uniter_adamw_grad_norm_ex(plan, grad_scale, max_norm, norm_out, nullptr, 0, stream);
 }
 
 static int fill_hyper(const UniterAdamGroup* groups, int32_t n_groups, HyperTable* ht) {

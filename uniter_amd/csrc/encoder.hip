@@ -96,6 +96,10 @@ ScratchLayout scratch_layout(const UniterEncoderShape& s) {
 // FFN1's epilogue saves act'(u) in the layer's `u` slot and the FFN2 data gradient multiplies by it (common.cuh, UH_ACT_SAVE_GRAD);
 // UNITER_AMD_SAVE_ACT_GRAD=0 keeps u and re-evaluates the derivative in the backward (the A/B of profiles/r06_save_act_grad_ab.txt)
 const int g_act_flags = [] { const char* e = getenv("UNITER_AMD_SAVE_ACT_GRAD"); return (e == nullptr || e[0] != '0') ? (int)UH_ACT_SAVE_GRAD : 0; }();
+// uniter_encoder_set_grad_sq / uniter_encoder_last_grad_sq: the deferred launch leaves one sum of squares per weight-gradient tile
+thread_local bool g_grad_sq_request = false;
+thread_local float* g_last_sq = nullptr;
+thread_local int g_last_sq_n = 0;
 thread_local bool g_grad_overwrite = false;       // uniter_encoder_set_grad_overwrite: consumed by the next backward call of this thread
 const bool g_fused_qkv_attn = [] { const char* e = getenv("UNITER_AMD_FUSED_QKV_ATTN"); return e == nullptr || e[0] != '0'; }();
 int g_chain = 0;     // overlapped kernel chains: a test / harness hook (uniter_encoder_debug_chain); measured neutral to -1 % at 32 x 96 tokens (EXPERIMENTS.md, round 4)
@@ -434,6 +438,8 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
         }
     }
     g_grad_overwrite = 0;                       // (per call: the caller states it before every call that wants it)
+    g_last_sq = nullptr;                        // (set again below when this call's deferred launch produced the per-tile sums)
+    g_last_sq_n = 0;
     if (defer_wg) {
         for (int k = 0; k < 2; ++k)
             if (g_stage.busy[k] == nullptr) UH_CHECK_HIP(hipEventCreateWithFlags(&g_stage.busy[k], hipEventDisableTiming));
@@ -651,8 +657,13 @@ int uniter_encoder_backward(const UniterEncoderShape* s, const UniterLayerParams
             }
         }
         RC(fork(3));
+        float* sq_ptr = nullptr;
+        int sq_n = 0;
+        const bool want_sq = g_grad_sq_request && mbp == nullptr;
         const int mrc = uh::gemm_wgrad_multi((int)vdy.size(), vdy.data(), vx.data(), vdw.data(), vdb.data(), T, vN.data(), vK.data(), grad_acc, ss,
-                                             (int)ln.size(), ln.data(), mbp);
+                                             (int)ln.size(), ln.data(), mbp, want_sq ? &sq_ptr : nullptr, want_sq ? &sq_n : nullptr);
+        g_last_sq = sq_ptr;
+        g_last_sq_n = sq_n;
         if (mrc != 0) {
             if (mrc == 1) uh_set_error("encoder backward: the deferred weight-gradient launch does not fit these shapes");
             return mrc == 1 ? -1 : mrc;
@@ -683,6 +694,18 @@ size_t uniter_encoder_wgrad_stage_bytes(const UniterEncoderShape* s, int32_t n_l
 int uniter_encoder_set_wgrad_stage(void* buf, size_t bytes) {
     g_stage.buf = (char*)buf;
     g_stage.bytes = buf != nullptr ? bytes : 0;
+    return 0;
+}
+
+int uniter_encoder_set_grad_sq(int32_t enable) {
+    g_grad_sq_request = enable != 0;
+    return 0;
+}
+
+int uniter_encoder_last_grad_sq(void** partials_out, int32_t* n_out) {
+    if (partials_out == nullptr || n_out == nullptr) { uh_set_error("encoder_last_grad_sq: null pointer"); return -1; }
+    *partials_out = (void*)g_last_sq;
+    *n_out = g_last_sq_n;
     return 0;
 }
 

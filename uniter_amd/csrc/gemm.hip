@@ -1744,6 +1744,8 @@ struct MultiState {
     hipEvent_t pinned_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int next = 0;
     float* tail_slabs[16] = {nullptr};                       // per device: fp32 slabs of the tiles that run as two K slices (64 x 256 KiB)
+    float* sq[16] = {nullptr};                               // per device: per-tile sums of squares of the last launch that asked for them
+    int sq_cap[16] = {0};
 };
 thread_local MultiState g_multi;
 constexpr int kMultiTailMax = 8;                             // tiles per XCD beyond whole rounds that are split (more: they run whole)
@@ -1751,7 +1753,9 @@ constexpr int kMultiTailMax = 8;                             // tiles per XCD be
 
 int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* const* dw, void* const* db, int64_t M,
                      const int64_t* N, const int64_t* K, int accumulate, hipStream_t st, int n_ln, const LnColsJob* ln,
-                     const MultiBuckets* buckets) {
+                     const MultiBuckets* buckets, float** sq_out, int* sq_n) {
+    if (sq_out != nullptr) *sq_out = nullptr;
+    if (sq_n != nullptr) *sq_n = 0;
     if (n < 1 || n > 128) { uh_set_error("gemm_wgrad_multi: 1..128 problems"); return -1; }
     if (buckets != nullptr && (buckets->nb < 1 || buckets->nb > G8_MAX_BUCKETS || buckets->prob_bucket == nullptr || buckets->flag == nullptr ||
                                buckets->count == nullptr || (n_ln > 0 && buckets->ln_bucket == nullptr))) {
@@ -1928,11 +1932,22 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
         for (int k = 0; k < bk.nb; ++k)
             grid_blocks += ((bk.strip_start[k + 1] - bk.strip_start[k] + 7) & ~7) + 8 * (bk.slot_start[k + 1] - bk.slot_start[k]);
     }
+    float* sq_dev = nullptr;
+    if (sq_out != nullptr && sq_n != nullptr && buckets == nullptr && dev >= 0 && dev < 16) {
+        if (g_multi.sq_cap[dev] < tiles) {
+            if (g_multi.sq[dev] != nullptr) (void)hipFree(g_multi.sq[dev]);
+            g_multi.sq[dev] = nullptr;
+            g_multi.sq_cap[dev] = 0;
+            if (hipMalloc(&g_multi.sq[dev], (size_t)tiles * sizeof(float)) == hipSuccess) g_multi.sq_cap[dev] = tiles;
+        }
+        sq_dev = g_multi.sq[dev];
+    }
     hipLaunchKernelGGL(gemm8_multi_kernel, dim3(grid_blocks), dim3(G8_THREADS), G8_LDS_BYTES, st,
                        (const GemmArgs*)T.dev, (const int*)((const char*)T.dev + meta_off), n, per, full, gemm_blocks,
                        (const G8LnJob*)((const char*)T.dev + ln_off), ln_strips_per_job, strips, tail_pairs, tail_slabs, stamp_dev,
-                       lead_strips, bk, lead_tiles, lead_strips2);
+                       lead_strips, bk, lead_tiles, lead_strips2, sq_dev);
     UH_LAUNCH_CHECK();
+    if (sq_dev != nullptr) { *sq_out = sq_dev; *sq_n = tiles; }
     if (stamp_dev != nullptr) {                              // harness profiling: synchronous, prints the launch's schedule
         const int nb = gemm_blocks + strips + n_ln * ln_strips_per_job;
         std::vector<unsigned long long> hs((size_t)2 * nb);

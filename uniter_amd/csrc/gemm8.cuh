@@ -535,6 +535,7 @@ __device__ __forceinline__ void gemm8_tile(const GemmArgs& p, const int bx, cons
     const G8Epi<EPI> ep(p);
     const int ncol = n0 + wc * 32 + (g & 1) * 16 + (g >> 1) * 8;           // + nq * 128
     uint32_t biasw[2][4];
+    float sq = 0.f;                                          // EPI_WGRAD with sq_out: sum of squares of what this thread stores
 #pragma unroll
     for (int nq = 0; nq < 2; ++nq) ep.template bias_words<8>(p, ncol + nq * 128, biasw[nq]);
 #pragma unroll
@@ -551,7 +552,30 @@ __device__ __forceinline__ void gemm8_tile(const GemmArgs& p, const int bx, cons
                 float v[8];
                 g8_swap8(acc[mq][nq][0][b], acc[mq][nq][1][b], v);
                 ep.template emit<8>(p, by, m0 + mq * 128 + wr * 64 + b * 16 + i, ncol + nq * 128, v, auxw[nq][b], biasw[nq]);
+                if constexpr (EPI == EPI_WGRAD) {
+                    if (p.sq_out != nullptr && m0 + mq * 128 + wr * 64 + b * 16 + i < p.M) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float r = bf2f(f2bf(v[e])); sq += r * r; }     // (v holds the final value: emit added the old gradient)
+                    }
+                }
             }
+    }
+    if constexpr (EPI == EPI_WGRAD) {
+        // one float per tile, summed in a fixed order (lanes by butterfly, waves 0..7 by thread 0): the gradient norm is as
+        // deterministic as the separate reduction kernel it replaces for these tensors (adamw.hip, uniter_adamw_grad_norm_ex)
+        if (p.sq_out != nullptr && !ep.to_partial) {
+            sq = wave_sum(sq);
+            __syncthreads();                                 // (every wave is past the K loop and the slab exchange: LDS is free)
+            float* red = reinterpret_cast<float*>(smem_raw);
+            if (lane == 0) red[wid] = sq;
+            __syncthreads();
+            if (t == 0) {
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < G8_THREADS / 64; ++w) tot += red[w];
+                *p.sq_out = tot;
+            }
+        }
     }
     if constexpr (!TRA) chain_signal(p.chain, m0, min(256, p.M - m0));    // (the epilogue's stores are write-through already)
 }
@@ -1012,7 +1036,7 @@ __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_multi_kernel(const GemmAr
                                                                     const int bias_strips, unsigned* __restrict__ tail_pairs,
                                                                     float* __restrict__ tail_slabs, unsigned long long* __restrict__ stamps,
                                                                     const int lead_strips, const G8Buckets bk, const int lead_tiles,
-                                                                    const int lead_strips2) {
+                                                                    const int lead_strips2, float* __restrict__ sq) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // Block order (all four counts multiples of 8, so a tile keeps the XCD its index implies): `lead_tiles` tiles, `lead_strips`
     // LayerNorm strips, `lead_strips2` more strips, the remaining tiles, the remaining strips.  The CUs that start with one 28 us
@@ -1115,6 +1139,7 @@ __global__ __launch_bounds__(G8_THREADS, 2) void gemm8_multi_kernel(const GemmAr
     const int tm = tiles_n >= tiles_m ? bx % tiles_m : bx / tiles_n;      // longer tile dimension outermost
     const int tn = tiles_n >= tiles_m ? bx / tiles_m : bx % tiles_n;
     const int tile = tm * tiles_n + tn;
+    p.sq_out = sq != nullptr ? sq + pos : nullptr;           // (plain order only: a data-parallel step norms the REDUCED gradients)
     if (slot >= 0) {
         if (tn == 0 && p.C2 != nullptr) {                   // this tile also sums the bias gradient over the WHOLE contraction
             if (slice == 1) return;

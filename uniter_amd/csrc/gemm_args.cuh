@@ -34,6 +34,8 @@ struct GemmArgs {
     int relu;             // EPI_BIAS_DROP_RES: 1 = clamp at zero after the bias, before the dropout (Linear + ReLU + Dropout heads);
                           // EPI_BIAS_GELU / EPI_GELU_BWD: the activation (UH_ACT_*: 0 = erf GELU, 1 = ReLU, 2 = swish)
     unsigned* pair;       // gemm8, two K slices combined inside the launch: one counter per output tile (zero between launches)
+    float* sq_out;        // gemm8 multi launch, EPI_WGRAD: this tile's sum of squares of the STORED (bf16-rounded) gradient values goes
+                          // here (one float per tile; the gradient norm adds them instead of re-reading the weights' gradients)
 #ifdef UNITER_GEMM_PROBE
     unsigned long long* probe;   // cycle stamps of wave 0 of every workgroup: [block][kt][5] (profiling builds only)
 #endif

@@ -85,7 +85,9 @@ struct LnColsJob { const void* dy; const void* z; const float* mean; const float
 struct MultiBuckets { int nb; const int* prob_bucket; const int* ln_bucket; unsigned* const* flag; unsigned* count; unsigned epoch; };
 int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* const* dw, void* const* db, int64_t M,
                      const int64_t* N, const int64_t* K, int accumulate, hipStream_t st, int n_ln = 0, const LnColsJob* ln = nullptr,
-                     const MultiBuckets* buckets = nullptr);
+                     const MultiBuckets* buckets = nullptr, float** sq_out = nullptr, int* sq_n = nullptr);
+// (sq_out / sq_n: when given and the launch is not bucketed, *sq_out receives a library-owned device array of *sq_n floats that the
+//  launch fills with one sum of squares of the stored gradient values per weight tile — the weights' share of the gradient norm)
 int gemm_group_autotune(int n, int64_t M, const int64_t* N, const int64_t* K, hipStream_t st);
 void gemm_debug_force(int cfg, int splits);
 int gemm_autotune(int kind, int64_t M, int64_t N, int64_t K, hipStream_t st);

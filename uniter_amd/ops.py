@@ -243,6 +243,16 @@ def _layer_table(layers, with_grads):
     return table, keep
 
 
+# Folded gradient norm (optim.AdamW.fold_norm): opt-in (UNITER_AMD_FOLD_NORM=1 or set_fold_norm(True)).  Measured a wash on the c2 step:
+# the gradient reduction gets 20 us shorter and AdamW 29 us longer, because the reduction was also what brought the gradients into the
+# Infinity Cache for the update that follows it (profiles/r06_fold_norm_ab.txt).
+_FOLD_NORM = os.environ.get("UNITER_AMD_FOLD_NORM", "0") == "1"
+
+
+def set_fold_norm(enable):
+    """Ask encoder backward calls for the per-tile sums of squares of their weight gradients (see optim.AdamW.fold_norm)."""
+    global _FOLD_NORM
+    _FOLD_NORM = bool(enable)
 _range_cache = {}
 
 
@@ -444,6 +454,7 @@ class _EncoderFn(torch.autograd.Function):
                     t.zero_()
             _lib.lazy_undefined = False
         _lib.lazy_ranges, _lib.lazy_tensors = g_ranges, g_tensors
+        _lib.sq_state = None
         # split the stack where an intermediate layer output received a gradient of its own
         if ctx.need_all:
             extra = [g for g in grads]
@@ -504,9 +515,19 @@ class _EncoderFn(torch.autograd.Function):
             else:
                 C.uniter_encoder_set_wgrad_stage(None, 0)       # (the registration is per thread and outlives a call)
             C.uniter_encoder_set_grad_overwrite(1 if overwrite else 0)       # (per call: the library consumes it)
+            # folded gradient norm: only a whole stack in one call without a reducer hook leaves usable per-tile sums
+            want_sq = _FOLD_NORM and (hook is None or type(hook) is DeferWgradJoin) and begin == 0 and end == n
+            C.uniter_encoder_set_grad_sq(1 if want_sq else 0)                # (per thread and sticky: stated every time)
             C.uniter_encoder_backward(ctypes.byref(s), table, begin, end, x_in,
                                       None if ctx.packed is not None else ptr(mask_bias), ptr(dy), ptr(dx),
                                       ptr(ctx.acts), ptr(scratch), ctx.seed, ctx.off, st)
+            if want_sq:
+                sq_ptr, sq_n = ctypes.c_void_p(), ctypes.c_int32()
+                C.uniter_encoder_last_grad_sq(ctypes.byref(sq_ptr), ctypes.byref(sq_n))
+                if sq_n.value > 0 and sq_ptr.value:
+                    wts = [gs[k] for _, gs in keep for k in (0, 2, 6, 8)]           # wqkv, wo, w1, w2 gradients (LayerView.NAMES)
+                    _lib.sq_state = dict(ptr=sq_ptr.value, n=sq_n.value, tensors=wts, versions=[t._version for t in wts],
+                                         ranges=frozenset((t.data_ptr(), t.numel() * t.element_size()) for t in wts))
             if hook is not None:
                 for l in range(end - 1, begin - 1, -1):
                     hook(l)

@@ -71,6 +71,13 @@ class AdamW(Optimizer):
         # them first (_lib.lazy_resolve).  UNITER_AMD_LAZY_ZERO=0 switches it off.
         self.lazy_zero = os.environ.get("UNITER_AMD_LAZY_ZERO", "1") != "0"
         self._keep_ranges = None      # the _lib.lazy_ranges the plan's keep flags were computed from
+        # fold_norm: grad_norm() takes the encoder weights' share of sum g^2 from the per-tile sums their deferred launch left
+        # (ops._EncoderFn.backward -> _lib.sq_state) instead of reading those 170 MB again; any doubt (a tensor touched since, a
+        # data-parallel reduction, parameters outside the plan) falls back to the full reduction.  Opt-in (UNITER_AMD_FOLD_NORM=1 +
+        # ops.set_fold_norm): on the c2 step the reduction gets 20 us shorter and the update 29 us longer — the reduction is also what
+        # brings the gradients into the Infinity Cache for the update (profiles/r06_fold_norm_ab.txt).
+        self.fold_norm = os.environ.get("UNITER_AMD_FOLD_NORM", "0") == "1"
+        self._skip_ranges = None
 
     # ---- plan management ------------------------------------------------------------------------------
     def _active(self):
@@ -147,26 +154,39 @@ class AdamW(Optimizer):
         C.uniter_adamw_plan_create(table, len(active), ctypes.byref(handle))
         self._plan, self._plan_groups = handle, groups
         self._plan_grads = [(int(table[k].grad), int(table[k].numel) * (2 if table[k].param_is_bf16 else 4)) for k in range(len(active))]
-        self._keep_ranges = None      # (a new device table: no keep flags yet)
-        self._keep_any = False
+        self._keep_ranges = self._skip_ranges = None      # (a new device table: no flags yet)
+        self._keep_any = self._skip_any = False
 
-    def _sync_keep_flags(self):
-        """Mark the plan's tensors whose gradient storage lies inside what the encoder's backward overwrites (lazy_zero)."""
-        ranges = _lib.lazy_ranges if self.lazy_zero else frozenset()
-        if ranges is self._keep_ranges or ranges == self._keep_ranges:
-            return self._keep_any
-        spans = sorted(ranges)
+    def _covered(self, ranges):
+        """Per plan tensor: does its gradient storage lie inside one of `ranges` (frozenset of (first byte, byte length))?"""
         import bisect
+        spans = sorted(ranges)
         starts = [a for a, _ in spans]
-        flags = (ctypes.c_uint8 * len(self._plan_grads))()
-        for k, (g, nbytes) in enumerate(self._plan_grads):
+        out = []
+        for g, nbytes in self._plan_grads:
             j = bisect.bisect_right(starts, g) - 1
-            if j >= 0 and g + nbytes <= spans[j][0] + spans[j][1]:
-                flags[k] = 1
-        C.uniter_adamw_plan_keep_grads(self._plan, flags, len(self._plan_grads))
-        self._keep_ranges = ranges
-        self._keep_any = any(flags)
-        return self._keep_any
+            out.append(j >= 0 and g + nbytes <= spans[j][0] + spans[j][1])
+        return out
+
+    def _sync_flags(self, skip_ranges=None):
+        """Bring the plan's per-tensor flags in line with lazy_zero (tensors the encoder's backward overwrites: KEEP_GRAD) and
+        fold_norm (tensors whose sum of squares comes with the backward: SKIP_NORM).  Returns (any kept, folding possible)."""
+        keep_ranges = _lib.lazy_ranges if self.lazy_zero else frozenset()
+        if skip_ranges is None:
+            skip_ranges = self._skip_ranges if self._skip_ranges is not None else frozenset()
+        if keep_ranges == self._keep_ranges and skip_ranges == self._skip_ranges:
+            return self._keep_any, self._skip_any
+        keep = self._covered(keep_ranges)
+        skip = self._covered(skip_ranges)
+        # the per-tile sums stand for WHOLE tensors of the encoder: they can replace the reduction only if the plan holds every byte
+        covered = sum(nb for (_, nb), f in zip(self._plan_grads, skip) if f)
+        if covered != sum(nb for _, nb in skip_ranges):
+            skip = [False] * len(skip)
+        flags = (ctypes.c_uint8 * len(self._plan_grads))(*[(1 if k else 0) | (2 if f else 0) for k, f in zip(keep, skip)])
+        C.uniter_adamw_plan_set_flags(self._plan, flags, len(self._plan_grads))
+        self._keep_ranges, self._skip_ranges = keep_ranges, skip_ranges
+        self._keep_any, self._skip_any = any(keep), any(skip)
+        return self._keep_any, self._skip_any
 
     def _destroy_plan(self):
         if self._plan is not None:
@@ -293,7 +313,12 @@ class AdamW(Optimizer):
         dev = self._plan_groups[0][1][0].device
         if self._norm_buf is None or self._norm_buf.device != dev:
             self._norm_buf = torch.zeros(2, dtype=torch.float32, device=dev)
-        C.uniter_adamw_grad_norm(self._plan, float(grad_scale), float(max_norm), ptr(self._norm_buf), _lib.stream_ptr())
+        st = _lib.sq_state if self.fold_norm else None
+        if st is not None and all(t._version == v for t, v in zip(st['tensors'], st['versions'])) and self._sync_flags(st['ranges'])[1]:
+            C.uniter_adamw_grad_norm_ex(self._plan, float(grad_scale), float(max_norm), ptr(self._norm_buf), st['ptr'], st['n'],
+                                        _lib.stream_ptr())
+        else:
+            C.uniter_adamw_grad_norm(self._plan, float(grad_scale), float(max_norm), ptr(self._norm_buf), _lib.stream_ptr())
         self._clip = self._norm_buf
         self._checked_for_step = True
         self._checked_epoch = _lib.grad_attach_epoch()
@@ -307,6 +332,7 @@ class AdamW(Optimizer):
             loss = closure()
         _lib.join_wgrads()
         _lib.lazy_resolve()
+        _lib.sq_state = None              # (the gradients are consumed by this step: per-tile sums of an earlier backward are history)
         if not self._ensure_plan(in_step=True):
             return loss           # nothing has a gradient: no-op, like the reference's dummy first step (pretrain.py:261-263)
         self._grads_zeroed = False    # whatever an earlier fused step zeroed has been written again by the backward in between
@@ -324,7 +350,7 @@ class AdamW(Optimizer):
         self._clip = None
         if self._overlap is not None and not torch.cuda.is_current_stream_capturing():
             arr, n, fuse = self._overlap
-            kept = self._sync_keep_flags() if fuse else False
+            kept = self._sync_flags()[0] if fuse else False
             C.uniter_adamw_step_async(self._plan, hyper, len(self._plan_groups), ptr(clip[1:]) if clip is not None else None,
                                       arr, n, 1 if fuse else 0, _lib.stream_ptr())
             self._grads_zeroed = fuse
@@ -332,7 +358,7 @@ class AdamW(Optimizer):
             _lib.set_async_pending(True)
             return loss
         if self.fuse_zero_grad:
-            kept = self._sync_keep_flags()
+            kept = self._sync_flags()[0]
             C.uniter_adamw_step_zero(self._plan, hyper, len(self._plan_groups), ptr(clip[1:]) if clip is not None else None,
                                      _lib.stream_ptr())
             self._grads_zeroed = True
