@@ -952,7 +952,7 @@ def test_paired_cross_attention_fused_equals_module_path(tmp_path, long_seq, mon
 
 def test_paired_cross_attention_cat_node_is_bit_identical_to_three_nodes(tmp_path, monkeypatch):
     """ops._PairedCrossAttnCatFn (regroup + both cross attentions + cat([attended, own]) written in place, round 6) against the
-    round-4 form it replaces (regroup copy, _PairedCrossAttnFn, torch.cat: UNITER_AMD_NLVR2_CAT_TORCH=1): same kernels on the same
+    round-4 form it replaces (regroup copy, _PairedCrossAttnFn, torch.cat: model.three_node_cat): same kernels on the same
     values through different row strides, dropout active with the same Philox offsets — loss and every gradient bit for bit."""
     import json
     from uniter_amd import ops
@@ -972,10 +972,7 @@ def test_paired_cross_attention_cat_node_is_bit_identical_to_three_nodes(tmp_pat
     batch = _to_dev(make_batch('nlvr2', 8, seed=6, ragged=True))
 
     def run(three_nodes):
-        if three_nodes:
-            monkeypatch.setenv("UNITER_AMD_NLVR2_CAT_TORCH", "1")
-        else:
-            monkeypatch.delenv("UNITER_AMD_NLVR2_CAT_TORCH", raising=False)
+        model.three_node_cat = three_nodes
         ops.manual_seed(1234)
         for p in model.parameters():
             p.grad = None

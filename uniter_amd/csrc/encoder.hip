@@ -92,16 +92,17 @@ ScratchLayout scratch_layout(const UniterEncoderShape& s) {
 // previous launch's flags, signal a fresh slot, drop the queue barrier); done() records what that launcher reported.  A
 // launcher that cannot take part (packed attention, split-K) clears produced: it has then run as an ordinary in-order kernel
 // without flags, and so does the kernel after it.
-// fused QKV projection + attention forward (gemm.hip EPI_QKV_ATTN); UNITER_AMD_FUSED_QKV_ATTN=0 keeps the two launches (A/B, tests)
-// FFN1's epilogue saves act'(u) in the layer's `u` slot and the FFN2 data gradient multiplies by it (common.cuh, UH_ACT_SAVE_GRAD);
-// UNITER_AMD_SAVE_ACT_GRAD=0 keeps u and re-evaluates the derivative in the backward (the A/B of profiles/r06_save_act_grad_ab.txt)
-const int g_act_flags = [] { const char* e = getenv("UNITER_AMD_SAVE_ACT_GRAD"); return (e == nullptr || e[0] != '0') ? (int)UH_ACT_SAVE_GRAD : 0; }();
+// fused QKV projection + attention forward (gemm.hip EPI_QKV_ATTN) wherever its shape conditions hold (dense batches, L = 96);
+// every other shape takes the two launches — bit-identical results (harness --qkvattn; A/B in profiles/: -6 us per layer)
+// FFN1's epilogue saves act'(u) in the layer's `u` slot and the FFN2 data gradient multiplies by it (common.cuh, UH_ACT_SAVE_GRAD;
+// A/B against saving u and re-evaluating the derivative: profiles/r06_save_act_grad_ab.txt, -0.10 ms per c2 step)
+constexpr int g_act_flags = (int)UH_ACT_SAVE_GRAD;
 // uniter_encoder_set_grad_sq / uniter_encoder_last_grad_sq: the deferred launch leaves one sum of squares per weight-gradient tile
 thread_local bool g_grad_sq_request = false;
 thread_local float* g_last_sq = nullptr;
 thread_local int g_last_sq_n = 0;
 thread_local bool g_grad_overwrite = false;       // uniter_encoder_set_grad_overwrite: consumed by the next backward call of this thread
-const bool g_fused_qkv_attn = [] { const char* e = getenv("UNITER_AMD_FUSED_QKV_ATTN"); return e == nullptr || e[0] != '0'; }();
+constexpr bool g_fused_qkv_attn = true;
 int g_chain = 0;     // overlapped kernel chains: a test / harness hook (uniter_encoder_debug_chain); measured neutral to -1 % at 32 x 96 tokens (EXPERIMENTS.md, round 4)
 struct Chain {
     bool on = false;

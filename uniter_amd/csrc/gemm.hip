@@ -1469,11 +1469,10 @@ int gemm_fwd_group(int n, const void* const* x, const int64_t* ldx, const void* 
     }
     LaunchTimer lt(TIME_GEMM_FWD_BIAS, M, flops_n, K, st);
     // A group whose 96 x 96 tiling would be more than two rounds of the chip (the NLVR2 head's four input projections: 768 tiles)
-    // takes the 96 x 192 tile of the encoder's QKV projection instead — 384 workgroups, two per CU, one round (A/B switch
-    // UNITER_AMD_GROUP_FWD_192=0; profiles/r06_nlvr2_head_ab.txt)
-    static const bool wide = [] { const char* e = getenv("UNITER_AMD_GROUP_FWD_192"); return e == nullptr || e[0] != '0'; }();
+    // takes the 96 x 192 tile of the encoder's QKV projection instead — 384 workgroups, two per CU, one round
+    // (A/B: profiles/r06_nlvr2_head_ab.txt)
     int64_t tiles96 = 0;
-    bool fits192 = wide;
+    bool fits192 = true;
     for (int q = 0; q < n; ++q) { tiles96 += ((M + 95) / 96) * (N[q] / 96); fits192 = fits192 && N[q] % 192 == 0 && N[q] % 96 == 0; }
     int rc = 1;
     if (fits192 && tiles96 > 2 * (int64_t)g_num_cus) rc = launch_group_layout<96, 192, false, false, EPI_BIAS, 2, 1>(ga, st);

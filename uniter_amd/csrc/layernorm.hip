@@ -403,11 +403,9 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel8(const bf16_t* __restr
     chain_signal(chain, blk * 4, 4);
 }
 
-// UNITER_AMD_LN_WIDE=0 keeps the 8-byte forms (A/B: profiles/r06_layernorm_wide_ab.txt)
-static bool ln_wide() {
-    static const bool on = [] { const char* e = getenv("UNITER_AMD_LN_WIDE"); return e == nullptr || e[0] != '0'; }();
-    return on;
-}
+// the 16-byte forms run wherever their shape conditions hold (A/B against the 8-byte forms: profiles/r06_layernorm_wide_ab.txt;
+// the 8-byte kernels remain for the other widths)
+static bool ln_wide() { return true; }
 
 // Column part: per-block partial sums over rows of (dy*xhat, dy, d) with d = `dsrc` (the bf16 dd / dz the row kernel
 // wrote; masked on the fly when `mask_dsrc`).  Grid (strips of 512 columns, row blocks); partial [gridDim.y][3][H].

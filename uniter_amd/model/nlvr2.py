@@ -4,7 +4,6 @@ All three share the encoder call and the token-type table growth (2 -> 3 rows, `
 model/nlvr2.py:26-34), factored into a base class here; public class names, constructor signatures and
 sub-module names (state_dict keys) are the reference's.
 """
-import os
 from collections import defaultdict
 
 import torch
@@ -116,6 +115,7 @@ class UniterForNlvr2PairedAttn(_Nlvr2Base):
                                 nn.Dropout(config.hidden_dropout_prob))
         self.attn_pool = AttentionPool(config.hidden_size, config.attention_probs_dropout_prob)
         self.nlvr2_output = nn.Linear(2 * config.hidden_size, 2)
+        self.three_node_cat = False      # tests: the round-4 form (regroup copy, cross-attention node, torch.cat) instead of the one node
         self.apply(self.init_weights)
 
     def forward(self, batch, compute_loss=True):
@@ -124,7 +124,7 @@ class UniterForNlvr2PairedAttn(_Nlvr2Base):
         n = bs // 2
         # rows 2i / 2i+1 are the left / right image of pair i (model/nlvr2.py:172-176): regroup as [side, pair, L, H]
         fused = self._fused_pair_attention(seq) and d % 64 == 0 and self.fc[0].weight.dtype == torch.bfloat16
-        if fused and batch['attn_masks'].dtype == torch.int64 and os.environ.get("UNITER_AMD_NLVR2_CAT_TORCH") != "1":
+        if fused and batch['attn_masks'].dtype == torch.int64 and not self.three_node_cat:
             from .. import ops
             # the shipped path: masks from one kernel; regrouping, both cross attentions and cat([attended, own]) as one autograd
             # node that writes the fc input in place (no torch.cat, no regrouped copy of its own) — ops._PairedCrossAttnCatFn
