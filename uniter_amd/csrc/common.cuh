@@ -379,7 +379,7 @@ __device__ __forceinline__ f32x2_t act_grad2(int act, const f32x2_t x) {
 // The encoder's FFN1 epilogue saves act'(u) in place of u (UH_ACT_SAVE_GRAD or-ed into the activation code): the normal cdf and
 // pdf that GELU needs give the derivative for one more fused multiply-add, and the backward's "x act'(u)" epilogue (FFN2 data
 // gradient, model/layer.py:139-142) becomes one multiply per element instead of an exponential, a reciprocal and a degree-5
-// polynomial (29.1 -> 21.2 us alone at 3072 x 3072 x 768, profiles/r06a_native_roofs.txt).  y has the bits of act_fwd2.
+// polynomial (alone at 3072 x 3072 x 768, profiles/r06_save_act_grad_ab.txt: 29.1 -> 24.6 us with the derivative read, 21.2 without any epilogue operand).  y has the bits of act_fwd2.
 enum { UH_ACT_SAVE_GRAD = 0x100, UH_ACT_MASK = 0xff };
 __device__ __forceinline__ void act_fwd_grad2(int act, const f32x2_t x, f32x2_t& y, f32x2_t& dy) {
     if (act == UH_ACT_GELU) {
