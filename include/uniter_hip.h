@@ -449,16 +449,6 @@ int uniter_encoder_set_grad_overwrite(int32_t enable);
  * next backward call of this thread; written on the weight-gradient stream: join it first) and its length, or NULL / 0 when the last
  * call produced none.  Together the floats are sum g^2 over the wqkv, wo, w1, w2 gradients of the layers of that call. */
 int uniter_encoder_set_grad_sq(int32_t enable);
-
-/* Deferred finalize steps (round 6).  uniter_layernorm_bwd (row counts up to 2048: the embedding LayerNorms), uniter_embed_type_bwd,
- * uniter_embed_pos_linear_bwd and uniter_embed_mask_bwd are a kernel that writes per-block partial sums into the caller's workspace
- * and a small reduction that adds them into the parameter gradient.  By default the reduction is launched by the same call.  After
- * uniter_finalize_defer(1) (process-wide) those calls QUEUE their reduction instead and uniter_finalize_flush(stream) runs every
- * queued one as ONE launch — the training loop's promise that (a) nobody reads those parameter gradients before the flush and (b)
- * every such call got a workspace of its own that stays untouched until then (uniter_embed_type_bwd: n_types regions).  Results are
- * bit-identical; beside the deferred weight-gradient launch it shortens the embedding backward by one launch wait per call. */
-int uniter_finalize_defer(int32_t enable);
-int uniter_finalize_flush(void* stream);
 int uniter_encoder_last_grad_sq(void** partials_out, int32_t* n_out);
 int uniter_encoder_side_join(void* stream);
 /* The same from ANY thread: makes `stream` wait for the weight-gradient streams of every thread of this process that left a

@@ -726,52 +726,6 @@ def test_lazy_zero_grad_is_bit_identical_over_steps(tmp_path):
         assert torch.equal(out[0][n], out[1][n]), n
 
 
-@pytest.mark.parametrize("task", ["nlvr2", "mrfr"])
-def test_deferred_finalize_steps_are_bit_identical(tmp_path, task):
-    """uniter_finalize_defer / _flush (round 6): the partial-sum reductions of the embedding backward (LayerNorm column sums, type and
-    mask embedding rows, the position projection) queued and run as ONE launch at _lib.join_wgrads() against the default (each call
-    launches its own): every gradient bit for bit, two backward passes accumulated (the arena slices of the first are flushed
-    before the second re-uses them); MRFR adds the mask-embedding job."""
-    import json
-    from uniter_amd import _lib as L, ops
-    from uniter_amd.utils.synthetic import make_batch
-    cfg = dict(BASE_CFG, num_hidden_layers=1)
-    path = tmp_path / "df.json"
-    path.write_text(json.dumps(cfg))
-    torch.manual_seed(21)
-    if task == "nlvr2":
-        from uniter_amd.model.nlvr2 import UniterForNlvr2PairedAttn
-        model = UniterForNlvr2PairedAttn.from_pretrained(str(path), {}, img_dim=2048)
-        model.init_type_embedding()
-        run_model = lambda b: model(b, compute_loss=True)
-    else:
-        from uniter_amd.model.pretrain import UniterForPretraining
-        model = UniterForPretraining.from_pretrained(str(path), {}, img_dim=2048, img_label_dim=LABEL_DIM)
-        run_model = lambda b: model(b, task='mrfr', compute_loss=True)
-    _prep(model)
-    batch = _to_dev(make_batch(task, 8, seed=40, ragged=True))
-
-    def grads(defer):
-        L.set_defer_finalize(defer)
-        try:
-            for p in model.parameters():
-                p.grad = None
-            for _ in range(2):
-                run_model(batch).float().mean().backward()
-                L.join_wgrads()                               # (the contract: before anything reads or re-produces the gradients)
-            torch.cuda.synchronize()
-            return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
-        finally:
-            L.set_defer_finalize(False)
-
-    g0, g1 = grads(False), grads(True)
-    assert set(g0) == set(g1) and len(g0) > 20
-    emb = [n for n in g0 if 'embeddings' in n]
-    assert len(emb) >= 10
-    for n in g0:
-        assert torch.equal(g0[n], g1[n]), n
-
-
 def test_folded_gradient_norm_equals_the_full_reduction(tmp_path, monkeypatch):
     """AdamW.fold_norm (round 6): the encoder weights' share of sum g^2 comes out of the deferred weight-gradient launch
     (uniter_encoder_last_grad_sq -> uniter_adamw_grad_norm_ex).  Same gradients, folded vs full reduction: equal to fp32 summation

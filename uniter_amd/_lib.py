@@ -145,8 +145,6 @@ SIGNATURES = {
     "uniter_encoder_defer_side_join": (c_int, [c_int]),
     "uniter_encoder_set_grad_overwrite": (c_int, [c_int32]),
     "uniter_encoder_set_grad_sq": (c_int, [c_int32]),
-    "uniter_finalize_defer": (c_int, [c_int32]),
-    "uniter_finalize_flush": (c_int, [_P]),
     "uniter_encoder_last_grad_sq": (c_int, [POINTER(c_void_p), POINTER(c_int32)]),
     "uniter_encoder_side_join": (c_int, [c_void_p]),
     "uniter_encoder_side_stream": (c_int, [POINTER(c_void_p)]),
@@ -376,57 +374,9 @@ def hold_until_wgrad_join(*tensors):
     _wgrads_pending = True
 
 
-# Deferred finalize steps of the embedding backward (include/uniter_hip.h "Deferred finalize steps"): a training loop switches them on
-# (set_defer_finalize) together with its promise to go through join_wgrads() before anything reads a parameter gradient; the
-# embedding ops then take a workspace slice of their own per call (fin_scratch) and join_wgrads() flushes the queue as one launch.
-_fin_defer = False
-_fin_buf = None
-_fin_off = 0
-_FIN_BYTES = 48 << 20
-
-
-def set_defer_finalize(enable):
-    global _fin_defer
-    if _fin_defer and not enable:
-        flush_finalize()
-    _fin_defer = bool(enable)
-    C.uniter_finalize_defer(1 if enable else 0)
-
-
-def defer_finalize():
-    return _fin_defer
-
-
-def fin_scratch(nbytes, device):
-    """A 256-byte aligned slice of the finalize arena that stays untouched until the next flush_finalize()."""
-    global _fin_buf, _fin_off
-    import torch
-    need = (int(nbytes) + 255) // 256 * 256
-    if _fin_buf is None or _fin_buf.device != device:
-        _fin_buf = torch.empty(max(_FIN_BYTES, need), dtype=torch.uint8, device=device)
-        _fin_off = 0
-    if _fin_off + need > _fin_buf.numel():
-        flush_finalize()                 # (what is queued reads the arena: it goes out before the arena is re-used)
-        if need > _fin_buf.numel():
-            _fin_buf = torch.empty(need, dtype=torch.uint8, device=device)
-    view = _fin_buf[_fin_off:_fin_off + need]
-    _fin_off += need
-    return view
-
-
-def flush_finalize():
-    global _fin_off
-    if _fin_defer:
-        C.uniter_finalize_flush(stream_ptr())
-    _fin_off = 0
-
-
 def join_wgrads():
-    """Make the current stream wait for every un-joined weight-gradient launch and run the queued finalize steps of the embedding
-    backward; no-op when nothing is outstanding."""
+    """Make the current stream wait for every un-joined weight-gradient launch; no-op when none is outstanding."""
     global _wgrads_pending
-    if _fin_defer:
-        flush_finalize()
     if _wgrads_pending:
         C.uniter_encoder_side_join_all(stream_ptr())
         _wgrads_pending = False

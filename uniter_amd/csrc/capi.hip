@@ -382,9 +382,6 @@ int uniter_layernorm_bwd(const void* dy, const void* dy_extra, const void* z, co
                              make_dropout(p_drop, seed, offset), drop_on_output, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-int uniter_finalize_defer(int32_t enable) { return uh::finalize_defer(enable); }
-int uniter_finalize_flush(void* stream) { return uh::finalize_flush((hipStream_t)stream); }
-
 size_t uniter_colsum_workspace_bytes(int64_t rows, int64_t N) { return uh::colsum_workspace_bytes(rows, N); }
 
 int uniter_colsum(const void* a, void* out, int64_t rows, int64_t N, int accumulate,

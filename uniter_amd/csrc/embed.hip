@@ -273,6 +273,26 @@ __global__ __launch_bounds__(256) void pos_linear_bwd_kernel(const void* __restr
 #pragma unroll
     for (int k = 0; k < 8; ++k) partial[((int64_t)blockIdx.y * 8 + k) * H + h] = acc[k];
 }
+__global__ __launch_bounds__(1024) void pos_linear_finalize_kernel(const float* __restrict__ partial, int nb, int H,
+                                                                   bf16_t* __restrict__ dw, bf16_t* __restrict__ db) {
+    __shared__ float red[16][64];
+    const int cx = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + cx;
+    float s = 0.f;
+    if (idx < 8 * H)
+        for (int b = grp; b < nb; b += 16) s += partial[(int64_t)b * 8 * H + idx];      // partial[b][k][h], idx = k*H + h
+    red[grp][cx] = s;
+    __syncthreads();
+    if (grp == 0 && idx < 8 * H) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][cx];
+        const int k = idx / H, h = idx % H;
+        if (k < 7) { if (dw) dw[h * 7 + k] = f2bf(bf2f(dw[h * 7 + k]) + t); }
+        else if (db) db[h] = f2bf(bf2f(db[h]) + t);
+    }
+}
+
 __global__ __launch_bounds__(256) void img_combine_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
                                                           const int64_t* __restrict__ tids, const bf16_t* __restrict__ type,
                                                           bf16_t* __restrict__ z, int64_t rows, int H) {
@@ -381,26 +401,16 @@ int uniter_embed_type_bwd(const void* dz, const int64_t* type_ids, void* dtype_t
     UH_CHECK_ARG(dz && dtype_table && workspace, "null pointer");
     UH_CHECK_ARG(rows > 0 && H > 0 && H % 8 == 0 && n_types > 0, "bad shape (H %% 8 == 0 required)");
     const int nb = filtered_blocks(rows, H);
-    const size_t region = (size_t)nb * H * sizeof(float);
-    UH_CHECK_ARG(workspace_bytes >= region, "workspace too small");
-    // one region of partials per type when the workspace has room for them (a queued finalize job reads its region at the flush:
-    // uniter_finalize_defer); otherwise the types share one region and each is finished before the next starts
-    const bool per_type = workspace_bytes >= region * (size_t)n_types;
+    UH_CHECK_ARG(workspace_bytes >= (size_t)nb * H * sizeof(float), "workspace too small");
     hipStream_t st = (hipStream_t)stream;
     for (int64_t k = 0; k < n_types; ++k) {
         if (type_ids == nullptr && k != default_type) continue;
-        float* part = (float*)((char*)workspace + (per_type ? region * (size_t)k : 0));
         hipLaunchKernelGGL(colsum_filtered_kernel, dim3((unsigned)((H + 511) / 512), nb), dim3(256), 0, st, (const bf16_t*)dz,
-                           type_ids, (const uint8_t*)nullptr, k, 1, part, (int)rows, (int)H);
+                           type_ids, (const uint8_t*)nullptr, k, 1, (float*)workspace, (int)rows, (int)H);
         UH_LAUNCH_CHECK();
-        if (per_type) {
-            const int rc = uh::finalize_submit(uh::FinalizeJob{part, nb, (int)H, uh::FIN_COLS, (int)H, 1, (bf16_t*)dtype_table + k * H, nullptr, nullptr}, st);
-            if (rc) return rc;
-        } else {
-            hipLaunchKernelGGL(add_partials_kernel, dim3((unsigned)((H + 63) / 64)), dim3(1024), 0, st, (const float*)part, nb,
-                               (int)H, (bf16_t*)dtype_table + k * H);
-            UH_LAUNCH_CHECK();
-        }
+        hipLaunchKernelGGL(add_partials_kernel, dim3((unsigned)((H + 63) / 64)), dim3(1024), 0, st, (const float*)workspace, nb,
+                           (int)H, (bf16_t*)dtype_table + k * H);
+        UH_LAUNCH_CHECK();
     }
     return 0;
 }
@@ -472,7 +482,10 @@ int uniter_embed_pos_linear_bwd(const void* pos_feat, int feat_is_fp32, const vo
     hipLaunchKernelGGL(pos_linear_bwd_kernel, dim3((unsigned)((H + 255) / 256), rb), dim3(256), 0, st, pos_feat, feat_is_fp32,
                        (const bf16_t*)d, (float*)workspace, (int)rows, (int)H);
     UH_LAUNCH_CHECK();
-    return uh::finalize_submit(uh::FinalizeJob{(const float*)workspace, rb, (int)(8 * H), uh::FIN_POS_LINEAR, (int)H, 1, dwpos, dbpos, nullptr}, st);
+    hipLaunchKernelGGL(pos_linear_finalize_kernel, dim3((unsigned)((8 * H + 63) / 64)), dim3(1024), 0, st, (const float*)workspace,
+                       rb, (int)H, (bf16_t*)dwpos, (bf16_t*)dbpos);
+    UH_LAUNCH_CHECK();
+    return 0;
 }
 
 int uniter_embed_img_combine_fwd(const void* a, const void* b, const int64_t* type_ids, const void* type,
@@ -496,7 +509,10 @@ int uniter_embed_mask_bwd(const void* df, const uint8_t* img_masks, void* dmask_
     hipLaunchKernelGGL(colsum_filtered_kernel, dim3((unsigned)((D + 511) / 512), nb), dim3(256), 0, st, (const bf16_t*)df,
                        (const int64_t*)nullptr, img_masks, (int64_t)1, 0, (float*)workspace, (int)rows, (int)D);
     UH_LAUNCH_CHECK();
-    return uh::finalize_submit(uh::FinalizeJob{(const float*)workspace, nb, (int)D, uh::FIN_COLS, (int)D, 1, dmask_row, nullptr, nullptr}, st);
+    hipLaunchKernelGGL(add_partials_kernel, dim3((unsigned)((D + 63) / 64)), dim3(1024), 0, st, (const float*)workspace, nb, (int)D,
+                       (bf16_t*)dmask_row);
+    UH_LAUNCH_CHECK();
+    return 0;
 }
 
 int uniter_embed_gather_fwd(const void* txt, const void* img, const int64_t* gather_index, void* out,

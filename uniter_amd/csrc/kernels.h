@@ -112,24 +112,6 @@ int attention_bwd(const void* qkv, const float* mask_bias, const void* ctx, cons
 // ---- layernorm.hip ----
 int layernorm_fwd(const void* z, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                   int64_t rows, int64_t H, float eps, const DropoutCfg& drop, hipStream_t st, ChainStep* chain = nullptr);
-// Reductions of per-block partial sums (out[.] (+)= sum_b partial[b][.]) — the second launch of every producer / finalize pair of the
-// embedding backward (LayerNorm column sums, type / mask embedding rows, the 7-wide position projection).  finalize_submit runs the
-// job at once, or — after uniter_finalize_defer(1), the training loop's promise that nobody reads these gradients before
-// uniter_finalize_flush — queues it, so that ALL of a backward pass's finalize steps are ONE launch (beside the deferred weight-
-// gradient launch every launch of that chain waits ~25 us for a free CU; EXPERIMENTS.md section 13).  The caller keeps the partials
-// of a queued job untouched until the flush.  Same summation order either way: bit-identical results.
-enum { FIN_COLS = 0, FIN_POS_LINEAR = 1 };
-struct FinalizeJob {
-    const float* partial;    // [nb][total] fp32
-    int nb, total;
-    int kind;                // FIN_COLS: total = nk * H, out_k[col] (k = idx / H <= 2; null = skipped); FIN_POS_LINEAR: total = 8 * H,
-                             // idx = k * H + h -> o0[h * 7 + k] (k < 7), o1[h] (k = 7), always accumulating
-    int H, accumulate;
-    void *o0, *o1, *o2;      // bf16
-};
-int finalize_submit(const FinalizeJob& j, hipStream_t st);
-int finalize_defer(int enable);
-int finalize_flush(hipStream_t st);
 size_t layernorm_bwd_workspace_bytes(int64_t rows, int64_t H);
 int layernorm_bwd(const void* dy, const void* dy_extra, const void* z, const float* mean, const float* rstd,
                   const void* gamma, void* dz, void* dd, void* dgamma, void* dbeta, void* dbias,

@@ -5,8 +5,6 @@
 // One wave64 owns a row; every lane keeps its slice of the row in registers (8-byte bf16x4 loads,
 // row fully coalesced), statistics by wave-level reductions, no LDS on the forward path.
 #include <cstdlib>
-#include <mutex>
-#include <vector>
 #include "common.cuh"
 #include "kernels.h"
 #include "layernorm_fwd.cuh"
@@ -514,71 +512,6 @@ __global__ __launch_bounds__(1024) void finalize_cols_kernel(const float* __rest
     }
 }
 
-// Every queued finalize job of a backward pass in one launch (kernels.h FinalizeJob): block -> (job, 64-column group) through the
-// table passed by value; per job the arithmetic and summation order of finalize_cols_kernel / add_partials_kernel /
-// pos_linear_finalize_kernel (16 interleaved groups of partial rows, then the groups in order).
-constexpr int FIN_MAX = 24;
-struct FinalizeTable {
-    int n;
-    int start[FIN_MAX + 1];
-    uh::FinalizeJob job[FIN_MAX];
-};
-__global__ __launch_bounds__(1024) void finalize_jobs_kernel(const FinalizeTable tbl) {
-    __shared__ float red[16][64];
-    int q = 0;
-    for (int k = 1; k < tbl.n; ++k) q = ((int)blockIdx.x >= tbl.start[k]) ? k : q;
-    const uh::FinalizeJob j = tbl.job[q];
-    const int cx = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int idx = ((int)blockIdx.x - tbl.start[q]) * 64 + cx;
-    float s = 0.f;
-    if (idx < j.total)
-        for (int b = grp; b < j.nb; b += 16) s += j.partial[(int64_t)b * j.total + idx];
-    red[grp][cx] = s;
-    __syncthreads();
-    if (grp == 0 && idx < j.total) {
-        float t = 0.f;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) t += red[g][cx];
-        const int k = idx / j.H, col = idx % j.H;
-        if (j.kind == uh::FIN_POS_LINEAR) {
-            bf16_t* dw = (bf16_t*)j.o0;
-            bf16_t* db = (bf16_t*)j.o1;
-            if (k < 7) { if (dw) dw[col * 7 + k] = f2bf(bf2f(dw[col * 7 + k]) + t); }
-            else if (db) db[col] = f2bf(bf2f(db[col]) + t);
-        } else {
-            bf16_t* out = (bf16_t*)(k == 0 ? j.o0 : (k == 1 ? j.o1 : j.o2));
-            if (out != nullptr) {
-                if (j.accumulate) t += bf2f(out[col]);
-                out[col] = f2bf(t);
-            }
-        }
-    }
-}
-
-// queue of the deferred mode: process-wide (the backward pass submits from the autograd thread, the training loop flushes from its
-// own), one stream at a time
-std::mutex g_fin_mu;
-bool g_fin_defer = false;
-std::vector<uh::FinalizeJob> g_fin_jobs;
-hipStream_t g_fin_stream = nullptr;
-
-int finalize_launch_locked(hipStream_t st) {
-    if (g_fin_jobs.empty()) return 0;
-    FinalizeTable tbl{};
-    tbl.n = (int)g_fin_jobs.size();
-    int blocks = 0;
-    for (int q = 0; q < tbl.n; ++q) {
-        tbl.start[q] = blocks;
-        tbl.job[q] = g_fin_jobs[(size_t)q];
-        blocks += (g_fin_jobs[(size_t)q].total + 63) / 64;
-    }
-    tbl.start[tbl.n] = blocks;
-    g_fin_jobs.clear();
-    hipLaunchKernelGGL(finalize_jobs_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, tbl);
-    UH_LAUNCH_CHECK();
-    return 0;
-}
-
 // per-block column sums of a[rows][N]: grid (strips of 512 cols, row blocks); partial [gridDim.y][N]
 __global__ __launch_bounds__(1024) void colsum_kernel(const bf16_t* __restrict__ a, float* __restrict__ partial,
                                                       int rows, int N) {
@@ -638,54 +571,6 @@ int colsum_blocks(int64_t rows, int64_t N) {
 }  // namespace
 
 namespace uh {
-
-int finalize_submit(const FinalizeJob& j, hipStream_t st) {
-    if (j.partial == nullptr || j.nb <= 0 || j.total <= 0 || j.H <= 0) { uh_set_error("finalize_submit: bad job"); return -1; }
-    std::lock_guard<std::mutex> lk(g_fin_mu);
-    if (g_fin_defer) {
-        if (!g_fin_jobs.empty() && (g_fin_stream != st || (int)g_fin_jobs.size() == FIN_MAX)) {
-            const int rc = finalize_launch_locked(g_fin_stream);        // another stream, or a full table: what is queued goes out first
-            if (rc) return rc;
-        }
-        g_fin_stream = st;
-        g_fin_jobs.push_back(j);
-        return 0;
-    }
-    if (j.kind == FIN_POS_LINEAR) {
-        FinalizeTable one{};
-        one.n = 1;
-        one.start[1] = (j.total + 63) / 64;
-        one.job[0] = j;
-        hipLaunchKernelGGL(finalize_jobs_kernel, dim3((unsigned)one.start[1]), dim3(1024), 0, st, one);
-    } else {
-        hipLaunchKernelGGL(finalize_cols_kernel, dim3((unsigned)((j.total + 63) / 64)), dim3(1024), 0, st, j.partial, j.nb, j.total / j.H,
-                           j.H, (bf16_t*)j.o0, (bf16_t*)j.o1, (bf16_t*)j.o2, j.accumulate);
-    }
-    UH_LAUNCH_CHECK();
-    return 0;
-}
-
-int finalize_defer(int enable) {
-    std::lock_guard<std::mutex> lk(g_fin_mu);
-    g_fin_defer = enable != 0;
-    return 0;
-}
-
-int finalize_flush(hipStream_t st) {
-    std::lock_guard<std::mutex> lk(g_fin_mu);
-    if (g_fin_jobs.empty()) return 0;
-    hipStream_t own = g_fin_stream;
-    const int rc = finalize_launch_locked(own);
-    if (rc) return rc;
-    if (own != st) {                                         // the flushing stream is not the one the partials were produced on
-        hipEvent_t ev;
-        UH_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        UH_CHECK_HIP(hipEventRecord(ev, own));
-        UH_CHECK_HIP(hipStreamWaitEvent(st, ev, 0));
-        UH_CHECK_HIP(hipEventDestroy(ev));
-    }
-    return 0;
-}
 
 int layernorm_fwd(const void* z, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                   int64_t rows, int64_t H, float eps, const DropoutCfg& drop, hipStream_t st, ChainStep* chain) {
@@ -842,7 +727,10 @@ int layernorm_bwd(const void* dy, const void* dy_extra, const void* z, const flo
     else LN_BWD(8, 4);
 #undef LN_BWD
     UH_LAUNCH_CHECK();
-    return finalize_submit(FinalizeJob{partial, nb, (int)(3 * H), FIN_COLS, (int)H, accumulate, dgamma, dbeta, dbias}, st);
+    hipLaunchKernelGGL(finalize_cols_kernel, dim3((unsigned)((3 * H + 63) / 64)), dim3(1024), 0, st,
+                       (const float*)partial, nb, 3, (int)H, (bf16_t*)dgamma, (bf16_t*)dbeta, (bf16_t*)dbias, accumulate);
+    UH_LAUNCH_CHECK();
+    return 0;
 }
 
 size_t colsum_workspace_bytes(int64_t rows, int64_t N) {

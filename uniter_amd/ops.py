@@ -660,8 +660,7 @@ def _ln_bwd(dy, z, mean, rstd, weight, bias_param, p, seed, off, post, dbias=Non
     rows, H = z.shape
     dz = torch.empty_like(z)
     wsb = C.uniter_layernorm_bwd_workspace_bytes(rows, H)
-    # (deferred finalize steps: the partial sums stay in a slice of their own until _lib.join_wgrads() flushes the queue)
-    ws = _lib.fin_scratch(wsb, z.device) if _lib.defer_finalize() else _scratch(("ln", z.device.index), wsb, z.device)
+    ws = _scratch(("ln", z.device.index), wsb, z.device)
     pool = {}
     gw = ensure_grad(weight) if weight.requires_grad else _dummy_grad_like(weight, pool)
     gb = ensure_grad(bias_param) if bias_param.requires_grad else _dummy_grad_like(bias_param, pool)
@@ -713,11 +712,7 @@ class _TxtEmbedFn(torch.autograd.Function):
         if typ.requires_grad:
             gtyp = ensure_grad(typ)
             wsb = C.uniter_embed_ws_bytes(B * Lt, H)
-            if _lib.defer_finalize():
-                wsb *= int(typ.shape[0])             # one region of partials per token type, untouched until the flush
-                ws = _lib.fin_scratch(wsb, z.device)
-            else:
-                ws = _scratch(("emb", z.device.index), wsb, z.device)
+            ws = _scratch(("emb", z.device.index), wsb, z.device)
             C.uniter_embed_type_bwd(ptr(dz), ptr(ctx.tids), ptr(gtyp), B * Lt, H, typ.shape[0], 0, ptr(ws), wsb, st)
         return (None,) * 10
 
@@ -787,24 +782,15 @@ class _ImgEmbedFn(torch.autograd.Function):
         dz = _ln_bwd(dy, z, mean_z, rstd_z, mod.LayerNorm.weight, mod.LayerNorm.bias, ctx.p, ctx.seed, ctx.off, post=True)
         wsb = max(C.uniter_embed_ws_bytes(rows, max(H, D)), C.uniter_gemm_wgrad_workspace_bytes(rows, H, D))
         ws = _scratch(("emb", dev.index), wsb, dev)
-        defer = _lib.defer_finalize()                 # every partial-sum producer below then gets a workspace slice of its own
         if type_table.requires_grad:
-            tws, tb = ws, wsb
-            if defer:
-                tb = C.uniter_embed_ws_bytes(rows, H) * int(type_table.shape[0])
-                tws = _lib.fin_scratch(tb, dev)
             C.uniter_embed_type_bwd(ptr(dz), ptr(ctx.tids), ptr(ensure_grad(type_table)), rows, H, type_table.shape[0], 1,
-                                    ptr(tws), tb, st)
+                                    ptr(ws), wsb, st)
         # position branch
         dpl = _ln_bwd(dz, pl, mean_p, rstd_p, mod.pos_layer_norm.weight, mod.pos_layer_norm.bias, 0.0, 0, 0, post=False)
         gwp = ensure_grad(mod.pos_linear.weight) if mod.pos_linear.weight.requires_grad else None
         gbp = ensure_grad(mod.pos_linear.bias) if mod.pos_linear.bias.requires_grad else None
-        pws, pb = ws, wsb
-        if defer:
-            pb = C.uniter_embed_ws_bytes(rows, H)
-            pws = _lib.fin_scratch(pb, dev)
         C.uniter_embed_pos_linear_bwd(ptr(ctx.posf), 1 if ctx.posf.dtype == torch.float32 else 0, ptr(dpl), ptr(gwp),
-                                      ptr(gbp), rows, H, ptr(pws), pb, st)
+                                      ptr(gbp), rows, H, ptr(ws), wsb, st)
         # feature branch
         gbi = ensure_grad(mod.img_linear.bias) if mod.img_linear.bias.requires_grad else None
         dlin = _ln_bwd(dz, lin, mean_i, rstd_i, mod.img_layer_norm.weight, mod.img_layer_norm.bias, 0.0, 0, 0, post=False,
@@ -816,11 +802,7 @@ class _ImgEmbedFn(torch.autograd.Function):
             df = torch.empty(rows, D, dtype=_BF16, device=dev)
             C.uniter_gemm_dgrad(ptr(dlin), ptr(w), None, ptr(df), rows, H, D, st)
             gme = ensure_grad(mod.mask_embedding.weight)
-            mws, mb = ws, wsb
-            if defer:
-                mb = C.uniter_embed_ws_bytes(rows, D)
-                mws = _lib.fin_scratch(mb, dev)
-            C.uniter_embed_mask_bwd(ptr(df), ptr(ctx.masks), ptr(gme[1]), rows, D, ptr(mws), mb, st)
+            C.uniter_embed_mask_bwd(ptr(df), ptr(ctx.masks), ptr(gme[1]), rows, D, ptr(ws), wsb, st)
         return (None,) * (7 + 11)
 
 

@@ -147,9 +147,6 @@ class StepRunner(object):
             # it (uniter_amd.optim.AdamW), so the embedding backward overlaps the deferred weight-gradient launch
             from . import ops as _ops
             self.model.uniter.encoder.grad_ready_hook = _ops.DeferWgradJoin()
-            # ... and the finalize steps of the embedding backward go out as ONE launch at that join (same contract)
-            from . import _lib as _l
-            _l.set_defer_finalize(os.environ.get("UNITER_AMD_DEFER_FINALIZE", "1") != "0")
         self.pool = [t for t, r in w.get('mix', ((tasks[0], 1),)) for _ in range(int(r))]
         self.rng = random.Random(seed)                                # same draw on every rank (data/loader.py:42-47)
         self.global_step = 0
