@@ -726,6 +726,121 @@ def test_lazy_zero_grad_is_bit_identical_over_steps(tmp_path):
         assert torch.equal(out[0][n], out[1][n]), n
 
 
+def test_image_embeddings_dense_type_embeddings_form(golden):
+    """UniterImageEmbeddings.forward(img_feat, img_pos_feat, type_embeddings [B, Li, H]) — the reference's own call convention
+    (model/model.py:261-272) — against the (table, ids) form UniterModel uses: same output bit for bit; the gradient w.r.t. the
+    dense tensor, summed per type id, is the table gradient of the other form; both against oracle.image_embeddings."""
+    from uniter_amd.model.model import UniterImageEmbeddings, UniterConfig
+    torch.manual_seed(41)
+    conf = UniterConfig.from_json_file(TINY_CONFIG)
+    emb = UniterImageEmbeddings(conf, IMG_DIM)
+    for p in emb.parameters():
+        torch.nn.init.normal_(p, std=0.1)
+    for m in (emb.img_layer_norm, emb.pos_layer_norm, emb.LayerNorm):
+        m.weight.data.add_(1.0)
+    _prep(emb)
+    H = conf.hidden_size
+    B, Li = 3, 20
+    dev = _dev()
+    feat = torch.randn(B, Li, IMG_DIM, device=dev).bfloat16()
+    pos = torch.rand(B, Li, 7, device=dev).bfloat16()
+    table = (torch.randn(2, H, device=dev) * 0.3).bfloat16().requires_grad_(True)
+    ids = torch.ones(B, Li, dtype=torch.int64, device=dev)
+    ids[:, ::3] = 0
+    go = torch.randn(B, Li, H, device=dev).bfloat16()
+    out_t = emb(feat, pos, (table, ids))
+    out_t.backward(go)
+    g_table = table.grad.detach().float().cpu().clone()
+    g_lin = emb.img_linear.weight.grad.detach().clone()
+    for p in emb.parameters():
+        p.grad = None
+    dense = table.detach()[ids].clone().requires_grad_(True)
+    out_d = emb(feat, pos, dense)
+    out_d.backward(go)
+    assert torch.equal(out_t, out_d)
+    assert torch.equal(g_lin, emb.img_linear.weight.grad)
+    gd = dense.grad.float().cpu()
+    per_type = torch.stack([gd[(ids == k).cpu()].sum(0) for k in range(2)])
+    assert rel_l2(per_type, g_table) <= 2e-2, rel_l2(per_type, g_table)
+    sd = {'e.' + n: p.detach().float().cpu() for n, p in emb.named_parameters()}
+    ref = O.image_embeddings(sd, 'e.', feat.float().cpu(), pos.float().cpu(), dense.detach().float().cpu())
+    _check_hidden(out_d.detach(), ref, "image embeddings, dense type form")
+
+
+def test_bert_sub_modules_called_on_their_own(tmp_path):
+    """BertSelfAttention / BertSelfOutput / BertAttention / BertIntermediate / BertOutput.forward (model/layer.py:75-156) as separate
+    calls — what third-party code written against the reference's modules does — against (1) the oracle's pieces in fp32 at the
+    survey's tolerances and (2) BertLayer.forward (the fused stack) on the same parameters: outputs bit for bit (same kernels, one
+    at a time), input and parameter gradients to 1e-2 relative L2 (the fused backward sums weight gradients in another tile order)."""
+    import json
+    from uniter_amd.model.model import UniterConfig
+    from uniter_amd.model.layer import BertLayer
+    cfg = dict(BASE_CFG)
+    conf = UniterConfig.from_dict(cfg) if hasattr(UniterConfig, 'from_dict') else None
+    if conf is None:
+        path = tmp_path / "sub.json"
+        path.write_text(json.dumps(cfg))
+        conf = UniterConfig.from_json_file(str(path))
+    torch.manual_seed(31)
+    layer = BertLayer(conf)
+    for p in layer.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    for m in (layer.attention.output.LayerNorm, layer.output.LayerNorm):
+        m.weight.data.add_(1.0)
+    _prep(layer)
+    B, L, H = 4, 96, cfg['hidden_size']
+    x = (torch.randn(B, L, H) * 0.7).to(_dev()).bfloat16()
+    valid = torch.ones(B, L)
+    valid[1, 70:] = 0
+    valid[3, 50:] = 0
+    ext = ((1.0 - valid) * -10000.0).view(B, 1, 1, L).to(_dev())
+    go = (torch.randn(B, L, H) * 0.5).to(_dev()).bfloat16()
+
+    def run(fused):
+        for p in layer.parameters():
+            p.grad = None
+        xin = x.clone().requires_grad_(True)
+        if fused:
+            out = layer(xin, ext)
+        else:
+            att = layer.attention(xin, ext)                     # = output(self(x, mask), x)
+            out = layer.output(layer.intermediate(att), att)
+        out.backward(go)
+        torch.cuda.synchronize()
+        return out.detach().clone(), xin.grad.detach().clone(), {n: p.grad.detach().float().cpu() for n, p in layer.named_parameters()}
+
+    out_s, dx_s, g_s = run(False)
+    out_f, dx_f, g_f = run(True)
+    assert torch.equal(out_s, out_f)
+    assert rel_l2(dx_s.float().cpu(), dx_f.float().cpu()) <= 1e-2
+    assert set(g_s) == set(g_f) and len(g_s) == 16
+    kb = 'attention.self.key.bias'       # mathematically zero (a shift of every key's score leaves the softmax alone): noise only
+    for g in (g_s, g_f):
+        assert float(g[kb].abs().max()) <= 0.1 * float(g['attention.self.query.bias'].abs().max())
+    for n in g_s:
+        if n != kb:
+            assert rel_l2(g_s[n], g_f[n]) <= 1e-2, (n, rel_l2(g_s[n], g_f[n]))
+    # the oracle, piece by piece (fp32 on the CPU; model/layer.py:75-156)
+    sd = {'l.' + n: p.detach().float().cpu().clone().requires_grad_(True) for n, p in layer.named_parameters()}
+    xr = x.float().cpu().clone().requires_grad_(True)
+    ref = O.bert_layer(xr, ext.float().cpu(), sd, 'l.', cfg['num_attention_heads'])
+    ref.backward(go.float().cpu())
+    _check_hidden(out_s, ref.detach(), "sub-module composition")
+    assert rel_l2(dx_s.float().cpu(), xr.grad) <= GRAD_L2
+    for n in g_s:
+        if n != kb:
+            assert cosine(g_s[n], sd['l.' + n].grad) >= GRAD_COS and rel_l2(g_s[n], sd['l.' + n].grad) <= GRAD_L2, n
+    # the pieces' own interfaces: context of the attention alone, the intermediate alone
+    ctx_ref = O.self_attention(x.float().cpu(), ext.float().cpu(), {k: v.detach() for k, v in sd.items()}, 'l.attention.self.', cfg['num_attention_heads'])
+    with torch.no_grad():
+        ctx_got = layer.attention.self(x, ext)
+        inter = layer.intermediate(x)
+    _check_hidden(ctx_got, ctx_ref, "BertSelfAttention alone")
+    inter_ref = O.gelu(O.linear(x.float().cpu(), sd['l.intermediate.dense.weight'].detach(), sd['l.intermediate.dense.bias'].detach()))
+    d = (inter.float().cpu() - inter_ref).abs()
+    assert float((d - (2e-2 + 1e-2 * inter_ref.abs())).max()) <= 0
+
+
 def test_folded_gradient_norm_equals_the_full_reduction(tmp_path, monkeypatch):
     """AdamW.fold_norm (round 6): the encoder weights' share of sum g^2 comes out of the deferred weight-gradient launch
     (uniter_encoder_last_grad_sq -> uniter_adamw_grad_norm_ex).  Same gradients, folded vs full reduction: equal to fp32 summation

@@ -145,9 +145,9 @@ class BertSelfAttention(nn.Module):
         return gw, gb
 
     def forward(self, hidden_states, attention_mask):
-        raise UniterHipError(
-            "BertSelfAttention has no standalone kernel path: it is fused into BertLayer.forward / "
-            "UniterEncoder.forward (uniter_encoder_forward).  Call the enclosing BertLayer.")
+        """model/layer.py:75-101 on its own (BertLayer / UniterEncoder run the fused stack instead): the fused [3H, H] projection
+        and the attention kernel as one autograd node."""
+        return ops.self_attention(self, hidden_states, attention_mask)
 
 
 class BertSelfOutput(nn.Module):
@@ -160,7 +160,8 @@ class BertSelfOutput(nn.Module):
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
 
     def forward(self, hidden_states, input_tensor):
-        raise UniterHipError("BertSelfOutput is fused into BertLayer.forward (bias+dropout+residual GEMM epilogue + LayerNorm kernel)")
+        """model/layer.py:111-115 on its own: bias + dropout + residual in the GEMM epilogue, then the LayerNorm kernel."""
+        return ops.dense_dropout_residual_layernorm(self, hidden_states, input_tensor)
 
 
 class BertAttention(nn.Module):
@@ -170,7 +171,8 @@ class BertAttention(nn.Module):
         self.output = BertSelfOutput(config)
 
     def forward(self, input_tensor, attention_mask):
-        raise UniterHipError("BertAttention is fused into BertLayer.forward")
+        """model/layer.py:124-127."""
+        return self.output(self.self(input_tensor, attention_mask), input_tensor)
 
 
 class BertIntermediate(nn.Module):
@@ -183,7 +185,10 @@ class BertIntermediate(nn.Module):
             self.intermediate_act_fn = config.hidden_act
 
     def forward(self, hidden_states):
-        raise UniterHipError("BertIntermediate is fused into BertLayer.forward (bias+GELU GEMM epilogue)")
+        """model/layer.py:139-142 on its own (erf GELU only: the other activations exist inside the fused stack)."""
+        if self.intermediate_act_fn is not gelu:
+            raise UniterHipError("BertIntermediate.forward on its own covers hidden_act = 'gelu'; relu / swish run inside BertLayer.forward")
+        return ops.dense_gelu(self, hidden_states)
 
 
 class BertOutput(nn.Module):
@@ -194,7 +199,8 @@ class BertOutput(nn.Module):
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
 
     def forward(self, hidden_states, input_tensor):
-        raise UniterHipError("BertOutput is fused into BertLayer.forward")
+        """model/layer.py:152-156 on its own."""
+        return ops.dense_dropout_residual_layernorm(self, hidden_states, input_tensor)
 
 
 def layer_dropouts(layer):

@@ -188,9 +188,8 @@ class UniterImageEmbeddings(nn.Module):
         if isinstance(type_embeddings, tuple):
             table, ids = type_embeddings
             return ops.img_embeddings(self, img_feat, img_pos_feat, table, ids, img_masks)
-        raise NotImplementedError(
-            "pass type_embeddings=(token_type_embeddings.weight, img_type_ids) — the dense [B,Li,H] form "
-            "of the reference is produced inside the fused kernel here")
+        # the reference's own call form (model/model.py:261-272, e.g. from third-party code): the rows are already looked up
+        return ops.img_embeddings(self, img_feat, img_pos_feat, type_embeddings, None, img_masks)
 
 
 def pack_indices(seq_lens, max_len, multiple=64):

@@ -644,6 +644,208 @@ def dgrad_group(dys, lddys, ws, resids, dxs, M, Ns, K):
 
 
 # ----------------------------------------------------------------------------------------------------
+# The sub-modules of a BertLayer called on their own (model/layer.py:47-156).  UniterEncoder / BertLayer run the fused stack
+# (uniter_encoder_forward); third-party code that calls BertSelfAttention, BertSelfOutput, BertAttention, BertIntermediate or
+# BertOutput directly gets the same kernels one operation at a time through these autograd nodes.  Parameter gradients are
+# accumulated into `.grad` as everywhere in this package.
+# ----------------------------------------------------------------------------------------------------
+def _grad_or_dummy(p, pool):
+    if p is None:
+        return None
+    return ensure_grad(p) if p.requires_grad else _dummy_grad_like(p, pool)
+
+
+def _wgrad_into(dy, x, gw, gb, M, N, K):
+    """gw[N, K] += dy[M, N]^T x[M, K]; gb[N] += column sums of dy (gb may be None)."""
+    wsb = C.uniter_gemm_wgrad_workspace_bytes(M, N, K)
+    ws = _scratch(("sub_wgrad", dy.device.index), wsb, dy.device)
+    C.uniter_gemm_wgrad(ptr(dy), ptr(x), ptr(gw), ptr(gb), M, N, K, 1, ptr(ws), wsb, _lib.stream_ptr())
+
+
+class _SelfAttentionFn(torch.autograd.Function):
+    """BertSelfAttention.forward (model/layer.py:75-101): fused [3H, H] projection, then softmax(QK^T / sqrt(dh) + mask) V per head."""
+
+    @staticmethod
+    def forward(ctx, x, mask_bias, att, p_attn, *anchor):
+        B, L, H = x.shape
+        T = B * L
+        heads = att.num_attention_heads
+        st = _lib.stream_ptr()
+        xc = x.contiguous()
+        wqkv, bqkv = att.fused_qkv()
+        qkv = torch.empty(T, 3 * H, dtype=_BF16, device=x.device)
+        out = torch.empty(B, L, H, dtype=_BF16, device=x.device)
+        lse = torch.empty(B * heads * L, dtype=torch.float32, device=x.device)
+        C.uniter_gemm_bias_fwd(ptr(xc), ptr(wqkv), ptr(bqkv), ptr(qkv), T, 3 * H, H, st)
+        seed, off = _next_offsets(1) if p_attn > 0.0 else (0, 0)
+        C.uniter_attention_fwd(ptr(qkv), ptr(mask_bias), ptr(out), ptr(lse), B, L, heads, p_attn, seed, off, st)
+        ctx.att, ctx.p, ctx.seed, ctx.off = att, p_attn, seed, off
+        ctx.save_for_backward(xc, mask_bias, qkv, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xc, mask_bias, qkv, out, lse = ctx.saved_tensors
+        att = ctx.att
+        B, L, H = xc.shape
+        T = B * L
+        heads = att.num_attention_heads
+        st = _lib.stream_ptr()
+        dout = dout.contiguous()
+        dqkv = torch.empty(T, 3 * H, dtype=_BF16, device=xc.device)
+        awb = C.uniter_attention_bwd_workspace_bytes(B, L, heads)
+        aws = _scratch(("sub_attn", xc.device.index), max(awb, 16), xc.device)
+        C.uniter_attention_bwd_ws(ptr(qkv), ptr(mask_bias), None, ptr(out), ptr(lse), ptr(dout), ptr(dqkv), B, L, heads,
+                                  ctx.p, ctx.seed, ctx.off, ptr(aws), awb, st)
+        wqkv, _ = att.fused_qkv()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(xc)
+            C.uniter_gemm_dgrad(ptr(dqkv), ptr(wqkv), None, ptr(dx), T, 3 * H, H, st)
+        if any(m.weight.requires_grad for m in (att.query, att.key, att.value)):
+            gw, gb = att.fused_qkv_grad()
+            _wgrad_into(dqkv, xc, gw, gb, T, 3 * H, H)
+        return (dx, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+class _DenseDropResLnFn(torch.autograd.Function):
+    """BertSelfOutput / BertOutput.forward (model/layer.py:111-115, 152-156): LayerNorm(dropout(dense(h)) + input)."""
+
+    @staticmethod
+    def forward(ctx, h, inp, mod, p, *anchor):
+        K = h.shape[-1]
+        H = inp.shape[-1]
+        hc = h.contiguous().view(-1, K)
+        ic = inp.contiguous().view(-1, H)
+        T = hc.shape[0]
+        st = _lib.stream_ptr()
+        z = torch.empty(T, H, dtype=_BF16, device=h.device)
+        seed, off = _next_offsets(1) if p > 0.0 else (0, 0)
+        C.uniter_gemm_bias_dropout_residual_fwd(ptr(hc), ptr(mod.dense.weight), ptr(mod.dense.bias), ptr(ic), ptr(z), T, H, K, p, seed, off, st)
+        y, mean, rstd = _ln_fwd(z, mod.LayerNorm.weight, mod.LayerNorm.bias, 1e-12, 0.0, 0, 0)
+        ctx.mod, ctx.p, ctx.seed, ctx.off, ctx.shape = mod, p, seed, off, tuple(inp.shape)
+        ctx.save_for_backward(hc, z, mean, rstd)
+        return y.view(inp.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        hc, z, mean, rstd = ctx.saved_tensors
+        mod = ctx.mod
+        T, K = hc.shape
+        H = z.shape[1]
+        st = _lib.stream_ptr()
+        dy = dy.contiguous().view(T, H)
+        dz = torch.empty_like(z)                      # gradient of the residual sum: goes to `input` as it is
+        dd = torch.empty_like(z)                      # ... and through the dropout mask to the dense branch
+        pool = {}
+        ln = mod.LayerNorm
+        wsb = C.uniter_layernorm_bwd_workspace_bytes(T, H)
+        ws = _scratch(("ln", z.device.index), wsb, z.device)
+        C.uniter_layernorm_bwd(ptr(dy), None, ptr(z), ptr(mean), ptr(rstd), ptr(ln.weight), ptr(dz), ptr(dd),
+                               ptr(_grad_or_dummy(ln.weight, pool)), ptr(_grad_or_dummy(ln.bias, pool)),
+                               ptr(_grad_or_dummy(mod.dense.bias, pool)), T, H, 1, ctx.p, ctx.seed, ctx.off, 0, ptr(ws), wsb, st)
+        dh = None
+        if ctx.needs_input_grad[0]:
+            dh = torch.empty_like(hc)
+            C.uniter_gemm_dgrad(ptr(dd), ptr(mod.dense.weight), None, ptr(dh), T, H, K, st)
+            dh = dh.view(ctx.shape[:-1] + (K,))
+        if mod.dense.weight.requires_grad:
+            _wgrad_into(dd, hc, ensure_grad(mod.dense.weight), None, T, H, K)
+        dinp = dz.view(ctx.shape) if ctx.needs_input_grad[1] else None
+        return (dh, dinp, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+class _DenseGeluFn(torch.autograd.Function):
+    """BertIntermediate.forward (model/layer.py:139-142) with the exact erf GELU: one GEMM with a fused epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, mod, *anchor):
+        H = x.shape[-1]
+        I = mod.dense.weight.shape[0]
+        xc = x.contiguous().view(-1, H)
+        T = xc.shape[0]
+        u = torch.empty(T, I, dtype=_BF16, device=x.device)
+        g = torch.empty(T, I, dtype=_BF16, device=x.device)
+        C.uniter_gemm_bias_gelu_fwd(ptr(xc), ptr(mod.dense.weight), ptr(mod.dense.bias), ptr(u), ptr(g), T, I, H, _lib.stream_ptr())
+        ctx.mod, ctx.shape = mod, tuple(x.shape)
+        ctx.save_for_backward(xc, u)
+        return g.view(x.shape[:-1] + (I,))
+
+    @staticmethod
+    def backward(ctx, dg):
+        xc, u = ctx.saved_tensors
+        mod = ctx.mod
+        T, H = xc.shape
+        I = u.shape[1]
+        st = _lib.stream_ptr()
+        dg = dg.contiguous().view(T, I)
+        du = torch.empty_like(u)
+        C.uniter_gelu_bwd(ptr(dg), ptr(u), ptr(du), u.numel(), st)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(xc)
+            C.uniter_gemm_dgrad(ptr(du), ptr(mod.dense.weight), None, ptr(dx), T, I, H, st)
+            dx = dx.view(ctx.shape)
+        pool = {}
+        if mod.dense.weight.requires_grad or mod.dense.bias.requires_grad:
+            _wgrad_into(du, xc, _grad_or_dummy(mod.dense.weight, pool), _grad_or_dummy(mod.dense.bias, pool), T, I, H)
+        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+def _anchor(params):
+    if not torch.is_grad_enabled():
+        return ()
+    a = next((q for q in params if q is not None and q.requires_grad), None)
+    return () if a is None else (a,)
+
+
+def _check_mod(params, what):
+    for q in params:
+        _check_dev(q, what)
+        if not q.is_contiguous():
+            raise _lib.UniterHipError("%s must be contiguous" % what)
+
+
+def self_attention(att, hidden_states, attention_mask):
+    """BertSelfAttention.forward: hidden_states [B, L, H] bf16, attention_mask additive ([B, 1, 1, L] or [B, L], (1 - m) * -10000)."""
+    _check_dev(hidden_states, "hidden_states")
+    if hidden_states.dim() != 3:
+        raise _lib.UniterHipError("hidden_states must be [B, L, H]")
+    B, L, H = hidden_states.shape
+    if att.attention_head_size != 64 or L > 512:
+        raise _lib.UniterHipError("the attention kernels need 64-wide heads and L <= 512")
+    lin = (att.query, att.key, att.value)
+    _check_mod([m.weight for m in lin] + [m.bias for m in lin], "attention parameter")
+    params_ready(*[m.weight for m in lin])
+    mb = attention_mask.float().reshape(B, L).contiguous()
+    p = float(att.dropout.p) if (att.training and torch.is_grad_enabled()) else 0.0
+    return _SelfAttentionFn.apply(hidden_states, mb, att, p, *_anchor([m.weight for m in lin] + [m.bias for m in lin]))
+
+
+def dense_dropout_residual_layernorm(mod, hidden_states, input_tensor):
+    """BertSelfOutput / BertOutput.forward."""
+    _check_dev(hidden_states, "hidden_states")
+    _check_dev(input_tensor, "input_tensor")
+    K, H = mod.dense.weight.shape[1], mod.dense.weight.shape[0]
+    if hidden_states.shape[-1] != K or input_tensor.shape[-1] != H or hidden_states.shape[:-1] != input_tensor.shape[:-1]:
+        raise _lib.UniterHipError("dense + residual: shapes %s / %s do not fit Linear(%d, %d)" % (tuple(hidden_states.shape), tuple(input_tensor.shape), K, H))
+    prm = [mod.dense.weight, mod.dense.bias, mod.LayerNorm.weight, mod.LayerNorm.bias]
+    _check_mod(prm, "output-block parameter")
+    params_ready(*prm)
+    p = float(mod.dropout.p) if (mod.training and torch.is_grad_enabled()) else 0.0
+    return _DenseDropResLnFn.apply(hidden_states, input_tensor, mod, p, *_anchor(prm))
+
+
+def dense_gelu(mod, hidden_states):
+    """BertIntermediate.forward for hidden_act = "gelu" (the exact erf form, model/layer.py:31-37)."""
+    _check_dev(hidden_states, "hidden_states")
+    prm = [mod.dense.weight, mod.dense.bias]
+    _check_mod(prm, "intermediate parameter")
+    params_ready(*prm)
+    return _DenseGeluFn.apply(hidden_states, mod, *_anchor(prm))
+
+
+# ----------------------------------------------------------------------------------------------------
 # LayerNorm (+ dropout on the output) as used by the embedding blocks
 # ----------------------------------------------------------------------------------------------------
 def _ln_fwd(z, weight, bias, eps, p, seed, off):
@@ -734,7 +936,7 @@ class _ImgEmbedFn(torch.autograd.Function):
         dev = type_table.device
         B, Li, D = img_feat.shape
         rows = B * Li
-        H = type_table.shape[1]
+        H = type_table.shape[-1]
         st = _lib.stream_ptr()
         feat = img_feat.contiguous()
         if feat.dtype not in (torch.float32, _BF16):
@@ -750,6 +952,14 @@ class _ImgEmbedFn(torch.autograd.Function):
             masks = img_masks.to(torch.uint8).contiguous().view(-1)
             mask_row = mod.mask_embedding.weight.data[1]
         tids = None if type_ids is None else type_ids.to(torch.int64).contiguous().view(-1)
+        # the reference's call convention (model/model.py:261-272): `type_embeddings` already looked up, [B, Li, H] — every row is
+        # its own "type": the fused combine kernel reads row r of the tensor, and the gradient w.r.t. it is dz itself
+        dense_type = type_table.dim() == 3
+        if dense_type:
+            if tuple(type_table.shape) != (B, Li, H) or type_ids is not None:
+                raise _lib.UniterHipError("dense type_embeddings must be [B, Li, H] = %s (and come without ids)" % ((B, Li, H),))
+            type_table = type_table.contiguous().view(rows, H)
+            tids = torch.arange(rows, dtype=torch.int64, device=dev)
         f = torch.empty(rows, D, dtype=_BF16, device=dev)
         C.uniter_embed_img_prep(ptr(feat), 1 if feat.dtype == torch.float32 else 0, ptr(masks), ptr(mask_row), ptr(f),
                                 rows, D, st)
@@ -766,6 +976,7 @@ class _ImgEmbedFn(torch.autograd.Function):
         seed, off = _next_offsets(1) if p > 0 else (0, 0)
         y, mean_z, rstd_z = _ln_fwd(z, mod.LayerNorm.weight, mod.LayerNorm.bias, 1e-12, p, seed, off)
         ctx.mod, ctx.type_table, ctx.p, ctx.seed, ctx.off = mod, type_table, p, seed, off
+        ctx.dense_type = dense_type
         ctx.tids, ctx.masks, ctx.posf, ctx.shape = tids, masks, posf, (B, Li, D, H)
         ctx.save_for_backward(f, lin, mean_i, rstd_i, pl, mean_p, rstd_p, z, mean_z, rstd_z)
         return y.view(B, Li, H)
@@ -782,7 +993,7 @@ class _ImgEmbedFn(torch.autograd.Function):
         dz = _ln_bwd(dy, z, mean_z, rstd_z, mod.LayerNorm.weight, mod.LayerNorm.bias, ctx.p, ctx.seed, ctx.off, post=True)
         wsb = max(C.uniter_embed_ws_bytes(rows, max(H, D)), C.uniter_gemm_wgrad_workspace_bytes(rows, H, D))
         ws = _scratch(("emb", dev.index), wsb, dev)
-        if type_table.requires_grad:
+        if type_table.requires_grad and not ctx.dense_type:
             C.uniter_embed_type_bwd(ptr(dz), ptr(ctx.tids), ptr(ensure_grad(type_table)), rows, H, type_table.shape[0], 1,
                                     ptr(ws), wsb, st)
         # position branch
@@ -803,7 +1014,8 @@ class _ImgEmbedFn(torch.autograd.Function):
             C.uniter_gemm_dgrad(ptr(dlin), ptr(w), None, ptr(df), rows, H, D, st)
             gme = ensure_grad(mod.mask_embedding.weight)
             C.uniter_embed_mask_bwd(ptr(df), ptr(ctx.masks), ptr(gme[1]), rows, D, ptr(ws), wsb, st)
-        return (None,) * (7 + 11)
+        d_type = dz.view(B, Li, H) if (ctx.dense_type and ctx.needs_input_grad[5]) else None
+        return (None,) * 5 + (d_type,) + (None,) * (1 + 11)
 
 
 def img_embeddings(mod, img_feat, img_pos_feat, type_table, type_ids, img_masks):
