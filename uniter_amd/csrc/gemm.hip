@@ -1731,10 +1731,18 @@ int gemm_wgrad_group(int n, const void* const* dy, const void* const* x, void* c
 // not fit the tile or the stream is being captured — the caller then runs its per-layer path.  The problem table lives in
 // device memory and is re-uploaded only when its content changes (training steps repeat the same pointers).
 namespace {
+// (four images per key: a training step alternates between a few versions of one table — the upstream gradient and the saved
+//  activations come back from the caching allocator at two or three addresses in turn — and an upload per step sits, with its
+//  4-5 us copy, on the weight-gradient stream right in front of the launch)
 struct MultiTable {
-    void* dev = nullptr;
-    size_t cap = 0;
-    std::vector<char> last;
+    struct Slot {
+        void* dev = nullptr;
+        size_t cap = 0;
+        std::vector<char> last;
+        uint64_t used = 0;
+    } slot[4];
+    uint64_t tick = 0;
+    void* dev = nullptr;                                     // the slot chosen for the current launch
 };
 struct MultiState {
     std::map<std::pair<int, uint64_t>, MultiTable> tables;   // (device, first dw pointer) -> table: one per layer range in use
@@ -1853,14 +1861,26 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
     int dev = 0;
     UH_CHECK_HIP(hipGetDevice(&dev));
     MultiTable& T = g_multi.tables[std::make_pair(dev, (uint64_t)(uintptr_t)dw[0])];
-    if (T.cap < bytes) {
-        if (T.dev) (void)hipFree(T.dev);
-        T.dev = nullptr;
-        UH_CHECK_HIP(hipMalloc(&T.dev, bytes));
-        T.cap = bytes;
-        T.last.clear();
+    MultiTable::Slot* ts = nullptr;
+    for (MultiTable::Slot& c : T.slot)
+        if (c.dev != nullptr && c.last.size() == bytes && memcmp(c.last.data(), img.data(), bytes) == 0) { ts = &c; break; }
+    const bool hit = ts != nullptr;
+    if (!hit) {
+        ts = &T.slot[0];
+        for (MultiTable::Slot& c : T.slot)
+            if (c.used < ts->used) ts = &c;                  // least recently used (empty slots first)
+        if (ts->cap < bytes) {
+            if (ts->dev) (void)hipFree(ts->dev);             // (stream-ordered: nothing newer than an earlier launch of `st` reads it)
+            ts->dev = nullptr;
+            ts->cap = 0;
+            UH_CHECK_HIP(hipMalloc(&ts->dev, bytes));
+            ts->cap = bytes;
+        }
+        ts->last.clear();
     }
-    if (T.last.size() != bytes || memcmp(T.last.data(), img.data(), bytes) != 0) {
+    ts->used = ++T.tick;
+    T.dev = ts->dev;
+    if (!hit) {
         const int slot = g_multi.next;
         g_multi.next = (slot + 1) & 3;
         if (g_multi.pinned_ev[slot] == nullptr) UH_CHECK_HIP(hipEventCreateWithFlags(&g_multi.pinned_ev[slot], hipEventDisableTiming));
@@ -1874,7 +1894,7 @@ int gemm_wgrad_multi(int n, const void* const* dy, const void* const* x, void* c
         memcpy(g_multi.pinned[slot], img.data(), bytes);
         UH_CHECK_HIP(hipMemcpyAsync(T.dev, g_multi.pinned[slot], bytes, hipMemcpyHostToDevice, st));
         UH_CHECK_HIP(hipEventRecord(g_multi.pinned_ev[slot], st));
-        T.last = img;
+        ts->last = img;
     }
     const int per = buckets != nullptr ? per_bucketed : (tiles + 7) / 8;
     if (buckets != nullptr) {
