@@ -9,7 +9,11 @@
 
 namespace {
 
-constexpr int PT = 256;                 // threads per workgroup
+constexpr int PT = 1024;                // threads per workgroup: 16 waves — one workgroup per SEQUENCE is all the parallelism there is (32 at the
+                                        // benchmark shape), so its two passes over the 147 KB of a sequence are latency chains per wave: with 4
+                                        // waves 16.6 / 16.5 us forward / backward, with 16 waves see profiles/r06_pool_threads_ab.txt
+constexpr int PNW = PT / 64;            // waves
+constexpr int PSL = PT / 128;           // row slices of the weighted-sum passes (thread = (slice, 8-column chunk))
 constexpr int PMAXL = 512;            // max_position_embeddings: the longest sequence the encoder itself takes
 
 struct PoolArgs {
@@ -34,7 +38,10 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     __syncthreads();
     if (lane == 0) red[wid] = v;
     __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < PNW; ++w) t += red[w];            // fixed order: deterministic
+    return t;
 }
 __device__ __forceinline__ float block_max(float v, float* red) {
     v = wave_max(v);
@@ -42,7 +49,10 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     __syncthreads();
     if (lane == 0) red[wid] = v;
     __syncthreads();
-    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float t = red[0];
+#pragma unroll
+    for (int w = 1; w < PNW; ++w) t = fmaxf(t, red[w]);
+    return t;
 }
 
 // dots of rows t0..t0+3 of x with a vector (H <= 1024: at most two 8-column chunks per lane); all eight row loads
@@ -77,8 +87,8 @@ __device__ __forceinline__ void row_dot4(const bf16_t* x, const bf16_t* vec, int
 
 __global__ __launch_bounds__(PT) void pool_fwd_kernel(const PoolArgs p) {
     __shared__ float sc[PMAXL];          // scores -> probabilities -> pooling weights
-    __shared__ float red[4];
-    __shared__ float acc2[2][1024];      // two row-halves of the weighted sum, H <= 1024
+    __shared__ float red[PNW];
+    __shared__ float acc2[PSL][1024];    // row slices of the weighted sum, H <= 1024
     const int b = blockIdx.x, L = p.L, H = p.H;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const bf16_t* x = p.x + (int64_t)b * L * H;
@@ -113,12 +123,13 @@ __global__ __launch_bounds__(PT) void pool_fwd_kernel(const PoolArgs p) {
         sc[t] = w;
     }
     __syncthreads();
-    // out[d] = sum_t w_t x[t][d]: thread = (row half, 8-column chunk)
+    // out[d] = sum_t w_t x[t][d]: thread = (row slice, 8-column chunk)
     const int nchunk = H >> 3;
     const int half = threadIdx.x / 128, c = threadIdx.x % 128;
+    const int lq = (L + PSL - 1) / PSL;
     if (c < nchunk) {
         float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const int t0 = half ? (L + 1) / 2 : 0, t1 = half ? L : (L + 1) / 2;
+        const int t0 = min(L, half * lq), t1 = min(L, (half + 1) * lq);
 #pragma unroll 8
         for (int t = t0; t < t1; ++t) {
             float v[8];
@@ -134,7 +145,12 @@ __global__ __launch_bounds__(PT) void pool_fwd_kernel(const PoolArgs p) {
     if (threadIdx.x < nchunk) {
         float o[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = acc2[0][threadIdx.x * 8 + e] + acc2[1][threadIdx.x * 8 + e];
+        for (int e = 0; e < 8; ++e) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < PSL; ++q) t += acc2[q][threadIdx.x * 8 + e];
+            o[e] = t;
+        }
         *reinterpret_cast<u32x4*>(p.out + (int64_t)b * H + threadIdx.x * 8) = pack8(o);
     }
 }
@@ -142,8 +158,8 @@ __global__ __launch_bounds__(PT) void pool_fwd_kernel(const PoolArgs p) {
 __global__ __launch_bounds__(PT) void pool_bwd_kernel(const PoolArgs p) {
     __shared__ float ds[PMAXL];          // d out / d (pre-relu score), then reused
     __shared__ float pwv[PMAXL];
-    __shared__ float red[4];
-    __shared__ float acc2[2][1024];
+    __shared__ float red[PNW];
+    __shared__ float acc2[PSL][1024];
     const int b = blockIdx.x, L = p.L, H = p.H;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const bf16_t* x = p.x + (int64_t)b * L * H;
@@ -176,11 +192,12 @@ __global__ __launch_bounds__(PT) void pool_bwd_kernel(const PoolArgs p) {
     // dx[t][d] = pw_t dout[d] + ds_t w[d] ; dw[d] partial = sum_t ds_t x[t][d]
     const int nchunk = H >> 3;
     const int half = threadIdx.x / 128, c = threadIdx.x % 128;
+    const int lq = (L + PSL - 1) / PSL;
     if (c < nchunk) {
         float dov[8], wv[8], a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         unpack8(*reinterpret_cast<const u32x4*>(dout + c * 8), dov);
         unpack8(*reinterpret_cast<const u32x4*>(p.w + c * 8), wv);
-        const int t0 = half ? (L + 1) / 2 : 0, t1 = half ? L : (L + 1) / 2;
+        const int t0 = min(L, half * lq), t1 = min(L, (half + 1) * lq);
 #pragma unroll 8
         for (int t = t0; t < t1; ++t) {
             float v[8], o[8];
@@ -195,7 +212,12 @@ __global__ __launch_bounds__(PT) void pool_bwd_kernel(const PoolArgs p) {
     }
     __syncthreads();
     float* part = p.part + (int64_t)b * (H + 1);
-    for (int d = threadIdx.x; d < H; d += PT) part[d] = acc2[0][d] + acc2[1][d];
+    for (int d = threadIdx.x; d < H; d += PT) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < PSL; ++q) t += acc2[q][d];
+        part[d] = t;
+    }
     if (threadIdx.x == 0) part[H] = dbias;
 }
 
