@@ -73,6 +73,11 @@ def main():
         arena = flatten_model(model)
         D.broadcast_tensors([p.data for p in model.parameters()], 0)
         opt = build_optimizer(model, opts)
+        # UNITER_W1_FUSE_ZERO=1: the training loop's optimizer mode (train.py::StepRunner) — zero_grad folded into the step and, with it,
+        # the lazy zero_grad of round 6: from the second step on the encoder's backward OVERWRITES its parameter gradients (bucketed
+        # deferred launch included).  The plain run keeps the eager zero_grad: the two must still end bit-identical.
+        fuse = os.environ.get("UNITER_W1_FUSE_ZERO") == "1"
+        opt.fuse_zero_grad = fuse and use_reducer
         reducer = D.GradientReducer(arena, model.uniter.encoder, layers_per_bucket=lpb,
                                     word_embeddings=model.uniter.embeddings.word_embeddings.weight) if use_reducer else None
         if not use_reducer:
@@ -80,7 +85,8 @@ def main():
             model.uniter.encoder.grad_ready_hook = _ops.DeferWgradJoin()      # the single-process training loop's hook
         before = calls["n"]
         buckets_seen = 0
-        for step in range(2):
+        n_steps = 3 if fuse else 2
+        for step in range(n_steps):
             if reducer is not None:
                 reducer.begin()
             model(batch, compute_loss=True).mean().backward()
@@ -98,7 +104,7 @@ def main():
     n_layers = len(model.uniter.encoder.layer)
     print(json.dumps({"identical": bool(same), "allreduce_calls": n_calls, "encoder_layers": n_layers, "flag_waits": buckets_seen,
                       "single_launch": bool(reducer.single_launch),
-                      "elements_reduced_per_step": calls["elems"] // 2 if n_calls else 0, "arena_elements": numel,
+                      "elements_reduced_per_step": calls["elems"] // n_steps if n_calls else 0, "arena_elements": numel, "steps": n_steps,
                       "backend": dist.get_backend()}))
     dist.destroy_process_group()
 

@@ -49,6 +49,22 @@ def test_single_launch_reducer_with_bucket_flags_over_one_rank_rccl(lpb):
     assert out["flag_waits"] == (out["encoder_layers"] + lpb - 1) // lpb, out        # every bucket of a step went behind its flag
 
 
+def test_single_launch_reducer_with_lazy_zero_grad_over_one_rank_rccl():
+    """Round 6: the training loop's optimizer mode under the data-parallel path — zero_grad folded into the AdamW step, the encoder's
+    parameter gradients left for the next backward to overwrite (bucketed deferred launch with accumulate off), three steps —
+    against the collective-free loop with the eager zero_grad: bit-identical parameters."""
+    env = dict(os.environ, UNITER_DIST_FORCE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29557", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", UNITER_W1_WIDE="1", UNITER_W1_LAYERS_PER_BUCKET="2",
+               UNITER_AMD_DP_SPARSE_WORD="1", UNITER_W1_FUSE_ZERO="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_world1_script.py")], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads(lines[-1])
+    assert out["backend"] == "nccl" and out["single_launch"] and out["steps"] == 3
+    assert out["identical"], out
+
+
 def test_raw_rccl_communicator_one_rank():
     code = r'''
 import ctypes, sys, torch

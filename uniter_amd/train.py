@@ -222,6 +222,11 @@ class StepRunner(object):
         self.set_dp_mode(single_launch)
         task, batch = next(iter(self.batches.items()))
         set_dropout(self.model, 0.0)
+        # (model/attention.py's MultiheadAttention — the NLVR2 paired-attention head — keeps its dropout as a float attribute that
+        #  set_dropout does not reach: left on, two runs of ONE mode already differ and the check would always fall back)
+        floats = [(m, m.dropout) for m in self.model.modules() if isinstance(getattr(m, 'dropout', None), float)]
+        for m, _ in floats:
+            m.dropout = 0.0
         try:
             self.reducer.begin()
             loss = self._loss(task, batch)
@@ -233,6 +238,8 @@ class StepRunner(object):
             digest = int((g * w).sum().item())
         finally:
             set_dropout(self.model, self.w['dropout'])
+            for m, v in floats:
+                m.dropout = v
             self.arena.grad.zero_()
         return digest
 
