@@ -261,3 +261,29 @@ def test_noop_and_parse_with_config(tmp_path):
     assert not hasattr(a, "config")
     b = parse_with_config(ap, ["--train_batch_size", "8"])
     assert b.train_batch_size == 8 and b.learning_rate == 3e-5 and not hasattr(b, "config")
+
+
+def test_lazy_zero_grad_host_state_machine():
+    """Host side of AdamW.lazy_zero / fold_norm (round 6), no GPU: which plan tensors lie inside the gradient storages an encoder
+    backward overwrites (`_covered`: whole-tensor containment, the three thirds of a fused q|k|v storage each), and that a reader
+    who comes before a backward gets zeros (`_lib.lazy_resolve`)."""
+    from uniter_amd import _lib
+    from uniter_amd.optim import AdamW
+    opt = AdamW([torch.nn.Parameter(torch.zeros(4))], lr=1e-3)
+    # plan tensors as (gradient address, bytes): three thirds of one fused storage, a neighbour, one straddling a range end, one apart
+    opt._plan_grads = [(1000, 100), (1100, 100), (1200, 100), (1300, 64), (1990, 20), (5000, 8)]
+    ranges = frozenset({(1000, 300), (1300, 64), (1900, 100)})
+    assert opt._covered(ranges) == [True, True, True, True, False, False]
+    assert opt._covered(frozenset()) == [False] * 6
+    # undefined gradients are resolved to zeros on demand, once
+    a, b = torch.ones(5), torch.full((3,), 2.0)
+    saved = (_lib.lazy_tensors, _lib.lazy_undefined)
+    try:
+        _lib.lazy_tensors, _lib.lazy_undefined = [a, b], True
+        _lib.lazy_resolve()
+        assert not _lib.lazy_undefined and float(a.abs().sum()) == 0.0 and float(b.abs().sum()) == 0.0
+        a.fill_(7.0)
+        _lib.lazy_resolve()                      # nothing is undefined any more: untouched
+        assert float(a[0]) == 7.0
+    finally:
+        _lib.lazy_tensors, _lib.lazy_undefined = saved
